@@ -1,0 +1,467 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference).  The reference is
+exposed as package ``bsr`` through a throw-away shim directory outside the repo
+(its modules do ``from bsr.funcs import ...``, codes/bsr_class.py:10-12).  No
+reference source is copied: the fixtures hold inputs and expected outputs only.
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tools/gen_golden.py [g1 g2 ...]
+
+Fixtures:
+  g1_edge.json        allcal edge semantics per opcode          (funcs.py:175-220)
+  g2_grow.json        grow + allcal on seeded random trees      (funcs.py:74-119,175-220)
+  g3_yloglike.json    ylogLike incl. scale/duplicate/zero cases (funcs.py:1147-1174)
+  g5_trace_*.json/npz per-proposal newProp traces of BSR.fit    (funcs.py:1184-1306)
+  g6_fit_f1.json      BSR(3,50).fit end to end on f1, seed 0    (bsr_class.py:77-278)
+  g7_rng.json         RNG primitives as consumed by the path    
+"""
+import os
+import sys
+import json
+import zlib
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+SHIM = "/tmp/refshim"
+os.makedirs(SHIM, exist_ok=True)
+if not os.path.islink(os.path.join(SHIM, "bsr")):
+    os.symlink("/root/reference/codes", os.path.join(SHIM, "bsr"))
+sys.path.insert(0, SHIM)
+warnings.filterwarnings("ignore")
+
+import numpy as np
+import pandas as pd
+import scipy
+import sklearn
+
+import bsr.funcs as RF
+import bsr.bsr_class as RC
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OPS = ['inv', 'ln', 'neg', 'sin', 'cos', 'exp', 'square', 'cubic', '+', '*']
+OPW = [1.0 / len(OPS)] * len(OPS)
+OPT = [1, 1, 1, 1, 1, 1, 1, 1, 2, 2]
+VERSIONS = {"numpy": np.__version__, "pandas": pd.__version__, "scipy": scipy.__version__,
+            "sklearn": sklearn.__version__, "python": sys.version.split()[0]}
+
+
+def fnum(v):
+    """JSON-safe float (None stays None; non-finite as strings)."""
+    if v is None:
+        return None
+    v = float(v)
+    if v != v:
+        return "nan"
+    if v in (float("inf"), float("-inf")):
+        return "inf" if v > 0 else "-inf"
+    return v
+
+
+def tree_json(node):
+    """Serialise a reference Node tree as plain data (structure + parameters)."""
+    if node is None:
+        return None
+    feat = None
+    if node.feature is not None:
+        feat = int(np.asarray(node.feature).reshape(-1)[0])
+    return {"type": int(node.type), "op": node.operator,
+            "op_ind": None if node.op_ind is None else int(node.op_ind),
+            "depth": int(node.depth), "feature": feat,
+            "a": fnum(node.a), "b": fnum(node.b),
+            "left": tree_json(node.left), "right": tree_json(node.right)}
+
+
+def rng_mark():
+    st = np.random.get_state()
+    return {"pos": int(st[2]), "crc": int(zlib.crc32(st[1].tobytes())),
+            "has_gauss": int(st[3]), "gauss": fnum(st[4])}
+
+
+def dump(name, obj):
+    path = os.path.join(OUT, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+# ---------------------------------------------------------------- data recipes
+def data_f1(n_train=100):
+    # archive/data_generate_funcs.py:12-17 (f1), values only
+    x1 = np.random.uniform(0.1, 5.9, n_train)
+    x2 = np.random.uniform(0.1, 5.9, n_train)
+    X = pd.concat([pd.DataFrame(x1), pd.DataFrame(x2)], axis=1)
+    y = X.iloc[:, 0] * X.iloc[:, 1] + np.sin((X.iloc[:, 0] - 1) * (X.iloc[:, 1] + 1))
+    return X, y
+
+
+def data_synth(N, d, seed):
+    # SURVEY 8d recipe: X~U(-3,3), y = 1.35 x0 x1 + 5.5 sin((x0-1)(x1-1)) + 0.1 N(0,1)
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    return pd.DataFrame(X), pd.Series(y)
+
+
+# ---------------------------------------------------------------- G1
+def mk_leaf(depth, feat):
+    n = RF.Node(depth)
+    n.type = 0
+    n.feature = np.array([feat])
+    return n
+
+
+def mk_unary(op, child, a=None, b=None):
+    n = RF.Node(0)
+    n.type = 1
+    n.operator = op
+    n.op_ind = OPS.index(op)
+    n.left = child
+    child.parent = n
+    n.a, n.b = a, b
+    return n
+
+
+def mk_binary(op, l, r):
+    n = RF.Node(0)
+    n.type = 2
+    n.operator = op
+    n.op_ind = OPS.index(op)
+    n.left, n.right = l, r
+    l.parent = n
+    r.parent = n
+    return n
+
+
+def g1():
+    edge = [-2.0, -1.0, -0.0, 0.0, 1e-320, 1.1, 200.0, 200.0000001, 1e200, float("nan"),
+            float("inf"), float("-inf"), -1e-320, 709.0, -745.0, 1e154, -1e103, 3.141592653589793, 1e22, 0.5]
+    x0 = np.array(edge)
+    x1 = np.array(edge[::-1])
+    X = pd.DataFrame({0: x0, 1: x1})
+    cases = []
+    trees = [("terminal", mk_leaf(0, 1))]
+    for op in OPS[:8]:
+        if op == 'ln':
+            trees.append((op, mk_unary(op, mk_leaf(1, 0), a=1.7, b=-0.3)))
+        else:
+            trees.append((op, mk_unary(op, mk_leaf(1, 0))))
+    trees.append(('+', mk_binary('+', mk_leaf(1, 0), mk_leaf(1, 1))))
+    trees.append(('*', mk_binary('*', mk_leaf(1, 0), mk_leaf(1, 1))))
+    # two-level compositions that exercise in-place aliasing of exp/inv (funcs.py:183,190)
+    trees.append(('exp(inv)', mk_unary('exp', mk_unary('inv', mk_leaf(2, 0)))))
+    trees.append(('inv(exp)', mk_unary('inv', mk_unary('exp', mk_leaf(2, 0)))))
+    trees.append(('sin(cubic)', mk_unary('sin', mk_unary('cubic', mk_leaf(2, 0)))))
+    trees.append(('square(exp)', mk_unary('square', mk_unary('exp', mk_leaf(2, 0)))))
+    for name, t in trees:
+        RF.upDepth(t)
+        with np.errstate(all="ignore"):
+            out = RF.allcal(t, X)
+        cases.append({"name": name, "tree": tree_json(t), "out": [fnum(v) for v in out[:, 0]]})
+    dump("g1_edge.json", {"versions": VERSIONS, "x0": [fnum(v) for v in x0], "x1": [fnum(v) for v in x1],
+                          "cases": cases})
+
+
+# ---------------------------------------------------------------- G2
+def g2():
+    cases = []
+    for seed in range(50):
+        d = 2 + seed % 9
+        np.random.seed(seed)
+        X = np.random.uniform(-3, 3, size=(64, d))
+        sa, sb = 0.5 + 0.1 * (seed % 7), 0.3 + 0.2 * (seed % 5)
+        root = RF.Node(0)
+        RF.grow(root, d, OPS, OPW, OPT, -1, sa, sb)
+        mark = rng_mark()
+        nxt = float(np.random.random_sample())
+        with np.errstate(all="ignore"):
+            out = RF.allcal(root, pd.DataFrame(X))
+        cases.append({"seed": seed, "d": d, "sigma_a": sa, "sigma_b": sb, "tree": tree_json(root),
+                      "n_nodes": int(RF.getNum(root)), "height": int(RF.getHeight(root)),
+                      "n_ln": int(RF.numLT(root)), "express": RF.Express(root),
+                      "rng_after": mark, "next_uniform": nxt,
+                      "out": [fnum(v) for v in out[:, 0]]})
+    dump("g2_grow.json", {"versions": VERSIONS, "note": "X = seed(s); uniform(-3,3,(64,d)) then grow",
+                          "cases": cases})
+
+
+# ---------------------------------------------------------------- G3
+def g3():
+    rs = np.random.RandomState(7)
+    cases = []
+
+    def add(name, y, O, sigma, series=True):
+        yy = pd.Series(y) if series else np.array(y)
+        with np.errstate(all="ignore"):
+            val = RF.ylogLike(yy, O, sigma)
+            scale = np.max(np.abs(O))
+            XX = O / scale
+            beta = np.linalg.inv(XX.T @ XX + 1e-6 * np.eye(O.shape[1])) @ (XX.T @ np.array(y).reshape(-1, 1))
+            sse = float(np.sum(np.square(np.array(y) - (XX @ beta)[:, 0])))
+            try:
+                rank = int(np.linalg.matrix_rank(O))
+            except np.linalg.LinAlgError:
+                rank = -1
+        cases.append({"name": name, "K": int(O.shape[1]), "sigma": sigma, "y": [fnum(v) for v in y],
+                      "O": [[fnum(v) for v in row] for row in O], "loglik": fnum(val),
+                      "scale": fnum(scale), "beta": [fnum(v) for v in beta[:, 0]], "sse": fnum(sse),
+                      "rank": rank, "y_is_series": series})
+
+    n = 256
+    for K in (1, 3, 8):
+        y = rs.normal(size=n) * 3
+        O = rs.normal(size=(n, K))
+        add("plain_K%d" % K, y, O, 0.7)
+        add("plain_K%d_ndarray_y" % K, y, O, 1.3, series=False)
+    for sc in (1e-8, 1e3, 1e40, 1e80, 1e160, 1e-200, 1e300):
+        y = rs.normal(size=n)
+        O = rs.normal(size=(n, 3))
+        O[:, 1] *= sc
+        add("graded_%g" % sc, y, O, 1.1)
+    for sc in (1e170, 1e-170):
+        y = rs.normal(size=n)
+        O = rs.normal(size=(n, 3)) * sc
+        add("allscaled_%g" % sc, y, O, 0.9)
+    y = rs.normal(size=n)
+    O = rs.normal(size=(n, 3))
+    O[:, 2] = O[:, 0]
+    add("duplicate_col", y, O, 0.5)
+    O = rs.normal(size=(n, 3))
+    O[:, 1] = 0.0
+    add("zero_col", y, O, 0.5)
+    O = rs.normal(size=(n, 3))
+    O[:, 2] = O[:, 0] + 1e-9 * rs.normal(size=n)
+    add("near_collinear_1e-9", y, O, 0.5)
+    O = rs.normal(size=(n, 3))
+    O[:, 2] = O[:, 0] + 1e-12 * rs.normal(size=n)
+    add("near_collinear_1e-12", y, O, 0.5)
+    O = rs.normal(size=(n, 3))
+    O[:, 2] = -2.5 * O[:, 1]
+    add("proportional", y, O, 2.0)
+    O = rs.normal(size=(n, 8))
+    O[:, 7] = O[:, 0] + O[:, 1]
+    add("sum_dependent_K8", y, O, 0.8)
+    O = rs.normal(size=(n, 3))
+    y2 = O @ np.array([1.0, -2.0, 0.5]) + 1e-3 * rs.normal(size=n)
+    add("good_fit", y2, O, 0.05)
+    dump("g3_yloglike.json", {"versions": VERSIONS, "cases": cases})
+
+
+# ---------------------------------------------------------------- G5 / G6 tracing
+class Tracer:
+    """Wraps the reference's call sites (never edits it) and logs per proposal."""
+
+    def __init__(self, max_props=None):
+        self.rows = []
+        self.cur = None
+        self.max_props = max_props
+        self.orig = {}
+
+    def install(self):
+        T = self
+        self.orig = {"newProp": RC.newProp, "Prop": RF.Prop, "auxProp": RF.auxProp,
+                     "ylogLike": RF.ylogLike, "rank": np.linalg.matrix_rank}
+
+        def prop_w(Root, *a, **k):
+            acts = {}
+
+            def prof(frame, event, arg):
+                if event == "return" and frame.f_code.co_name == "Prop":
+                    acts["action"] = frame.f_locals.get("action")
+                return None
+            sys.setprofile(prof)
+            try:
+                res = T.orig["Prop"](Root, *a, **k)
+            finally:
+                sys.setprofile(None)
+            T.cur["action"] = acts.get("action")
+            T.cur["change"] = res[3]
+            T.cur["Q"] = fnum(res[4])
+            T.cur["Qinv"] = fnum(res[5])
+            T.cur["_prop_root"] = res[1]
+            return res
+
+        def aux_w(change, *a, **k):
+            res = T.orig["auxProp"](change, *a, **k)
+            if len(res) == 4:
+                T.cur["hratio"], T.cur["detjacob"] = fnum(res[0]), fnum(res[1])
+                T.cur["new_sa2"], T.cur["new_sb2"] = fnum(res[2]), fnum(res[3])
+            else:
+                T.cur["new_sa2"], T.cur["new_sb2"] = fnum(res[0]), fnum(res[1])
+            return res
+
+        def yll_w(y, outputs, sigma):
+            v = T.orig["ylogLike"](y, outputs, sigma)
+            T.cur.setdefault("ylls", []).append([fnum(sigma), fnum(v)])
+            return v
+
+        def rank_w(M, *a, **k):
+            r = T.orig["rank"](M, *a, **k)
+            if T.cur is not None:
+                T.cur["rank"] = int(r)
+                T.cur["new_maxabs"] = fnum(np.max(np.abs(M)))
+            return r
+
+        def newprop_w(Roots, count, sigma, y, indata, n_feature, Ops, Op_weights, Op_type, beta, sigma_a, sigma_b):
+            T.cur = {"count": int(count), "sigma_in": fnum(sigma), "sa_in": fnum(sigma_a), "sb_in": fnum(sigma_b)}
+            with np.errstate(all="ignore"):
+                res = T.orig["newProp"](Roots, count, sigma, y, indata, n_feature, Ops, Op_weights, Op_type, beta,
+                                        sigma_a, sigma_b)
+            c = T.cur
+            c["accepted"] = bool(res[0])
+            c["sigma_out"], c["sa_out"], c["sb_out"] = fnum(res[1]), fnum(res[3]), fnum(res[4])
+            c["proposed"] = tree_json(c.pop("_prop_root"))
+            c["result"] = tree_json(res[2]) if res[0] else None
+            c["rng"] = rng_mark()
+            if "ylls" in c:
+                c["new_sigma"] = c["ylls"][0][0]
+                c["yllstar"], c["yll"] = c["ylls"][0][1], c["ylls"][1][1]
+                del c["ylls"]
+            T.rows.append(c)
+            T.cur = None
+            if T.max_props is not None and len(T.rows) >= T.max_props:
+                raise StopIteration
+            return res
+
+        RF.Prop = prop_w
+        RF.auxProp = aux_w
+        RF.ylogLike = yll_w
+        np.linalg.matrix_rank = rank_w
+        RC.newProp = newprop_w
+
+    def remove(self):
+        RC.newProp = self.orig["newProp"]
+        RF.Prop = self.orig["Prop"]
+        RF.auxProp = self.orig["auxProp"]
+        RF.ylogLike = self.orig["ylogLike"]
+        np.linalg.matrix_rank = self.orig["rank"]
+
+
+def trace_fit(name, X, y, K, seed, max_props, val=100):
+    """Seed, run ONE chain of BSR.fit under the tracer, cut after max_props proposals."""
+    tr = Tracer(max_props)
+    tr.install()
+    np.random.seed(seed)
+    est = RC.BSR(treeNum=K, itrNum=1, val=val)
+    # capture the initial trees: grow() is called K times before the first newProp
+    init = []
+    orig_grow = RF.grow
+    state = {"depth": 0}
+
+    def grow_w(node, *a, **k):
+        state["depth"] += 1
+        try:
+            return orig_grow(node, *a, **k)
+        finally:
+            state["depth"] -= 1
+            if state["depth"] == 0 and not tr.rows and tr.cur is None:
+                init.append(tree_json(node))
+    RF.grow = grow_w
+    RC.grow = grow_w
+    stopped = False
+    try:
+        est.fit(X, y)
+    except StopIteration:
+        stopped = True
+    finally:
+        RF.grow = orig_grow
+        RC.grow = orig_grow
+        tr.remove()
+    meta = {"versions": VERSIONS, "name": name, "K": K, "seed": seed, "val": val, "N": int(X.shape[0]),
+            "d": int(X.shape[1]), "truncated": stopped, "n_props": len(tr.rows),
+            "init_trees": init[:K], "props": tr.rows}
+    if not stopped:
+        meta["final_models"] = est.model()
+        meta["betas"] = [fnum(v) for v in np.asarray(est.betas_[-1]).reshape(-1)]
+        meta["train_err"] = [fnum(v) for v in est.train_err_[-1]]
+    dump("g5_trace_%s.json" % name, meta)
+    np.savez_compressed(os.path.join(OUT, "g5_trace_%s.npz" % name), X=np.asarray(X, dtype=np.float64),
+                        y=np.asarray(y, dtype=np.float64))
+
+
+def g5():
+    np.random.seed(0)
+    X, y = data_f1(100)
+    trace_fit("f1_s0", X, y, K=3, seed=0, max_props=500)
+    trace_fit("f1_s7", X, y, K=3, seed=7, max_props=500)
+    X, y = data_synth(1000, 10, seed=0)
+    trace_fit("synth_d10_s1000", X, y, K=3, seed=1000, max_props=400)
+    X, y = data_synth(500, 5, seed=1)
+    trace_fit("synth_K8_s1001", X, y, K=8, seed=1001, max_props=300)
+    X, y = data_synth(300, 3, seed=2)
+    trace_fit("synth_K1_s5", X, y, K=1, seed=5, max_props=200)
+    trace_fit("synth_K2_s11_yarr", X, np.asarray(y), K=2, seed=11, max_props=300)
+
+
+def g6():
+    np.random.seed(0)
+    X, y = data_f1(100)
+    grid = np.array([[-0.15 + 0.2 * i, -0.15 + 0.2 * (29 - i)] for i in range(30)])
+    counts = []
+    orig = RC.newProp
+
+    def cnt(*a, **k):
+        counts[-1] += 1
+        with np.errstate(all="ignore"):
+            return orig(*a, **k)
+    RC.newProp = cnt
+    # one chain boundary = one `sigma = invgamma.rvs(1)` at bsr_class.py:123; count via grow at depth 0
+    orig_grow = RC.grow
+    st = {"n": 0}
+
+    def grow_w(node, *a, **k):
+        if node.depth == 0 and node.parent is None:
+            st["n"] += 1
+            if st["n"] % 3 == 1:
+                counts.append(0)
+        return orig_grow(node, *a, **k)
+    RC.grow = grow_w
+    est = RC.BSR(treeNum=3, itrNum=50)
+    try:
+        est.fit(X, y)
+    finally:
+        RC.newProp = orig
+        RC.grow = orig_grow
+    models = [[RF.Express(r) for r in roots] for roots in est.roots_]
+    trees = [[tree_json(r) for r in roots] for roots in est.roots_]
+    out = {"versions": VERSIONS, "seed": 0, "K": 3, "itrNum": 50, "val": 100,
+           "X": [[fnum(v) for v in row] for row in np.asarray(X)], "y": [fnum(v) for v in np.asarray(y)],
+           "grid": grid.tolist(), "props_per_chain": counts, "total_props": int(sum(counts)),
+           "models": models, "trees": trees,
+           "betas": [[fnum(v) for v in np.asarray(b).reshape(-1)] for b in est.betas_],
+           "train_err": [[fnum(v) for v in e] for e in est.train_err_],
+           "model_last": est.model(), "complexity": int(est.complexity()),
+           "predict_grid": [fnum(v) for v in est.predict(grid)[:, 0]],
+           "predict_grid_last2": [fnum(v) for v in est.predict(grid, last_ind=2)[:, 0]],
+           "rng_end": rng_mark()}
+    dump("g6_fit_f1.json", out)
+
+
+def g7():
+    from scipy.stats import invgamma, norm
+    np.random.seed(123)
+    seq = []
+    seq.append(["uniform", float(np.random.uniform(0, 1, 1)[0])])
+    seq.append(["randint5", int(np.random.randint(0, 5, 1)[0])])
+    seq.append(["randint1_7", int(np.random.randint(1, 7, 1)[0])])
+    seq.append(["choice10", int(np.random.choice(np.arange(10), p=OPW))])
+    seq.append(["norm_1_0.7", float(norm.rvs(loc=1, scale=0.7))])
+    seq.append(["norm_0_2", float(norm.rvs(loc=0, scale=2.0))])
+    seq.append(["norm_0_3", float(norm.rvs(loc=0, scale=3.0))])
+    seq.append(["invgamma1", float(invgamma.rvs(1))])
+    seq.append(["invgamma4", float(invgamma.rvs(4))])
+    seq.append(["randint1", int(np.random.randint(0, 1, 1)[0])])
+    seq.append(["randint1000", int(np.random.randint(0, 1000, 1)[0])])
+    seq.append(["uniform", float(np.random.uniform(0, 1, 1)[0])])
+    pdfs = [[x, a, float(invgamma.pdf(x, a))] for x in (0.05, 0.3, 1.0, 2.5, 40.0) for a in (1, 4)]
+    npdf = [[x, m, s, float(norm.pdf(x, loc=m, scale=s))] for x in (-3.0, 0.0, 0.4) for m, s in ((0, 1.0), (1, 0.3))]
+    dump("g7_rng.json", {"versions": VERSIONS, "seed": 123, "sequence": seq, "rng_end": rng_mark(),
+                         "invgamma_pdf": pdfs, "norm_pdf": npdf})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
+    for t in todo:
+        globals()[t]()
