@@ -1,0 +1,185 @@
+/*
+ * bsr_hip.h -- C ABI of libbsr_hip.so: the MI355X (gfx950) implementation of the
+ * MCMC-SymReg per-proposal likelihood hot path.
+ *
+ * The reference (ying531/MCMC-SymReg) is pure Python and has no FFI seam; the
+ * seam is its Python surface.  The Python package `bsr` in
+ * mcmc-symreg_amd/bsr binds these entry points with ctypes and keeps the
+ * reference's BSR.fit/predict + Node/allcal/ylogLike/newProp surface on top.
+ * Each entry point names the reference code it replaces (path:line under the
+ * reference repository).
+ *
+ * Conventions
+ *   - every function returns BSR_OK (0) or a negative BSR_E_* code; nothing
+ *     throws across the boundary; bsr_last_error() gives the text
+ *   - host buffers are caller-allocated and only touched during the call
+ *   - a ctx owns its device memory and one HIP stream; it is NOT thread-safe
+ *     (one ctx per device per host thread; ctypes drops the GIL during calls)
+ *   - all floating-point host buffers are IEEE binary64 whatever BSR_DTYPE_*
+ *     the ctx computes in
+ */
+#ifndef BSR_HIP_H
+#define BSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSR_ABI_VERSION 1
+
+/* limits */
+#define BSR_MAX_K 8          /* trees per chain (reference default treeNum=3; paper uses up to 8) */
+#define BSR_MAX_TAPE 16384   /* nodes per tape (depth<=12 binary tree has <= 8191 nodes) */
+#define BSR_MAX_STACK 24     /* value-stack depth of the interpreter (incl. the accumulator) */
+
+/* opcodes = index into the reference's operator table, codes/bsr_class.py:110-112
+ * ['inv','ln','neg','sin','cos','exp','square','cubic','+','*'], then the terminal */
+enum {
+  BSR_OP_INV = 0, BSR_OP_LN = 1, BSR_OP_NEG = 2, BSR_OP_SIN = 3, BSR_OP_COS = 4,
+  BSR_OP_EXP = 5, BSR_OP_SQUARE = 6, BSR_OP_CUBIC = 7, BSR_OP_ADD = 8, BSR_OP_MUL = 9,
+  BSR_OP_TERMINAL = 10
+};
+
+enum { BSR_DTYPE_F64 = 0, BSR_DTYPE_F32 = 1 };
+
+/* error codes */
+enum {
+  BSR_OK = 0,
+  BSR_E_ARG = -1,       /* bad argument (null pointer, index out of range, ...) */
+  BSR_E_HIP = -2,       /* HIP runtime error (text in bsr_last_error) */
+  BSR_E_NODEVICE = -3,  /* no usable gfx950 device */
+  BSR_E_TOOBIG = -4,    /* tape longer than BSR_MAX_TAPE / deeper than BSR_MAX_STACK / batch too large */
+  BSR_E_TAPE = -5,      /* malformed tape (not a valid postfix program) */
+  BSR_E_STATE = -6,     /* chain state not initialised for the requested operation */
+  BSR_E_COMM = -7       /* RCCL error */
+};
+
+/* One row of a postfix (RPN) tape = one node of codes/funcs.py:30-55 (Node).
+ * Rows are in evaluation order; `left`/`right` are row indices of the children
+ * inside the same tape (-1 = none) and keep the tree recoverable from the tape.
+ * opcode 0..9: operator; `a`,`b` only meaningful for BSR_OP_LN (a*x+b).
+ * opcode 10:   terminal, `feature` = column of X. */
+typedef struct bsr_node {
+  int32_t opcode;
+  int32_t left;
+  int32_t right;
+  int32_t feature;
+  double a;
+  double b;
+} bsr_node; /* 32 bytes */
+
+/* per-proposal result flags */
+#define BSR_F_INF 1u          /* candidate column (or a sibling column) holds +-inf: reference rank gate returns 0 */
+#define BSR_F_NAN 2u          /* ... holds NaN: reference raises LinAlgError at codes/funcs.py:1226 */
+#define BSR_F_RANKDEF 4u      /* rank(new_outputs) < K : rejected by the gate at codes/funcs.py:1226-1228 */
+#define BSR_F_SCALE_RETRY 8u  /* K==1 only: column magnitude outside the accumulation range; rescored internally */
+
+/* Data-side result of one Metropolis-Hastings proposal: everything
+ * codes/funcs.py:1212-1235 (newProp) takes from the N rows. */
+typedef struct bsr_score {
+  double loglik;            /* ylogLike(y, new_outputs, new_sigma), codes/funcs.py:1147-1174 */
+  double sse;               /* sum((y - XX@Beta)^2),               codes/funcs.py:1162 */
+  double scale;             /* max|new_outputs|,                    codes/funcs.py:1149 */
+  double maxabs;            /* max|candidate column| */
+  double smin, smax;        /* extreme singular values of new_outputs (relative to an internal power-of-two scale) */
+  double beta[BSR_MAX_K];   /* OLS weights on the scaled columns,   codes/funcs.py:1154-1155 */
+  int32_t rank;             /* np.linalg.matrix_rank(new_outputs); 0 if inf present; -1 if NaN present */
+  uint32_t flags;
+} bsr_score;
+
+/* State of one chain's K current trees ("old_outputs" of codes/funcs.py:1199-1224). */
+typedef struct bsr_chain_info {
+  double sse_old;           /* SSE of ylogLike(y, old_outputs, .), codes/funcs.py:1235; NaN if a column is non-finite */
+  double scale_old;         /* max|old_outputs| */
+  double maxabs[BSR_MAX_K]; /* per current column */
+  double beta_old[BSR_MAX_K];
+  uint32_t colflags[BSR_MAX_K]; /* BSR_F_INF / BSR_F_NAN per current column */
+  int32_t rank_old;         /* matrix_rank(old_outputs) (informational) */
+  int32_t pad;
+} bsr_chain_info;
+
+typedef struct bsr_ctx bsr_ctx;
+
+/* ---- device / context ------------------------------------------------------ */
+
+int bsr_abi_version(void);
+int bsr_device_count(int* count);
+
+/* Uploads the training data once.  X is row-major (N,d) as in a C-order numpy
+ * array / DataFrame.values (the `indata` of codes/funcs.py:175); it is stored
+ * feature-major on the device.  y may be NULL for an evaluate-only context
+ * (allcal / predict).  K, n_chains, max_batch size the chain caches and the
+ * per-batch scratch (candidate columns: max_batch * N values). */
+int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor,
+                   const double* y, int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype);
+int bsr_ctx_destroy(bsr_ctx* ctx);
+const char* bsr_last_error(const bsr_ctx* ctx); /* ctx may be NULL: last error of a failed create */
+
+/* ---- allcal: codes/funcs.py:175-220 ---------------------------------------- */
+
+/* Evaluates n_tapes tapes over all N rows.  rows = concatenated tapes,
+ * tape_off[n_tapes+1] = row offsets.  out_cols (n_tapes*N, tape-major) may be
+ * NULL; maxabs[n_tapes] / flags[n_tapes] (BSR_F_INF|BSR_F_NAN) may be NULL.
+ * n_tapes <= max_batch. */
+int bsr_eval_tapes(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, int32_t n_tapes,
+                   double* out_cols, double* maxabs, uint32_t* flags);
+
+/* ---- chain state: the K current columns of codes/funcs.py:1212-1224 -------- */
+
+/* (Re)computes current column k of `chain` from its tape (initial trees, codes/bsr_class.py:128-151). */
+int bsr_set_current(bsr_ctx* ctx, int32_t chain, int32_t k, const bsr_node* tape, int32_t len);
+/* Adopts candidate `slot` of the LAST bsr_score_batch call as current column k of `chain`
+ * (an accepted proposal, codes/bsr_class.py:200-204); no re-evaluation. */
+int bsr_commit(bsr_ctx* ctx, int32_t chain, int32_t k, int32_t slot);
+/* Rebuilds the chain's cached factors (leave-one-out orthonormal bases, old-state SSE). Must be
+ * called after bsr_set_current/bsr_commit and before the next bsr_score_batch on that chain. */
+int bsr_refresh(bsr_ctx* ctx, int32_t chain, bsr_chain_info* info);
+
+/* ---- scoring: codes/funcs.py:1212-1235 + 1147-1174 ------------------------- */
+
+/* Scores B proposals in one pass.  Proposal i replaces tree which_k[i] of chain[i] by tape i and is
+ * scored with noise scale sigma[i] (new_sigma of codes/funcs.py:1195).  All proposals are scored
+ * against the chains' CURRENT columns (speculative batches are exact because a rejected proposal
+ * leaves the chain unchanged, codes/funcs.py:1300-1303).  B <= max_batch. */
+int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                    const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out);
+
+/* ---- on-accept / initial OLS with intercept: codes/bsr_class.py:147-163, 211-233 */
+
+/* beta_out[K+1] = Beta/scale (intercept first), rmse_out = sqrt(mean((fitted-y)^2)). */
+int bsr_fit_beta(bsr_ctx* ctx, int32_t chain, double* beta_out, double* rmse_out);
+
+/* Copies the chain's K current columns to the host (K*N, column-major); for predict / tests. */
+int bsr_get_current(bsr_ctx* ctx, int32_t chain, double* out_cols);
+
+/* ---- ylogLike on caller-provided outputs: codes/funcs.py:1147-1174 --------- */
+
+/* outputs is row-major (N,K).  skipna != 0 reproduces the pandas Series.sum(skipna=True) behaviour the
+ * reference gets when y is a Series (codes/funcs.py:1162).  Runs on `device`; includes PCIe transfers. */
+int bsr_yloglike_host(int device, int64_t N, int32_t K, const double* outputs_rowmajor, const double* y,
+                      double sigma, int32_t skipna, double* loglik, double* sse, double* scale, double* beta,
+                      int32_t* rank);
+
+/* ---- timing hooks for bench.py (HIP events on the ctx stream) --------------- */
+
+/* Average duration in microseconds of each kernel of the LAST bsr_score_batch call:
+ * us[0]=tree-eval+dots pass, us[1]=K x K solve, us[2]=residual pass, us[3]=finalise, us[4]=whole batch
+ * (first launch to last, device time).  Valid only if profiling was enabled. */
+int bsr_set_profiling(bsr_ctx* ctx, int32_t enable);
+int bsr_last_timing(bsr_ctx* ctx, double* us5);
+
+/* ---- multi-GPU: one process per GPU, one gather of accepted trees */
+
+#define BSR_COMM_ID_BYTES 128
+int bsr_comm_unique_id(void* id128);                       /* rank 0 creates, host side distributes */
+int bsr_comm_init(bsr_ctx* ctx, int32_t nranks, int32_t rank, const void* id128);
+/* all-gather of fixed-size records over RCCL: recv holds nranks*bytes_per_rank bytes, rank-major */
+int bsr_comm_allgather(bsr_ctx* ctx, const void* send, void* recv, int64_t bytes_per_rank);
+int bsr_comm_destroy(bsr_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSR_HIP_H */

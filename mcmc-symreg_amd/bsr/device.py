@@ -1,0 +1,140 @@
+"""DeviceContext: numpy-facing wrapper of one bsr_ctx (training data + chain caches on one MI355X)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .tape import NODE_DTYPE, pack
+
+
+class DeviceContext:
+    """Owns one bsr_ctx.  X: (N,d) array-like, y: (N,) or None.  Not thread-safe (one per device per thread)."""
+
+    def __init__(self, X, y=None, K=0, n_chains=0, max_batch=64, device=0, dtype="f64"):
+        L = _lib.lib()
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        if X.ndim != 2:
+            raise ValueError("X must be 2-D")
+        self.N, self.d = X.shape
+        self.K, self.n_chains, self.max_batch = int(K), int(n_chains), int(max_batch)
+        self.device = device
+        yv = None if y is None else np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        if yv is not None and yv.shape[0] != self.N:
+            raise ValueError("y has %d rows, X has %d" % (yv.shape[0], self.N))
+        self._h = C.c_void_p()
+        dt = _lib.DTYPE_F64 if dtype in ("f64", "float64") else _lib.DTYPE_F32
+        rc = L.bsr_ctx_create(C.byref(self._h), device, self.N, self.d, _lib.ptr(X),
+                              None if yv is None else _lib.ptr(yv), self.K, self.n_chains, self.max_batch, dt)
+        _lib.check(rc, None)
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.bsr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- allcal
+    def eval_tapes(self, tapes, want_cols=True):
+        """tapes: list of NODE_DTYPE arrays -> (cols (n,N) or None, maxabs (n,), flags (n,))."""
+        n = len(tapes)
+        rows, off = pack(tapes)
+        cols = np.empty((n, self.N), dtype=np.float64) if want_cols else None
+        maxabs = np.empty(n, dtype=np.float64)
+        flags = np.empty(n, dtype=np.uint32)
+        rc = self._L.bsr_eval_tapes(self._h, _lib.ptr(rows), _lib.ptr(off), n,
+                                    None if cols is None else _lib.ptr(cols), _lib.ptr(maxabs), _lib.ptr(flags))
+        _lib.check(rc, self._h)
+        return cols, maxabs, flags
+
+    # ---- chain state
+    def set_current(self, chain, k, tape):
+        tape = np.ascontiguousarray(tape, dtype=NODE_DTYPE)
+        _lib.check(self._L.bsr_set_current(self._h, chain, k, _lib.ptr(tape), len(tape)), self._h)
+
+    def commit(self, chain, k, slot):
+        _lib.check(self._L.bsr_commit(self._h, chain, k, slot), self._h)
+
+    def refresh(self, chain):
+        info = _lib.ChainInfo()
+        _lib.check(self._L.bsr_refresh(self._h, chain, C.byref(info)), self._h)
+        K = self.K
+        return {"sse_old": info.sse_old, "scale_old": info.scale_old, "maxabs": list(info.maxabs)[:K],
+                "beta_old": list(info.beta_old)[:K], "colflags": list(info.colflags)[:K]}
+
+    def score_batch(self, tapes, chains, ks, sigmas):
+        B = len(tapes)
+        rows, off = pack(tapes)
+        chains = np.ascontiguousarray(chains, dtype=np.int32)
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        sig = np.ascontiguousarray(sigmas, dtype=np.float64)
+        out = np.zeros(B, dtype=_lib.SCORE_DTYPE)
+        rc = self._L.bsr_score_batch(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
+                                     _lib.ptr(sig), B, _lib.ptr(out))
+        _lib.check(rc, self._h)
+        return out
+
+    def score_packed(self, rows, off, chains, ks, sig, out):
+        """Same as score_batch with pre-packed, reusable arrays (bench / chain engine inner loop)."""
+        rc = self._L.bsr_score_batch(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
+                                     _lib.ptr(sig), len(chains), _lib.ptr(out))
+        _lib.check(rc, self._h)
+        return out
+
+    def fit_beta(self, chain):
+        beta = np.empty(self.K + 1, dtype=np.float64)
+        rmse = C.c_double(0.0)
+        _lib.check(self._L.bsr_fit_beta(self._h, chain, _lib.ptr(beta), C.byref(rmse)), self._h)
+        return beta.reshape(-1, 1), rmse.value
+
+    def get_current(self, chain):
+        out = np.empty((self.K, self.N), dtype=np.float64)
+        _lib.check(self._L.bsr_get_current(self._h, chain, _lib.ptr(out)), self._h)
+        return out
+
+    # ---- profiling
+    def set_profiling(self, on=True):
+        _lib.check(self._L.bsr_set_profiling(self._h, 1 if on else 0), self._h)
+
+    def last_timing(self):
+        us = np.zeros(5, dtype=np.float64)
+        _lib.check(self._L.bsr_last_timing(self._h, _lib.ptr(us)), self._h)
+        return us
+
+    # ---- RCCL
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(_lib.COMM_ID_BYTES, dtype=np.uint8)
+        _lib.check(_lib.lib().bsr_comm_unique_id(_lib.ptr(buf)), None)
+        return buf
+
+    def comm_init(self, nranks, rank, uid):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        _lib.check(self._L.bsr_comm_init(self._h, nranks, rank, _lib.ptr(uid)), self._h)
+        self._nranks = nranks
+
+    def comm_allgather(self, send_bytes):
+        send = np.ascontiguousarray(send_bytes, dtype=np.uint8)
+        recv = np.empty(send.size * self._nranks, dtype=np.uint8)
+        _lib.check(self._L.bsr_comm_allgather(self._h, _lib.ptr(send), _lib.ptr(recv), send.size), self._h)
+        return recv.reshape(self._nranks, send.size)
+
+
+def yloglike_device(y, outputs, sigma, skipna=True, device=0):
+    """ylogLike(y, outputs, sigma) computed on the GPU (codes/funcs.py:1147-1174) -> dict."""
+    L = _lib.lib()
+    O = np.ascontiguousarray(np.asarray(outputs, dtype=np.float64))
+    yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+    N, K = O.shape
+    ll, sse, scale = C.c_double(), C.c_double(), C.c_double()
+    beta = np.zeros(_lib.MAX_K, dtype=np.float64)
+    rank = C.c_int32()
+    rc = L.bsr_yloglike_host(device, N, K, _lib.ptr(O), _lib.ptr(yv), float(sigma), 1 if skipna else 0,
+                             C.byref(ll), C.byref(sse), C.byref(scale), _lib.ptr(beta), C.byref(rank))
+    _lib.check(rc, None)
+    return {"loglik": ll.value, "sse": sse.value, "scale": scale.value, "beta": beta[:K].copy(), "rank": rank.value}

@@ -1,0 +1,103 @@
+// Internal declarations shared by the kernel and API translation units of libbsr_hip.so.
+// gfx950 (MI355X) only: wave64, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bsr_hip.h"
+
+#define BSR_NQ_MAX (BSR_MAX_K - 1)  // basis columns per proposal
+#define BSR_WAVE 64
+#define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
+#define BSR_REG_STACK 7             // interpreter stack slots held in VGPRs (plus the accumulator)
+#define BSR_ROW_ALIGN 4096          // device columns are padded to a multiple of this many rows
+#define BSR_P1_WORDS 12             // doubles per (proposal,row block) partial of pass 1
+#define BSR_P2_WORDS 2              // doubles per (proposal,row block) partial of pass 2
+
+enum { BSR_MODE_SCORE = 0, BSR_MODE_EVAL = 1 };
+
+// Cached factors of one (chain, k): leave-one-out basis of the K-1 sibling columns, scaled by the
+// power of two `s`:  s * O_j = Q R  (j != k ascending).  See DESIGN.md "rank gate and OLS".
+struct ChainK {
+  double R[BSR_NQ_MAX * BSR_NQ_MAX];     // upper triangular, row-major [row][col]
+  double RtR[BSR_NQ_MAX * BSR_NQ_MAX];   // R^T R  (Gram of the scaled sibling columns)
+  double Rtqy[BSR_NQ_MAX];               // R^T (Q^T y)
+  double s;                              // power-of-two prescale
+  double m_other;                        // max |sibling columns| (unscaled)
+  uint32_t flags;                        // BSR_F_INF / BSR_F_NAN of the sibling columns
+  uint32_t pad;
+};
+
+// Device-side descriptor of one tape to run in the row passes.
+struct PropDesc {
+  int32_t tape_off;     // first row in the uploaded tape buffer
+  int32_t tape_len;
+  int32_t mode;         // BSR_MODE_*
+  int32_t nq;           // basis columns (K-1), 0 in eval mode
+  int32_t k;            // tree index being replaced
+  int32_t K;
+  int32_t ck;           // index into the ChainK array (chain*K + k)
+  int32_t spill_need;   // stack slots beyond the register stack
+  const void* qbase;    // first basis column (nq columns, stride ld)
+  void* zout;           // where the candidate column goes (ld values) or nullptr
+  double s;             // prescale applied to the candidate column in all accumulations
+  double sigma;         // new_sigma
+};
+
+// What the solve step hands to the residual pass.
+struct PropCoef {
+  double g[BSR_NQ_MAX];   // tau * (R beta_others)   : weights of the basis columns in the fitted values
+  double c[BSR_NQ_MAX];   // Q^T (s z)               : projection of the candidate on the basis
+  double bz;              // tau * s * beta_k        : weight of the unscaled candidate column
+  double s;
+  double zz;              // |s z|^2
+  double tau;
+  double scale;           // reference scale max|new_outputs|
+  double maxabs;
+  double beta[BSR_MAX_K];
+  uint32_t flags;
+  int32_t skip;           // 1: residual pass not needed (non-finite / eval mode)
+};
+
+struct ChainFitOut {
+  double sse, scale;
+  double beta[BSR_MAX_K + 1];      // weights on the scaled columns (reference's Beta before "/ scale")
+  double beta_unscaled[BSR_MAX_K + 1];
+  double maxabs[BSR_MAX_K];
+  uint32_t colflags[BSR_MAX_K];
+  uint32_t anyflags;
+  uint32_t pad;
+};
+
+struct LaunchGeom {
+  int rb_rows;      // rows per row block (multiple of 128)
+  int n_rb;         // row blocks
+  int pg;           // proposals per workgroup
+  int n_pg;         // proposal groups
+};
+
+// kernels (bsr_kernels.hip)
+template <typename T>
+void launch_pass1(hipStream_t st, const LaunchGeom& g, const T* Xt, const T* y, int64_t ld, int64_t N,
+                  const bsr_node* tapes, const PropDesc* desc, int P, double* part1, double* spill,
+                  int spill_slots);
+void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
+                  PropCoef* coef);
+template <typename T>
+void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, int64_t N, const PropDesc* desc,
+                  const PropCoef* coef, int P, double* part2);
+void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
+                     const double* part2, int64_t N, bsr_score* out);
+template <typename T>
+void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
+                          const double* col_maxabs, const uint32_t* col_flags, ChainK* ck_chain);
+template <typename T>
+void launch_chain_fit(hipStream_t st, const T* cols, const T* y, int64_t ld, int64_t N, int K, int intercept,
+                      ChainFitOut* out);
+template <typename T>
+void launch_transpose_in(hipStream_t st, const double* src_rowmajor, T* dst, int64_t N, int d, int64_t ld);
+template <typename T>
+void launch_convert_out(hipStream_t st, const T* src, double* dst, int64_t n);
+template <typename T>
+void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n);

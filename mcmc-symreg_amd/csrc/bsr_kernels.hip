@@ -1,0 +1,1013 @@
+// HIP kernels of the MCMC-SymReg likelihood hot path for gfx950 (MI355X, wave64).
+//
+// Row passes (the O(N) work, one launch scores a whole batch of proposals):
+//   k_pass1    : postfix stack-machine over each candidate tape (allcal, codes/funcs.py:175-220), fused with the
+//                projections of the candidate column on the cached sibling basis, |z|^2, z.y, max|z| and the
+//                inf/NaN census; stores the candidate column.
+//   k_pass2    : direct residual sum of squares of the OLS fit (codes/funcs.py:1157-1162) and the residual norm of
+//                the candidate against the sibling basis (feeds the rank gate, codes/funcs.py:1226).
+// Per-proposal scalar work (K <= 8, one wave per proposal, lanes form an 8x8 grid):
+//   k_solve    : reduce pass-1 partials, assemble XX^T XX + 1e-6 I (codes/funcs.py:1151-1155), invert, Beta.
+//   k_finalize : reduce pass-2 partials, singular values of the K x K factor -> matrix_rank, log-likelihood.
+// Rare path (initialisation / accepted proposal), one workgroup each:
+//   k_refresh_basis : leave-one-out orthonormal bases of the chain's current columns.
+//   k_chain_fit     : ridge OLS of y on the K current columns, with or without intercept
+//                     (codes/funcs.py:1235 old state; codes/bsr_class.py:147-163, 211-233).
+//
+// Everything is deterministic: partial sums are written per (proposal,row block) and reduced in a fixed order.
+// Compiled with -ffp-contract=off so that a*x+b keeps numpy's two roundings; accumulations use explicit fma().
+#include "bsr_internal.h"
+
+#define CONSTANT_AS __attribute__((address_space(4)))
+
+template <typename T>
+__device__ __forceinline__ const T CONSTANT_AS* as_const(const T* p) {
+  return (const T CONSTANT_AS*)p;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// opcode semantics (codes/funcs.py:179-212)
+template <typename T> __device__ __forceinline__ T op_exp(T x);
+template <> __device__ __forceinline__ double op_exp<double>(double x) { return (x <= 200.0) ? exp(x) : 1e10; }
+template <> __device__ __forceinline__ float op_exp<float>(float x) { return (x <= 200.0f) ? expf(x) : 1e10f; }
+template <typename T> __device__ __forceinline__ T op_sin(T x);
+template <> __device__ __forceinline__ double op_sin<double>(double x) { return sin(x); }
+template <> __device__ __forceinline__ float op_sin<float>(float x) { return sinf(x); }
+template <typename T> __device__ __forceinline__ T op_cos(T x);
+template <> __device__ __forceinline__ double op_cos<double>(double x) { return cos(x); }
+template <> __device__ __forceinline__ float op_cos<float>(float x) { return cosf(x); }
+
+// np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
+// Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
+template <typename T> __device__ __forceinline__ T op_cube(T x);
+template <> __device__ __forceinline__ double op_cube<double>(double x) {
+  const double x2 = x * x;
+  const double e = fma(x, x, -x2);
+  const double p = x2 * x;
+  const double pe = fma(x2, x, -p);
+  const double r = p + (pe + e * x);
+  return (isfinite(p) && isfinite(r)) ? r : p;  // keep inf/NaN and overflow behaviour of the plain product
+}
+template <> __device__ __forceinline__ float op_cube<float>(float x) {
+  const double xd = (double)x;
+  return (float)(xd * xd * xd);
+}
+
+// Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.
+#define BSR_STACK_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+
+template <typename T, int U>
+struct RegStack {
+  T s0[U], s1[U], s2[U], s3[U], s4[U], s5[U], s6[U];
+  T* spill;  // per-wave global spill area: slot-major [slot][64*U]
+  int lane;
+
+  __device__ __forceinline__ void push(int sp, const T (&v)[U]) {
+    switch (sp) {
+#define X(i) \
+  case i:    \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) s##i[u] = v[u]; \
+    break;
+      BSR_STACK_CASES(X)
+#undef X
+      default: {
+        T* q = spill + (size_t)(sp - BSR_REG_STACK) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] = v[u];
+      }
+    }
+  }
+  __device__ __forceinline__ void pop(int sp, T (&v)[U]) {
+    switch (sp) {
+#define X(i) \
+  case i:    \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s##i[u]; \
+    break;
+      BSR_STACK_CASES(X)
+#undef X
+      default: {
+        const T* q = spill + (size_t)(sp - BSR_REG_STACK) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = q[u];
+      }
+    }
+  }
+};
+
+// Evaluates one postfix tape on U consecutive rows per lane starting at r0.  The tape is read through the constant
+// address space (scalar loads); opcode, stack pointer and all branches are wave-uniform.
+template <typename T, int U>
+__device__ __forceinline__ void run_tape(const bsr_node* tape, int len, const T* __restrict__ Xt, int64_t ld,
+                                         int64_t r0, T (&acc)[U], T* spill, int lane) {
+  const bsr_node CONSTANT_AS* tp = as_const(tape);
+  RegStack<T, U> st;
+  st.spill = spill;
+  st.lane = lane;
+  int sp = 0;  // values on the stack below the accumulator
+  {
+    const int f = tp[0].feature;
+    const T* col = Xt + (int64_t)f * ld + r0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = col[u];
+  }
+  for (int i = 1; i < len; ++i) {
+    const int op = tp[i].opcode;
+    if (op == BSR_OP_TERMINAL) {
+      st.push(sp, acc);
+      ++sp;
+      const int f = tp[i].feature;
+      const T* col = Xt + (int64_t)f * ld + r0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = col[u];
+    } else if (op >= BSR_OP_ADD) {
+      T lhs[U];
+      --sp;
+      st.pop(sp, lhs);
+      if (op == BSR_OP_ADD) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = lhs[u] + acc[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = lhs[u] * acc[u];
+      }
+    } else {
+      switch (op) {
+        case BSR_OP_INV:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
+          break;
+        case BSR_OP_LN: {
+          const T a = (T)tp[i].a, b = (T)tp[i].b;
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
+        } break;
+        case BSR_OP_NEG:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = -acc[u];
+          break;
+        case BSR_OP_SIN:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_sin<T>(acc[u]);
+          break;
+        case BSR_OP_COS:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_cos<T>(acc[u]);
+          break;
+        case BSR_OP_EXP:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_exp<T>(acc[u]);
+          break;
+        case BSR_OP_SQUARE:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
+          break;
+        default:  // BSR_OP_CUBIC
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_cube<T>(acc[u]);
+          break;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 1: grid = (row blocks, proposal groups), 4 waves per workgroup, one wave per (proposal,row block).
+template <typename T, int U>
+__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass1(
+    const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const bsr_node* __restrict__ tapes,
+    const PropDesc* __restrict__ desc, int P, int rb_rows, int pg, int n_rb, double* __restrict__ part1,
+    T* __restrict__ spill, int spill_slots) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rb = blockIdx.x;
+  const int64_t row_base = (int64_t)rb * rb_rows;
+  const int iters = rb_rows / (BSR_WAVE * U);
+  const int gwave = (blockIdx.y * gridDim.x + blockIdx.x) * BSR_WG_WAVES + wave;
+  T* my_spill = spill ? spill + (size_t)gwave * spill_slots * (BSR_WAVE * U) : nullptr;
+  const PropDesc CONSTANT_AS* dsc = as_const(desc);
+
+  for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
+    const int p = blockIdx.y * pg + pi;
+    if (p >= P) break;
+    const int nq = dsc[p].nq;
+    const T* qbase = (const T*)dsc[p].qbase;
+    T* zout = (T*)dsc[p].zout;
+    const double s = dsc[p].s;
+    const bsr_node* tape = tapes + dsc[p].tape_off;
+    const int len = dsc[p].tape_len;
+
+    double c[BSR_NQ_MAX];
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = 0.0;
+    double zz = 0.0, zy = 0.0, amax = 0.0;
+    uint32_t fl = 0;
+
+    for (int it = 0; it < iters; ++it) {
+      const int64_t r0 = row_base + (int64_t)it * (BSR_WAVE * U) + lane * U;
+      T acc[U];
+      run_tape<T, U>(tape, len, Xt, ld, r0, acc, my_spill, lane);
+      T yv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) yv[u] = y ? y[r0 + u] : (T)0;
+      double zs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool valid = (r0 + u) < N;
+        const T z = valid ? acc[u] : (T)0;
+        acc[u] = z;
+        const double zd = (double)z;
+        if (isinf(zd)) fl |= BSR_F_INF;
+        if (isnan(zd)) fl |= BSR_F_NAN;
+        amax = fmax(amax, fabs(zd));
+        zs[u] = zd * s;
+        zz = fma(zs[u], zs[u], zz);
+        zy = fma(zs[u], (double)yv[u], zy);
+      }
+#pragma unroll
+      for (int i = 0; i < BSR_NQ_MAX; ++i) {
+        if (i < nq) {
+          const T* q = qbase + (int64_t)i * ld + r0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) c[i] = fma((double)q[u], zs[u], c[i]);
+        }
+      }
+      if (zout) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) zout[r0 + u] = acc[u];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = wave_sum(c[i]);
+    zz = wave_sum(zz);
+    zy = wave_sum(zy);
+    amax = wave_max(amax);
+    fl = wave_or(fl);
+    if (lane == 0) {
+      double* o = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
+#pragma unroll
+      for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = c[i];
+      o[7] = zz;
+      o[8] = zy;
+      o[9] = amax;
+      o[10] = (double)fl;
+      o[11] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve: one wave per proposal.  Lane (i,j) = (lane>>3, lane&7) owns element [i][j] of the K x K system.
+__global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainK* __restrict__ cks,
+                                                    int P, int n_rb, const double* __restrict__ part1,
+                                                    PropCoef* __restrict__ coef) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const PropDesc CONSTANT_AS* dsc = as_const(desc);
+  __shared__ double sh_c[8];
+  __shared__ double sh_beta[8];
+
+  double sum[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sum[i] = 0.0;
+  double amax = 0.0;
+  uint32_t fl = 0;
+  for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
+    const double* q = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sum[i] += q[i];
+    amax = fmax(amax, q[9]);
+    fl |= (uint32_t)q[10];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sum[i] = wave_sum(sum[i]);
+  amax = wave_max(amax);
+  fl = wave_or(fl);
+  if (fl & BSR_F_INF) amax = INFINITY;
+
+  PropCoef* out = coef + p;
+  if (dsc[p].mode == BSR_MODE_EVAL) {
+    if (lane == 0) {
+      out->maxabs = amax;
+      out->flags = fl;
+      out->skip = 1;
+      out->zz = sum[7];
+    }
+    return;
+  }
+  const int K = dsc[p].K, k = dsc[p].k, nq = dsc[p].nq;
+  const double s = dsc[p].s;
+  const ChainK* ck = cks + dsc[p].ck;
+  const uint32_t flags = fl | ck->flags;
+  const double m_other = ck->m_other;
+  const double scale_ref = fmax(m_other, amax);
+  const double tau = 1.0 / (s * scale_ref);
+  const double zz = sum[7], zy = sum[8];
+
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX; ++i) sh_c[i] = sum[i];
+  }
+  __syncthreads();
+
+  const int i = lane >> 3, j = lane & 7;
+  const int oi = (i < k) ? i : i - 1, oj = (j < k) ? j : j - 1;
+  // (R^T c)[a] for the lane's sibling index
+  auto rtc = [&](int a) {
+    double t = 0.0;
+    for (int m = 0; m <= a; ++m) t = fma(ck->R[m * BSR_NQ_MAX + a], sh_c[m], t);
+    return t;
+  };
+  double A = (i == j) ? 1.0 : 0.0;
+  if (i < K && j < K) {
+    double gij;
+    if (i != k && j != k) gij = ck->RtR[oi * BSR_NQ_MAX + oj];
+    else if (i == k && j == k) gij = zz;
+    else gij = rtc((i == k) ? oj : oi);
+    A = tau * (tau * gij);
+    if (i == j) A += 1e-6;
+  }
+  // right-hand side XX^T y, held per column index j in every row
+  double gv = 0.0;
+  if (j < K) gv = tau * ((j == k) ? zy : ck->Rtqy[oj]);
+  double Inv = (i == j) ? 1.0 : 0.0;
+
+  // Gauss-Jordan with partial pivoting on [A | I]; rows >= K are identity and stay untouched
+  for (int col = 0; col < K; ++col) {
+    double best = -1.0;
+    int piv = col;
+    for (int r = col; r < K; ++r) {
+      const double v = fabs(__shfl(A, r * 8 + col));
+      if (v > best) { best = v; piv = r; }
+    }
+    if (piv != col) {
+      const int src = (i == col) ? piv : ((i == piv) ? col : i);
+      A = __shfl(A, src * 8 + j);
+      Inv = __shfl(Inv, src * 8 + j);
+    }
+    const double d = __shfl(A, col * 8 + col);
+    const double rowA = __shfl(A, col * 8 + j);
+    const double rowI = __shfl(Inv, col * 8 + j);
+    const double f = __shfl(A, i * 8 + col) / d;
+    if (i == col) {
+      A = rowA / d;
+      Inv = rowI / d;
+    } else {
+      A = A - f * rowA;
+      Inv = Inv - f * rowI;
+    }
+  }
+  // Beta = inv(A) @ (XX^T y)
+  double t = Inv * gv;
+  t += __shfl_xor(t, 1);
+  t += __shfl_xor(t, 2);
+  t += __shfl_xor(t, 4);
+  if (j == 0) sh_beta[i] = t;
+  __syncthreads();
+
+  if (lane < nq) {
+    double gam = 0.0;
+    for (int b = lane; b < nq; ++b) {
+      const int ob = (b < k) ? b : b + 1;
+      gam = fma(ck->R[lane * BSR_NQ_MAX + b], sh_beta[ob], gam);
+    }
+    out->g[lane] = tau * gam;
+    out->c[lane] = sh_c[lane];
+  }
+  if (lane < K) out->beta[lane] = sh_beta[lane];
+  if (lane == 0) {
+    out->bz = tau * s * sh_beta[k];
+    out->s = s;
+    out->zz = zz;
+    out->tau = tau;
+    out->scale = scale_ref;
+    out->maxabs = amax;
+    uint32_t f2 = flags;
+    if (nq == 0 && !(flags & (BSR_F_INF | BSR_F_NAN))) {
+      // K == 1: no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
+      const double as = amax * s;
+      if (as > 0.0 && (as > 0x1p400 || as < 0x1p-400)) f2 |= BSR_F_SCALE_RETRY;
+    }
+    out->flags = f2;
+    out->skip = (f2 & (BSR_F_INF | BSR_F_NAN | BSR_F_SCALE_RETRY)) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 2: residual sum of squares with the solved weights + residual of the candidate against the sibling basis.
+template <typename T, int U>
+__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass2(const T* __restrict__ y, int64_t ld, int64_t N,
+                                                                  const PropDesc* __restrict__ desc,
+                                                                  const PropCoef* __restrict__ coef, int P,
+                                                                  int rb_rows, int pg, int n_rb,
+                                                                  double* __restrict__ part2) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rb = blockIdx.x;
+  const int64_t row_base = (int64_t)rb * rb_rows;
+  const int iters = rb_rows / (BSR_WAVE * U);
+  const PropDesc CONSTANT_AS* dsc = as_const(desc);
+  const PropCoef CONSTANT_AS* cf = as_const(coef);
+
+  for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
+    const int p = blockIdx.y * pg + pi;
+    if (p >= P) break;
+    if (cf[p].skip) continue;
+    const int nq = dsc[p].nq;
+    const T* qbase = (const T*)dsc[p].qbase;
+    const T* z = (const T*)dsc[p].zout;
+    const double s = cf[p].s, bz = cf[p].bz;
+    double g[BSR_NQ_MAX], c[BSR_NQ_MAX];
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX; ++i) {
+      g[i] = cf[p].g[i];
+      c[i] = cf[p].c[i];
+    }
+    double sse = 0.0, rho2 = 0.0;
+    for (int it = 0; it < iters; ++it) {
+      const int64_t r0 = row_base + (int64_t)it * (BSR_WAVE * U) + lane * U;
+      double zv[U], fit[U], w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        zv[u] = (double)z[r0 + u];
+        fit[u] = bz * zv[u];
+        w[u] = s * zv[u];
+      }
+#pragma unroll
+      for (int i = 0; i < BSR_NQ_MAX; ++i) {
+        if (i < nq) {
+          const T* q = qbase + (int64_t)i * ld + r0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double qv = (double)q[u];
+            fit[u] = fma(g[i], qv, fit[u]);
+            w[u] = fma(-c[i], qv, w[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((r0 + u) < N) {
+          const double r = (double)y[r0 + u] - fit[u];
+          sse = fma(r, r, sse);
+          rho2 = fma(w[u], w[u], rho2);
+        }
+      }
+    }
+    sse = wave_sum(sse);
+    rho2 = wave_sum(rho2);
+    if (lane == 0) {
+      double* o = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
+      o[0] = sse;
+      o[1] = rho2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// finalize: one wave per proposal; one-sided Jacobi on the K x K factor [[R, c],[0, rho]] held one element per lane.
+__device__ __forceinline__ double col_reduce(double v) {  // sum over the 8 rows of a column (lanes differ in bits 3..5)
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Returns, in every lane, the singular value belonging to the lane's column j (valid for j < K).
+__device__ __forceinline__ double jacobi_singular_values(double S, int K, int lane) {
+  const int j = lane & 7;
+  const int base = lane & ~7;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int a = 0; a < K - 1; ++a) {
+      for (int b = a + 1; b < K; ++b) {
+        const double sa = __shfl(S, base + a), sb = __shfl(S, base + b);  // my row's entries of columns a,b
+        const double alpha = col_reduce(sa * sa), beta = col_reduce(sb * sb), gamma = col_reduce(sa * sb);
+        const double lim = sqrt(alpha) * sqrt(beta);
+        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {  // wave-uniform condition
+          off = fmax(off, fabs(gamma) / lim);
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+          if (j == a) S = cs * sa - sn * sb;
+          else if (j == b) S = sn * sa + cs * sb;
+        }
+      }
+    }
+    if (off <= 1e-15) break;
+  }
+  return sqrt(col_reduce(S * S));
+}
+
+__global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
+                                                       const ChainK* __restrict__ cks,
+                                                       const PropCoef* __restrict__ coef, int P, int n_rb,
+                                                       const double* __restrict__ part2, int64_t N,
+                                                       bsr_score* __restrict__ outv) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const PropDesc CONSTANT_AS* dsc = as_const(desc);
+  const PropCoef* cf = coef + p;
+  bsr_score* out = outv + p;
+  const uint32_t flags = cf->flags;
+  if (dsc[p].mode == BSR_MODE_EVAL) {
+    if (lane == 0) {
+      out->maxabs = cf->maxabs;
+      out->flags = flags;
+      out->rank = 0;
+      out->loglik = out->sse = out->scale = out->smin = out->smax = 0.0;
+    }
+    return;
+  }
+  const int K = dsc[p].K, nq = dsc[p].nq;
+  if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
+    if (lane == 0) {
+      out->loglik = NAN;
+      out->sse = NAN;
+      out->scale = cf->scale;
+      out->maxabs = cf->maxabs;
+      out->smin = out->smax = NAN;
+      out->rank = (flags & BSR_F_NAN) ? -1 : 0;
+      out->flags = flags | BSR_F_RANKDEF;
+    }
+    if (lane < BSR_MAX_K) out->beta[lane] = NAN;
+    return;
+  }
+  if (flags & BSR_F_SCALE_RETRY) {
+    if (lane == 0) {
+      out->maxabs = cf->maxabs;
+      out->flags = flags;
+      out->rank = 0;
+      out->loglik = out->sse = NAN;
+    }
+    return;
+  }
+  double sse = 0.0, rho2 = 0.0;
+  for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
+    const double* q = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
+    sse += q[0];
+    rho2 += q[1];
+  }
+  sse = wave_sum(sse);
+  rho2 = wave_sum(rho2);
+
+  // K x K factor with the singular values of s*new_outputs: [[R, c], [0, rho]]
+  const ChainK* ck = cks + dsc[p].ck;
+  const int i = lane >> 3, j = lane & 7;
+  double S = 0.0;
+  if (i < K && j < K) {
+    if (j < nq) S = (i <= j) ? ck->R[i * BSR_NQ_MAX + j] : 0.0;
+    else S = (i < nq) ? cf->c[i] : sqrt(rho2);  // j == nq == K-1
+  }
+  const double sv = jacobi_singular_values(S, K, lane);
+  double smax = 0.0, smin = INFINITY;
+  for (int a = 0; a < K; ++a) {
+    const double v = __shfl(sv, a);
+    smax = fmax(smax, v);
+    smin = fmin(smin, v);
+  }
+  // np.linalg.matrix_rank default tolerance: S.max() * max(M.shape) * eps; rank = count(S > tol)
+  const double dimmax = (double)((N > (int64_t)K) ? N : (int64_t)K);
+  const double tol = smax * dimmax * 2.220446049250313e-16;
+  int rank = 0;
+  for (int a = 0; a < K; ++a) rank += (__shfl(sv, a) > tol) ? 1 : 0;
+  // codes/funcs.py:1172-1173
+  const double sigma = dsc[p].sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)N * log(2 * M_PI * sigma * sigma);
+  if (lane == 0) {
+    out->loglik = ll;
+    out->sse = sse;
+    out->scale = cf->scale;
+    out->maxabs = cf->maxabs;
+    out->smin = smin / cf->s;
+    out->smax = smax / cf->s;
+    out->rank = rank;
+    out->flags = flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+  }
+  if (lane < BSR_MAX_K) out->beta[lane] = (lane < K) ? cf->beta[lane] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rare path: single-workgroup kernels (1024 threads = 16 waves)
+#define BSR_BLK 1024
+#define BSR_BLK_WAVES (BSR_BLK / BSR_WAVE)
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sh) {  // sh: (BSR_BLK_WAVES+1)*NV doubles
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sh[w * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double t = 0.0;
+    for (int ww = 0; ww < BSR_BLK_WAVES; ++ww) t += sh[ww * NV + threadIdx.x];
+    sh[BSR_BLK_WAVES * NV + threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = sh[BSR_BLK_WAVES * NV + i];
+}
+
+__device__ __forceinline__ double pow2_prescale(double m) {
+  if (!(m > 0.0) || isinf(m)) return 1.0;
+  int e;
+  frexp(m, &e);
+  e = max(-1000, min(1000, e));
+  return ldexp(1.0, -e);
+}
+
+// Leave-one-out bases.  grid.x = K (which column is left out), block = 1024 threads.
+// s * O_j = Q R for the siblings j != kk in ascending order; Gram-Schmidt with three orthogonalisation sweeps.
+template <typename T>
+__global__ __launch_bounds__(BSR_BLK) void k_refresh_basis(const T* __restrict__ cur, T* __restrict__ Qc,
+                                                           const T* __restrict__ y, int64_t ld, int64_t N, int K,
+                                                           const double* __restrict__ col_maxabs,
+                                                           const uint32_t* __restrict__ col_flags,
+                                                           ChainK* __restrict__ ck_chain) {
+  const int kk = blockIdx.x;
+  const int nq = K - 1;
+  T* Q = Qc + (int64_t)kk * nq * ld;
+  ChainK* ck = ck_chain + kk;
+  __shared__ double sh[(BSR_BLK_WAVES + 1) * 8];
+  __shared__ double shR[BSR_NQ_MAX * BSR_NQ_MAX];
+  __shared__ double shqy[BSR_NQ_MAX];
+
+  double m_other = 0.0;
+  uint32_t flags = 0;
+  for (int j = 0; j < K; ++j) {
+    if (j == kk) continue;
+    m_other = fmax(m_other, col_maxabs[j]);
+    flags |= col_flags[j];
+  }
+  if (flags & BSR_F_INF) m_other = INFINITY;
+  const double s = pow2_prescale(m_other);
+  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) shR[threadIdx.x] = 0.0;
+  if (threadIdx.x < BSR_NQ_MAX) shqy[threadIdx.x] = 0.0;
+  __syncthreads();
+
+  if (!(flags & (BSR_F_INF | BSR_F_NAN))) {
+    for (int m = 0; m < nq; ++m) {
+      const int jm = (m < kk) ? m : m + 1;
+      const T* src = cur + (int64_t)jm * ld;
+      T* v = Q + (int64_t)m * ld;
+      double h[8];
+      // sweep 0: v = s * O_jm ; h = Q^T v
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = 0.0;
+      for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+        const double x = s * (double)src[n];
+        v[n] = (T)x;
+        const double xv = (double)v[n];
+#pragma unroll
+        for (int i = 0; i < BSR_NQ_MAX; ++i)
+          if (i < m) h[i] = fma((double)Q[(int64_t)i * ld + n], xv, h[i]);
+      }
+      block_sum<8>(h, sh);
+      // three orthogonalisation sweeps: v -= Q h ; h = Q^T v
+      for (int sweep = 0; sweep < 3; ++sweep) {
+        if (threadIdx.x < BSR_NQ_MAX && (int)threadIdx.x < m) shR[threadIdx.x * BSR_NQ_MAX + m] += h[threadIdx.x];
+        double hn[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hn[i] = 0.0;
+        for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+          double x = (double)v[n];
+#pragma unroll
+          for (int i = 0; i < BSR_NQ_MAX; ++i)
+            if (i < m) x = fma(-h[i], (double)Q[(int64_t)i * ld + n], x);
+          v[n] = (T)x;
+          const double xv = (double)v[n];
+#pragma unroll
+          for (int i = 0; i < BSR_NQ_MAX; ++i)
+            if (i < m) hn[i] = fma((double)Q[(int64_t)i * ld + n], xv, hn[i]);
+          hn[7] = fma(xv, xv, hn[7]);
+        }
+        block_sum<8>(hn, sh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = hn[i];
+        if (m == 0) break;
+      }
+      const double r = sqrt(h[7]);
+      const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+      double qy[1] = {0.0};
+      for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+        const double x = (double)v[n] * inv;
+        v[n] = (T)x;
+        qy[0] = fma((double)v[n], (double)y[n], qy[0]);
+      }
+      block_sum<1>(qy, sh);
+      if (threadIdx.x == 0) {
+        shR[m * BSR_NQ_MAX + m] = r;
+        shqy[m] = qy[0];
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) {
+    const int a = threadIdx.x / BSR_NQ_MAX, b = threadIdx.x % BSR_NQ_MAX;
+    ck->R[threadIdx.x] = shR[threadIdx.x];
+    double t = 0.0;
+    for (int mm = 0; mm < BSR_NQ_MAX; ++mm) t = fma(shR[mm * BSR_NQ_MAX + a], shR[mm * BSR_NQ_MAX + b], t);
+    ck->RtR[threadIdx.x] = t;
+    if (b == 0) {
+      double u = 0.0;
+      for (int mm = 0; mm < BSR_NQ_MAX; ++mm) u = fma(shR[mm * BSR_NQ_MAX + a], shqy[mm], u);
+      ck->Rtqy[a] = u;
+    }
+  }
+  if (threadIdx.x == 0) {
+    ck->s = s;
+    ck->m_other = m_other;
+    ck->flags = flags;
+    ck->pad = 0;
+  }
+}
+
+// Ridge OLS of y on [1?, O_0..O_{K-1}] exactly as codes/funcs.py:1148-1162 / codes/bsr_class.py:147-163.
+#define BSR_FIT_M (BSR_MAX_K + 1)
+template <typename T>
+__global__ __launch_bounds__(BSR_BLK) void k_chain_fit(const T* __restrict__ cols, const T* __restrict__ y,
+                                                       int64_t ld, int64_t N, int K, int icpt,
+                                                       ChainFitOut* __restrict__ out) {
+  const int M = K + icpt;
+  __shared__ double sh[(BSR_BLK_WAVES + 1) * 8];
+  __shared__ double shA[BSR_FIT_M * BSR_FIT_M], shI[BSR_FIT_M * BSR_FIT_M], shg[BSR_FIT_M], shb[BSR_FIT_M];
+  __shared__ double shmax[BSR_MAX_K];
+  __shared__ uint32_t shfl[BSR_MAX_K];
+  __shared__ int shpiv;
+
+  // sweep A: max |.| and inf/NaN census per column
+  for (int j = 0; j < K; ++j) {
+    double mx = 0.0;
+    uint32_t fl = 0;
+    const T* c = cols + (int64_t)j * ld;
+    for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+      const double v = (double)c[n];
+      if (isinf(v)) fl |= BSR_F_INF;
+      if (isnan(v)) fl |= BSR_F_NAN;
+      mx = fmax(mx, fabs(v));
+    }
+    mx = wave_max(mx);
+    fl = wave_or(fl);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      sh[threadIdx.x >> 6] = mx;
+      sh[BSR_BLK_WAVES + (threadIdx.x >> 6)] = (double)fl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double m2 = 0.0;
+      uint32_t f2 = 0;
+      for (int w = 0; w < BSR_BLK_WAVES; ++w) {
+        m2 = fmax(m2, sh[w]);
+        f2 |= (uint32_t)sh[BSR_BLK_WAVES + w];
+      }
+      if (f2 & BSR_F_INF) m2 = INFINITY;
+      shmax[j] = m2;
+      shfl[j] = f2;
+    }
+    __syncthreads();
+  }
+  double scale = icpt ? 1.0 : 0.0;
+  uint32_t anyfl = 0;
+  for (int j = 0; j < K; ++j) {
+    scale = fmax(scale, shmax[j]);
+    anyfl |= shfl[j];
+  }
+  if (threadIdx.x < K) {
+    out->maxabs[threadIdx.x] = shmax[threadIdx.x];
+    out->colflags[threadIdx.x] = shfl[threadIdx.x];
+  }
+  if (anyfl & (BSR_F_INF | BSR_F_NAN)) {
+    if (threadIdx.x == 0) {
+      out->sse = NAN;
+      out->scale = (anyfl & BSR_F_NAN) ? NAN : INFINITY;
+      out->anyflags = anyfl;
+    }
+    if (threadIdx.x < BSR_FIT_M) {
+      out->beta[threadIdx.x] = NAN;
+      out->beta_unscaled[threadIdx.x] = NAN;
+    }
+    return;
+  }
+  const double s = pow2_prescale(scale);
+  const double tau = 1.0 / (s * scale);
+
+  // sweep B: Gram of the prescaled columns and X^T y, one (i,j) pair group at a time
+  for (int i = 0; i < M; ++i) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    // columns j = i..M-1 handled in chunks of 7, slot 7 = X_i . y
+    for (int j0 = i; j0 < M; j0 += 7) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+      for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+        const double vi = (icpt && i == 0) ? s : s * (double)cols[(int64_t)(i - icpt) * ld + n];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int j = j0 + q;
+          if (j < M) {
+            const double vj = (icpt && j == 0) ? s : s * (double)cols[(int64_t)(j - icpt) * ld + n];
+            acc[q] = fma(vi, vj, acc[q]);
+          }
+        }
+        if (j0 == i) acc[7] = fma(vi, (double)y[n], acc[7]);
+      }
+      block_sum<8>(acc, sh);
+      if (threadIdx.x == 0) {
+        for (int q = 0; q < 7; ++q) {
+          const int j = j0 + q;
+          if (j < M) {
+            const double a = tau * (tau * acc[q]);
+            shA[i * BSR_FIT_M + j] = a;
+            shA[j * BSR_FIT_M + i] = a;
+          }
+        }
+        if (j0 == i) shg[i] = tau * acc[7];
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x < BSR_FIT_M * BSR_FIT_M) {
+    const int i = threadIdx.x / BSR_FIT_M, j = threadIdx.x % BSR_FIT_M;
+    if (i < M && j < M) {
+      if (i == j) shA[threadIdx.x] += 1e-6;
+      shI[threadIdx.x] = (i == j) ? 1.0 : 0.0;
+    } else {
+      shA[threadIdx.x] = (i == j) ? 1.0 : 0.0;
+      shI[threadIdx.x] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  // Gauss-Jordan with partial pivoting, one thread per matrix element
+  for (int col = 0; col < M; ++col) {
+    if (threadIdx.x == 0) {
+      double best = -1.0;
+      int piv = col;
+      for (int r = col; r < M; ++r) {
+        const double v = fabs(shA[r * BSR_FIT_M + col]);
+        if (v > best) { best = v; piv = r; }
+      }
+      shpiv = piv;
+    }
+    __syncthreads();
+    const int piv = shpiv;
+    double a = 0.0, b = 0.0;
+    const int i = threadIdx.x / BSR_FIT_M, j = threadIdx.x % BSR_FIT_M;
+    const bool act = threadIdx.x < BSR_FIT_M * BSR_FIT_M;
+    if (act) {
+      const int si = (i == col) ? piv : ((i == piv) ? col : i);  // row after the swap
+      const double d = shA[piv * BSR_FIT_M + col];
+      const double rowA = shA[piv * BSR_FIT_M + j], rowI = shI[piv * BSR_FIT_M + j];
+      if (i == col) {
+        a = rowA / d;
+        b = rowI / d;
+      } else {
+        const double f = shA[si * BSR_FIT_M + col] / d;
+        a = shA[si * BSR_FIT_M + j] - f * rowA;
+        b = shI[si * BSR_FIT_M + j] - f * rowI;
+      }
+    }
+    __syncthreads();
+    if (act) {
+      shA[threadIdx.x] = a;
+      shI[threadIdx.x] = b;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < BSR_FIT_M) {
+    double t = 0.0;
+    for (int j = 0; j < M; ++j) t += shI[threadIdx.x * BSR_FIT_M + j] * shg[j];
+    shb[threadIdx.x] = (threadIdx.x < (unsigned)M) ? t : 0.0;
+  }
+  __syncthreads();
+  // sweep C: direct residual
+  double sse[1] = {0.0};
+  for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+    double fit = icpt ? shb[0] * (tau * s) : 0.0;
+    for (int j = 0; j < K; ++j) fit = fma(shb[j + icpt] * (tau * s), (double)cols[(int64_t)j * ld + n], fit);
+    const double r = (double)y[n] - fit;
+    sse[0] = fma(r, r, sse[0]);
+  }
+  block_sum<1>(sse, sh);
+  if (threadIdx.x == 0) {
+    out->sse = sse[0];
+    out->scale = scale;
+    out->anyflags = anyfl;
+  }
+  if (threadIdx.x < BSR_FIT_M) {
+    out->beta[threadIdx.x] = shb[threadIdx.x];
+    out->beta_unscaled[threadIdx.x] = shb[threadIdx.x] / scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout helpers
+template <typename T>
+__global__ void k_transpose_in(const double* __restrict__ src, T* __restrict__ dst, int64_t N, int d, int64_t ld) {
+  // 64 rows x d features per workgroup through LDS so both sides stay coalesced
+  extern __shared__ double tile[];
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int rows = (int)min((int64_t)64, N - n0);
+  for (int idx = threadIdx.x; idx < rows * d; idx += blockDim.x) tile[idx] = src[n0 * d + idx];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < d * 64; idx += blockDim.x) {
+    const int f = idx >> 6, r = idx & 63;
+    if (r < rows) dst[(int64_t)f * ld + n0 + r] = (T)tile[r * d + f];
+  }
+}
+template <typename T>
+__global__ void k_convert_out(const T* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (double)src[i];
+}
+template <typename T>
+__global__ void k_convert_in(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (T)src[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+template <typename T>
+void launch_pass1(hipStream_t st, const LaunchGeom& g, const T* Xt, const T* y, int64_t ld, int64_t N,
+                  const bsr_node* tapes, const PropDesc* desc, int P, double* part1, double* spill,
+                  int spill_slots) {
+  dim3 grid(g.n_rb, g.n_pg), block(BSR_WG_WAVES * BSR_WAVE);
+  hipLaunchKernelGGL((k_pass1<T, 2>), grid, block, 0, st, Xt, y, ld, N, tapes, desc, P, g.rb_rows, g.pg, g.n_rb,
+                     part1, (T*)spill, spill_slots);
+}
+template <typename T>
+void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, int64_t N, const PropDesc* desc,
+                  const PropCoef* coef, int P, double* part2) {
+  dim3 grid(g.n_rb, g.n_pg), block(BSR_WG_WAVES * BSR_WAVE);
+  hipLaunchKernelGGL((k_pass2<T, 2>), grid, block, 0, st, y, ld, N, desc, coef, P, g.rb_rows, g.pg, g.n_rb, part2);
+}
+void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
+                  PropCoef* coef) {
+  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, coef);
+}
+void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
+                     const double* part2, int64_t N, bsr_score* out) {
+  hipLaunchKernelGGL(k_finalize, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out);
+}
+template <typename T>
+void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
+                          const double* col_maxabs, const uint32_t* col_flags, ChainK* ck_chain) {
+  hipLaunchKernelGGL((k_refresh_basis<T>), dim3(K), dim3(BSR_BLK), 0, st, cur, Q, y, ld, N, K, col_maxabs,
+                     col_flags, ck_chain);
+}
+template <typename T>
+void launch_chain_fit(hipStream_t st, const T* cols, const T* y, int64_t ld, int64_t N, int K, int intercept,
+                      ChainFitOut* out) {
+  hipLaunchKernelGGL((k_chain_fit<T>), dim3(1), dim3(BSR_BLK), 0, st, cols, y, ld, N, K, intercept, out);
+}
+template <typename T>
+void launch_transpose_in(hipStream_t st, const double* src_rowmajor, T* dst, int64_t N, int d, int64_t ld) {
+  const int64_t nb = (N + 63) / 64;
+  hipLaunchKernelGGL((k_transpose_in<T>), dim3((unsigned)nb), dim3(256), (size_t)64 * d * sizeof(double), st,
+                     src_rowmajor, dst, N, d, ld);
+}
+template <typename T>
+void launch_convert_out(hipStream_t st, const T* src, double* dst, int64_t n) {
+  hipLaunchKernelGGL((k_convert_out<T>), dim3(1024), dim3(256), 0, st, src, dst, n);
+}
+template <typename T>
+void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n) {
+  hipLaunchKernelGGL((k_convert_in<T>), dim3(1024), dim3(256), 0, st, src, dst, n);
+}
+
+#define BSR_INSTANTIATE(T)                                                                                          \
+  template void launch_pass1<T>(hipStream_t, const LaunchGeom&, const T*, const T*, int64_t, int64_t,               \
+                                const bsr_node*, const PropDesc*, int, double*, double*, int);                      \
+  template void launch_pass2<T>(hipStream_t, const LaunchGeom&, const T*, int64_t, int64_t, const PropDesc*,        \
+                                const PropCoef*, int, double*);                                                     \
+  template void launch_refresh_basis<T>(hipStream_t, const T*, T*, const T*, int64_t, int64_t, int, const double*,  \
+                                        const uint32_t*, ChainK*);                                                  \
+  template void launch_chain_fit<T>(hipStream_t, const T*, const T*, int64_t, int64_t, int, int, ChainFitOut*);     \
+  template void launch_transpose_in<T>(hipStream_t, const double*, T*, int64_t, int, int64_t);                      \
+  template void launch_convert_out<T>(hipStream_t, const T*, double*, int64_t);                                     \
+  template void launch_convert_in<T>(hipStream_t, const double*, T*, int64_t);
+BSR_INSTANTIATE(double)
+BSR_INSTANTIATE(float)

@@ -42,3 +42,41 @@ def rng_mark():
     import zlib
     st = np.random.get_state()
     return {"pos": int(st[2]), "crc": int(zlib.crc32(st[1].tobytes())), "has_gauss": int(st[3])}
+
+
+def node_from_spec(spec, parent=None):
+    """Product-side Node tree from the plain-data tree form of the golden fixtures."""
+    from bsr.node import Node
+    if spec is None:
+        return None
+    n = Node(spec["depth"])
+    n.type = spec["type"]
+    n.operator = spec["op"]
+    n.op_ind = spec["op_ind"]
+    n.feature = None if spec["feature"] is None else np.array([spec["feature"]])
+    n.a = unf(spec["a"])
+    n.b = unf(spec["b"])
+    n.parent = parent
+    n.left = node_from_spec(spec["left"], n)
+    n.right = node_from_spec(spec["right"], n)
+    return n
+
+
+def spec_from_node(node):
+    """Plain-data form of a Node / ONode tree (shared between oracle and product objects)."""
+    if node is None:
+        return None
+    feat = None if node.feature is None else int(np.asarray(node.feature).reshape(-1)[0])
+    return {"type": int(node.type), "op": node.operator,
+            "op_ind": None if node.op_ind is None else int(node.op_ind), "depth": int(node.depth),
+            "feature": feat, "a": None if node.a is None else float(node.a),
+            "b": None if node.b is None else float(node.b),
+            "left": spec_from_node(node.left), "right": spec_from_node(node.right)}
+
+
+def have_gpu():
+    try:
+        from bsr import _lib
+        return _lib.device_count() > 0
+    except Exception:
+        return False
