@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MH proposals scored per second (N=100k, d=10, K=3) on N MI355X + kernel roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chains C] [--workload c2|c3|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+A "step" is one bsr_score_batch call: B speculative proposals per chain, drawn by the real move mix (all seven
+actions, codes/funcs.py:475-480) from a seeded chain state, are scored against the chain's current trees: tree
+evaluation over all N rows, rank gate, OLS fit, Gaussian log-likelihood (codes/funcs.py:1212-1235).  X, y and the
+chain caches are resident in HBM; the call still uploads the tapes (KBs) and downloads the B result records, because
+that is what the C ABI boundary hands over.  Independent chains shard one per rank with no data-path collective
+(weak scaling); the only exchange is the RCCL all-gather of the chains' accepted trees after the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mcmc-symreg_amd"))
+
+import numpy as np
+
+WORKLOADS = {
+    "c2": dict(N=100_000, d=10, K=3, desc="N=100k, d=10, K=3, 1 chain per GPU (BASELINE configs[1])"),
+    "c3": dict(N=100_000, d=10, K=8, desc="N=100k, d=10, K=8, batched multi-proposal (BASELINE configs[2])"),
+    "c5": dict(N=1_000_000, d=50, K=3, desc="N=1M, d=50, K=3 (BASELINE configs[4])"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def synth(N, d, seed=0):
+    """SURVEY 8d recipe: X~U(-3,3), y = 1.35 x0 x1 + 5.5 sin((x0-1)(x1-1)) + 0.1 N(0,1)."""
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    return X, y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="speculative proposals per chain and step")
+    ap.add_argument("--chains", type=int, default=1, help="chains per GPU")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--burnin", type=int, default=300, help="real MCMC proposals run before freezing the state")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="proposals timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from bsr import _lib
+    from bsr.chain import Chain, DeviceScorer, run_chains
+    from bsr.tape import pack
+
+    W = WORKLOADS[args.workload]
+    N, d, K = W["N"], W["d"], W["K"]
+    B, C = args.batch, args.chains
+    X, y = synth(N, d, seed=0)
+    scorer = DeviceScorer(X, y, K, n_chains=C, max_batch=B * C, device=local if world > 1 else 0, dtype=args.dtype)
+    ctx = scorer.ctx
+
+    # chain states: seeded chains advanced by a short real run, then frozen
+    chains = []
+    for c in range(C):
+        np.random.seed(1000 + rank * C + c)
+        chains.append(Chain(c, scorer, N, d, K, val=10 ** 9))
+    run_chains(chains, scorer, batch_per_chain=B, max_props=args.burnin)
+
+    # pre-generate the step inputs: every step scores a fresh batch drawn from the frozen states
+    n_batches = args.warmup + args.steps
+    packed = []
+    feats = set()
+    n_nodes = n_trans = 0
+    for _ in range(n_batches):
+        tapes, chs, ks, sig = [], [], [], []
+        for ch in chains:
+            for cd in ch.generate(B):
+                tapes.append(cd.tape)
+                chs.append(ch.index)
+                ks.append(cd.k)
+                sig.append(cd.new_sigma)
+            ch.rng_state = ch._end_state      # keep drawing new proposals from the same frozen state
+        rows, off = pack(tapes)
+        for t in tapes:
+            n_nodes += len(t)
+            n_trans += int(np.isin(t["opcode"], (0, 3, 4, 5)).sum())
+            feats.update(int(f) for f in t["feature"][t["opcode"] == 10])
+        packed.append((rows, off, np.array(chs, np.int32), np.array(ks, np.int32), np.array(sig, np.float64),
+                       np.zeros(len(tapes), dtype=_lib.SCORE_DTYPE), tapes))
+    P = len(packed[0][2])
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ctx.set_profiling(True)
+    for i in range(args.warmup):
+        r = packed[i]
+        ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
+    kern_us = np.zeros(5)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        r = packed[i]
+        ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])   # synchronous: returns with results on the host
+        kern_us += ctx.last_timing()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_us /= args.steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the one exchange of the path: gather every chain's current (accepted) trees over RCCL
+    gathered = None
+    if dist is not None:
+        import torch
+        uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.from_numpy(ctx.comm_unique_id()))
+        dist.broadcast(uid, 0)
+        ctx.comm_init(world, rank, uid.cpu().numpy())
+        from bsr.dist import pack_chain_record, RECORD_BYTES
+        rec = np.concatenate([pack_chain_record(ch) for ch in chains])
+        gathered = ctx.comm_allgather(rec)
+        assert gathered.shape == (world, RECORD_BYTES * C)
+
+    if rank == 0:
+        total_props = world * P * args.steps
+        value = total_props / elapsed
+        # roofline of the dominant kernel (tree-eval + projection pass), SURVEY 8d formula:
+        # bytes = s * N * (|F| + 1 + C_r + C_w): features referenced, y, K-1 cached sibling columns per chain,
+        # C_w = 0 (candidate columns are scratch; reported separately)
+        s = 8 if args.dtype == "f64" else 4
+        alg_bytes = s * N * (len(feats) + 1 + C * (K - 1))
+        alg_bytes_scratch = alg_bytes + s * N * P
+        p1 = kern_us[0] * 1e-6
+        out = {
+            "metric": "MH proposals scored/sec (N=100k,d=10,K=3) at 1/2/4/8 MI355X; HBM GB/s",
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": W["desc"], "N": N, "d": d, "K": K, "chains_per_gpu": C,
+                       "proposals_per_step_per_gpu": P, "speculative_batch": B, "parallelism": "chains x%d" % world,
+                       "avg_nodes_per_tape": n_nodes / (n_batches * P),
+                       "transcendental_node_frac": n_trans / max(1, n_nodes)},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / p1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / p1 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_pass1 (tree-eval + projection)", "kernel_us": kern_us[0],
+                         "algorithmic_bytes": alg_bytes,
+                         "achieved_incl_candidate_columns": alg_bytes_scratch / p1 / 1e9},
+            "kernel_us": {"pass1_eval": kern_us[0], "solve": kern_us[1], "pass2_resid": kern_us[2],
+                          "finalize": kern_us[3], "device_total": kern_us[4]},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(X, y, K, chains, packed[args.warmup], args.cpu_sample)
+        if gathered is not None:
+            out["gathered_records"] = int(gathered.shape[0] * C)
+        print(json.dumps(out))
+    scorer.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(X, y, K, chains, batch, n_sample):
+    """Times the oracle's reference-faithful restatement of the same scoring work on the host CPU (1 thread):
+    per proposal K+1 tree evaluations with per-element exp/inv loops, SVD rank gate, two ylogLike passes
+    (codes/funcs.py:1212-1235).  Bounded sample of the first timed batch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pandas as pd
+    import bsr_oracle as O
+    from bsr.tape import unflatten
+
+    def onode(n):
+        m = O.ONode(n.depth)
+        m.type, m.operator, m.op_ind, m.feature, m.a, m.b = n.type, n.operator, n.op_ind, n.feature, n.a, n.b
+        m.left = onode(n.left) if n.left is not None else None
+        m.right = onode(n.right) if n.right is not None else None
+        return m
+    Xdf = pd.DataFrame(X)
+    ys = pd.Series(y)
+    tapes, chs, ks, sig = batch[6], batch[2], batch[3], batch[4]
+    n = min(n_sample, len(tapes))
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n):
+        ch = chains[int(chs[i])]
+        k = int(ks[i])
+        new_o = np.zeros((len(y), K))
+        old_o = np.zeros((len(y), K))
+        with np.errstate(all="ignore"):
+            for j in range(K):
+                if j == k:
+                    new_o[:, j] = O.allcal(onode(unflatten(tapes[i])), Xdf, faithful=True)[:, 0]
+                    old_o[:, j] = O.allcal(onode(ch.roots[j]), Xdf, faithful=True)[:, 0]
+                else:
+                    col = O.allcal(onode(ch.roots[j]), Xdf, faithful=True)[:, 0]
+                    new_o[:, j] = col
+                    old_o[:, j] = col
+            try:
+                full = np.linalg.matrix_rank(new_o) == K
+            except np.linalg.LinAlgError:
+                full = False
+            if full:
+                O.yloglike(ys, new_o, float(sig[i]))
+                O.yloglike(ys, old_o, ch.sigma)
+        done += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+            "sample": "%d proposals of the first timed batch, oracle reference-faithful flavour "
+                      "(K+1 allcal with per-element exp/inv loops + matrix_rank + 2 ylogLike), %.1f s" % (done, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -4,4 +4,7 @@ Same package name and re-exports as the reference (setup.py:14-20, codes/__init_
 tree evaluation, OLS fit across the K trees, Gaussian log-likelihood, rank gate -- runs in hand-written HIP kernels
 behind the C ABI of include/bsr_hip.h; this package is the Python host side.
 """
-from .node import Operator, Node, genList, shrink, upgOd, display, getHeight, getNum, numLT, upDepth, Express
+from .funcs import Operator, Node
+from .funcs import grow, genList, shrink, upgOd, allcal, display, getHeight, getNum, numLT, upDepth, Express, fStruc
+from .funcs import ylogLike, newProp, Prop, auxProp
+from .bsr_class import BSR

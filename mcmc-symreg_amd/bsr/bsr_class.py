@@ -1,0 +1,114 @@
+"""BSR estimator: the reference's public class (codes/bsr_class.py:26-278) on top of the GPU scorer.
+
+Constructor arguments, fit/predict/model/complexity and the fitted attributes roots_/betas_/train_err_ keep the
+reference's meaning.  Extra keyword-only options (defaults preserve the reference's behaviour):
+  device, dtype          GPU index and compute type ("f64" | "f32")
+  batch                  speculative proposals per launch and chain
+  chain_seeds            None: chains run one after the other on the global numpy RNG stream exactly like the
+                         reference; a list of ints: chain c is seeded with chain_seeds[c] and chains advance
+                         together, several per launch (independent restarts are the reference's only parallelism,
+                         codes/bsr_class.py:99)
+"""
+import numpy as np
+
+from . import proposal as P
+from . import rng
+from .chain import Chain, DeviceScorer, run_chains
+from .node import Express, getNum
+
+try:  # sklearn is optional on the GPU box
+    from sklearn.base import BaseEstimator, RegressorMixin
+except Exception:  # pragma: no cover
+    class BaseEstimator(object):
+        pass
+
+    class RegressorMixin(object):
+        pass
+
+
+class BSR(BaseEstimator, RegressorMixin):
+    def __init__(self, treeNum=3, itrNum=5000, alpha1=0.4, alpha2=0.4, beta=-1, disp=False, val=100,
+                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8):
+        self.treeNum = treeNum
+        self.itrNum = itrNum
+        self.alpha1 = alpha1
+        self.alpha2 = alpha2
+        self.beta = beta
+        self.disp = disp
+        self.val = val
+        self.device = device
+        self.dtype = dtype
+        self.batch = batch
+        self.chain_seeds = chain_seeds
+        self.chains_per_launch = chains_per_launch
+
+    # ---- codes/bsr_class.py:37-51
+    def model(self, last_ind=1):
+        return [Express(self.roots_[-last_ind][i]) for i in range(self.treeNum)]
+
+    def complexity(self):
+        return sum(getNum(self.roots_[-1][i]) for i in range(self.treeNum))
+
+    # ---- codes/bsr_class.py:53-68
+    def predict(self, test_data, method='last', last_ind=1):
+        from .device import DeviceContext
+        from .tape import flatten
+        X = np.ascontiguousarray(np.asarray(test_data, dtype=np.float64))
+        K = self.treeNum
+        if method != 'last':
+            raise UnboundLocalError("local variable 'toutput' referenced before assignment")  # codes/bsr_class.py:59,68
+        ctx = DeviceContext(X, None, max_batch=max(K, 1), device=self.device, dtype=self.dtype)
+        try:
+            cols, _, _ = ctx.eval_tapes([flatten(self.roots_[-last_ind][k]) for k in range(K)])
+        finally:
+            ctx.close()
+        XX = np.concatenate((np.ones((X.shape[0], 1)), cols.T), axis=1)
+        return np.matmul(XX, self.betas_[-last_ind])
+
+    # ---- codes/bsr_class.py:77-278
+    def fit(self, train_data, train_y):
+        self.roots_, self.betas_, self.train_err_ = [], [], []
+        y_is_series = hasattr(train_y, "iloc")
+        X = np.ascontiguousarray(np.asarray(train_data, dtype=np.float64))
+        y = np.ascontiguousarray(np.asarray(train_y, dtype=np.float64).reshape(-1))
+        N, d = X.shape
+        K = self.treeNum
+        T = P.default_table()
+        seeds = self.chain_seeds
+        n_slots = 1 if seeds is None else max(1, min(self.chains_per_launch, len(seeds), self.itrNum))
+        scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, self.batch * n_slots), device=self.device,
+                              dtype=self.dtype)
+        self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
+        results = []
+        try:
+            if seeds is None:
+                if self.disp:
+                    print('starting training...')
+                for _ in range(self.itrNum):
+                    ch = Chain(0, scorer, N, d, K, beta=self.beta, val=self.val, table=T, y_is_series=y_is_series)
+                    run_chains([ch], scorer, batch_per_chain=self.batch)
+                    rng.set_state(ch.rng_state)      # the next chain continues the same stream
+                    results.append(ch)
+            else:
+                todo = list(range(min(self.itrNum, len(seeds))))
+                while todo:
+                    wave, todo = todo[:n_slots], todo[n_slots:]
+                    chains = []
+                    for slot, ci in enumerate(wave):
+                        np.random.seed(seeds[ci])
+                        chains.append(Chain(slot, scorer, N, d, K, beta=self.beta, val=self.val, table=T,
+                                            y_is_series=y_is_series))
+                    run_chains(chains, scorer, batch_per_chain=self.batch)
+                    results.extend(chains)
+        finally:
+            scorer.close()
+        for ch in results:
+            r = ch.result()
+            self.roots_.append(r["roots"])
+            self.betas_.append(r["beta"])
+            self.train_err_.append(r["errs"])
+            self.stats_["proposals"] += ch.n_props
+            self.stats_["accepts"] += ch.n_accept
+            self.stats_["rank_rejects"] += ch.n_rank_rejects
+            self.stats_["discarded"] += ch.n_discarded
+        return

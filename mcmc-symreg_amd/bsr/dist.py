@@ -1,0 +1,128 @@
+"""Sharding of independent chains over the GPUs of a node and the one exchange of the path: an all-gather of the
+chains' accepted trees.
+
+A "chain" is one pass of the reference's restart loop (codes/bsr_class.py:99): fresh sigma, fresh K trees, no data
+flowing between chains except the final append to ROOTS/BETAS/trainERRS (codes/bsr_class.py:270-273).  Chain c runs
+on rank c % world with its own RNG stream (np.random.seed(seed_base + c)), so results do not depend on the world
+size.  The gather moves fixed-size records (K padded tapes + Beta + counters), tens of KB per rank: latency-bound.
+"""
+import numpy as np
+
+from .tape import NODE_DTYPE, flatten, unflatten
+
+MAX_K = 8
+RECORD_NODES = 255            # nodes kept per tree in a record (longer tapes are flagged, not sent)
+HEADER_I32 = 16 + MAX_K       # chain id, K, n_props, n_accept, n_errs, truncated, ... , tape lengths
+HEADER_F64 = 4 + (MAX_K + 1)  # sigma, last rmse, best rmse, spare, Beta[K+1]
+RECORD_BYTES = HEADER_I32 * 4 + HEADER_F64 * 8 + MAX_K * RECORD_NODES * NODE_DTYPE.itemsize
+assert RECORD_BYTES % 8 == 0
+
+
+def shard(n_chains, world, rank):
+    """Chain ids owned by `rank` (round-robin)."""
+    return [c for c in range(n_chains) if c % world == rank]
+
+
+def pack_record(chain_id, roots, beta, sigma, errs, n_props, n_accept):
+    """One chain's outcome as RECORD_BYTES bytes."""
+    K = len(roots)
+    hi = np.zeros(HEADER_I32, dtype=np.int32)
+    hf = np.zeros(HEADER_F64, dtype=np.float64)
+    tapes = np.zeros((MAX_K, RECORD_NODES), dtype=NODE_DTYPE)
+    hi[0], hi[1], hi[2], hi[3], hi[4] = chain_id, K, n_props, n_accept, len(errs)
+    for k, r in enumerate(roots):
+        t = flatten(r)
+        if len(t) > RECORD_NODES:
+            hi[5] |= (1 << k)
+            hi[16 + k] = -len(t)
+        else:
+            hi[16 + k] = len(t)
+            tapes[k, :len(t)] = t
+    hf[0] = sigma
+    hf[1] = errs[-1] if len(errs) else np.nan
+    hf[2] = min(errs) if len(errs) else np.nan
+    b = np.asarray(beta, dtype=np.float64).reshape(-1)
+    hf[4:4 + len(b)] = b
+    out = np.concatenate([hi.view(np.uint8), hf.view(np.uint8), tapes.reshape(-1).view(np.uint8)])
+    assert out.size == RECORD_BYTES
+    return out
+
+
+def pack_chain_record(chain):
+    """Record of a live bsr.chain.Chain (its current, i.e. last accepted, trees)."""
+    return pack_record(chain.index, chain.roots, chain.Beta, chain.sigma, chain.errs, chain.n_props, chain.n_accept)
+
+
+def unpack_record(buf):
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    assert buf.size == RECORD_BYTES
+    ni = HEADER_I32 * 4
+    nf = HEADER_F64 * 8
+    hi = buf[:ni].view(np.int32)
+    hf = buf[ni:ni + nf].view(np.float64)
+    tapes = buf[ni + nf:].view(NODE_DTYPE).reshape(MAX_K, RECORD_NODES)
+    K = int(hi[1])
+    roots, lens = [], []
+    for k in range(K):
+        n = int(hi[16 + k])
+        lens.append(n)
+        roots.append(unflatten(tapes[k, :n]) if n > 0 else None)
+    return {"chain": int(hi[0]), "K": K, "n_props": int(hi[2]), "n_accept": int(hi[3]), "n_errs": int(hi[4]),
+            "truncated": int(hi[5]), "tape_len": lens, "sigma": float(hf[0]), "last_rmse": float(hf[1]),
+            "best_rmse": float(hf[2]), "beta": hf[4:4 + K + 1].copy().reshape(-1, 1), "roots": roots,
+            "tapes": [tapes[k, :max(0, lens[k])].copy() for k in range(K)]}
+
+
+class TorchGather:
+    """All-gather through torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests)."""
+
+    def __init__(self, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.device = device
+
+    def world(self):
+        return self.dist.get_world_size()
+
+    def allgather(self, send):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(send, dtype=np.uint8))
+        if self.device is not None:
+            t = t.to(self.device)
+        outs = [torch.empty_like(t) for _ in range(self.world())]
+        self.dist.all_gather(outs, t)
+        return np.stack([o.cpu().numpy() for o in outs])
+
+
+class RcclGather:
+    """All-gather through the C ABI's RCCL communicator (bsr_comm_*), device buffers over xGMI."""
+
+    def __init__(self, ctx, world, rank, uid):
+        self.ctx = ctx
+        self._world = world
+        ctx.comm_init(world, rank, uid)
+
+    def world(self):
+        return self._world
+
+    def allgather(self, send):
+        return self.ctx.comm_allgather(send)
+
+
+def gather_chains(gather, local_records, chains_per_rank):
+    """local_records: list of packed records (padded to chains_per_rank with empty records).
+    Returns every rank's records unpacked, ordered by chain id."""
+    recs = list(local_records)
+    empty = np.zeros(RECORD_BYTES, dtype=np.uint8)
+    empty[:4] = np.array([-1], dtype=np.int32).view(np.uint8)
+    while len(recs) < chains_per_rank:
+        recs.append(empty)
+    got = gather.allgather(np.concatenate(recs))
+    out = []
+    for r in range(got.shape[0]):
+        for i in range(chains_per_rank):
+            rec = got[r, i * RECORD_BYTES:(i + 1) * RECORD_BYTES]
+            if rec[:4].view(np.int32)[0] >= 0:
+                out.append(unpack_record(rec))
+    out.sort(key=lambda d: d["chain"])
+    return out

@@ -1,0 +1,132 @@
+"""End-to-end parity on the GPU: the reference's golden chain traces and BSR.fit run through the HIP scorer."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, farr, load_golden, node_from_spec, unf
+
+pytestmark = pytest.mark.gpu
+
+import bsr_oracle as O
+from test_host_driver import TRACES, replay_trace
+
+
+def _device_scorer(X, y, K):
+    from bsr.chain import DeviceScorer
+    return DeviceScorer(X, y, K, n_chains=1, max_batch=64)
+
+
+@pytest.mark.parametrize("name", TRACES)
+@pytest.mark.parametrize("batch", [1, 32])
+def test_reference_traces_through_the_hip_scorer(name, batch):
+    """Accepted-tree sequence, actions, rank-gate decisions and RNG position bit-exact; log-likelihoods to 1e-6."""
+    if batch == 1 and name in ("f1_s0", "synth_K8_s1001"):
+        pytest.skip("long trace covered at batch 32")
+    ch = replay_trace(name, _device_scorer, batch, 1e-6)
+    ch.scorer.close()
+
+
+def test_bsr_fit_f1_matches_reference_end_to_end():
+    """BSR(3,50).fit on f1, np.random.seed(0): every chain's model strings, proposal counts, Beta, RMSE history,
+    predict() -- the reference's config 1 (20 061 proposals)."""
+    from bsr import BSR
+    g = load_golden("g6_fit_f1.json")
+    X = pd.DataFrame(np.array(g["X"], dtype=np.float64))
+    y = pd.Series(farr(g["y"]))
+    np.random.seed(0)
+    np.random.uniform(0.1, 5.9, 100)
+    np.random.uniform(0.1, 5.9, 100)
+    est = BSR(treeNum=3, itrNum=50)
+    assert est.fit(X, y) is None
+    assert est.stats_["proposals"] == g["total_props"]
+    from bsr.node import Express
+    loose = 0
+    for c in range(50):
+        assert [Express(t) for t in est.roots_[c]] == g["models"][c], c          # accepted trees: exact
+        assert len(est.train_err_[c]) == len(g["train_err"][c]), c
+        want_b, want_e = farr(g["betas"][c]), farr(g["train_err"][c])
+        got_b, got_e = np.asarray(est.betas_[c]).reshape(-1), np.asarray(est.train_err_[c])
+        dev = 0.0
+        if len(want_e):
+            dev = float(np.max(np.abs(got_e - want_e) / np.abs(want_e)))
+        dev_b = float(np.max(np.abs(got_b - want_b) / (np.abs(want_b) + 1e-6 * np.max(np.abs(want_b)))))
+        # values agree to 1e-7 except for chains that visit trees which are chaotic at the ulp level
+        # (sin/cos of 1e12-sized arguments): there only the libm build decides the last digits
+        if dev > 1e-7 or dev_b > 1e-5:
+            loose += 1
+            assert dev < 5e-2 and np.isfinite(dev_b), (c, dev, dev_b, g["models"][c])
+    assert loose <= 6, loose
+    assert est.model() == g["model_last"]
+    assert est.complexity() == g["complexity"]
+    grid = np.array(g["grid"])
+    assert np.allclose(est.predict(grid)[:, 0], farr(g["predict_grid"]), rtol=1e-6, atol=1e-8)
+    assert np.allclose(est.predict(grid, last_ind=2)[:, 0], farr(g["predict_grid_last2"]), rtol=1e-6, atol=1e-8)
+    m = np.random.get_state()
+    import zlib
+    assert int(m[2]) == g["rng_end"]["pos"] and int(zlib.crc32(m[1].tobytes())) == g["rng_end"]["crc"]
+
+
+def test_module_functions_allcal_yloglike_newprop():
+    """bsr.allcal / bsr.ylogLike / bsr.newProp keep the reference's call signatures and results."""
+    import bsr
+    g = load_golden("g5_trace_f1_s7.json")
+    dat = np.load(os.path.join(GOLDEN, "g5_trace_f1_s7.npz"))
+    X = pd.DataFrame(dat["X"])
+    y = pd.Series(dat["y"])
+    Ops, W, T = list(O.OPS), list(O.OP_WEIGHTS), list(O.OP_ARITY)
+    roots = [node_from_spec(s) for s in g["init_trees"]]
+    cols = []
+    for s, r in zip(g["init_trees"], roots):
+        out = bsr.allcal(r, X)
+        assert out.shape == (len(y), 1)
+        with np.errstate(all="ignore"):
+            want = O.allcal(O.tree_from_json(s), X)
+        assert np.allclose(out, want, rtol=1e-12, atol=1e-12)
+        cols.append(out[:, 0])
+    cols = np.stack(cols, axis=1)
+    ll = bsr.ylogLike(y, cols, 0.9)
+    assert abs(ll - O.yloglike(y, cols, 0.9)) <= 1e-9 * abs(ll)
+    # replay the first proposals of the trace through newProp, one call per proposal like BSR.fit does
+    np.random.seed(g["seed"])
+    from bsr import rng
+    from bsr import proposal as P
+    sigma = rng.invgamma_rvs(1)
+    cur, siga, sigb = [], [], []
+    for k in range(3):
+        root = bsr.Node(0)
+        sa, sb = rng.invgamma_rvs(1), rng.invgamma_rvs(1)
+        bsr.grow(root, 2, Ops, W, T, -1, sa, sb)
+        cur.append(root)
+        siga.append(sa)
+        sigb.append(sb)
+    n_acc = 0
+    for i, ref in enumerate(g["props"][:120]):
+        k = ref["count"]
+        res, sigma, Root, siga[k], sigb[k] = bsr.newProp(cur, k, sigma, y, X, 2, Ops, W, T, -1, siga[k], sigb[k])
+        assert res == ref["accepted"], i
+        assert abs(sigma - unf(ref["sigma_out"])) <= 1e-13 * sigma, i
+        if res:
+            n_acc += 1
+            cur[k] = Root
+    assert n_acc == sum(1 for r in g["props"][:120] if r["accepted"])
+
+
+def test_parallel_chains_equal_single_chain_runs():
+    """Chains seeded individually and advanced several per launch give exactly the single-chain results."""
+    from bsr import BSR
+    from bsr.node import Express
+    rs = np.random.RandomState(3)
+    X = rs.uniform(-3, 3, size=(400, 3))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(400)
+    seeds = [1000 + c for c in range(6)]
+    par = BSR(treeNum=3, itrNum=6, val=60, chain_seeds=seeds, chains_per_launch=4, batch=16)
+    par.fit(X, y)
+    for c, s in enumerate(seeds):
+        np.random.seed(s)
+        one = BSR(treeNum=3, itrNum=1, val=60)
+        one.fit(X, y)
+        assert [Express(t) for t in one.roots_[0]] == [Express(t) for t in par.roots_[c]], c
+        assert np.array_equal(one.betas_[0], par.betas_[c]), c
+        assert one.train_err_[0] == par.train_err_[c], c
