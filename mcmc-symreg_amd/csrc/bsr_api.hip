@@ -306,7 +306,7 @@ static int run_descs(bsr_ctx* c, int P, bool need_pass2) {
     launch_pass1<float>(c->stream, g, (const float*)c->Xt, c->has_y ? (const float*)c->y : nullptr, c->ld, c->N,
                         c->d_tapes, c->d_desc, P, c->part1, spill_slots ? c->spill : nullptr, spill_slots);
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  launch_solve(c->stream, c->d_desc, c->d_ck, P, g.n_rb, c->part1, c->d_coef);
+  launch_solve(c->stream, c->d_desc, c->d_ck, P, g.n_rb, c->part1, c->N, c->d_coef, c->d_out);
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (need_pass2) {
     if (f64)
@@ -315,7 +315,7 @@ static int run_descs(bsr_ctx* c, int P, bool need_pass2) {
       launch_pass2<float>(c->stream, g, (const float*)c->y, c->ld, c->N, c->d_desc, c->d_coef, P, c->part2);
   }
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-  launch_finalize(c->stream, c->d_desc, c->d_ck, c->d_coef, P, g.n_rb, c->part2, c->N, c->d_out);
+  if (need_pass2) launch_finalize(c->stream, c->d_desc, c->d_ck, c->d_coef, P, g.n_rb, c->part2, c->N, c->d_out);
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(bsr_score) * P, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -21,8 +21,8 @@ enum { BSR_MODE_SCORE = 0, BSR_MODE_EVAL = 1 };
 // power of two `s`:  s * O_j = Q R  (j != k ascending).  See DESIGN.md "rank gate and OLS".
 struct ChainK {
   double R[BSR_NQ_MAX * BSR_NQ_MAX];     // upper triangular, row-major [row][col]
-  double RtR[BSR_NQ_MAX * BSR_NQ_MAX];   // R^T R  (Gram of the scaled sibling columns)
-  double Rtqy[BSR_NQ_MAX];               // R^T (Q^T y)
+  double qy[BSR_NQ_MAX];                 // Q^T y
+  double yperp2;                         // |y - Q Q^T y|^2, measured directly
   double s;                              // power-of-two prescale
   double m_other;                        // max |sibling columns| (unscaled)
   uint32_t flags;                        // BSR_F_INF / BSR_F_NAN of the sibling columns
@@ -47,17 +47,14 @@ struct PropDesc {
 
 // What the solve step hands to the residual pass.
 struct PropCoef {
-  double g[BSR_NQ_MAX];   // tau * (R beta_others)   : weights of the basis columns in the fitted values
   double c[BSR_NQ_MAX];   // Q^T (s z)               : projection of the candidate on the basis
-  double bz;              // tau * s * beta_k        : weight of the unscaled candidate column
   double s;
   double zz;              // |s z|^2
   double tau;
   double scale;           // reference scale max|new_outputs|
   double maxabs;
-  double beta[BSR_MAX_K];
   uint32_t flags;
-  int32_t skip;           // 1: residual pass not needed (non-finite / eval mode)
+  int32_t skip;           // 1: proposal already complete (or eval mode): the residual pass skips it
 };
 
 struct ChainFitOut {
@@ -83,7 +80,7 @@ void launch_pass1(hipStream_t st, const LaunchGeom& g, const T* Xt, const T* y, 
                   const bsr_node* tapes, const PropDesc* desc, int P, double* part1, double* spill,
                   int spill_slots);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
-                  PropCoef* coef);
+                  int64_t N, PropCoef* coef, bsr_score* out);
 template <typename T>
 void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, int64_t N, const PropDesc* desc,
                   const PropCoef* coef, int P, double* part2);

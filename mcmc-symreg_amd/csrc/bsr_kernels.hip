@@ -272,15 +272,144 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass1(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// solve: one wave per proposal.  Lane (i,j) = (lane>>3, lane&7) owns element [i][j] of the K x K system.
+// Per-proposal K x K algebra.  One wave per proposal; lane (i,j) = (lane>>3, lane&7) owns element [i][j].
+//
+// With s*O_siblings = Q R (cached) and the candidate s*z = Q c + w (w orthogonal to Q, |w| = rho):
+//   s * new_outputs = [Q, w/rho] S,   S = [[R, c], [0, rho]]   (columns: siblings ascending, then the candidate)
+// so the singular values of S are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with
+// XX = new_outputs/scale = [Q, w/rho] (tau S), tau = 1/(s*scale), h = [Q^T y, w.y/rho]:
+//   Beta = V (tau Sigma)/(tau^2 Sigma^2 + 1e-6) U^T h                  (ridge OLS, codes/funcs.py:1151-1155)
+//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + sum_j (1e-6/(tau^2 sigma_j^2 + 1e-6))^2 (u_j^T h)^2   (codes/funcs.py:1162)
+// where S = U Sigma V^T comes from a one-sided Jacobi sweep.  Everything is K-dimensional; the only O(N) inputs
+// are c, |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2
+// would cancel (candidate nearly inside the sibling span).
+__device__ __forceinline__ double col_reduce(double v) {  // sum over the 8 rows of a column (lane bits 3..5)
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double row_reduce(double v) {  // sum over the 8 columns of a row (lane bits 0..2)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+
+// One-sided Jacobi: on return W = S V has mutually orthogonal columns (W[:,j] = sigma_j u_j) and V is accumulated.
+__device__ __forceinline__ void jacobi_svd(double& W, double& V, int K, int lane) {
+  const int j = lane & 7;
+  const int base = lane & ~7;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int a = 0; a < K - 1; ++a) {
+      for (int b = a + 1; b < K; ++b) {
+        const double wa = __shfl(W, base + a), wb = __shfl(W, base + b);  // my row's entries of columns a,b
+        const double va = __shfl(V, base + a), vb = __shfl(V, base + b);
+        const double alpha = col_reduce(wa * wa), beta = col_reduce(wb * wb), gamma = col_reduce(wa * wb);
+        const double lim = sqrt(alpha) * sqrt(beta);
+        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {  // wave-uniform
+          off = fmax(off, fabs(gamma) / lim);
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+          if (j == a) {
+            W = cs * wa - sn * wb;
+            V = cs * va - sn * vb;
+          } else if (j == b) {
+            W = sn * wa + cs * wb;
+            V = sn * va + cs * vb;
+          }
+        }
+      }
+    }
+    if (off <= 1e-15) break;
+  }
+}
+
+struct SolveIn {
+  const ChainK* ck;
+  const double* c;   // LDS: projections of s*z on the basis (nq values)
+  double rho2;       // |w|^2
+  double wy;         // w . y
+  double tau, s, sigma, scale, maxabs;
+  int K, k, nq;
+  int64_t N;
+  uint32_t flags;
+};
+
+// Completes one proposal: singular values -> rank, Beta, SSE, log-likelihood.  Called by all 64 lanes.
+__device__ __forceinline__ void solve_complete(const SolveIn& in, int lane, bsr_score* out) {
+  const int K = in.K, nq = in.nq, k = in.k;
+  const int i = lane >> 3, j = lane & 7;
+  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
+  double W = 0.0;
+  if (i < K && j < K) {
+    if (j < nq) W = (i <= j) ? in.ck->R[i * BSR_NQ_MAX + j] : 0.0;
+    else W = (i < nq) ? in.c[i] : rho;  // j == nq == K-1
+  }
+  double V = (i == j) ? 1.0 : 0.0;
+  jacobi_svd(W, V, K, lane);
+  const double sv = sqrt(col_reduce(W * W));                       // sigma_j, identical in every row of column j
+  double h = 0.0;                                                   // h_i for the lane's row
+  if (i < nq) h = in.ck->qy[i];
+  else if (i == nq) h = (rho > 0.0) ? in.wy / rho : 0.0;
+  const double hh = col_reduce(((j == 0) ? h : 0.0) * h);          // |h|^2 (column 0 lanes carry one copy)
+  const double hh_all = __shfl(hh, 0);
+  const double tj = col_reduce(W * h);                             // sigma_j * (u_j . h)
+  const double aj = (sv > 0.0 && j < K) ? tj / sv : 0.0;          // u_j . h
+  const double dj = (in.tau * sv) * (in.tau * sv);
+  const double eps = 1e-6;
+  const double wj = eps / (dj + eps);
+  // sums over the K columns, taken from row 0's lanes in a fixed order
+  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
+  int rank = 0;
+  for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a));
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tol = smax * dimmax * 2.220446049250313e-16;       // numpy matrix_rank default tolerance
+  for (int a = 0; a < K; ++a) {
+    const double sva = __shfl(sv, a), aa = __shfl(aj, a), wa = __shfl(wj, a);
+    smin = fmin(smin, sva);
+    rank += (sva > tol) ? 1 : 0;
+    if (sva > 0.0) {
+      misfit = fma(wa * wa, aa * aa, misfit);
+      seen = fma(aa, aa, seen);
+    }
+  }
+  misfit += fmax(0.0, hh_all - seen);                              // directions with sigma == 0 keep all of h
+  const double hz = __shfl(h, nq * 8);                             // w.y / rho
+  const double sse = fmax(0.0, in.ck->yperp2 - hz * hz) + misfit;
+  // Beta' = V diag(tau sigma / (tau^2 sigma^2 + eps)) (U^T h), in S column order -> original tree order
+  const double coef = (j < K) ? (in.tau * sv) / (dj + eps) * aj : 0.0;
+  const double bi = row_reduce(V * coef);                          // Beta'_i, identical in every column of row i
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  if (lane == 0) {
+    out->loglik = ll;
+    out->sse = sse;
+    out->scale = in.scale;
+    out->maxabs = in.maxabs;
+    out->smin = smin / in.s;
+    out->smax = smax / in.s;
+    out->rank = rank;
+    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+  }
+  if (j == 0 && i < BSR_MAX_K) {
+    if (i < K) {
+      const int tree = (i == nq) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bi;
+    }
+  }
+  if (lane >= K && lane < BSR_MAX_K) out->beta[lane] = 0.0;
+}
+
 __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainK* __restrict__ cks,
-                                                    int P, int n_rb, const double* __restrict__ part1,
-                                                    PropCoef* __restrict__ coef) {
+                                                    int P, int n_rb, const double* __restrict__ part1, int64_t N,
+                                                    PropCoef* __restrict__ coef, bsr_score* __restrict__ outv) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   __shared__ double sh_c[8];
-  __shared__ double sh_beta[8];
 
   double sum[9];
 #pragma unroll
@@ -300,13 +429,15 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   fl = wave_or(fl);
   if (fl & BSR_F_INF) amax = INFINITY;
 
-  PropCoef* out = coef + p;
+  PropCoef* cf = coef + p;
+  bsr_score* out = outv + p;
   if (dsc[p].mode == BSR_MODE_EVAL) {
     if (lane == 0) {
+      cf->skip = 1;
       out->maxabs = amax;
       out->flags = fl;
-      out->skip = 1;
-      out->zz = sum[7];
+      out->rank = 0;
+      out->loglik = out->sse = out->scale = out->smin = out->smax = 0.0;
     }
     return;
   }
@@ -314,102 +445,87 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   const double s = dsc[p].s;
   const ChainK* ck = cks + dsc[p].ck;
   const uint32_t flags = fl | ck->flags;
-  const double m_other = ck->m_other;
-  const double scale_ref = fmax(m_other, amax);
-  const double tau = 1.0 / (s * scale_ref);
+  const double scale_ref = fmax(ck->m_other, amax);
+  if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
+    if (lane == 0) {
+      cf->skip = 1;
+      out->loglik = NAN;
+      out->sse = NAN;
+      out->scale = (flags & BSR_F_NAN) ? NAN : INFINITY;
+      out->maxabs = amax;
+      out->smin = out->smax = NAN;
+      out->rank = (flags & BSR_F_NAN) ? -1 : 0;
+      out->flags = flags | BSR_F_RANKDEF;
+    }
+    if (lane < BSR_MAX_K) out->beta[lane] = NAN;
+    return;
+  }
   const double zz = sum[7], zy = sum[8];
-
+  if (nq == 0) {
+    // K == 1: no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
+    const double as = amax * s;
+    if (as > 0.0 && (as > 0x1p400 || as < 0x1p-400)) {
+      if (lane == 0) {
+        cf->skip = 1;
+        out->maxabs = amax;
+        out->flags = flags | BSR_F_SCALE_RETRY;
+        out->rank = 0;
+        out->loglik = out->sse = NAN;
+      }
+      return;
+    }
+  }
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < BSR_NQ_MAX; ++i) sh_c[i] = sum[i];
   }
   __syncthreads();
-
-  const int i = lane >> 3, j = lane & 7;
-  const int oi = (i < k) ? i : i - 1, oj = (j < k) ? j : j - 1;
-  // (R^T c)[a] for the lane's sibling index
-  auto rtc = [&](int a) {
-    double t = 0.0;
-    for (int m = 0; m <= a; ++m) t = fma(ck->R[m * BSR_NQ_MAX + a], sh_c[m], t);
-    return t;
-  };
-  double A = (i == j) ? 1.0 : 0.0;
-  if (i < K && j < K) {
-    double gij;
-    if (i != k && j != k) gij = ck->RtR[oi * BSR_NQ_MAX + oj];
-    else if (i == k && j == k) gij = zz;
-    else gij = rtc((i == k) ? oj : oi);
-    A = tau * (tau * gij);
-    if (i == j) A += 1e-6;
-  }
-  // right-hand side XX^T y, held per column index j in every row
-  double gv = 0.0;
-  if (j < K) gv = tau * ((j == k) ? zy : ck->Rtqy[oj]);
-  double Inv = (i == j) ? 1.0 : 0.0;
-
-  // Gauss-Jordan with partial pivoting on [A | I]; rows >= K are identity and stay untouched
-  for (int col = 0; col < K; ++col) {
-    double best = -1.0;
-    int piv = col;
-    for (int r = col; r < K; ++r) {
-      const double v = fabs(__shfl(A, r * 8 + col));
-      if (v > best) { best = v; piv = r; }
-    }
-    if (piv != col) {
-      const int src = (i == col) ? piv : ((i == piv) ? col : i);
-      A = __shfl(A, src * 8 + j);
-      Inv = __shfl(Inv, src * 8 + j);
-    }
-    const double d = __shfl(A, col * 8 + col);
-    const double rowA = __shfl(A, col * 8 + j);
-    const double rowI = __shfl(Inv, col * 8 + j);
-    const double f = __shfl(A, i * 8 + col) / d;
-    if (i == col) {
-      A = rowA / d;
-      Inv = rowI / d;
-    } else {
-      A = A - f * rowA;
-      Inv = Inv - f * rowI;
+  double cc = 0.0, cqy = 0.0;
+#pragma unroll
+  for (int i = 0; i < BSR_NQ_MAX; ++i) {
+    if (i < nq) {
+      cc = fma(sum[i], sum[i], cc);
+      cqy = fma(sum[i], ck->qy[i], cqy);
     }
   }
-  // Beta = inv(A) @ (XX^T y)
-  double t = Inv * gv;
-  t += __shfl_xor(t, 1);
-  t += __shfl_xor(t, 2);
-  t += __shfl_xor(t, 4);
-  if (j == 0) sh_beta[i] = t;
-  __syncthreads();
-
-  if (lane < nq) {
-    double gam = 0.0;
-    for (int b = lane; b < nq; ++b) {
-      const int ob = (b < k) ? b : b + 1;
-      gam = fma(ck->R[lane * BSR_NQ_MAX + b], sh_beta[ob], gam);
+  const double rho2 = zz - cc;
+  // the candidate is (nearly) inside the sibling span: |w|^2 and w.y come from the direct residual pass instead
+  const bool ambiguous = (nq > 0) && !(rho2 > 1e-6 * zz);
+  if (ambiguous) {
+    if (lane < BSR_NQ_MAX) cf->c[lane] = (lane < nq) ? sh_c[lane] : 0.0;
+    if (lane == 0) {
+      cf->s = s;
+      cf->zz = zz;
+      cf->tau = 1.0 / (s * scale_ref);
+      cf->scale = scale_ref;
+      cf->maxabs = amax;
+      cf->flags = flags;
+      cf->skip = 0;
     }
-    out->g[lane] = tau * gam;
-    out->c[lane] = sh_c[lane];
+    return;
   }
-  if (lane < K) out->beta[lane] = sh_beta[lane];
-  if (lane == 0) {
-    out->bz = tau * s * sh_beta[k];
-    out->s = s;
-    out->zz = zz;
-    out->tau = tau;
-    out->scale = scale_ref;
-    out->maxabs = amax;
-    uint32_t f2 = flags;
-    if (nq == 0 && !(flags & (BSR_F_INF | BSR_F_NAN))) {
-      // K == 1: no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
-      const double as = amax * s;
-      if (as > 0.0 && (as > 0x1p400 || as < 0x1p-400)) f2 |= BSR_F_SCALE_RETRY;
-    }
-    out->flags = f2;
-    out->skip = (f2 & (BSR_F_INF | BSR_F_NAN | BSR_F_SCALE_RETRY)) ? 1 : 0;
-  }
+  if (lane == 0) cf->skip = 1;
+  SolveIn in;
+  in.ck = ck;
+  in.c = sh_c;
+  in.rho2 = rho2;
+  in.wy = zy - cqy;
+  in.tau = 1.0 / (s * scale_ref);
+  in.s = s;
+  in.sigma = dsc[p].sigma;
+  in.scale = scale_ref;
+  in.maxabs = amax;
+  in.K = K;
+  in.k = k;
+  in.nq = nq;
+  in.N = N;
+  in.flags = flags;
+  solve_complete(in, lane, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 2: residual sum of squares with the solved weights + residual of the candidate against the sibling basis.
+// pass 2 (only proposals flagged by k_solve): direct residual of the candidate against the sibling basis,
+// w = s z - Q c, accumulated as |w|^2 and w.y.
 template <typename T, int U>
 __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass2(const T* __restrict__ y, int64_t ld, int64_t N,
                                                                   const PropDesc* __restrict__ desc,
@@ -431,89 +547,43 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass2(const T* __res
     const int nq = dsc[p].nq;
     const T* qbase = (const T*)dsc[p].qbase;
     const T* z = (const T*)dsc[p].zout;
-    const double s = cf[p].s, bz = cf[p].bz;
-    double g[BSR_NQ_MAX], c[BSR_NQ_MAX];
+    const double s = cf[p].s;
+    double c[BSR_NQ_MAX];
 #pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX; ++i) {
-      g[i] = cf[p].g[i];
-      c[i] = cf[p].c[i];
-    }
-    double sse = 0.0, rho2 = 0.0;
+    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = cf[p].c[i];
+    double ww = 0.0, wy = 0.0;
     for (int it = 0; it < iters; ++it) {
       const int64_t r0 = row_base + (int64_t)it * (BSR_WAVE * U) + lane * U;
-      double zv[U], fit[U], w[U];
+      double w[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        zv[u] = (double)z[r0 + u];
-        fit[u] = bz * zv[u];
-        w[u] = s * zv[u];
-      }
+      for (int u = 0; u < U; ++u) w[u] = s * (double)z[r0 + u];
 #pragma unroll
       for (int i = 0; i < BSR_NQ_MAX; ++i) {
         if (i < nq) {
           const T* q = qbase + (int64_t)i * ld + r0;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const double qv = (double)q[u];
-            fit[u] = fma(g[i], qv, fit[u]);
-            w[u] = fma(-c[i], qv, w[u]);
-          }
+          for (int u = 0; u < U; ++u) w[u] = fma(-c[i], (double)q[u], w[u]);
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if ((r0 + u) < N) {
-          const double r = (double)y[r0 + u] - fit[u];
-          sse = fma(r, r, sse);
-          rho2 = fma(w[u], w[u], rho2);
+          ww = fma(w[u], w[u], ww);
+          wy = fma(w[u], (double)y[r0 + u], wy);
         }
       }
     }
-    sse = wave_sum(sse);
-    rho2 = wave_sum(rho2);
+    ww = wave_sum(ww);
+    wy = wave_sum(wy);
     if (lane == 0) {
       double* o = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
-      o[0] = sse;
-      o[1] = rho2;
+      o[0] = ww;
+      o[1] = wy;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// finalize: one wave per proposal; one-sided Jacobi on the K x K factor [[R, c],[0, rho]] held one element per lane.
-__device__ __forceinline__ double col_reduce(double v) {  // sum over the 8 rows of a column (lanes differ in bits 3..5)
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-
-// Returns, in every lane, the singular value belonging to the lane's column j (valid for j < K).
-__device__ __forceinline__ double jacobi_singular_values(double S, int K, int lane) {
-  const int j = lane & 7;
-  const int base = lane & ~7;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    double off = 0.0;
-    for (int a = 0; a < K - 1; ++a) {
-      for (int b = a + 1; b < K; ++b) {
-        const double sa = __shfl(S, base + a), sb = __shfl(S, base + b);  // my row's entries of columns a,b
-        const double alpha = col_reduce(sa * sa), beta = col_reduce(sb * sb), gamma = col_reduce(sa * sb);
-        const double lim = sqrt(alpha) * sqrt(beta);
-        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {  // wave-uniform condition
-          off = fmax(off, fabs(gamma) / lim);
-          const double zeta = (beta - alpha) / (2.0 * gamma);
-          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-          if (j == a) S = cs * sa - sn * sb;
-          else if (j == b) S = sn * sa + cs * sb;
-        }
-      }
-    }
-    if (off <= 1e-15) break;
-  }
-  return sqrt(col_reduce(S * S));
-}
-
+// finalize (only proposals flagged by k_solve): same algebra with the directly measured |w|^2 and w.y
 __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
                                                        const ChainK* __restrict__ cks,
                                                        const PropCoef* __restrict__ coef, int P, int n_rb,
@@ -523,85 +593,37 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   const PropCoef* cf = coef + p;
-  bsr_score* out = outv + p;
-  const uint32_t flags = cf->flags;
-  if (dsc[p].mode == BSR_MODE_EVAL) {
-    if (lane == 0) {
-      out->maxabs = cf->maxabs;
-      out->flags = flags;
-      out->rank = 0;
-      out->loglik = out->sse = out->scale = out->smin = out->smax = 0.0;
-    }
-    return;
-  }
-  const int K = dsc[p].K, nq = dsc[p].nq;
-  if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
-    if (lane == 0) {
-      out->loglik = NAN;
-      out->sse = NAN;
-      out->scale = cf->scale;
-      out->maxabs = cf->maxabs;
-      out->smin = out->smax = NAN;
-      out->rank = (flags & BSR_F_NAN) ? -1 : 0;
-      out->flags = flags | BSR_F_RANKDEF;
-    }
-    if (lane < BSR_MAX_K) out->beta[lane] = NAN;
-    return;
-  }
-  if (flags & BSR_F_SCALE_RETRY) {
-    if (lane == 0) {
-      out->maxabs = cf->maxabs;
-      out->flags = flags;
-      out->rank = 0;
-      out->loglik = out->sse = NAN;
-    }
-    return;
-  }
-  double sse = 0.0, rho2 = 0.0;
+  if (cf->skip) return;
+  __shared__ double sh_c[8];
+  double ww = 0.0, wy = 0.0;
   for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
     const double* q = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
-    sse += q[0];
-    rho2 += q[1];
+    ww += q[0];
+    wy += q[1];
   }
-  sse = wave_sum(sse);
-  rho2 = wave_sum(rho2);
-
-  // K x K factor with the singular values of s*new_outputs: [[R, c], [0, rho]]
-  const ChainK* ck = cks + dsc[p].ck;
-  const int i = lane >> 3, j = lane & 7;
-  double S = 0.0;
-  if (i < K && j < K) {
-    if (j < nq) S = (i <= j) ? ck->R[i * BSR_NQ_MAX + j] : 0.0;
-    else S = (i < nq) ? cf->c[i] : sqrt(rho2);  // j == nq == K-1
-  }
-  const double sv = jacobi_singular_values(S, K, lane);
-  double smax = 0.0, smin = INFINITY;
-  for (int a = 0; a < K; ++a) {
-    const double v = __shfl(sv, a);
-    smax = fmax(smax, v);
-    smin = fmin(smin, v);
-  }
-  // np.linalg.matrix_rank default tolerance: S.max() * max(M.shape) * eps; rank = count(S > tol)
-  const double dimmax = (double)((N > (int64_t)K) ? N : (int64_t)K);
-  const double tol = smax * dimmax * 2.220446049250313e-16;
-  int rank = 0;
-  for (int a = 0; a < K; ++a) rank += (__shfl(sv, a) > tol) ? 1 : 0;
-  // codes/funcs.py:1172-1173
-  const double sigma = dsc[p].sigma;
-  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)N * log(2 * M_PI * sigma * sigma);
-  if (lane == 0) {
-    out->loglik = ll;
-    out->sse = sse;
-    out->scale = cf->scale;
-    out->maxabs = cf->maxabs;
-    out->smin = smin / cf->s;
-    out->smax = smax / cf->s;
-    out->rank = rank;
-    out->flags = flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
-  }
-  if (lane < BSR_MAX_K) out->beta[lane] = (lane < K) ? cf->beta[lane] : 0.0;
+  ww = wave_sum(ww);
+  wy = wave_sum(wy);
+  if (lane < 8) sh_c[lane] = (lane < BSR_NQ_MAX) ? cf->c[lane] : 0.0;
+  __syncthreads();
+  SolveIn in;
+  in.ck = cks + dsc[p].ck;
+  in.c = sh_c;
+  in.rho2 = ww;
+  in.wy = wy;
+  in.tau = cf->tau;
+  in.s = cf->s;
+  in.sigma = dsc[p].sigma;
+  in.scale = cf->scale;
+  in.maxabs = cf->maxabs;
+  in.K = dsc[p].K;
+  in.k = dsc[p].k;
+  in.nq = dsc[p].nq;
+  in.N = N;
+  in.flags = cf->flags;
+  solve_complete(in, lane, outv + p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------
 // rare path: single-workgroup kernels (1024 threads = 16 waves)
 #define BSR_BLK 1024
@@ -723,19 +745,25 @@ __global__ __launch_bounds__(BSR_BLK) void k_refresh_basis(const T* __restrict__
     }
   }
   __syncthreads();
-  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) {
-    const int a = threadIdx.x / BSR_NQ_MAX, b = threadIdx.x % BSR_NQ_MAX;
-    ck->R[threadIdx.x] = shR[threadIdx.x];
-    double t = 0.0;
-    for (int mm = 0; mm < BSR_NQ_MAX; ++mm) t = fma(shR[mm * BSR_NQ_MAX + a], shR[mm * BSR_NQ_MAX + b], t);
-    ck->RtR[threadIdx.x] = t;
-    if (b == 0) {
-      double u = 0.0;
-      for (int mm = 0; mm < BSR_NQ_MAX; ++mm) u = fma(shR[mm * BSR_NQ_MAX + a], shqy[mm], u);
-      ck->Rtqy[a] = u;
+  // |y - Q Q^T y|^2 measured directly (with no finite basis: |y|^2)
+  double yp[1] = {0.0};
+  {
+    const bool useq = !(flags & (BSR_F_INF | BSR_F_NAN));
+    for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+      double r = (double)y[n];
+      if (useq) {
+#pragma unroll
+        for (int i = 0; i < BSR_NQ_MAX; ++i)
+          if (i < nq) r = fma(-shqy[i], (double)Q[(int64_t)i * ld + n], r);
+      }
+      yp[0] = fma(r, r, yp[0]);
     }
   }
+  block_sum<1>(yp, sh);
+  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) ck->R[threadIdx.x] = shR[threadIdx.x];
+  if (threadIdx.x < BSR_NQ_MAX) ck->qy[threadIdx.x] = shqy[threadIdx.x];
   if (threadIdx.x == 0) {
+    ck->yperp2 = yp[0];
     ck->s = s;
     ck->m_other = m_other;
     ck->flags = flags;
@@ -965,8 +993,8 @@ void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, i
   hipLaunchKernelGGL((k_pass2<T, 2>), grid, block, 0, st, y, ld, N, desc, coef, P, g.rb_rows, g.pg, g.n_rb, part2);
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
-                  PropCoef* coef) {
-  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, coef);
+                  int64_t N, PropCoef* coef, bsr_score* out) {
+  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out) {
