@@ -130,8 +130,9 @@ int bsr_eval_tapes(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, 
 
 /* (Re)computes current column k of `chain` from its tape (initial trees, codes/bsr_class.py:128-151). */
 int bsr_set_current(bsr_ctx* ctx, int32_t chain, int32_t k, const bsr_node* tape, int32_t len);
-/* Adopts candidate `slot` of the LAST bsr_score_batch call as current column k of `chain`
- * (an accepted proposal, codes/bsr_class.py:200-204); no re-evaluation. */
+/* Adopts candidate `slot` of the LAST scored batch (bsr_score_batch / the last bsr_score_wait) as current column k
+ * of `chain` (an accepted proposal, codes/bsr_class.py:200-204).  Candidate columns are not kept by the scoring
+ * pass; the still-staged tape is re-run straight into the chain cache. */
 int bsr_commit(bsr_ctx* ctx, int32_t chain, int32_t k, int32_t slot);
 /* Rebuilds the chain's cached factors (leave-one-out orthonormal bases, old-state SSE). Must be
  * called after bsr_set_current/bsr_commit and before the next bsr_score_batch on that chain. */
@@ -145,6 +146,14 @@ int bsr_refresh(bsr_ctx* ctx, int32_t chain, bsr_chain_info* info);
  * leaves the chain unchanged, codes/funcs.py:1300-1303).  B <= max_batch. */
 int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                     const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out);
+
+/* Asynchronous form of bsr_score_batch: submit enqueues upload + kernels + download and returns at once with a
+ * ticket (0 or 1); wait blocks until that batch is done and copies its B results.  Two batches may be in flight, so
+ * the host can stage batch i+1 while the GPU scores batch i (chains of batch i+1 must not depend on accepts of
+ * batch i).  bsr_commit refers to the batch most recently waited for. */
+int bsr_score_submit(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                     const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket);
+int bsr_score_wait(bsr_ctx* ctx, int32_t ticket, bsr_score* out);
 
 /* ---- on-accept / initial OLS with intercept: codes/bsr_class.py:147-163, 211-233 */
 
@@ -164,10 +173,11 @@ int bsr_yloglike_host(int device, int64_t N, int32_t K, const double* outputs_ro
 
 /* ---- timing hooks for bench.py (HIP events on the ctx stream) --------------- */
 
-/* Average duration in microseconds of each kernel of the LAST bsr_score_batch call:
- * us[0]=tree-eval+dots pass, us[1]=K x K solve, us[2]=residual pass, us[3]=finalise, us[4]=whole batch
- * (first launch to last, device time).  Valid only if profiling was enabled. */
-int bsr_set_profiling(bsr_ctx* ctx, int32_t enable);
+/* HIP-event timing of the LAST waited batch, in microseconds.  level 1: events around the row pass only
+ * (us[0] = tree-eval + projection kernel; what bench.py uses in its timed region); level 2: events around every
+ * kernel: us[1]=K x K solve, us[2]=residual pass, us[3]=finalise, us[4]=first launch to last (diagnostic: each
+ * event adds a few microseconds of its own).  level 0 disables. */
+int bsr_set_profiling(bsr_ctx* ctx, int32_t level);
 int bsr_last_timing(bsr_ctx* ctx, double* us5);
 
 /* ---- multi-GPU: one process per GPU, one gather of accepted trees */

@@ -62,6 +62,8 @@ def lib():
         "bsr_commit": (C.c_int, [vp, i32, i32, i32]),
         "bsr_refresh": (C.c_int, [vp, i32, C.POINTER(ChainInfo)]),
         "bsr_score_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp]),
+        "bsr_score_submit": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, pi]),
+        "bsr_score_wait": (C.c_int, [vp, i32, vp]),
         "bsr_fit_beta": (C.c_int, [vp, i32, vp, pd]),
         "bsr_get_current": (C.c_int, [vp, i32, vp]),
         "bsr_yloglike_host": (C.c_int, [C.c_int, i64, i32, vp, vp, dbl, i32, pd, pd, pd, vp, pi]),
@@ -83,7 +85,8 @@ def lib():
 
 
 EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_destroy", "bsr_last_error",
-           "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_fit_beta",
+           "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_score_submit",
+           "bsr_score_wait", "bsr_fit_beta",
            "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_comm_unique_id",
            "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy"]
 

@@ -86,6 +86,18 @@ class DeviceContext:
         _lib.check(rc, self._h)
         return out
 
+    def score_submit(self, rows, off, chains, ks, sig):
+        """Asynchronous scoring: enqueue a pre-packed batch, return its ticket (two batches may be in flight)."""
+        t = C.c_int32(-1)
+        rc = self._L.bsr_score_submit(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
+                                      _lib.ptr(sig), len(chains), C.byref(t))
+        _lib.check(rc, self._h)
+        return t.value
+
+    def score_wait(self, ticket, out):
+        _lib.check(self._L.bsr_score_wait(self._h, ticket, _lib.ptr(out)), self._h)
+        return out
+
     def fit_beta(self, chain):
         beta = np.empty(self.K + 1, dtype=np.float64)
         rmse = C.c_double(0.0)
@@ -98,8 +110,9 @@ class DeviceContext:
         return out
 
     # ---- profiling
-    def set_profiling(self, on=True):
-        _lib.check(self._L.bsr_set_profiling(self._h, 1 if on else 0), self._h)
+    def set_profiling(self, level=1):
+        """0 off, 1 events around the row pass only, 2 events around every kernel (diagnostic)."""
+        _lib.check(self._L.bsr_set_profiling(self._h, int(level)), self._h)
 
     def last_timing(self):
         us = np.zeros(5, dtype=np.float64)

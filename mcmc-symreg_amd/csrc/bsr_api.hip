@@ -14,6 +14,38 @@
 
 static thread_local std::string g_create_error;
 
+struct TapeLoc {
+  int code_off, n_nodes, feat_off, ln_off, max_sp;
+};
+
+// Everything one batch in flight owns.  Two slots let the host stage batch i+1 while the GPU scores batch i.
+// The input block is one pinned host buffer mirrored by one device buffer and uploaded with a single copy:
+//   [ feature list (d int32) | descriptors (max_batch + 1 PropDesc) | opcode words | column words | ln pairs ]
+struct BatchSlot {
+  uint8_t* h_in = nullptr;
+  uint8_t* d_in = nullptr;
+  size_t in_cap = 0;
+  size_t off_desc = 0, off_streams = 0;
+  size_t code_words = 0, feat_words = 0, ln_words = 0;
+  bsr_score* d_out = nullptr;
+  bsr_score* h_out = nullptr;
+  hipEvent_t done = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int P = 0;
+  int nF = 0;
+  bool use_lds = false;
+  int rb_rows = 512;
+  bool pending = false;
+  bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
+
+  int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
+  PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
+  uint64_t* h_streams() const { return reinterpret_cast<uint64_t*>(h_in + off_streams); }
+  const int32_t* d_feat() const { return reinterpret_cast<const int32_t*>(d_in); }
+  PropDesc* d_desc() const { return reinterpret_cast<PropDesc*>(d_in + off_desc); }
+  const uint64_t* d_streams() const { return reinterpret_cast<const uint64_t*>(d_in + off_streams); }
+};
+
 struct bsr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -25,35 +57,31 @@ struct bsr_ctx {
   void* y = nullptr;
   void* cur = nullptr;   // [chain][k][ld]
   void* Q = nullptr;     // [chain][k][K-1][ld]
-  void* zbuf = nullptr;  // [max_batch][ld]
+  void* zbuf = nullptr;  // [max_batch][ld], allocated on the first bsr_eval_tapes that wants columns
   ChainK* d_ck = nullptr;
   std::vector<ChainK> h_ck;
   ChainFitOut* d_fit = nullptr;  // [chain] no-intercept fit (also carries per-column max/flags) + 1 scratch slot
   std::vector<ChainFitOut> h_fit;
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
-  // per-batch buffers
-  bsr_node* d_tapes = nullptr;
-  bsr_node* h_tapes = nullptr;
-  size_t tapes_cap = 0;
-  PropDesc* d_desc = nullptr;
-  PropDesc* h_desc = nullptr;
+  BatchSlot slot[2];
+  int next_slot = 0;
+  int last_waited = -1;
   PropCoef* d_coef = nullptr;
-  bsr_score* d_out = nullptr;
-  bsr_score* h_out = nullptr;
   double* part1 = nullptr;
   double* part2 = nullptr;
-  size_t part_cap = 0;  // in (proposal,row block) records
-  double* spill = nullptr;
+  size_t part_cap = 0;   // in (proposal,row block) records
+  void* spill = nullptr;
   size_t spill_cap = 0;  // bytes
   double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
-  int last_B = 0;
+  std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
   // tuning
   int rb_rows = 512;
   int target_wgs = 2048;
-  // profiling
-  bool prof = false;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int rows_per_lane = 2;
+  int no_lds = 0;
+  // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
+  int prof = 0;
   double last_us[5] = {0, 0, 0, 0, 0};
   ncclComm_t comm = nullptr;
   void* comm_buf = nullptr;
@@ -108,13 +136,17 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
-  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_tapes, c->d_desc, c->d_coef,
-                 c->d_out, c->part1, c->part2, c->spill, c->d_stage, c->comm_buf};
+  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_coef, c->part1, c->part2, c->spill,
+                 c->d_stage, c->comm_buf};
   for (void* p : dev) if (p) (void)hipFree(p);
-  if (c->h_tapes) (void)hipHostFree(c->h_tapes);
-  if (c->h_desc) (void)hipHostFree(c->h_desc);
-  if (c->h_out) (void)hipHostFree(c->h_out);
-  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (BatchSlot& s : c->slot) {
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.done) (void)hipEventDestroy(s.done);
+    for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return BSR_OK;
@@ -142,7 +174,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
                               int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype) {
   if (!out) return BSR_E_ARG;
   *out = nullptr;
-  if (!X || N <= 0 || d <= 0 || d > 64 * 1024) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
+  if (!X || N <= 0 || d <= 0 || d > 65536) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
   if (K < 0 || K > BSR_MAX_K || n_chains < 0 || max_batch <= 0)
     return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad K/n_chains/max_batch");
   if (dtype != BSR_DTYPE_F64 && dtype != BSR_DTYPE_F32) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad dtype");
@@ -160,9 +192,15 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   c->dtype = dtype;
   c->esz = (dtype == BSR_DTYPE_F64) ? 8 : 4;
   c->has_y = (y != nullptr);
+  c->rows_per_lane = env_int("BSR_P1_U", 2);
+  if (c->rows_per_lane != 2 && c->rows_per_lane != 4 && c->rows_per_lane != 8) c->rows_per_lane = 2;
   c->rb_rows = env_int("BSR_RB_ROWS", 512);
-  if (c->rb_rows < 128 || c->rb_rows > BSR_ROW_ALIGN || (BSR_ROW_ALIGN % c->rb_rows) != 0) c->rb_rows = 512;
+  if (c->rb_rows < 256 || c->rb_rows > BSR_ROW_ALIGN || (BSR_ROW_ALIGN % c->rb_rows) != 0 ||
+      (c->rb_rows % (64 * c->rows_per_lane)) != 0)
+    c->rb_rows = 512;
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
+  c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
+  c->slot_of.assign(d, -1);
   int rc = BSR_OK;
   auto bail = [&](int code) {
     g_create_error = c->err;
@@ -184,8 +222,6 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   CK(hipMemsetAsync(c->Xt, 0, colb * d, c->stream));
   CK(hipMalloc(&c->y, colb));
   CK(hipMemsetAsync(c->y, 0, colb, c->stream));
-  CK(hipMalloc(&c->zbuf, colb * max_batch));
-  CK(hipMemsetAsync(c->zbuf, 0, colb * max_batch, c->stream));
   if (K > 0 && n_chains > 0) {
     CK(hipMalloc(&c->cur, colb * n_chains * K));
     CK(hipMemsetAsync(c->cur, 0, colb * n_chains * K, c->stream));
@@ -201,12 +237,15 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
   c->h_fit.resize(n_chains + 1);
-  CK(hipMalloc((void**)&c->d_desc, sizeof(PropDesc) * max_batch));
-  CK(hipHostMalloc((void**)&c->h_desc, sizeof(PropDesc) * max_batch));
-  CK(hipMalloc((void**)&c->d_coef, sizeof(PropCoef) * max_batch));
-  CK(hipMalloc((void**)&c->d_out, sizeof(bsr_score) * max_batch));
-  CK(hipHostMalloc((void**)&c->h_out, sizeof(bsr_score) * max_batch));
-  for (auto& e : c->ev) CK(hipEventCreate(&e));
+  CK(hipMalloc((void**)&c->d_coef, sizeof(PropCoef) * (max_batch + 1)));
+  for (BatchSlot& s : c->slot) {
+    s.off_desc = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
+    CK(hipMalloc((void**)&s.d_out, sizeof(bsr_score) * (max_batch + 1)));
+    CK(hipHostMalloc((void**)&s.h_out, sizeof(bsr_score) * (max_batch + 1)));
+    CK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    for (auto& e : s.ev) CK(hipEventCreate(&e));
+  }
 #undef CK
   rc = (dtype == BSR_DTYPE_F64) ? upload_data<double>(c, X, y) : upload_data<float>(c, X, y);
   if (rc != BSR_OK) return bail(rc);
@@ -240,22 +279,23 @@ static int check_tape(bsr_ctx* c, const bsr_node* t, int len, int* max_sp) {
   return BSR_OK;
 }
 
-static int ensure_tapes(bsr_ctx* c, size_t rows) {
-  if (rows <= c->tapes_cap) return BSR_OK;
-  size_t cap = std::max(rows, std::max((size_t)4096, c->tapes_cap * 2));
-  if (c->d_tapes) HIPCHK(c, hipFree(c->d_tapes));
-  if (c->h_tapes) HIPCHK(c, hipHostFree(c->h_tapes));
-  c->d_tapes = nullptr;
-  c->h_tapes = nullptr;
-  HIPCHK(c, hipMalloc((void**)&c->d_tapes, cap * sizeof(bsr_node)));
-  HIPCHK(c, hipHostMalloc((void**)&c->h_tapes, cap * sizeof(bsr_node)));
-  c->tapes_cap = cap;
+static int ensure_input(bsr_ctx* c, BatchSlot& s, size_t stream_words) {
+  const size_t need = s.off_streams + stream_words * 8;
+  if (need <= s.in_cap) return BSR_OK;
+  const size_t cap = std::max(need, std::max(s.off_streams + (size_t)64 * 1024, s.in_cap * 2));
+  if (s.d_in) HIPCHK(c, hipFree(s.d_in));
+  if (s.h_in) HIPCHK(c, hipHostFree(s.h_in));
+  s.d_in = nullptr;
+  s.h_in = nullptr;
+  HIPCHK(c, hipMalloc((void**)&s.d_in, cap));
+  HIPCHK(c, hipHostMalloc((void**)&s.h_in, cap));
+  s.in_cap = cap;
   return BSR_OK;
 }
 
-static LaunchGeom geometry(const bsr_ctx* c, int P) {
+static LaunchGeom geometry(const bsr_ctx* c, const BatchSlot& s, int P) {
   LaunchGeom g;
-  g.rb_rows = c->rb_rows;
+  g.rb_rows = s.rb_rows;
   g.n_rb = (int)((c->N + g.rb_rows - 1) / g.rb_rows);
   const int want_pg = std::max(1, c->target_wgs / g.n_rb);       // proposal groups wanted
   int pg = (P + want_pg - 1) / want_pg;                            // proposals per workgroup
@@ -269,6 +309,7 @@ static LaunchGeom geometry(const bsr_ctx* c, int P) {
 static int ensure_partials(bsr_ctx* c, const LaunchGeom& g, int P, int spill_slots) {
   const size_t recs = (size_t)P * g.n_rb;
   if (recs > c->part_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // a batch in flight may still use the old buffers
     if (c->part1) HIPCHK(c, hipFree(c->part1));
     if (c->part2) HIPCHK(c, hipFree(c->part2));
     c->part1 = c->part2 = nullptr;
@@ -278,107 +319,258 @@ static int ensure_partials(bsr_ctx* c, const LaunchGeom& g, int P, int spill_slo
     c->part_cap = cap;
   }
   if (spill_slots > 0) {
-    const size_t need = (size_t)g.n_rb * g.n_pg * BSR_WG_WAVES * spill_slots * BSR_WAVE * 2 * c->esz;
+    const size_t need = (size_t)((g.n_rb + 7) / 8 * 8) * g.n_pg * BSR_WG_WAVES * spill_slots * BSR_WAVE * 8 * c->esz;
     if (need > c->spill_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
       if (c->spill) HIPCHK(c, hipFree(c->spill));
       c->spill = nullptr;
-      HIPCHK(c, hipMalloc((void**)&c->spill, need));
+      HIPCHK(c, hipMalloc(&c->spill, need));
       c->spill_cap = need;
     }
   }
   return BSR_OK;
 }
 
-// Runs the four kernels over the P descriptors already in h_desc (tapes already uploaded); results land in h_out.
-static int run_descs(bsr_ctx* c, int P, bool need_pass2) {
-  int spill_slots = 0;
-  for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, c->h_desc[i].spill_need);
-  const LaunchGeom g = geometry(c, P);
-  int rc = ensure_partials(c, g, P, spill_slots);
-  if (rc != BSR_OK) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PropDesc) * P, hipMemcpyHostToDevice, c->stream));
-  const bool f64 = (c->dtype == BSR_DTYPE_F64);
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (f64)
-    launch_pass1<double>(c->stream, g, (const double*)c->Xt, c->has_y ? (const double*)c->y : nullptr, c->ld, c->N,
-                         c->d_tapes, c->d_desc, P, c->part1, spill_slots ? c->spill : nullptr, spill_slots);
-  else
-    launch_pass1<float>(c->stream, g, (const float*)c->Xt, c->has_y ? (const float*)c->y : nullptr, c->ld, c->N,
-                        c->d_tapes, c->d_desc, P, c->part1, spill_slots ? c->spill : nullptr, spill_slots);
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  launch_solve(c->stream, c->d_desc, c->d_ck, P, g.n_rb, c->part1, c->N, c->d_coef, c->d_out);
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  if (need_pass2) {
-    if (f64)
-      launch_pass2<double>(c->stream, g, (const double*)c->y, c->ld, c->N, c->d_desc, c->d_coef, P, c->part2);
-    else
-      launch_pass2<float>(c->stream, g, (const float*)c->y, c->ld, c->N, c->d_desc, c->d_coef, P, c->part2);
-  }
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-  if (need_pass2) launch_finalize(c->stream, c->d_desc, c->d_ck, c->d_coef, P, g.n_rb, c->part2, c->N, c->d_out);
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(bsr_score) * P, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipGetLastError());
-  if (c->prof) {
-    float ms = 0;
-    for (int i = 0; i < 4; ++i) {
-      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-      c->last_us[i] = ms * 1e3;
-    }
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
-    c->last_us[4] = ms * 1e3;
-  }
-  return BSR_OK;
-}
-
-static int stage_tapes(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, int n, std::vector<int>* max_sp) {
+// Validates the tapes, chooses LDS staging, and writes the compact streams the interpreter reads into the slot's
+// pinned input block:
+//   opcode stream  : 4 bits per node, 16 nodes per 64-bit word, one padding word per tape
+//   column stream  : 16 bits per terminal in tape order (LDS slot when staging, else the X column), 4 per word,
+//                    padded with a valid id so the kernel may request one terminal past the end
+//   ln stream      : (a,b) per ln node in tape order plus one padding pair
+static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* tape_off, int n,
+                       std::vector<TapeLoc>* loc) {
   if (!rows || !tape_off || n <= 0) return fail(c, BSR_E_ARG, "null tapes / empty batch");
   if (n > c->max_batch) return fail(c, BSR_E_TOOBIG, "batch larger than max_batch");
   if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
-  max_sp->resize(n);
+  loc->resize(n);
+  size_t cw = 0, fw = 0, lw = 0;
+  std::fill(c->slot_of.begin(), c->slot_of.end(), -1);
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
-    int rc = check_tape(c, rows + tape_off[i], len, &(*max_sp)[i]);
+    TapeLoc& L = (*loc)[i];
+    int rc = check_tape(c, rows + tape_off[i], len, &L.max_sp);
     if (rc != BSR_OK) return rc;
+    int nt = 0, nl = 0;
+    for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
+      if (rows[j].opcode == BSR_OP_TERMINAL) {
+        ++nt;
+        c->slot_of[rows[j].feature] = 0;
+      } else if (rows[j].opcode == BSR_OP_LN) {
+        ++nl;
+      }
+    }
+    L.n_nodes = len;
+    L.code_off = (int)cw;
+    L.feat_off = (int)fw;
+    L.ln_off = (int)lw;
+    cw += (size_t)(len + 15) / 16 + 1;
+    fw += (size_t)(nt + 1 + 3) / 4 + 1;
+    lw += (size_t)nl + 1;
   }
-  const size_t total = (size_t)tape_off[n];
-  int rc = ensure_tapes(c, total);
+  int rc = ensure_input(c, s, cw + fw + 2 * lw);
   if (rc != BSR_OK) return rc;
-  memcpy(c->h_tapes, rows, total * sizeof(bsr_node));
-  HIPCHK(c, hipMemcpyAsync(c->d_tapes, c->h_tapes, total * sizeof(bsr_node), hipMemcpyHostToDevice, c->stream));
+  // columns of X referenced by this batch -> LDS slots (ascending feature order)
+  s.nF = 0;
+  int32_t* hfeat = s.h_feat();
+  for (int f = 0; f < c->d; ++f)
+    if (c->slot_of[f] == 0) {
+      c->slot_of[f] = s.nF;
+      hfeat[s.nF++] = f;
+    }
+  const size_t lds_budget = 64 * 1024;
+  s.use_lds = false;
+  s.rb_rows = c->rb_rows;
+  if (!c->no_lds) {
+    for (int rb = c->rb_rows; rb >= 64 * c->rows_per_lane && rb >= 256; rb >>= 1) {
+      if ((size_t)(s.nF + 1) * rb * c->esz <= lds_budget) {
+        s.use_lds = true;
+        s.rb_rows = rb;
+        break;
+      }
+    }
+  }
+  s.code_words = cw;
+  s.feat_words = fw;
+  s.ln_words = 2 * lw;
+  uint64_t* hc = s.h_streams();
+  uint64_t* hf = hc + cw;
+  double* hl = reinterpret_cast<double*>(hf + fw);
+  memset(hc, 0, (cw + fw) * 8);
+  for (int i = 0; i < n; ++i) {
+    const TapeLoc& L = (*loc)[i];
+    uint64_t* pc = hc + L.code_off;
+    uint64_t* pf = hf + L.feat_off;
+    double* pl = hl + 2 * (size_t)L.ln_off;
+    int nt = 0, nl = 0;
+    for (int j = 0; j < L.n_nodes; ++j) {
+      const bsr_node& r = rows[tape_off[i] + j];
+      pc[j >> 4] |= (uint64_t)(r.opcode & 15) << (4 * (j & 15));
+      if (r.opcode == BSR_OP_TERMINAL) {
+        const uint64_t id = (uint64_t)(s.use_lds ? c->slot_of[r.feature] : r.feature);
+        pf[nt >> 2] |= id << (16 * (nt & 3));
+        ++nt;
+      } else if (r.opcode == BSR_OP_LN) {
+        pl[2 * nl] = r.a;
+        pl[2 * nl + 1] = r.b;
+        ++nl;
+      }
+    }
+    pl[2 * nl] = 1.0;
+    pl[2 * nl + 1] = 0.0;
+    if (!s.use_lds) {  // padding ids must name a valid column: repeat the first terminal's
+      const uint64_t id0 = pf[0] & 0xFFFFu;
+      const int words = (nt + 1 + 3) / 4 + 1;
+      for (int t = nt; t < words * 4; ++t) pf[t >> 2] |= id0 << (16 * (t & 3));
+    }
+  }
   return BSR_OK;
 }
 
-static void fill_eval_desc(bsr_ctx* c, PropDesc* D, int off, int len, int max_sp, void* zout) {
+static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
   memset(D, 0, sizeof *D);
-  D->tape_off = off;
-  D->tape_len = len;
+  D->code_off = L.code_off;
+  D->n_nodes = L.n_nodes;
+  D->feat_off = L.feat_off;
+  D->ln_off = L.ln_off;
+  D->spill_need = std::max(0, L.max_sp - 1 - 2);  // sized for the smallest register stack (2 slots at 8 rows/lane)
+}
+
+static void fill_eval_desc(bsr_ctx* c, PropDesc* D, const TapeLoc& L, void* zout) {
+  fill_desc_tape(D, L);
   D->mode = BSR_MODE_EVAL;
   D->nq = 0;
   D->K = c->K;
-  D->spill_need = std::max(0, max_sp - 1 - BSR_REG_STACK);
   D->qbase = nullptr;
   D->zout = zout;
   D->s = 1.0;
   D->sigma = 1.0;
 }
 
+template <typename T>
+static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPassArgs<T>* a, const PropDesc* desc,
+                          int P, int spill_slots, int residual) {
+  const uint64_t* codes = s.d_streams();
+  const uint64_t* feats = codes + s.code_words;
+  a->g = g;
+  a->Xt = (const T*)c->Xt;
+  a->y = c->has_y ? (const T*)c->y : nullptr;
+  a->ld = c->ld;
+  a->N = c->N;
+  a->codes = codes;
+  a->feats = feats;
+  a->lnp = reinterpret_cast<const double*>(feats + s.feat_words);
+  a->desc = desc;
+  a->coef = c->d_coef;
+  a->P = P;
+  a->feat_list = s.use_lds ? s.d_feat() : nullptr;
+  a->nF = s.nF;
+  a->part = residual ? c->part2 : c->part1;
+  a->spill = spill_slots ? c->spill : nullptr;
+  a->spill_slots = spill_slots;
+  a->rows_per_lane = c->rows_per_lane;
+}
+
+static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const PropDesc* desc, int P,
+                            int spill_slots, int nq, int residual) {
+  if (c->dtype == BSR_DTYPE_F64) {
+    RowPassArgs<double> a;
+    fill_row_args<double>(c, s, g, &a, desc, P, spill_slots, residual);
+    launch_rows<double>(c->stream, a, nq, residual);
+  } else {
+    RowPassArgs<float> a;
+    fill_row_args<float>(c, s, g, &a, desc, P, spill_slots, residual);
+    launch_rows<float>(c->stream, a, nq, residual);
+  }
+}
+
+// Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
+static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
+  PropDesc* hd = s.h_desc();
+  int spill_slots = 0;
+  for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
+  const LaunchGeom g = geometry(c, s, P);
+  int rc = ensure_partials(c, g, P, spill_slots);
+  if (rc != BSR_OK) return rc;
+  const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
+  HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+  const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
+  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[0], c->stream));
+  launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
+  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[1], c->stream));
+  launch_solve(c->stream, s.d_desc(), c->d_ck, P, g.n_rb, c->part1, c->N, c->d_coef, s.d_out);
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[2], c->stream));
+  if (scoring) launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1);
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[3], c->stream));
+  if (scoring) launch_finalize(c->stream, s.d_desc(), c->d_ck, c->d_coef, P, g.n_rb, c->part2, c->N, s.d_out);
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[4], c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out, sizeof(bsr_score) * P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(s.done, c->stream));
+  s.P = P;
+  s.pending = true;
+  return BSR_OK;
+}
+
+static int wait_slot(bsr_ctx* c, BatchSlot& s) {
+  if (!s.pending) return BSR_OK;
+  HIPCHK(c, hipEventSynchronize(s.done));
+  HIPCHK(c, hipGetLastError());
+  s.pending = false;
+  if (c->prof) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
+    c->last_us[0] = ms * 1e3;
+    if (c->prof > 1) {
+      for (int i = 1; i < 4; ++i) {
+        HIPCHK(c, hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+        c->last_us[i] = ms * 1e3;
+      }
+      HIPCHK(c, hipEventElapsedTime(&ms, s.ev[0], s.ev[4]));
+      c->last_us[4] = ms * 1e3;
+    }
+  }
+  return BSR_OK;
+}
+
+// The evaluate-only entry points are synchronous: they drain both slots and run in slot 0.
+static int drain(bsr_ctx* c) {
+  for (BatchSlot& s : c->slot) {
+    int rc = wait_slot(c, s);
+    if (rc != BSR_OK) return rc;
+  }
+  return BSR_OK;
+}
+
+static int ensure_zbuf(bsr_ctx* c) {
+  if (c->zbuf) return BSR_OK;
+  const size_t bytes = (size_t)c->ld * c->esz * c->max_batch;
+  HIPCHK(c, hipMalloc(&c->zbuf, bytes));
+  HIPCHK(c, hipMemsetAsync(c->zbuf, 0, bytes, c->stream));
+  return BSR_OK;
+}
+
 extern "C" int bsr_eval_tapes(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, int32_t n_tapes,
                               double* out_cols, double* maxabs, uint32_t* flags) {
   if (!c) return BSR_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<int> msp;
-  int rc = stage_tapes(c, rows, tape_off, n_tapes, &msp);
+  int rc = drain(c);
   if (rc != BSR_OK) return rc;
+  BatchSlot& s = c->slot[0];
+  std::vector<TapeLoc> loc;
+  rc = stage_tapes(c, s, rows, tape_off, n_tapes, &loc);
+  if (rc != BSR_OK) return rc;
+  if (out_cols) {
+    rc = ensure_zbuf(c);
+    if (rc != BSR_OK) return rc;
+  }
   for (int i = 0; i < n_tapes; ++i)
-    fill_eval_desc(c, &c->h_desc[i], tape_off[i], tape_off[i + 1] - tape_off[i], msp[i], col_ptr(c, c->zbuf, i));
-  rc = run_descs(c, n_tapes, false);
+    fill_eval_desc(c, &s.h_desc()[i], loc[i], out_cols ? col_ptr(c, c->zbuf, i) : nullptr);
+  s.scored = false;
+  rc = enqueue(c, s, n_tapes, false);
+  if (rc == BSR_OK) rc = wait_slot(c, s);
   if (rc != BSR_OK) return rc;
-  c->last_B = 0;  // candidate slots no longer hold a scored batch
   for (int i = 0; i < n_tapes; ++i) {
-    if (maxabs) maxabs[i] = c->h_out[i].maxabs;
-    if (flags) flags[i] = c->h_out[i].flags & (BSR_F_INF | BSR_F_NAN);
+    if (maxabs) maxabs[i] = s.h_out[i].maxabs;
+    if (flags) flags[i] = s.h_out[i].flags & (BSR_F_INF | BSR_F_NAN);
   }
   if (out_cols) {
     if (c->dtype == BSR_DTYPE_F64) {
@@ -409,26 +601,47 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
   int rc = chain_ok(c, chain, k);
   if (rc != BSR_OK) return rc;
   HIPCHK(c, hipSetDevice(c->device));
-  const int32_t off[2] = {0, len};
-  std::vector<int> msp;
-  rc = stage_tapes(c, tape, off, 1, &msp);
+  rc = drain(c);
   if (rc != BSR_OK) return rc;
-  fill_eval_desc(c, &c->h_desc[0], 0, len, msp[0], col_ptr(c, c->cur, (int64_t)chain * c->K + k));
-  rc = run_descs(c, 1, false);
+  BatchSlot& s = c->slot[0];
+  const int32_t off[2] = {0, len};
+  std::vector<TapeLoc> loc;
+  rc = stage_tapes(c, s, tape, off, 1, &loc);
+  if (rc != BSR_OK) return rc;
+  fill_eval_desc(c, &s.h_desc()[0], loc[0], col_ptr(c, c->cur, (int64_t)chain * c->K + k));
+  s.scored = false;
+  rc = enqueue(c, s, 1, false);
+  if (rc == BSR_OK) rc = wait_slot(c, s);
   if (rc != BSR_OK) return rc;
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
   return BSR_OK;
 }
 
-extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t slot) {
+extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   if (!c) return BSR_E_ARG;
   int rc = chain_ok(c, chain, k);
   if (rc != BSR_OK) return rc;
-  if (slot < 0 || slot >= c->last_B) return fail(c, BSR_E_STATE, "bsr_commit: slot is not part of the last scored batch");
+  if (c->last_waited < 0 || !c->slot[c->last_waited].scored)
+    return fail(c, BSR_E_STATE, "bsr_commit: no scored batch to commit from");
+  BatchSlot& s = c->slot[c->last_waited];
+  if (idx < 0 || idx >= s.P) return fail(c, BSR_E_STATE, "bsr_commit: index is not part of the last scored batch");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(col_ptr(c, c->cur, (int64_t)chain * c->K + k), col_ptr(c, c->zbuf, slot),
-                           (size_t)c->ld * c->esz, hipMemcpyDeviceToDevice, c->stream));
+  // Candidate columns are not kept by the scoring pass: re-run the still-staged tape straight into the chain cache.
+  // The one-off descriptor goes to the spare entry behind the batch's own, so the batch stays intact.
+  PropDesc D = s.h_desc()[idx];
+  D.mode = BSR_MODE_EVAL;
+  D.nq = 0;
+  D.qbase = nullptr;
+  D.zout = col_ptr(c, c->cur, (int64_t)chain * c->K + k);
+  D.s = 1.0;
+  const int at = c->max_batch;
+  s.h_desc()[at] = D;
+  HIPCHK(c, hipMemcpyAsync(s.d_desc() + at, &s.h_desc()[at], sizeof(PropDesc), hipMemcpyHostToDevice, c->stream));
+  const LaunchGeom g = geometry(c, s, 1);
+  rc = ensure_partials(c, g, 1, D.spill_need);
+  if (rc != BSR_OK) return rc;
+  launch_row_pass(c, s, g, s.d_desc() + at, 1, D.spill_need, 0, 0);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
   return BSR_OK;
@@ -477,48 +690,65 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
   return BSR_OK;
 }
 
-extern "C" int bsr_score_batch(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
-                               const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out) {
-  if (!c || !chain || !which_k || !sigma || !out) return BSR_E_ARG;
-  if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_batch: context has no y / no chains");
+extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                                const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket) {
+  if (!c || !chain || !which_k || !sigma || !ticket) return BSR_E_ARG;
+  if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
   HIPCHK(c, hipSetDevice(c->device));
   const int K = c->K;
   for (int i = 0; i < B; ++i) {
     int rc = chain_ok(c, chain[i], which_k[i]);
     if (rc != BSR_OK) return rc;
-    if (!c->ready[chain[i]]) return fail(c, BSR_E_STATE, "bsr_score_batch: chain not refreshed");
+    if (!c->ready[chain[i]]) return fail(c, BSR_E_STATE, "bsr_score_submit: chain not refreshed");
   }
-  std::vector<int> msp;
-  int rc = stage_tapes(c, rows, tape_off, B, &msp);
+  const int si = c->next_slot;
+  BatchSlot& s = c->slot[si];
+  if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: both batch slots are in flight (wait first)");
+  std::vector<TapeLoc> loc;
+  int rc = stage_tapes(c, s, rows, tape_off, B, &loc);
   if (rc != BSR_OK) return rc;
+  PropDesc* hd = s.h_desc();
   for (int i = 0; i < B; ++i) {
-    PropDesc* D = &c->h_desc[i];
-    memset(D, 0, sizeof *D);
+    PropDesc* D = &hd[i];
+    fill_desc_tape(D, loc[i]);
     const int ckidx = chain[i] * K + which_k[i];
-    D->tape_off = tape_off[i];
-    D->tape_len = tape_off[i + 1] - tape_off[i];
     D->mode = BSR_MODE_SCORE;
     D->nq = K - 1;
     D->k = which_k[i];
     D->K = K;
     D->ck = ckidx;
-    D->spill_need = std::max(0, msp[i] - 1 - BSR_REG_STACK);
     D->qbase = (K > 1) ? col_ptr(c, c->Q, (int64_t)ckidx * (K - 1)) : nullptr;
-    D->zout = col_ptr(c, c->zbuf, i);
+    D->zout = nullptr;
     D->s = c->h_ck[ckidx].s;
     D->sigma = sigma[i];
   }
-  rc = run_descs(c, B, true);
+  s.scored = true;
+  rc = enqueue(c, s, B, true);
   if (rc != BSR_OK) return rc;
-  memcpy(out, c->h_out, sizeof(bsr_score) * B);
-  c->last_B = B;
-  if (K == 1) {
+  *ticket = si;
+  c->next_slot = si ^ 1;
+  return BSR_OK;
+}
+
+extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
+  if (!c || !out || ticket < 0 || ticket > 1) return BSR_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  BatchSlot& s = c->slot[ticket];
+  if (!s.scored) return fail(c, BSR_E_STATE, "bsr_score_wait: nothing submitted under this ticket");
+  int rc = wait_slot(c, s);
+  if (rc != BSR_OK) return rc;
+  const int B = s.P;
+  memcpy(out, s.h_out, sizeof(bsr_score) * B);
+  c->last_waited = ticket;
+  if (c->K == 1) {
     // no sibling column fixes the accumulation scale: rescore candidates whose |z|^2 left the double range
     std::vector<int> redo;
     for (int i = 0; i < B; ++i)
       if (out[i].flags & BSR_F_SCALE_RETRY) redo.push_back(i);
     if (!redo.empty()) {
-      std::vector<PropDesc> keep(c->h_desc, c->h_desc + B);
+      rc = drain(c);
+      if (rc != BSR_OK) return rc;
+      std::vector<PropDesc> keep(s.h_desc(), s.h_desc() + B);
       double timing[5];
       memcpy(timing, c->last_us, sizeof timing);
       for (size_t j = 0; j < redo.size(); ++j) {
@@ -527,18 +757,32 @@ extern "C" int bsr_score_batch(bsr_ctx* c, const bsr_node* rows, const int32_t* 
         std::frexp(out[redo[j]].maxabs, &e);
         e = std::max(-1000, std::min(1000, e));
         D.s = std::ldexp(1.0, -e);
-        c->h_desc[j] = D;
+        s.h_desc()[j] = D;
       }
-      rc = run_descs(c, (int)redo.size(), true);
+      rc = enqueue(c, s, (int)redo.size(), true);
+      if (rc == BSR_OK) rc = wait_slot(c, s);
       if (rc != BSR_OK) return rc;
       for (size_t j = 0; j < redo.size(); ++j) {
-        out[redo[j]] = c->h_out[j];
+        out[redo[j]] = s.h_out[j];
         out[redo[j]].flags &= ~BSR_F_SCALE_RETRY;
       }
+      // restore the batch's own descriptors (host and device) so bsr_commit sees the original order
+      memcpy(s.h_desc(), keep.data(), sizeof(PropDesc) * B);
+      HIPCHK(c, hipMemcpyAsync(s.d_desc(), s.h_desc(), sizeof(PropDesc) * B, hipMemcpyHostToDevice, c->stream));
+      s.P = B;
       memcpy(c->last_us, timing, sizeof timing);
     }
   }
   return BSR_OK;
+}
+
+extern "C" int bsr_score_batch(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                               const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out) {
+  if (!c || !out) return BSR_E_ARG;
+  int32_t ticket = -1;
+  int rc = bsr_score_submit(c, rows, tape_off, chain, which_k, sigma, B, &ticket);
+  if (rc != BSR_OK) return rc;
+  return bsr_score_wait(c, ticket, out);
 }
 
 extern "C" int bsr_fit_beta(bsr_ctx* c, int32_t chain, double* beta_out, double* rmse_out) {
@@ -633,9 +877,9 @@ extern "C" int bsr_yloglike_host(int device, int64_t N, int32_t K, const double*
   return BSR_OK;
 }
 
-extern "C" int bsr_set_profiling(bsr_ctx* c, int32_t enable) {
+extern "C" int bsr_set_profiling(bsr_ctx* c, int32_t level) {
   if (!c) return BSR_E_ARG;
-  c->prof = enable != 0;
+  c->prof = std::max(0, std::min(2, (int)level));
   return BSR_OK;
 }
 extern "C" int bsr_last_timing(bsr_ctx* c, double* us5) {

@@ -10,7 +10,7 @@
 #define BSR_NQ_MAX (BSR_MAX_K - 1)  // basis columns per proposal
 #define BSR_WAVE 64
 #define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
-#define BSR_REG_STACK 7             // interpreter stack slots held in VGPRs (plus the accumulator)
+#define BSR_REG_STACK 3             // interpreter stack slots held in VGPRs (plus the accumulator)
 #define BSR_ROW_ALIGN 4096          // device columns are padded to a multiple of this many rows
 #define BSR_P1_WORDS 12             // doubles per (proposal,row block) partial of pass 1
 #define BSR_P2_WORDS 2              // doubles per (proposal,row block) partial of pass 2
@@ -31,14 +31,17 @@ struct ChainK {
 
 // Device-side descriptor of one tape to run in the row passes.
 struct PropDesc {
-  int32_t tape_off;     // first row in the uploaded tape buffer
-  int32_t tape_len;
+  int32_t code_off;     // first 64-bit word of the tape's opcode stream
+  int32_t n_nodes;
+  int32_t feat_off;     // first 64-bit word of the tape's terminal-column stream
+  int32_t ln_off;       // first (a,b) pair of the tape's ln-parameter stream
   int32_t mode;         // BSR_MODE_*
   int32_t nq;           // basis columns (K-1), 0 in eval mode
   int32_t k;            // tree index being replaced
   int32_t K;
   int32_t ck;           // index into the ChainK array (chain*K + k)
   int32_t spill_need;   // stack slots beyond the register stack
+  int32_t pad0, pad1;
   const void* qbase;    // first basis column (nq columns, stride ld)
   void* zout;           // where the candidate column goes (ld values) or nullptr
   double s;             // prescale applied to the candidate column in all accumulations
@@ -68,7 +71,7 @@ struct ChainFitOut {
 };
 
 struct LaunchGeom {
-  int rb_rows;      // rows per row block (multiple of 128)
+  int rb_rows;      // rows per row block (multiple of 256)
   int n_rb;         // row blocks
   int pg;           // proposals per workgroup
   int n_pg;         // proposal groups
@@ -76,14 +79,28 @@ struct LaunchGeom {
 
 // kernels (bsr_kernels.hip)
 template <typename T>
-void launch_pass1(hipStream_t st, const LaunchGeom& g, const T* Xt, const T* y, int64_t ld, int64_t N,
-                  const bsr_node* tapes, const PropDesc* desc, int P, double* part1, double* spill,
-                  int spill_slots);
+struct RowPassArgs {
+  LaunchGeom g;
+  const T* Xt;
+  const T* y;
+  int64_t ld, N;
+  const uint64_t* codes;
+  const uint64_t* feats;
+  const double* lnp;
+  const PropDesc* desc;
+  const PropCoef* coef;
+  int P;
+  const int32_t* feat_list;   // non-null: stage these X columns (+y) in LDS; null: read X/y from global memory
+  int nF;
+  double* part;
+  void* spill;
+  int spill_slots;
+  int rows_per_lane;          // 2, 4 or 8 (rb_rows must be a multiple of 64*rows_per_lane)
+};
+template <typename T>
+void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out);
-template <typename T>
-void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, int64_t N, const PropDesc* desc,
-                  const PropCoef* coef, int P, double* part2);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out);
 template <typename T>

@@ -1,14 +1,16 @@
 // HIP kernels of the MCMC-SymReg likelihood hot path for gfx950 (MI355X, wave64).
 //
-// Row passes (the O(N) work, one launch scores a whole batch of proposals):
-//   k_pass1    : postfix stack-machine over each candidate tape (allcal, codes/funcs.py:175-220), fused with the
-//                projections of the candidate column on the cached sibling basis, |z|^2, z.y, max|z| and the
-//                inf/NaN census; stores the candidate column.
-//   k_pass2    : direct residual sum of squares of the OLS fit (codes/funcs.py:1157-1162) and the residual norm of
-//                the candidate against the sibling basis (feeds the rank gate, codes/funcs.py:1226).
+// Row pass (the O(N) work; one launch covers a whole batch of proposals):
+//   k_rows<MODE_PROJECT>  : postfix stack-machine over each candidate tape (allcal, codes/funcs.py:175-220) fused
+//                           with the projections of the candidate column on the cached orthonormal sibling basis,
+//                           |z|^2, z.y, max|z| and the inf/NaN census.  Candidate columns are NOT stored: the few
+//                           consumers (near-dependent candidates, an accepted proposal) re-run the tape instead.
+//   k_rows<MODE_RESIDUAL> : same interpreter; direct residual of the candidate against the sibling basis
+//                           (|w|^2, w.y) for the proposals k_solve could not settle from the projections.
 // Per-proposal scalar work (K <= 8, one wave per proposal, lanes form an 8x8 grid):
-//   k_solve    : reduce pass-1 partials, assemble XX^T XX + 1e-6 I (codes/funcs.py:1151-1155), invert, Beta.
-//   k_finalize : reduce pass-2 partials, singular values of the K x K factor -> matrix_rank, log-likelihood.
+//   k_solve    : reduce the partials, singular values of the K x K factor -> matrix_rank (codes/funcs.py:1226),
+//                ridge OLS (codes/funcs.py:1151-1155), SSE and log-likelihood (codes/funcs.py:1162-1173).
+//   k_finalize : the same algebra for the proposals that needed the residual pass.
 // Rare path (initialisation / accepted proposal), one workgroup each:
 //   k_refresh_basis : leave-one-out orthonormal bases of the chain's current columns.
 //   k_chain_fit     : ridge OLS of y on the K current columns, with or without intercept
@@ -18,6 +20,8 @@
 // Compiled with -ffp-contract=off so that a*x+b keeps numpy's two roundings; accumulations use explicit fma().
 #include "bsr_internal.h"
 
+#include <cstdlib>
+
 #define CONSTANT_AS __attribute__((address_space(4)))
 
 template <typename T>
@@ -25,15 +29,40 @@ __device__ __forceinline__ const T CONSTANT_AS* as_const(const T* p) {
   return (const T CONSTANT_AS*)p;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// Wave-level reductions on the VALU with DPP (no LDS traffic, unlike __shfl which lowers to ds_bpermute).
+// Fixed combination order -> deterministic.  After the six steps lane 63 holds the reduction of all 64 lanes;
+// v_readlane broadcasts it.  DPP controls: quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1], 0x141 row_half_mirror,
+// 0x140 row_mirror, 0x142 row_bcast:15 (rows 1,3), 0x143 row_bcast:31 (rows 2,3).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(h2, l2);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+__device__ __forceinline__ double readlane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0xB1, 0xF>(v);
+  v += dpp_f64<0x4E, 0xF>(v);
+  v += dpp_f64<0x141, 0xF>(v);
+  v += dpp_f64<0x140, 0xF>(v);
+  // rows not selected by the row mask receive 0 (old = 0, bound_ctrl off keeps `old`): add is a no-op there
+  v += dpp_f64<0x142, 0xA>(v);
+  v += dpp_f64<0x143, 0xC>(v);
+  return readlane63(v);
+}
+__device__ __forceinline__ double wave_max(double v) {  // inputs are non-negative (|z| maxima): 0 is neutral
+  v = fmax(v, dpp_f64<0xB1, 0xF>(v));
+  v = fmax(v, dpp_f64<0x4E, 0xF>(v));
+  v = fmax(v, dpp_f64<0x141, 0xF>(v));
+  v = fmax(v, dpp_f64<0x140, 0xF>(v));
+  v = fmax(v, dpp_f64<0x142, 0xA>(v));
+  v = fmax(v, dpp_f64<0x143, 0xC>(v));
+  return readlane63(v);
 }
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 #pragma unroll
@@ -44,14 +73,30 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // ---------------------------------------------------------------------------------------------------------------
 // opcode semantics (codes/funcs.py:179-212)
 template <typename T> __device__ __forceinline__ T op_exp(T x);
-template <> __device__ __forceinline__ double op_exp<double>(double x) { return (x <= 200.0) ? exp(x) : 1e10; }
-template <> __device__ __forceinline__ float op_exp<float>(float x) { return (x <= 200.0f) ? expf(x) : 1e10f; }
-template <typename T> __device__ __forceinline__ T op_sin(T x);
-template <> __device__ __forceinline__ double op_sin<double>(double x) { return sin(x); }
-template <> __device__ __forceinline__ float op_sin<float>(float x) { return sinf(x); }
-template <typename T> __device__ __forceinline__ T op_cos(T x);
-template <> __device__ __forceinline__ double op_cos<double>(double x) { return cos(x); }
-template <> __device__ __forceinline__ float op_cos<float>(float x) { return cosf(x); }
+// exp is evaluated unconditionally on min(x,200) and the clamp applied by a select: a lane-divergent branch around
+// it would turn the interpreter loop into a structurized region (see sin_rows below).
+template <> __device__ __forceinline__ double op_exp<double>(double x) {
+  const double e = exp(fmin(x, 200.0));
+  return (x <= 200.0) ? e : 1e10;
+}
+template <> __device__ __forceinline__ float op_exp<float>(float x) {
+  const float e = expf(fminf(x, 200.0f));
+  return (x <= 200.0f) ? e : 1e10f;
+}
+// sin/cos carry lane-divergent branches (large-argument reduction).  Inlined into the interpreter they make the whole
+// node loop a divergent region, which LLVM then structurizes into long chains of flag-guarded blocks (~150 scalar
+// instructions per node).  Kept out of line, the loop has only wave-uniform branches and stays a plain scalar
+// switch; the call costs a few dozen cycles against the ~85 fp64 instructions of the function itself.
+template <typename T, int U>
+struct VecOf;
+template <>
+struct VecOf<double, 2> { using type = double2; };
+template <>
+struct VecOf<float, 2> { using type = float2; };
+__device__ __attribute__((noinline)) double2 sin_rows(double2 v) { return make_double2(sin(v.x), sin(v.y)); }
+__device__ __attribute__((noinline)) double2 cos_rows(double2 v) { return make_double2(cos(v.x), cos(v.y)); }
+__device__ __attribute__((noinline)) float2 sin_rows(float2 v) { return make_float2(sinf(v.x), sinf(v.y)); }
+__device__ __attribute__((noinline)) float2 cos_rows(float2 v) { return make_float2(cosf(v.x), cosf(v.y)); }
 
 // np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
 // Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
@@ -69,72 +114,148 @@ template <> __device__ __forceinline__ float op_cube<float>(float x) {
   return (float)(xd * xd * xd);
 }
 
-// Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.
-#define BSR_STACK_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
-
-template <typename T, int U>
+// Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.  S slots live in VGPRs,
+// deeper entries (Strahler number of the tree > S+1, rare) go to a per-wave global spill area.
+template <typename T, int U, int S>
 struct RegStack {
-  T s0[U], s1[U], s2[U], s3[U], s4[U], s5[U], s6[U];
-  T* spill;  // per-wave global spill area: slot-major [slot][64*U]
+  T s[S][U];
+  T* spill;  // per-wave: slot-major [slot][64*U]
   int lane;
 
   __device__ __forceinline__ void push(int sp, const T (&v)[U]) {
-    switch (sp) {
-#define X(i) \
-  case i:    \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) s##i[u] = v[u]; \
+    if (sp < S) {
+      switch (sp) {
+#define X(i)                                                             \
+  case i:                                                                \
+    if constexpr (i < S) {                                               \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) s[i][u] = v[u];      \
+    }                                                                    \
     break;
-      BSR_STACK_CASES(X)
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #undef X
-      default: {
-        T* q = spill + (size_t)(sp - BSR_REG_STACK) * (BSR_WAVE * U) + lane * U;
-#pragma unroll
-        for (int u = 0; u < U; ++u) q[u] = v[u];
       }
+    } else {
+      T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+      for (int u = 0; u < U; ++u) q[u] = v[u];
     }
   }
   __device__ __forceinline__ void pop(int sp, T (&v)[U]) {
-    switch (sp) {
-#define X(i) \
-  case i:    \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s##i[u]; \
+    if (sp < S) {
+      switch (sp) {
+#define X(i)                                                             \
+  case i:                                                                \
+    if constexpr (i < S) {                                               \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s[i][u];      \
+    }                                                                    \
     break;
-      BSR_STACK_CASES(X)
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #undef X
-      default: {
-        const T* q = spill + (size_t)(sp - BSR_REG_STACK) * (BSR_WAVE * U) + lane * U;
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = q[u];
       }
+    } else {
+      const T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = q[u];
     }
   }
 };
 
-// Evaluates one postfix tape on U consecutive rows per lane starting at r0.  The tape is read through the constant
-// address space (scalar loads); opcode, stack pointer and all branches are wave-uniform.
+// Terminal loaders.  A lane owns U/2 pairs of adjacent rows, pair j at chunk offset j*128 + 2*lane, so every
+// 16-byte access of the wave covers 1 KiB of consecutive addresses (LDS: conflict-free ds_read_b128).
+// LdsCols reads the workgroup's staged tile [slot][rb_rows]; GlobalCols reads the feature-major matrix directly.
 template <typename T, int U>
-__device__ __forceinline__ void run_tape(const bsr_node* tape, int len, const T* __restrict__ Xt, int64_t ld,
-                                         int64_t r0, T (&acc)[U], T* spill, int lane) {
-  const bsr_node CONSTANT_AS* tp = as_const(tape);
-  RegStack<T, U> st;
+struct LdsCols {
+  const T* sx;
+  int rb_rows;
+  int off;  // sweep offset + 2*lane, inside the tile
+  __device__ __forceinline__ void load(int slot, T (&v)[U]) const {
+    const T* col = sx + slot * rb_rows + off;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      v[2 * j] = col[j * 128];
+      v[2 * j + 1] = col[j * 128 + 1];
+    }
+  }
+};
+template <typename T, int U>
+struct GlobalCols {
+  const T* __restrict__ Xt;
+  int64_t ld, r0;  // r0 = absolute row of the lane's first pair
+  __device__ __forceinline__ void load(int feature, T (&v)[U]) const {
+    const T* col = Xt + (int64_t)feature * ld + r0;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      v[2 * j] = col[j * 128];
+      v[2 * j + 1] = col[j * 128 + 1];
+    }
+  }
+};
+
+// XCD-aware work mapping for the row passes.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the
+// XCD's group), each with a private 4 MiB L2.  All proposal groups of one row block, and a fixed eighth of the row
+// blocks, go to the same group, so an XCD's L2 only ever holds its 1/8 slice of X, y and the cached basis columns
+// (1.7 MB at N=100k, d=10, K=3) instead of all of it.  Placement only affects speed, never results.
+struct WorkItem {
+  int rb, pgi;
+  bool valid;
+};
+__device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg) {
+  const int w = blockIdx.x;
+  const int xcd = w & 7, j = w >> 3;
+  WorkItem it;
+  it.pgi = j % n_pg;
+  it.rb = (j / n_pg) * 8 + xcd;
+  it.valid = it.rb < n_rb;
+  return it;
+}
+
+// Evaluates one tape on the lane's U rows.  The tape arrives as three compact streams built by the host from the
+// bsr_node rows (bsr_api.hip: build_streams): 4-bit opcodes (16 per 64-bit word), 16-bit column ids of the terminals
+// in tape order (4 per word) and the (a,b) pairs of the ln nodes.  They are read through the constant address space
+// (scalar loads) a whole word at a time, so the node loop itself is register-only: opcode, stack pointer and every
+// branch are wave-uniform, and the only memory operation on the critical path is the terminal read, which is
+// requested one terminal ahead.  Each stream is padded so that reading one element past the end is always valid.
+template <typename T, int U, int S, typename Loader>
+__device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* feats, const double* lnp, int n,
+                                         const Loader& ldr, T (&acc)[U], T* spill, int lane) {
+  const uint64_t CONSTANT_AS* cw = as_const(codes);
+  const uint64_t CONSTANT_AS* fw = as_const(feats);
+  const double CONSTANT_AS* lp = as_const(lnp);
+  RegStack<T, U, S> st;
   st.spill = spill;
   st.lane = lane;
+  uint64_t code = cw[0], code_next = cw[1];
+  uint64_t fhead = fw[0], fnext = fw[1];
+  double la = lp[0], lb = lp[1];
+  int ci = 1, fi = 1, li = 1, nt = 0;
   int sp = 0;  // values on the stack below the accumulator
-  {
-    const int f = tp[0].feature;
-    const T* col = Xt + (int64_t)f * ld + r0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = col[u];
-  }
-  for (int i = 1; i < len; ++i) {
-    const int op = tp[i].opcode;
+  T pre[U];
+  ldr.load((int)(fhead & 0xFFFFu), acc);  // node 0 is always a terminal
+  fhead >>= 16;
+  nt = 1;
+  ldr.load((int)(fhead & 0xFFFFu), pre);  // data of the next terminal (padding repeats a valid column)
+  code >>= 4;
+  for (int i = 1; i < n; ++i) {
+    if ((i & 15) == 0) {
+      code = code_next;
+      ++ci;
+      code_next = cw[ci];
+    }
+    const int op = (int)(code & 15u);
+    code >>= 4;
     if (op == BSR_OP_TERMINAL) {
       st.push(sp, acc);
       ++sp;
-      const int f = tp[i].feature;
-      const T* col = Xt + (int64_t)f * ld + r0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[u] = col[u];
+      for (int u = 0; u < U; ++u) acc[u] = pre[u];
+      fhead >>= 16;
+      if (++nt == 4) {
+        fhead = fnext;
+        ++fi;
+        fnext = fw[fi];
+        nt = 0;
+      }
+      ldr.load((int)(fhead & 0xFFFFu), pre);
     } else if (op >= BSR_OP_ADD) {
       T lhs[U];
       --sp;
@@ -153,9 +274,12 @@ __device__ __forceinline__ void run_tape(const bsr_node* tape, int len, const T*
           for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
           break;
         case BSR_OP_LN: {
-          const T a = (T)tp[i].a, b = (T)tp[i].b;
+          const T a = (T)la, b = (T)lb;
 #pragma unroll
           for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
+          la = lp[2 * li];
+          lb = lp[2 * li + 1];
+          ++li;
         } break;
         case BSR_OP_NEG:
 #pragma unroll
@@ -163,11 +287,25 @@ __device__ __forceinline__ void run_tape(const bsr_node* tape, int len, const T*
           break;
         case BSR_OP_SIN:
 #pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = op_sin<T>(acc[u]);
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            r = sin_rows(v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
           break;
         case BSR_OP_COS:
 #pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = op_cos<T>(acc[u]);
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            r = cos_rows(v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
           break;
         case BSR_OP_EXP:
 #pragma unroll
@@ -187,86 +325,173 @@ __device__ __forceinline__ void run_tape(const bsr_node* tape, int len, const T*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 1: grid = (row blocks, proposal groups), 4 waves per workgroup, one wave per (proposal,row block).
-template <typename T, int U>
-__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass1(
-    const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const bsr_node* __restrict__ tapes,
-    const PropDesc* __restrict__ desc, int P, int rb_rows, int pg, int n_rb, double* __restrict__ part1,
-    T* __restrict__ spill, int spill_slots) {
+// Row pass.  grid = 8 * ceil(n_rb/8) * n_pg workgroups of 4 waves (XCD-aware mapping above); a workgroup owns one
+// row block of rb_rows rows and one group of pg proposals, a wave walks its share of the group's tapes over the
+// block, 64*U rows per sweep.
+//   LDS = true : the X columns referenced by the batch (feat_list) and y are staged once per workgroup in LDS;
+//                terminals are ds_read_b128 (ids in the feature stream are LDS slots).
+//   LDS = false: terminals and y come from global memory (L2); used when the referenced columns exceed the LDS
+//                budget.
+//   MODE_PROJECT : c = Q^T (s z), |s z|^2, (s z).y, max|z|, inf/NaN census -> part[(p,rb)][12]; optional z store
+//                  (allcal / set_current).
+//   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
+enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
+
+template <typename T, int NQ, int U, bool LDS, int MODE>
+__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_rows(
+    const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const uint64_t* __restrict__ codes,
+    const uint64_t* __restrict__ feats, const double* __restrict__ lnp, const PropDesc* __restrict__ desc,
+    const PropCoef* __restrict__ coef, int P, int rb_rows, int pg, int n_rb, int n_pg,
+    const int32_t* __restrict__ feat_list, int nF, double* __restrict__ part, T* __restrict__ spill,
+    int spill_slots) {
+  constexpr int S = (U >= 8) ? 2 : BSR_REG_STACK;
+  constexpr int VEC = 16 / sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [nF][rb_rows] then y[rb_rows]   (LDS variant only)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rb = blockIdx.x;
+  const WorkItem wi = map_work(n_rb, n_pg);
+  if (!wi.valid) return;
+  const int rb = wi.rb;
   const int64_t row_base = (int64_t)rb * rb_rows;
-  const int iters = rb_rows / (BSR_WAVE * U);
-  const int gwave = (blockIdx.y * gridDim.x + blockIdx.x) * BSR_WG_WAVES + wave;
-  T* my_spill = spill ? spill + (size_t)gwave * spill_slots * (BSR_WAVE * U) : nullptr;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
+  const PropCoef CONSTANT_AS* cf = as_const(coef);
+  if (MODE == MODE_RESIDUAL) {  // nothing to do for this group? leave before staging anything
+    bool any = false;
+    for (int pi = 0; pi < pg; ++pi) {
+      const int p = wi.pgi * pg + pi;
+      if (p < P && !cf[p].skip) any = true;
+    }
+    if (!any) return;
+  }
+  if (LDS) {
+    const int nvec = rb_rows / VEC;
+    using V4 = __attribute__((ext_vector_type(4))) float;
+    for (int idx = threadIdx.x; idx < (nF + 1) * nvec; idx += BSR_WG_WAVES * BSR_WAVE) {
+      const int f = idx / nvec, v = idx - f * nvec;
+      const T* src = (f < nF) ? Xt + (int64_t)feat_list[f] * ld : y;
+      V4 val = {0.f, 0.f, 0.f, 0.f};
+      if (src) val = *reinterpret_cast<const V4*>(src + row_base + (int64_t)v * VEC);
+      *reinterpret_cast<V4*>(sx + (size_t)f * rb_rows + (size_t)v * VEC) = val;
+    }
+    __syncthreads();
+  }
+  const T* sy = sx + (size_t)nF * rb_rows;
+  const int sweeps = rb_rows / (BSR_WAVE * U);
+  const int gwave = blockIdx.x * BSR_WG_WAVES + wave;
+  T* my_spill = spill ? spill + (size_t)gwave * spill_slots * (BSR_WAVE * 8) : nullptr;
 
   for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
-    const int p = blockIdx.y * pg + pi;
+    const int p = wi.pgi * pg + pi;
     if (p >= P) break;
-    const int nq = dsc[p].nq;
+    if (MODE == MODE_RESIDUAL && cf[p].skip) continue;
     const T* qbase = (const T*)dsc[p].qbase;
     T* zout = (T*)dsc[p].zout;
     const double s = dsc[p].s;
-    const bsr_node* tape = tapes + dsc[p].tape_off;
-    const int len = dsc[p].tape_len;
+    const uint64_t* pc = codes + dsc[p].code_off;
+    const uint64_t* pf = feats + dsc[p].feat_off;
+    const double* pl = lnp + 2 * (size_t)dsc[p].ln_off;
+    const int n_nodes = dsc[p].n_nodes;
 
-    double c[BSR_NQ_MAX];
+    double c[NQ > 0 ? NQ : 1];
 #pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = 0.0;
-    double zz = 0.0, zy = 0.0, amax = 0.0;
-    uint32_t fl = 0;
+    for (int i = 0; i < NQ; ++i) c[i] = (MODE == MODE_RESIDUAL) ? cf[p].c[i] : 0.0;
+    double a0 = 0.0, a1 = 0.0, amax = 0.0;  // PROJECT: |s z|^2, s z.y   RESIDUAL: |w|^2, w.y
 
-    for (int it = 0; it < iters; ++it) {
-      const int64_t r0 = row_base + (int64_t)it * (BSR_WAVE * U) + lane * U;
-      T acc[U];
-      run_tape<T, U>(tape, len, Xt, ld, r0, acc, my_spill, lane);
+    for (int sw = 0; sw < sweeps; ++sw) {
+      const int off = sw * (BSR_WAVE * U) + 2 * lane;  // lane's pair 0 inside the row block
+      // sibling-basis values first: their latency hides under the tape
+      T qv[NQ > 0 ? NQ : 1][U];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const T* q = qbase + (int64_t)i * ld + row_base + off;
+#pragma unroll
+        for (int j = 0; j < U / 2; ++j) {
+          qv[i][2 * j] = q[j * 128];
+          qv[i][2 * j + 1] = q[j * 128 + 1];
+        }
+      }
       T yv[U];
+      if (!LDS) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) yv[u] = y ? y[r0 + u] : (T)0;
-      double zs[U];
+        for (int j = 0; j < U / 2; ++j) {
+          yv[2 * j] = y ? y[row_base + off + j * 128] : (T)0;
+          yv[2 * j + 1] = y ? y[row_base + off + j * 128 + 1] : (T)0;
+        }
+      }
+      T acc[U];
+      if (LDS) {
+        LdsCols<T, U> ldr{sx, rb_rows, off};
+        run_tape<T, U, S>(pc, pf, pl, n_nodes, ldr, acc, my_spill, lane);
+#pragma unroll
+        for (int j = 0; j < U / 2; ++j) {
+          yv[2 * j] = sy[off + j * 128];
+          yv[2 * j + 1] = sy[off + j * 128 + 1];
+        }
+      } else {
+        GlobalCols<T, U> ldr{Xt, ld, row_base + off};
+        run_tape<T, U, S>(pc, pf, pl, n_nodes, ldr, acc, my_spill, lane);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool valid = (r0 + u) < N;
+        const int r = off + (u >> 1) * 128 + (u & 1);
+        const bool valid = (row_base + r) < N;
         const T z = valid ? acc[u] : (T)0;
         acc[u] = z;
         const double zd = (double)z;
-        if (isinf(zd)) fl |= BSR_F_INF;
-        if (isnan(zd)) fl |= BSR_F_NAN;
-        amax = fmax(amax, fabs(zd));
-        zs[u] = zd * s;
-        zz = fma(zs[u], zs[u], zz);
-        zy = fma(zs[u], (double)yv[u], zy);
-      }
+        const double zs = zd * s;
+        if (MODE == MODE_PROJECT) {
+          amax = fmax(amax, fabs(zd));
+          a0 = fma(zs, zs, a0);
+          a1 = fma(zs, (double)yv[u], a1);
 #pragma unroll
-      for (int i = 0; i < BSR_NQ_MAX; ++i) {
-        if (i < nq) {
-          const T* q = qbase + (int64_t)i * ld + r0;
+          for (int i = 0; i < NQ; ++i) c[i] = fma((double)qv[i][u], zs, c[i]);
+        } else {
+          double w = zs;
 #pragma unroll
-          for (int u = 0; u < U; ++u) c[i] = fma((double)q[u], zs[u], c[i]);
+          for (int i = 0; i < NQ; ++i) w = fma(-c[i], (double)qv[i][u], w);
+          if (valid) {
+            a0 = fma(w, w, a0);
+            a1 = fma(w, (double)yv[u], a1);
+          }
         }
       }
-      if (zout) {
+      if (MODE == MODE_PROJECT && zout) {
+        T* zo = zout + row_base + off;
 #pragma unroll
-        for (int u = 0; u < U; ++u) zout[r0 + u] = acc[u];
+        for (int j = 0; j < U / 2; ++j) {
+          zo[j * 128] = acc[2 * j];
+          zo[j * 128 + 1] = acc[2 * j + 1];
+        }
       }
     }
+    if (MODE == MODE_PROJECT) {
 #pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = wave_sum(c[i]);
-    zz = wave_sum(zz);
-    zy = wave_sum(zy);
-    amax = wave_max(amax);
-    fl = wave_or(fl);
-    if (lane == 0) {
-      double* o = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
+      for (int i = 0; i < NQ; ++i) c[i] = wave_sum(c[i]);
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      amax = wave_max(amax);
+      // census after the fact: max|z| is +inf iff an inf is present (fmax ignores NaN); the sum of squares is
+      // NaN iff a NaN is present (squares are non-negative, so no inf-inf)
+      const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
+      if (lane == 0) {
+        double* o = part + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
 #pragma unroll
-      for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = c[i];
-      o[7] = zz;
-      o[8] = zy;
-      o[9] = amax;
-      o[10] = (double)fl;
-      o[11] = 0.0;
+        for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = (i < NQ) ? c[i < NQ ? i : 0] : 0.0;
+        o[7] = a0;
+        o[8] = a1;
+        o[9] = amax;
+        o[10] = (double)fl;
+        o[11] = 0.0;
+      }
+    } else {
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (lane == 0) {
+        double* o = part + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
+        o[0] = a0;
+        o[1] = a1;
+      }
     }
   }
 }
@@ -524,65 +749,6 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 2 (only proposals flagged by k_solve): direct residual of the candidate against the sibling basis,
-// w = s z - Q c, accumulated as |w|^2 and w.y.
-template <typename T, int U>
-__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_pass2(const T* __restrict__ y, int64_t ld, int64_t N,
-                                                                  const PropDesc* __restrict__ desc,
-                                                                  const PropCoef* __restrict__ coef, int P,
-                                                                  int rb_rows, int pg, int n_rb,
-                                                                  double* __restrict__ part2) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rb = blockIdx.x;
-  const int64_t row_base = (int64_t)rb * rb_rows;
-  const int iters = rb_rows / (BSR_WAVE * U);
-  const PropDesc CONSTANT_AS* dsc = as_const(desc);
-  const PropCoef CONSTANT_AS* cf = as_const(coef);
-
-  for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
-    const int p = blockIdx.y * pg + pi;
-    if (p >= P) break;
-    if (cf[p].skip) continue;
-    const int nq = dsc[p].nq;
-    const T* qbase = (const T*)dsc[p].qbase;
-    const T* z = (const T*)dsc[p].zout;
-    const double s = cf[p].s;
-    double c[BSR_NQ_MAX];
-#pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX; ++i) c[i] = cf[p].c[i];
-    double ww = 0.0, wy = 0.0;
-    for (int it = 0; it < iters; ++it) {
-      const int64_t r0 = row_base + (int64_t)it * (BSR_WAVE * U) + lane * U;
-      double w[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = s * (double)z[r0 + u];
-#pragma unroll
-      for (int i = 0; i < BSR_NQ_MAX; ++i) {
-        if (i < nq) {
-          const T* q = qbase + (int64_t)i * ld + r0;
-#pragma unroll
-          for (int u = 0; u < U; ++u) w[u] = fma(-c[i], (double)q[u], w[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if ((r0 + u) < N) {
-          ww = fma(w[u], w[u], ww);
-          wy = fma(w[u], (double)y[r0 + u], wy);
-        }
-      }
-    }
-    ww = wave_sum(ww);
-    wy = wave_sum(wy);
-    if (lane == 0) {
-      double* o = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
-      o[0] = ww;
-      o[1] = wy;
-    }
-  }
-}
-
 // finalize (only proposals flagged by k_solve): same algebra with the directly measured |w|^2 and w.y
 __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
                                                        const ChainK* __restrict__ cks,
@@ -978,19 +1144,40 @@ __global__ void k_convert_in(const double* __restrict__ src, T* __restrict__ dst
 
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
-template <typename T>
-void launch_pass1(hipStream_t st, const LaunchGeom& g, const T* Xt, const T* y, int64_t ld, int64_t N,
-                  const bsr_node* tapes, const PropDesc* desc, int P, double* part1, double* spill,
-                  int spill_slots) {
-  dim3 grid(g.n_rb, g.n_pg), block(BSR_WG_WAVES * BSR_WAVE);
-  hipLaunchKernelGGL((k_pass1<T, 2>), grid, block, 0, st, Xt, y, ld, N, tapes, desc, P, g.rb_rows, g.pg, g.n_rb,
-                     part1, (T*)spill, spill_slots);
+template <typename T, int NQ, int MODE, int U>
+static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
+  const LaunchGeom& g = a.g;
+  dim3 grid((unsigned)(((g.n_rb + 7) / 8) * 8 * g.n_pg)), block(BSR_WG_WAVES * BSR_WAVE);
+  if (a.feat_list) {
+    const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
+    hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
+                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
+                       (T*)a.spill, a.spill_slots);
+  } else {
+    hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
+                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
+                       (T*)a.spill, a.spill_slots);
+  }
+}
+template <typename T, int NQ, int MODE>
+static void launch_rows_nq(hipStream_t st, const RowPassArgs<T>& a) {
+  switch (a.rows_per_lane) {
+    case 8: launch_rows_u<T, NQ, MODE, 8>(st, a); break;
+    case 4: launch_rows_u<T, NQ, MODE, 4>(st, a); break;
+    default: launch_rows_u<T, NQ, MODE, 2>(st, a); break;
+  }
 }
 template <typename T>
-void launch_pass2(hipStream_t st, const LaunchGeom& g, const T* y, int64_t ld, int64_t N, const PropDesc* desc,
-                  const PropCoef* coef, int P, double* part2) {
-  dim3 grid(g.n_rb, g.n_pg), block(BSR_WG_WAVES * BSR_WAVE);
-  hipLaunchKernelGGL((k_pass2<T, 2>), grid, block, 0, st, y, ld, N, desc, coef, P, g.rb_rows, g.pg, g.n_rb, part2);
+void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) {
+#define BSR_CASE(n)                                        \
+  case n:                                                  \
+    if (residual) launch_rows_nq<T, n, MODE_RESIDUAL>(st, a); \
+    else launch_rows_nq<T, n, MODE_PROJECT>(st, a);        \
+    break;
+  switch (nq) {
+    BSR_CASE(0) BSR_CASE(1) BSR_CASE(2) BSR_CASE(3) BSR_CASE(4) BSR_CASE(5) BSR_CASE(6) BSR_CASE(7)
+  }
+#undef BSR_CASE
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out) {
@@ -1027,10 +1214,7 @@ void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n) {
 }
 
 #define BSR_INSTANTIATE(T)                                                                                          \
-  template void launch_pass1<T>(hipStream_t, const LaunchGeom&, const T*, const T*, int64_t, int64_t,               \
-                                const bsr_node*, const PropDesc*, int, double*, double*, int);                      \
-  template void launch_pass2<T>(hipStream_t, const LaunchGeom&, const T*, int64_t, int64_t, const PropDesc*,        \
-                                const PropCoef*, int, double*);                                                     \
+  template void launch_rows<T>(hipStream_t, const RowPassArgs<T>&, int, int);                                       \
   template void launch_refresh_basis<T>(hipStream_t, const T*, T*, const T*, int64_t, int64_t, int, const double*,  \
                                         const uint32_t*, ChainK*);                                                  \
   template void launch_chain_fit<T>(hipStream_t, const T*, const T*, int64_t, int64_t, int, int, ChainFitOut*);     \

@@ -1,0 +1,11 @@
+run() { python bench.py --steps 60 --warmup 5 --cpu-sample 0 --batch ${B:-64} > gpurun_out/x.json; python -c "
+import json,sys; d=json.load(open('gpurun_out/x.json')); print('$1', round(d['value']), round(d['ms_per_step']*1000,1), round(d["roofline"]["kernel_us"],1))"; }
+BSR_P1_U=2 run lds_u2
+BSR_P1_U=4 run lds_u4
+BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2
+BSR_NO_LDS=1 BSR_P1_U=4 run glb_u4
+BSR_RB_ROWS=256 BSR_P1_U=2 run lds_u2_rb256
+BSR_RB_ROWS=1024 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_rb1024
+BSR_RB_ROWS=256 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_rb256
+BSR_TARGET_WGS=4096 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_wgs4096
+BSR_TARGET_WGS=1024 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_wgs1024
