@@ -628,6 +628,131 @@ __device__ __forceinline__ void solve_complete(const SolveIn& in, int lane, bsr_
   if (lane >= K && lane < BSR_MAX_K) out->beta[lane] = 0.0;
 }
 
+// Same algebra as solve_complete for K <= 4, with the K x K factor, its Jacobi SVD and the ridge formulas held
+// entirely in registers (K is a template parameter: every index is static).  All lanes compute the same values, so
+// there is no cross-lane traffic at all: the cooperative version above spends its time in ds_bpermute latency
+// (~26 dependent shuffles per Jacobi rotation).
+template <int K>
+__device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out) {
+  constexpr int NQ = K - 1;
+  const int k = in.k;
+  const ChainK* ck = in.ck;
+  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
+  double W[K][K], V[K][K];
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      W[i][j] = (j < NQ) ? ((i <= j) ? ck->R[i * BSR_NQ_MAX + j] : 0.0) : ((i < NQ) ? in.c[i < NQ ? i : 0] : rho);
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int a = 0; a < K - 1; ++a) {
+#pragma unroll
+      for (int b = a + 1; b < K; ++b) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          alpha = fma(W[i][a], W[i][a], alpha);
+          beta = fma(W[i][b], W[i][b], beta);
+          gamma = fma(W[i][a], W[i][b], gamma);
+        }
+        const double lim = sqrt(alpha) * sqrt(beta);
+        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {
+          off = fmax(off, fabs(gamma) / lim);
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+          for (int i = 0; i < K; ++i) {
+            const double wa = W[i][a], wb = W[i][b], va = V[i][a], vb = V[i][b];
+            W[i][a] = cs * wa - sn * wb;
+            W[i][b] = sn * wa + cs * wb;
+            V[i][a] = cs * va - sn * vb;
+            V[i][b] = sn * va + cs * vb;
+          }
+        }
+      }
+    }
+    if (off <= 1e-15) break;
+  }
+  double h[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) h[i] = (i < NQ) ? ck->qy[i < NQ ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  double hh = 0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) hh = fma(h[i], h[i], hh);
+  const double eps = 1e-6;
+  double sv[K], coefj[K];
+  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    double n2 = 0.0, tj = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      n2 = fma(W[i][j], W[i][j], n2);
+      tj = fma(W[i][j], h[i], tj);
+    }
+    sv[j] = sqrt(n2);
+    const double aj = (sv[j] > 0.0) ? tj / sv[j] : 0.0;
+    const double dj = (in.tau * sv[j]) * (in.tau * sv[j]);
+    const double wj = eps / (dj + eps);
+    coefj[j] = (in.tau * sv[j]) / (dj + eps) * aj;
+    smax = fmax(smax, sv[j]);
+    smin = fmin(smin, sv[j]);
+    if (sv[j] > 0.0) {
+      misfit = fma(wj * wj, aj * aj, misfit);
+      seen = fma(aj, aj, seen);
+    }
+  }
+  misfit += fmax(0.0, hh - seen);
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tol = smax * dimmax * 2.220446049250313e-16;
+  int rank = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) rank += (sv[j] > tol) ? 1 : 0;
+  const double sse = fmax(0.0, ck->yperp2 - h[NQ] * h[NQ]) + misfit;
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  double bt[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double bi = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) bi = fma(V[i][j], coefj[j], bi);
+    bt[i] = bi;
+  }
+  if (lane == 0) {
+    out->loglik = ll;
+    out->sse = sse;
+    out->scale = in.scale;
+    out->maxabs = in.maxabs;
+    out->smin = smin / in.s;
+    out->smax = smax / in.s;
+    out->rank = rank;
+    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+#pragma unroll
+    for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tree = (i == NQ) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bt[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score* out) {
+  switch (in.K) {
+    case 1: solve_regs<1>(in, lane, out); break;
+    case 2: solve_regs<2>(in, lane, out); break;
+    case 3: solve_regs<3>(in, lane, out); break;
+    case 4: solve_regs<4>(in, lane, out); break;
+    default: solve_complete(in, lane, out); break;
+  }
+}
+
 __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainK* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv) {
@@ -745,7 +870,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   in.nq = nq;
   in.N = N;
   in.flags = flags;
-  solve_complete(in, lane, out);
+  solve_any(in, lane, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -786,7 +911,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   in.nq = dsc[p].nq;
   in.N = N;
   in.flags = cf->flags;
-  solve_complete(in, lane, outv + p);
+  solve_any(in, lane, outv + p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
