@@ -100,9 +100,9 @@ struct RowPassArgs {
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor);
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
                           const double* col_maxabs, const uint32_t* col_flags, ChainK* ck_chain);

@@ -561,6 +561,7 @@ struct SolveIn {
   int K, k, nq;
   int64_t N;
   uint32_t flags;
+  double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
 };
 
 // Completes one proposal: singular values -> rank, Beta, SSE, log-likelihood.  Called by all 64 lanes.
@@ -591,7 +592,7 @@ __device__ __forceinline__ void solve_complete(const SolveIn& in, int lane, bsr_
   int rank = 0;
   for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a));
   const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
-  const double tol = smax * dimmax * 2.220446049250313e-16;       // numpy matrix_rank default tolerance
+  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);  // numpy matrix_rank default
   for (int a = 0; a < K; ++a) {
     const double sva = __shfl(sv, a), aa = __shfl(aj, a), wa = __shfl(wj, a);
     smin = fmin(smin, sva);
@@ -709,7 +710,7 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
   }
   misfit += fmax(0.0, hh - seen);
   const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
-  const double tol = smax * dimmax * 2.220446049250313e-16;
+  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);
   int rank = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) rank += (sv[j] > tol) ? 1 : 0;
@@ -755,7 +756,8 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
 
 __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainK* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
-                                                    PropCoef* __restrict__ coef, bsr_score* __restrict__ outv) {
+                                                    PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
+                                                    double rank_floor) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
@@ -870,6 +872,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   in.nq = nq;
   in.N = N;
   in.flags = flags;
+  in.rank_floor = rank_floor;
   solve_any(in, lane, out);
 }
 
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
                                                        const ChainK* __restrict__ cks,
                                                        const PropCoef* __restrict__ coef, int P, int n_rb,
                                                        const double* __restrict__ part2, int64_t N,
-                                                       bsr_score* __restrict__ outv) {
+                                                       bsr_score* __restrict__ outv, double rank_floor) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
@@ -911,6 +914,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   in.nq = dsc[p].nq;
   in.N = N;
   in.flags = cf->flags;
+  in.rank_floor = rank_floor;
   solve_any(in, lane, outv + p);
 }
 
@@ -1305,12 +1309,12 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 #undef BSR_CASE
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out) {
-  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor) {
+  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out) {
-  hipLaunchKernelGGL(k_finalize, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor) {
+  hipLaunchKernelGGL(k_finalize, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out, rank_floor);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,

@@ -1,0 +1,136 @@
+"""Full-size checks of the HIP path at BASELINE.json's configurations through size-independent properties (the CPU
+oracle would take minutes per proposal at these sizes), plus the fp32-vs-fp64 tolerance sweep of config 5."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from bsr.device import DeviceContext
+from bsr.node import Node
+from bsr.tape import flatten
+
+
+def leaf(f):
+    n = Node(1)
+    n.type = 0
+    n.feature = np.array([f])
+    return n
+
+
+def un(op, c, a=None, b=None):
+    n = Node(0)
+    n.type, n.operator, n.left, n.a, n.b = 1, op, c, a, b
+    c.parent = n
+    return n
+
+
+def bi(op, l, r):
+    n = Node(0)
+    n.type, n.operator, n.left, n.right = 2, op, l, r
+    l.parent = r.parent = n
+    return n
+
+
+def synth(N, d, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    return X, y
+
+
+def current_trees(K, d):
+    pool = [bi('*', leaf(0), leaf(1)), un('sin', bi('*', un('ln', leaf(0), 1.0, -1.0), un('ln', leaf(1), 1.0, -1.0))),
+            un('ln', leaf(2 % d), 0.7, -0.2), un('cos', leaf(3 % d)), un('square', leaf(4 % d)),
+            bi('+', leaf(5 % d), un('exp', un('neg', un('square', leaf(6 % d))))), un('cubic', leaf(7 % d)),
+            un('inv', un('ln', un('square', leaf(8 % d)), 1.0, 1.0))]
+    return pool[:K]
+
+
+def loglik_from_sse(sse, N, sigma):
+    return -sse / (2 * sigma * sigma) - 0.5 * N * np.log(2 * np.pi * sigma * sigma)
+
+
+@pytest.mark.parametrize("N,d,K", [(100_000, 10, 3), (100_000, 10, 8), (1_000_000, 50, 3)])
+def test_fullsize_properties(N, d, K):
+    X, y = synth(N, d)
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=16)
+    cur = current_trees(K, d)
+    tapes = [flatten(t) for t in cur]
+    for k in range(K):
+        ctx.set_current(0, k, tapes[k])
+    info = ctx.refresh(0)
+    sse_old = info["sse_old"]
+    assert np.isfinite(sse_old) and sse_old > 0
+    sig = 0.9
+    # (1) idempotence: proposing tree k itself reproduces the old-state fit, for every k
+    res = ctx.score_batch(tapes, [0] * K, list(range(K)), [sig] * K)
+    for k in range(K):
+        assert res["rank"][k] == K
+        assert abs(res["sse"][k] - sse_old) <= 1e-9 * sse_old, (k, res["sse"][k], sse_old)
+        assert abs(res["loglik"][k] - loglik_from_sse(sse_old, N, sig)) <= 1e-9 * abs(res["loglik"][k])
+        assert abs(res["scale"][k] - info["scale_old"]) <= 1e-15 * info["scale_old"]
+    # (2) a candidate equal to a sibling (K>1) or identically zero is rank-deficient: rejected by the gate
+    if K > 1:
+        r = ctx.score_batch([tapes[1], flatten(un('neg', cur[1]))], [0, 0], [0, 0], [sig, sig])
+        assert r["rank"][0] == K - 1 and r["rank"][1] == K - 1
+    zero = flatten(bi('+', leaf(0), un('neg', leaf(0))))
+    r = ctx.score_batch([zero], [0], [0], [sig])
+    assert r["rank"][0] == K - 1 and (r["flags"][0] & 4)
+    # (3) OLS is invariant to an affine-free rescaling of the candidate column (ridge 1e-6 on unit-scaled columns)
+    cand = un('sin', bi('+', leaf(0), leaf(1)))
+    scaled = un('ln', un('sin', bi('+', leaf(0), leaf(1))), 0.125, 0.0)
+    r = ctx.score_batch([flatten(cand), flatten(scaled)], [0, 0], [K - 1, K - 1], [sig, sig])
+    assert r["rank"][0] == K and r["rank"][1] == K
+    assert abs(r["sse"][0] - r["sse"][1]) <= 1e-7 * r["sse"][0]
+    # (4) inf and NaN candidates: rank 0 and -1 like np.linalg.matrix_rank / LinAlgError
+    big = lambda: un('cubic', un('square', un('square', un('exp', un('square', un('square', leaf(0)))))))  # (e^(x^4))^12
+    blow = flatten(big())
+    nan = flatten(un('sin', big()))
+    r = ctx.score_batch([blow, nan], [0, 0], [0, 0], [sig, sig])
+    assert r["rank"][0] == 0 and (r["flags"][0] & 1)
+    assert r["rank"][1] == -1 and (r["flags"][1] & 2)
+    # (5) accept: commit == set_current, bit for bit; the new old-state equals the candidate's score
+    r = ctx.score_batch([flatten(cand)], [0], [K - 1], [sig])
+    ctx.commit(0, K - 1, 0)
+    a = ctx.refresh(0)
+    ba, ra = ctx.fit_beta(0)
+    ctx.set_current(0, K - 1, flatten(cand))
+    b = ctx.refresh(0)
+    bb, rb = ctx.fit_beta(0)
+    assert a["sse_old"] == b["sse_old"] and ra == rb and np.array_equal(ba, bb)
+    assert abs(a["sse_old"] - r["sse"][0]) <= 1e-9 * a["sse_old"]
+    # (6) determinism of a mixed batch, twice
+    batch = [flatten(cand), zero, tapes[0], blow]
+    r1 = ctx.score_batch(batch, [0] * 4, [0, 1 % K, 0, 0], [sig] * 4)
+    r2 = ctx.score_batch(batch, [0] * 4, [0, 1 % K, 0, 0], [sig] * 4)
+    assert r1.tobytes() == r2.tobytes()
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,d", [(200_000, 50), (1_000_000, 50)])
+def test_fp32_vs_fp64_loglik_tolerance(N, d):
+    """Config 5: the f32 context (f32 storage and tree arithmetic, f64 accumulation) against the f64 one."""
+    K = 3
+    X, y = synth(N, d)
+    cur = current_trees(K, d)
+    cands = [un('sin', bi('+', leaf(0), leaf(1))), bi('*', un('cos', leaf(7)), leaf(12)), un('ln', un('square', leaf(20)), 0.3, 1.5),
+             bi('+', un('exp', un('neg', un('square', leaf(3)))), un('inv', un('ln', un('square', leaf(9)), 1.0, 0.5))),
+             un('cubic', un('sin', leaf(33))), bi('*', leaf(0), leaf(1))]   # last one duplicates current tree 0
+    out = {}
+    for dt in ("f64", "f32"):
+        ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=16, dtype=dt)
+        for k in range(K):
+            ctx.set_current(0, k, flatten(cur[k]))
+        info = ctx.refresh(0)
+        res = ctx.score_batch([flatten(c) for c in cands], [0] * len(cands), [i % K for i in range(len(cands))],
+                              [0.8] * len(cands))
+        out[dt] = (info["sse_old"], res.copy())
+        ctx.close()
+    s64, r64 = out["f64"]
+    s32, r32 = out["f32"]
+    assert abs(s32 - s64) <= 2e-5 * s64
+    assert np.array_equal(r64["rank"], r32["rank"]) and list(r64["rank"]) == [3, 3, 3, 3, 3, 2]
+    ok = r64["rank"] == K
+    rel = np.abs(r32["loglik"][ok] - r64["loglik"][ok]) / np.abs(r64["loglik"][ok])
+    assert np.all(rel <= 5e-5), rel          # fp32 tolerance of the log-posterior on well-conditioned trees
+    assert np.all(np.abs(r32["sse"][ok] - r64["sse"][ok]) <= 5e-5 * r64["sse"][ok])
