@@ -177,10 +177,18 @@ def main():
                        "transcendental_node_frac": n_trans / max(1, n_nodes)},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / p1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / p1 / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_pass1 (tree-eval + projection)", "kernel_us": kern_us[0],
+                         "kernel": "k_rows<PROJECT> (tree-eval + projection)", "kernel_us": kern_us[0],
                          "algorithmic_bytes": alg_bytes},
             "batches_in_flight": depth,
         }
+        # HBM traffic per launch of that kernel from the committed rocprofv3 PMC run of this same command
+        # (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 on gfx950)
+        tpath = os.path.join(ROOT, "profiles", "r01c_traffic_%s_B%d.json" % (args.workload, B))
+        if C == 1 and args.dtype == "f64" and os.path.exists(tpath):
+            for kname, rec in json.load(open(tpath)).items():
+                if "k_rows" in kname:
+                    out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(X, y, K, chains, packed[args.warmup:], args.cpu_sample)
         if gathered is not None:
