@@ -53,7 +53,8 @@ enum {
   BSR_E_TOOBIG = -4,    /* tape longer than BSR_MAX_TAPE / deeper than BSR_MAX_STACK / batch too large */
   BSR_E_TAPE = -5,      /* malformed tape (not a valid postfix program) */
   BSR_E_STATE = -6,     /* chain state not initialised for the requested operation */
-  BSR_E_COMM = -7       /* RCCL error */
+  BSR_E_COMM = -7,      /* RCCL error */
+  BSR_E_LINALG = -8     /* NaN reached the rank gate: the reference raises numpy.linalg.LinAlgError (codes/funcs.py:1226) */
 };
 
 /* One row of a postfix (RPN) tape = one node of codes/funcs.py:30-55 (Node).
@@ -188,6 +189,37 @@ int bsr_comm_init(bsr_ctx* ctx, int32_t nranks, int32_t rank, const void* id128)
 /* all-gather of fixed-size records over RCCL: recv holds nranks*bytes_per_rank bytes, rank-major */
 int bsr_comm_allgather(bsr_ctx* ctx, const void* send, void* recv, int64_t bytes_per_rank);
 int bsr_comm_destroy(bsr_ctx* ctx);
+
+/* ---- native sampler: Prop/auxProp/grow/fStruc/newProp + the chain loop of BSR.fit in C++ ----
+ * Replaces, draw for draw, codes/funcs.py:74-119, 349-398, 406-1138, 1184-1306 and codes/bsr_class.py:99-273; the
+ * data side goes through the entry points above.  Random streams are numpy legacy RandomState streams (MT19937,
+ * polar normal with cached value, masked-rejection randint), one per chain. */
+typedef struct bsr_engine bsr_engine;
+
+typedef struct bsr_trace {   /* one consumed proposal (optional diagnostics / parity tests) */
+  int32_t chain, count, action, change, rank, accepted, n_nodes, pad;
+  double Q, Qinv, new_sigma, new_sa2, new_sb2, yllstar, yll, logR, u, rmse;
+  uint64_t tree_hash;        /* FNV-1a over the proposed tree's pre-order (type, operator|100+feature) */
+} bsr_trace;
+
+int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chains, int32_t K, int64_t N, int32_t n_feature,
+                      double beta, int32_t val, int32_t y_is_series);
+int bsr_engine_destroy(bsr_engine* e);
+const char* bsr_engine_last_error(const bsr_engine* e);
+int bsr_engine_seed(bsr_engine* e, int32_t chain, uint32_t seed);   /* == np.random.seed(seed) for that chain */
+int bsr_engine_set_rng(bsr_engine* e, int32_t chain, const uint32_t* key624, int32_t pos, int32_t has_gauss,
+                       double gauss);                                /* == np.random.set_state(...) */
+int bsr_engine_get_rng(bsr_engine* e, int32_t chain, uint32_t* key624, int32_t* pos, int32_t* has_gauss,
+                       double* gauss);
+int bsr_engine_init_chain(bsr_engine* e, int32_t chain);            /* codes/bsr_class.py:116-163 */
+int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t max_props, bsr_trace* trace, int64_t trace_cap,
+                   int64_t* n_trace, int32_t max_batch);
+/* tapes: K*tape_cap rows; current != 0: the chain's current trees, else the `Roots` list BSR.fit would append
+ * (codes/bsr_class.py:270-273). counters[5] = proposals, accepts, rank-gate rejections, discarded, done. */
+int bsr_engine_chain_result(bsr_engine* e, int32_t chain, bsr_node* tapes, int32_t tape_cap, int32_t* tape_len,
+                            double* beta, double* errs, int32_t errs_cap, int32_t* n_errs, int64_t* counters,
+                            double* sigma, int32_t current);
+int bsr_rng_selftest(uint32_t seed, int32_t n, const int32_t* kind, const int64_t* lo, const int64_t* hi, double* out);
 
 #ifdef __cplusplus
 }

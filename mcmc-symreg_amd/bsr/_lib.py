@@ -11,7 +11,7 @@ F_INF, F_NAN, F_RANKDEF, F_SCALE_RETRY = 1, 2, 4, 8
 DTYPE_F64, DTYPE_F32 = 0, 1
 
 ERRORS = {-1: "BSR_E_ARG", -2: "BSR_E_HIP", -3: "BSR_E_NODEVICE", -4: "BSR_E_TOOBIG", -5: "BSR_E_TAPE",
-          -6: "BSR_E_STATE", -7: "BSR_E_COMM"}
+          -6: "BSR_E_STATE", -7: "BSR_E_COMM", -8: "BSR_E_LINALG"}
 
 
 class BsrError(RuntimeError):
@@ -73,6 +73,16 @@ def lib():
         "bsr_comm_init": (C.c_int, [vp, i32, i32, vp]),
         "bsr_comm_allgather": (C.c_int, [vp, vp, vp, i64]),
         "bsr_comm_destroy": (C.c_int, [vp]),
+        "bsr_engine_create": (C.c_int, [C.POINTER(vp), vp, i32, i32, i64, i32, dbl, i32, i32]),
+        "bsr_engine_destroy": (C.c_int, [vp]),
+        "bsr_engine_last_error": (C.c_char_p, [vp]),
+        "bsr_engine_seed": (C.c_int, [vp, i32, C.c_uint32]),
+        "bsr_engine_set_rng": (C.c_int, [vp, i32, vp, i32, i32, dbl]),
+        "bsr_engine_get_rng": (C.c_int, [vp, i32, vp, pi, pi, pd]),
+        "bsr_engine_init_chain": (C.c_int, [vp, i32]),
+        "bsr_engine_run": (C.c_int, [vp, i32, i64, vp, i64, C.POINTER(i64), i32]),
+        "bsr_engine_chain_result": (C.c_int, [vp, i32, vp, i32, vp, vp, vp, i32, pi, vp, pd, i32]),
+        "bsr_rng_selftest": (C.c_int, [C.c_uint32, i32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -88,7 +98,17 @@ EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_des
            "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_score_submit",
            "bsr_score_wait", "bsr_fit_beta",
            "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_comm_unique_id",
-           "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy"]
+           "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy", "bsr_engine_create", "bsr_engine_destroy",
+           "bsr_engine_last_error", "bsr_engine_seed", "bsr_engine_set_rng", "bsr_engine_get_rng",
+           "bsr_engine_init_chain", "bsr_engine_run", "bsr_engine_chain_result", "bsr_rng_selftest"]
+
+TRACE_DTYPE = np.dtype([("chain", "<i4"), ("count", "<i4"), ("action", "<i4"), ("change", "<i4"), ("rank", "<i4"),
+                        ("accepted", "<i4"), ("n_nodes", "<i4"), ("pad", "<i4"), ("Q", "<f8"), ("Qinv", "<f8"),
+                        ("new_sigma", "<f8"), ("new_sa2", "<f8"), ("new_sb2", "<f8"), ("yllstar", "<f8"),
+                        ("yll", "<f8"), ("logR", "<f8"), ("u", "<f8"), ("rmse", "<f8"), ("tree_hash", "<u8")],
+                       align=True)
+ACTIONS = ["stay", "grow", "prune", "detransform", "transform", "ReassignOperator", "ReassignFeature"]
+CHANGES = ["", "shrinkage", "expansion"]
 
 
 def check(rc, ctx=None):

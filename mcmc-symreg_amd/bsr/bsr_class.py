@@ -4,6 +4,8 @@ Constructor arguments, fit/predict/model/complexity and the fitted attributes ro
 reference's meaning.  Extra keyword-only options (defaults preserve the reference's behaviour):
   device, dtype          GPU index and compute type ("f64" | "f32")
   batch                  speculative proposals per launch and chain
+  engine                 "native": the C++ sampler of libbsr_hip.so drives the GPU (default); "python": the
+                         bsr.chain / bsr.proposal implementation of the same algorithm (same results)
   chain_seeds            None: chains run one after the other on the global numpy RNG stream exactly like the
                          reference; a list of ints: chain c is seeded with chain_seeds[c] and chains advance
                          together, several per launch (independent restarts are the reference's only parallelism,
@@ -28,7 +30,7 @@ except Exception:  # pragma: no cover
 
 class BSR(BaseEstimator, RegressorMixin):
     def __init__(self, treeNum=3, itrNum=5000, alpha1=0.4, alpha2=0.4, beta=-1, disp=False, val=100,
-                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8):
+                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8, engine="native"):
         self.treeNum = treeNum
         self.itrNum = itrNum
         self.alpha1 = alpha1
@@ -41,6 +43,7 @@ class BSR(BaseEstimator, RegressorMixin):
         self.batch = batch
         self.chain_seeds = chain_seeds
         self.chains_per_launch = chains_per_launch
+        self.engine = engine
 
     # ---- codes/bsr_class.py:37-51
     def model(self, last_ind=1):
@@ -81,14 +84,17 @@ class BSR(BaseEstimator, RegressorMixin):
         self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
         results = []
         try:
-            if seeds is None:
+            if self.engine == "native":
+                results = self._fit_native(scorer, N, d, K, seeds, n_slots, y_is_series)
+            elif seeds is None:
                 if self.disp:
                     print('starting training...')
                 for _ in range(self.itrNum):
                     ch = Chain(0, scorer, N, d, K, beta=self.beta, val=self.val, table=T, y_is_series=y_is_series)
                     run_chains([ch], scorer, batch_per_chain=self.batch)
                     rng.set_state(ch.rng_state)      # the next chain continues the same stream
-                    results.append(ch)
+                    results.append(ch.result())
+                    results[-1].update(n_rank_rejects=ch.n_rank_rejects, n_discarded=ch.n_discarded)
             else:
                 todo = list(range(min(self.itrNum, len(seeds))))
                 while todo:
@@ -99,16 +105,44 @@ class BSR(BaseEstimator, RegressorMixin):
                         chains.append(Chain(slot, scorer, N, d, K, beta=self.beta, val=self.val, table=T,
                                             y_is_series=y_is_series))
                     run_chains(chains, scorer, batch_per_chain=self.batch)
-                    results.extend(chains)
+                    for ch in chains:
+                        results.append(ch.result())
+                        results[-1].update(n_rank_rejects=ch.n_rank_rejects, n_discarded=ch.n_discarded)
         finally:
             scorer.close()
-        for ch in results:
-            r = ch.result()
+        for r in results:
             self.roots_.append(r["roots"])
             self.betas_.append(r["beta"])
             self.train_err_.append(r["errs"])
-            self.stats_["proposals"] += ch.n_props
-            self.stats_["accepts"] += ch.n_accept
-            self.stats_["rank_rejects"] += ch.n_rank_rejects
-            self.stats_["discarded"] += ch.n_discarded
+            self.stats_["proposals"] += r["n_props"]
+            self.stats_["accepts"] += r["n_accept"]
+            self.stats_["rank_rejects"] += r["n_rank_rejects"]
+            self.stats_["discarded"] += r["n_discarded"]
         return
+
+    def _fit_native(self, scorer, N, d, K, seeds, n_slots, y_is_series):
+        from .native import NativeEngine
+        eng = NativeEngine(scorer.ctx, n_slots, d, beta=self.beta, val=self.val, y_is_series=y_is_series)
+        results = []
+        try:
+            if seeds is None:
+                # chains one after the other on numpy's global stream, exactly like the reference
+                eng.set_numpy_state(0)
+                for _ in range(self.itrNum):
+                    eng.init_chain(0)
+                    eng.run(batch_per_chain=self.batch)
+                    results.append(eng.result(0))
+                np.random.set_state(eng.get_numpy_state(0))
+            else:
+                todo = list(range(min(self.itrNum, len(seeds))))
+                while todo:
+                    wave, todo = todo[:n_slots], todo[n_slots:]
+                    for slot, ci in enumerate(wave):
+                        eng.seed(slot, seeds[ci])
+                        eng.init_chain(slot)
+                    eng.run(batch_per_chain=self.batch)
+                    for slot, ci in enumerate(wave):
+                        results.append(eng.result(slot))
+        finally:
+            eng.close()
+        return results

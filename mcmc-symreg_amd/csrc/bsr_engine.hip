@@ -1,0 +1,1274 @@
+// Native host-side sampler: the reference's proposal generator and chain loop in C++, driving the
+// GPU scorer through the same C ABI entry points the Python engine uses.  Not data-parallel; it exists because once
+// the O(N) work is on the GPU the Python proposal generator (~100 us/proposal) caps chain throughput.
+//
+// Every branch follows the reference's behaviour, quirks included, because the accepted-tree sequence for a seed is
+// pinned by the ORDER and KIND of random draws:
+//   grow      codes/funcs.py:74-119      fStruc   codes/funcs.py:349-398
+//   Prop      codes/funcs.py:406-923     auxProp  codes/funcs.py:935-1138
+//   newProp   codes/funcs.py:1184-1306   chain loop codes/bsr_class.py:99-273
+// The random stream is numpy's legacy RandomState: MT19937, random_sample = (a>>5, b>>6) doubles, masked-rejection
+// randint on 32-bit draws, polar-method standard_normal with a cached second value, choice via cdf search, and
+// scipy's invgamma.rvs(a) = 1 / gammainccinv(a, U).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/bsr_hip.h"
+
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+
+// ------------------------------------------------------------------------------------------------ RNG
+struct LegacyRng {
+  uint32_t key[624];
+  int pos = 624;
+  int has_gauss = 0;
+  double gauss = 0.0;
+
+  void seed(uint32_t s) {  // np.random.seed(int): mt19937_seed
+    for (int i = 0; i < 624; ++i) {
+      key[i] = s;
+      s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+    }
+    pos = 624;
+    has_gauss = 0;
+    gauss = 0.0;
+  }
+  void refill() {
+    const uint32_t UP = 0x80000000u, LOW = 0x7fffffffu, MAT = 0x9908b0dfu;
+    int i;
+    uint32_t yv;
+    for (i = 0; i < 624 - 397; ++i) {
+      yv = (key[i] & UP) | (key[i + 1] & LOW);
+      key[i] = key[i + 397] ^ (yv >> 1) ^ ((yv & 1u) ? MAT : 0u);
+    }
+    for (; i < 623; ++i) {
+      yv = (key[i] & UP) | (key[i + 1] & LOW);
+      key[i] = key[i + (397 - 624)] ^ (yv >> 1) ^ ((yv & 1u) ? MAT : 0u);
+    }
+    yv = (key[623] & UP) | (key[0] & LOW);
+    key[623] = key[396] ^ (yv >> 1) ^ ((yv & 1u) ? MAT : 0u);
+    pos = 0;
+  }
+  uint32_t next32() {
+    if (pos == 624) refill();
+    uint32_t yv = key[pos++];
+    yv ^= (yv >> 11);
+    yv ^= (yv << 7) & 0x9d2c5680u;
+    yv ^= (yv << 15) & 0xefc60000u;
+    yv ^= (yv >> 18);
+    return yv;
+  }
+  double uniform() {  // random_sample / uniform(0,1,1)[0]
+    const uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+  int64_t randint(int64_t lo, int64_t hi) {  // np.random.randint(lo, hi): masked rejection on 32-bit draws
+    const uint64_t rng = (uint64_t)(hi - 1 - lo);
+    if (rng == 0) return lo;
+    uint64_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    mask |= mask >> 32;
+    if (rng == 0xFFFFFFFFull) return lo + (int64_t)next32();
+    uint32_t v;
+    do {
+      v = next32() & (uint32_t)mask;
+    } while (v > rng);
+    return lo + (int64_t)v;
+  }
+  double standard_normal() {  // legacy_gauss
+    if (has_gauss) {
+      const double t = gauss;
+      has_gauss = 0;
+      gauss = 0.0;
+      return t;
+    }
+    double f, x1, x2, r2;
+    do {
+      x1 = 2.0 * uniform() - 1.0;
+      x2 = 2.0 * uniform() - 1.0;
+      r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = std::sqrt(-2.0 * std::log(r2) / r2);
+    gauss = f * x1;
+    has_gauss = 1;
+    return f * x2;
+  }
+  double normal(double loc, double scale) { return loc + scale * standard_normal(); }
+};
+
+// Q(a,x) = p solved for x, a in {1,4} (scipy.special.gammainccinv; invgamma.rvs(a) = 1/gammainccinv(a, U))
+double gammainccinv_int(int a, double p) {
+  if (a == 1) return -std::log(p);
+  if (p <= 0.0) return kInf;
+  if (p >= 1.0) return 0.0;
+  // a == 4: Q = e^-x (1 + x + x^2/2 + x^3/6); P = 1 - Q = e^-x sum_{n>=4} x^n/n!
+  auto Qf = [](double x) { return std::exp(-x) * (1.0 + x * (1.0 + x * (0.5 + x / 6.0))); };
+  auto Pf = [](double x) {
+    double term = x * x * x * x / 24.0, sum = term;
+    for (int n = 5; n < 200; ++n) {
+      term *= x / n;
+      sum += term;
+      if (term < 1e-18 * sum) break;
+    }
+    return std::exp(-x) * sum;
+  };
+  // start from the Wilson-Hilferty approximation of the chi-square quantile (x = chi2_{2a}/2)
+  double x;
+  {
+    const double q = p;  // upper tail probability
+    // normal quantile by a coarse rational approximation, refined by Newton below anyway
+    double t = std::sqrt(-2.0 * std::log(q < 0.5 ? q : 1.0 - q));
+    double z = t - (2.515517 + 0.802853 * t + 0.010328 * t * t) / (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
+    if (q >= 0.5) z = -z;
+    const double k = 8.0;  // degrees of freedom 2a
+    double c = 1.0 - 2.0 / (9.0 * k) + z * std::sqrt(2.0 / (9.0 * k));
+    x = 0.5 * k * c * c * c;
+    if (!(x > 1e-6)) x = std::pow(24.0 * (1.0 - q), 0.25);
+  }
+  const bool use_p = p > 0.5;  // near p = 1 solve P(x) = 1 - p instead (no cancellation)
+  for (int it = 0; it < 100; ++it) {
+    const double dens = x * x * x * std::exp(-x) / 6.0;  // dP/dx = -dQ/dx
+    const double step = use_p ? ((1.0 - p) - Pf(x)) / dens : (Qf(x) - p) / dens;
+    double xn = x + step;
+    if (!(xn > 0.0)) xn = 0.5 * x;
+    const bool conv = std::fabs(xn - x) <= 2e-16 * xn;
+    x = xn;
+    if (conv) break;
+  }
+  return x;
+}
+
+double invgamma_rvs(LegacyRng& r, int a) { return 1.0 / gammainccinv_int(a, r.uniform()); }
+
+inline double flog(double x) { return x > 0 ? std::log(x) : (x == 0 ? -kInf : kNaN); }
+inline double fexp(double x) { return std::exp(x); }
+inline double fdiv(double a, double b) {
+  if (b != 0) return a / b;
+  if (a != a || a == 0) return kNaN;
+  return ((a > 0) == !std::signbit(b)) ? kInf : -kInf;
+}
+inline double invgamma_pdf(double x, int a) {
+  if (!(x > 0)) return 0.0;
+  return fexp(-(a + 1) * std::log(x) - std::lgamma((double)a) - 1.0 / x);
+}
+const double kSqrt2Pi = std::sqrt(2 * M_PI);
+inline double norm_pdf(double x, double loc, double scale) {
+  const double z = (x - loc) / scale;
+  return std::exp(-z * z / 2.0) / kSqrt2Pi / scale;
+}
+inline double pymax(double a, double b) { return b > a ? b : a; }  // Python max(a, b), NaN included
+
+// ------------------------------------------------------------------------------------------------ trees
+enum { OP_INV = 0, OP_LN = 1, OP_TERMINAL = 10 };
+const int kOpType[10] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2};  // codes/bsr_class.py:112
+const double kOpW = 0.1;                                   // uniform weights, codes/bsr_class.py:111
+
+struct TNode {
+  int type = -1;     // -1 not grown, 0 terminal, 1 unary, 2 binary
+  int op = -1;       // operator index (current), -1 none
+  int op_ind = -1;   // index assigned at creation (stale after ReassignOperator, as in the reference)
+  int depth = 0;
+  int left = -1, right = -1, parent = -1;
+  int feature = 0;
+  double a = 0.0, b = 0.0;
+};
+
+struct Tree {
+  std::vector<TNode> n;
+  int root = 0;
+  int add(int depth) {
+    n.emplace_back();
+    n.back().depth = depth;
+    return (int)n.size() - 1;
+  }
+};
+
+void preorder(const Tree& t, int root, std::vector<int>& out) {
+  out.clear();
+  std::vector<int> st;
+  st.push_back(root);
+  while (!st.empty()) {
+    const int i = st.back();
+    st.pop_back();
+    out.push_back(i);
+    if (t.n[i].left >= 0) {
+      if (t.n[i].right >= 0) st.push_back(t.n[i].right);
+      st.push_back(t.n[i].left);
+    }
+  }
+}
+
+Tree clone_tree(const Tree& src, int root) {  // compact copy of the subtree reachable from root
+  Tree d;
+  std::vector<int> order;
+  preorder(src, root, order);
+  std::vector<int> map(src.n.size(), -1);
+  d.n.reserve(order.size() + 8);
+  for (int i : order) {
+    map[i] = (int)d.n.size();
+    d.n.push_back(src.n[i]);
+  }
+  for (auto& nd : d.n) {
+    nd.left = nd.left >= 0 ? map[nd.left] : -1;
+    nd.right = nd.right >= 0 ? map[nd.right] : -1;
+    nd.parent = (nd.parent >= 0 && map[nd.parent] >= 0) ? map[nd.parent] : -1;
+  }
+  d.root = map[root];
+  d.n[d.root].parent = -1;
+  return d;
+}
+
+int count_nodes(const Tree& t, int i) {
+  int c = 0;
+  std::vector<int> st{i};
+  while (!st.empty()) {
+    const int j = st.back();
+    st.pop_back();
+    ++c;
+    if (t.n[j].type == 1) st.push_back(t.n[j].left);
+    else if (t.n[j].type != 0) {
+      st.push_back(t.n[j].left);
+      st.push_back(t.n[j].right);
+    }
+  }
+  return c;
+}
+int count_ln(const Tree& t, int i) {
+  int c = 0;
+  std::vector<int> st{i};
+  while (!st.empty()) {
+    const int j = st.back();
+    st.pop_back();
+    if (t.n[j].type == 1) {
+      if (t.n[j].op == OP_LN) ++c;
+      st.push_back(t.n[j].left);
+    } else if (t.n[j].type != 0) {
+      st.push_back(t.n[j].left);
+      st.push_back(t.n[j].right);
+    }
+  }
+  return c;
+}
+void up_depth(Tree& t, int root) {
+  t.n[root].depth = t.n[root].parent < 0 ? 0 : t.n[t.n[root].parent].depth + 1;
+  std::vector<int> st{root};
+  while (!st.empty()) {
+    const int i = st.back();
+    st.pop_back();
+    if (t.n[i].left >= 0) {
+      t.n[t.n[i].left].depth = t.n[i].depth + 1;
+      st.push_back(t.n[i].left);
+      if (t.n[i].right >= 0) {
+        t.n[t.n[i].right].depth = t.n[i].depth + 1;
+        st.push_back(t.n[i].right);
+      }
+    }
+  }
+}
+
+struct Params {
+  int n_feature;
+  double beta;
+};
+
+int choose_op(LegacyRng& r) {  // np.random.choice(arange(10), p=uniform): cdf.searchsorted(u, 'right')
+  static double cdf[10];
+  static bool init = false;
+  if (!init) {
+    double c = 0;
+    for (int i = 0; i < 10; ++i) {
+      c += kOpW;
+      cdf[i] = c;
+    }
+    const double last = cdf[9];
+    for (int i = 0; i < 10; ++i) cdf[i] /= last;
+    init = true;
+  }
+  const double u = r.uniform();
+  return (int)(std::upper_bound(cdf, cdf + 10, u) - cdf);
+}
+
+void grow(Tree& t, int i, const Params& P, double sigma_a, double sigma_b, LegacyRng& r) {  // codes/funcs.py:74-119
+  const int depth = t.n[i].depth;
+  bool pick = true;
+  if (depth > 0) {
+    const double prob = 1 / std::pow(1 + depth, -P.beta);
+    if (r.uniform() > prob) {
+      t.n[i].feature = (int)r.randint(0, P.n_feature);  // :83, overwritten by the second draw at :99
+      t.n[i].type = 0;
+      pick = false;
+    }
+  }
+  if (pick) {
+    const int k = choose_op(r);
+    t.n[i].op = k;
+    t.n[i].type = kOpType[k];
+    t.n[i].op_ind = k;
+  }
+  if (t.n[i].type == 0) {
+    t.n[i].feature = (int)r.randint(0, P.n_feature);
+  } else if (t.n[i].type == 1) {
+    const int l = t.add(depth + 1);
+    t.n[i].left = l;
+    t.n[l].parent = i;
+    if (t.n[i].op == OP_LN) {
+      t.n[i].a = r.normal(1, std::sqrt(sigma_a));
+      t.n[i].b = r.normal(0, std::sqrt(sigma_b));
+    }
+    grow(t, l, P, sigma_a, sigma_b, r);
+  } else {
+    const int l = t.add(depth + 1);
+    t.n[i].left = l;
+    t.n[l].parent = i;
+    const int rr = t.add(depth + 1);
+    t.n[i].right = rr;
+    t.n[rr].parent = i;
+    grow(t, l, P, sigma_a, sigma_b, r);
+    grow(t, rr, P, sigma_a, sigma_b, r);
+  }
+}
+
+void fstruc(const Tree& t, int i, const Params& P, double sigma_a, double sigma_b, double* ls_out, double* lp_out) {
+  // codes/funcs.py:349-398; uses each node's STORED depth and op_ind
+  const TNode& nd = t.n[i];
+  double ls = 0, lp = 0;
+  const double logw = std::log(kOpW);
+  if (nd.type == 0) {
+    ls += flog(1 - 1 / std::pow(1 + nd.depth, -P.beta));
+    ls -= std::log((double)P.n_feature);
+  } else {
+    if (nd.depth == 0) ls += logw;
+    else ls += std::log((double)(1 + nd.depth)) * P.beta + logw;
+    if (nd.type == 1 && nd.op == OP_LN) {
+      lp -= std::pow(nd.a - 1, 2) / (2 * sigma_a);
+      lp -= std::pow(nd.b, 2) / (2 * sigma_b);
+      lp -= 0.5 * std::log(2 * M_PI * sigma_a);
+      lp -= 0.5 * std::log(2 * M_PI * sigma_b);
+    }
+  }
+  if (nd.left >= 0) {
+    double a, b;
+    fstruc(t, nd.left, P, sigma_a, sigma_b, &a, &b);
+    ls += a;
+    lp += b;
+    if (nd.right >= 0) {
+      fstruc(t, nd.right, P, sigma_a, sigma_b, &a, &b);
+      ls += a;
+      lp += b;
+    }
+  }
+  *ls_out = ls;
+  *lp_out = lp;
+}
+double fstruc0(const Tree& t, int i, const Params& P, double sa, double sb) {
+  double a, b;
+  fstruc(t, i, P, sa, sb, &a, &b);
+  return a;
+}
+
+void detr_candidates(const Tree& t, const std::vector<int>& order, std::vector<int>& out) {  // codes/funcs.py:454-468
+  out.clear();
+  for (int i : order) {
+    const TNode& nd = t.n[i];
+    if (nd.type == 0) continue;
+    if (nd.parent < 0) {
+      if (nd.right < 0) {
+        if (t.n[nd.left].type == 0) continue;
+      } else if (t.n[nd.left].type == 0 && t.n[nd.right].type == 0) {
+        continue;
+      }
+    }
+    out.push_back(i);
+  }
+}
+
+void swap_child(Tree& t, int parent, int old_c, int new_c) {
+  if (t.n[parent].left == old_c) t.n[parent].left = new_c;
+  else t.n[parent].right = new_c;
+  t.n[new_c].parent = parent;
+}
+
+enum { CH_NONE = 0, CH_SHRINK = 1, CH_EXPAND = 2 };
+enum { A_STAY = 0, A_GROW, A_PRUNE, A_DETR, A_TRANS, A_ROP, A_RFEAT };
+
+struct Move {
+  int root = 0;
+  std::vector<int> ln_nodes;
+  std::vector<double> last_a, last_b;
+  int change = CH_NONE;
+  double Q = 1, Qinv = 1;
+  int action = 0;
+};
+
+int count_terms(const Tree& t, int root, int* total) {
+  std::vector<int> o;
+  preorder(t, root, o);
+  int nt = 0;
+  for (int i : o) nt += t.n[i].type == 0;
+  *total = (int)o.size();
+  return nt;
+}
+
+// One structural proposal on the private copy `t` (codes/funcs.py:406-923)
+void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, LegacyRng& r, Move& mv) {
+  int Root = t.root;
+  std::vector<int> tree;
+  preorder(t, Root, tree);
+  mv.ln_nodes.clear();
+  mv.last_a.clear();
+  mv.last_b.clear();
+  std::vector<int> term, nterm, detcd;
+  for (int i : tree) {
+    if (t.n[i].op == OP_LN && t.n[i].type == 1) {
+      mv.ln_nodes.push_back(i);
+      mv.last_a.push_back(t.n[i].a);
+      mv.last_b.push_back(t.n[i].b);
+    }
+    (t.n[i].type == 0 ? term : nterm).push_back(i);
+  }
+  const int ltNum = (int)mv.ln_nodes.size();
+  int change = CH_NONE;
+  double Q = 1, Qinv = 1;
+  detr_candidates(t, tree, detcd);
+
+  const double p_stay = 0.25 * ltNum / (ltNum + 3);                                    // :475-480
+  const double p_grow = (1 - p_stay) * std::min(1.0, 4.0 / ((double)nterm.size() + 2)) / 3;
+  const double p_prune = (1 - p_stay) / 3 - p_grow;
+  const double p_detr = (1 - p_stay) * (1.0 / 3) * (double)detcd.size() / (3 + (double)detcd.size());
+  const double p_trans = (1 - p_stay) / 3 - p_detr;
+  const double p_rop = (1 - p_stay) / 6;
+  const double u = r.uniform();                                                         // :483
+  int action;
+
+  if (u <= p_stay) {                                                                    // :490-500
+    action = A_STAY;
+    Q = Qinv = p_stay;
+    const double sa = std::sqrt(sigma_a), sb = std::sqrt(sigma_b);
+    for (int i : mv.ln_nodes) {
+      t.n[i].a = r.normal(1, sa);
+      t.n[i].b = r.normal(1, sb);
+    }
+  } else if (u <= p_stay + p_grow) {                                                    // :503-536
+    action = A_GROW;
+    const int tgt = term[r.randint(0, (int64_t)term.size())];
+    grow(t, tgt, P, sigma_a, sigma_b, r);
+    if (t.n[tgt].type != 0) {
+      const double fs = fstruc0(t, tgt, P, sigma_a, sigma_b);
+      Q = p_grow * fexp(fs) / (double)term.size();
+      const int new_lt = count_ln(t, Root);
+      int new_n;
+      const int nt = count_terms(t, Root, &new_n);
+      const double new_p = (1 - 0.25 * new_lt / (new_lt + 3)) * (1 - std::min(1.0, 4.0 / ((new_n - nt) + 2))) / 3;
+      Qinv = new_p / std::max(1, new_n - nt - 1);
+      if (new_lt > ltNum) change = CH_EXPAND;
+    }
+  } else if (u <= p_stay + p_grow + p_prune) {                                          // :539-579
+    action = A_PRUNE;
+    const int tgt = nterm[r.randint(1, (int64_t)nterm.size())];
+    const double fs = fstruc0(t, tgt, P, sigma_a, sigma_b);
+    if (count_ln(t, tgt) > 0) change = CH_SHRINK;
+    t.n[tgt].left = -1;
+    t.n[tgt].right = -1;
+    t.n[tgt].op = -1;
+    t.n[tgt].type = 0;
+    t.n[tgt].feature = (int)r.randint(0, P.n_feature);
+    const int new_lt = count_ln(t, Root);
+    int new_n;
+    const int nt = count_terms(t, Root, &new_n);
+    Q = p_prune / (((double)nterm.size() - 1) * P.n_feature);
+    const double pg = 1 - 0.25 * new_lt / (new_lt + 3) * 0.75 * std::min(1.0, 4.0 / ((new_n - nt) + 2));
+    Qinv = pg * fexp(fs) / nt;
+  } else if (u <= p_stay + p_grow + p_prune + p_detr) {                                 // :582-673
+    action = A_DETR;
+    const int dn = detcd[r.randint(0, (int64_t)detcd.size())];
+    int cut = -1;
+    Q = p_detr / (double)detcd.size();
+    if (t.n[dn].parent < 0) {
+      if (t.n[dn].right < 0) {
+        Root = t.n[Root].left;
+      } else if (t.n[t.n[dn].left].type == 0) {
+        cut = t.n[Root].left;
+        Root = t.n[Root].right;
+      } else if (t.n[t.n[dn].right].type == 0) {
+        cut = t.n[Root].right;
+        Root = t.n[Root].left;
+      } else {
+        if (r.uniform() <= 0.5) {
+          cut = t.n[Root].right;
+          Root = t.n[Root].left;
+        } else {
+          cut = t.n[Root].left;
+          Root = t.n[Root].right;
+        }
+        Q = Q / 2;
+      }
+    } else if (t.n[dn].type == 1) {
+      swap_child(t, t.n[dn].parent, dn, t.n[dn].left);
+    } else {
+      if (r.uniform() <= 0.5) {
+        cut = t.n[dn].right;
+        swap_child(t, t.n[dn].parent, dn, t.n[dn].left);
+      } else {
+        cut = t.n[dn].left;
+        swap_child(t, t.n[dn].parent, dn, t.n[dn].right);
+      }
+      Q = Q / 2;
+    }
+    t.n[Root].parent = -1;
+    up_depth(t, Root);
+    std::vector<int> nt_order, ndet;
+    preorder(t, Root, nt_order);
+    int new_lt = 0;
+    for (int i : nt_order) new_lt += (t.n[i].op == OP_LN && t.n[i].type == 1);
+    if (new_lt < ltNum) change = CH_SHRINK;
+    const double new_pstay = 0.25 * new_lt / (new_lt + 3);
+    detr_candidates(t, nt_order, ndet);
+    const double nd = (double)ndet.size();
+    const double new_pdetr = (1 - new_pstay) * (1.0 / 3) * nd / (nd + 3);
+    const double new_ptr = (1 - new_pstay) / 3 - new_pdetr;
+    Qinv = new_ptr * kOpW / (double)nt_order.size();
+    if (cut >= 0) Qinv = Qinv * fexp(fstruc0(t, cut, P, sigma_a, sigma_b));  // cut keeps its stale depths
+  } else if (u <= p_stay + p_grow + p_prune + p_detr + p_trans) {                       // :679-786
+    action = A_TRANS;
+    const int ins = tree[r.randint(0, (int64_t)tree.size())];
+    const int k = choose_op(r);
+    const int nn = t.add(t.n[ins].depth);
+    t.n[nn].op = k;
+    t.n[nn].type = kOpType[k];
+    t.n[nn].op_ind = k;
+    if (t.n[nn].type == 1 && k == OP_LN) change = CH_EXPAND;
+    const int par = t.n[ins].parent;
+    if (par < 0) {
+      Root = nn;
+    } else {
+      if (t.n[par].left == ins) t.n[par].left = nn;
+      else t.n[par].right = nn;
+      t.n[nn].parent = par;
+    }
+    t.n[nn].left = ins;
+    t.n[ins].parent = nn;
+    if (t.n[nn].type == 1) {
+      up_depth(t, Root);
+      Q = p_trans * kOpW / (double)tree.size();
+    } else {
+      const int nr = t.add(t.n[nn].depth + 1);
+      t.n[nn].right = nr;
+      t.n[nr].parent = nn;
+      up_depth(t, Root);
+      grow(t, nr, P, sigma_a, sigma_b, r);
+      Q = p_trans * kOpW * fexp(fstruc0(t, nr, P, sigma_a, sigma_b)) / (double)tree.size();
+    }
+    std::vector<int> nt_order, ndet;
+    preorder(t, Root, nt_order);
+    int new_lt = 0;
+    for (int i : nt_order) new_lt += (t.n[i].op == OP_LN && t.n[i].type == 1);
+    if (new_lt > ltNum) change = CH_EXPAND;
+    const double new_pstay = 0.25 * new_lt / (new_lt + 3);
+    detr_candidates(t, nt_order, ndet);
+    const double nd = (double)ndet.size();
+    const double new_pdetr = (1 - new_pstay) * (1.0 / 3) * nd / (nd + 3);
+    Qinv = new_pdetr / nd;
+    if (t.n[nn].type == 2 && t.n[t.n[nn].left].type > 0 && t.n[t.n[nn].right].type > 0) Qinv = Qinv / 2;
+  } else if (u <= p_stay + p_grow + p_prune + p_detr + p_trans + p_rop) {               // :791-903
+    action = A_ROP;
+    const int cn = nterm[r.randint(0, (int64_t)nterm.size())];
+    const int last_op = t.n[cn].op, last_type = t.n[cn].type;
+    const int k = choose_op(r);
+    const int new_type = kOpType[k];
+    if (last_type == 1 && new_type == 1) {  // unary -> unary (op_ind not updated)
+      t.n[cn].op = k;
+      if (last_op == OP_LN) {
+        if (k != OP_LN) change = CH_SHRINK;
+      } else if (k == OP_LN) {
+        change = CH_EXPAND;
+      }
+      Q = kOpW;
+      Qinv = kOpW;
+    } else if (last_type == 1) {  // unary -> binary
+      t.n[cn].op = k;
+      t.n[cn].type = 2;
+      const int rr = t.add(t.n[cn].depth + 1);
+      t.n[cn].right = rr;
+      t.n[rr].parent = cn;
+      grow(t, rr, P, sigma_a, sigma_b, r);
+      const double fs = fstruc0(t, rr, P, sigma_a, sigma_b);
+      Q = p_rop * fexp(fs) * kOpW / (double)nterm.size();
+      int new_n;
+      const int nt = count_terms(t, Root, &new_n);
+      const int new_lt = count_ln(t, Root);
+      const double new_p0 = (double)new_lt / (4 * (new_lt + 3));
+      Qinv = 0.125 * (1 - new_p0) * kOpW / (new_n - nt);
+      if (new_lt > ltNum) change = CH_EXPAND;
+      else if (new_lt < ltNum) change = CH_SHRINK;
+    } else if (new_type == 1) {  // binary -> unary
+      const int cut = t.n[cn].right;
+      const int p_lt = count_ln(t, cut);
+      if (p_lt > 1) change = CH_SHRINK;
+      else if (k == OP_LN && p_lt == 0) change = CH_EXPAND;
+      t.n[cn].right = -1;
+      t.n[cn].op = k;
+      t.n[cn].type = new_type;
+      Q = p_rop * kOpW / (double)nterm.size();
+      const int new_n = count_nodes(t, Root);
+      const int new_lt = count_ln(t, Root);
+      const double new_p0 = (double)new_lt / (4 * (new_lt + 3));
+      const double fs = fstruc0(t, cut, P, sigma_a, sigma_b);
+      Qinv = 0.125 * (1 - new_p0) * fexp(fs) * kOpW / new_n;  // newTerm empty at :893-894
+    } else {  // binary -> binary
+      t.n[cn].op = k;
+      Q = kOpW;
+      Qinv = kOpW;
+    }
+  } else {                                                                              // :907-917
+    action = A_RFEAT;
+    const int tgt = term[r.randint(0, (int64_t)term.size())];
+    t.n[tgt].feature = (int)r.randint(0, P.n_feature);
+    Q = Qinv = 1;
+  }
+  t.n[Root].parent = -1;
+  up_depth(t, Root);
+  t.root = Root;
+  mv.root = Root;
+  mv.change = change;
+  mv.Q = Q;
+  mv.Qinv = Qinv;
+  mv.action = action;
+}
+
+// codes/funcs.py:935-1138
+void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, LegacyRng& r, double* sa2_out,
+                 double* sb2_out, double* hratio, double* detjacob) {
+  std::vector<int> order, lns;
+  preorder(t, t.root, order);
+  for (int i : order)
+    if (t.n[i].op == OP_LN && t.n[i].type == 1) lns.push_back(i);
+  double new_sa2 = invgamma_rvs(r, 1);                                                  // :945-946
+  double new_sb2 = invgamma_rvs(r, 1);
+  const std::vector<double>& last_a = mv.last_a;
+  const std::vector<double>& last_b = mv.last_b;
+  *hratio = kNaN;
+  *detjacob = kNaN;
+  if (mv.change == CH_SHRINK) {                                                         // :950-1026
+    std::vector<double> keep_a, keep_b, cut_a, cut_b;
+    for (size_t i = 0; i < mv.ln_nodes.size(); ++i) {
+      const TNode& p = t.n[mv.ln_nodes[i]];
+      if (p.op == OP_LN) {  // includes nodes detached with a cut subtree: nobody reset them
+        keep_a.push_back(last_a[i]);
+        keep_b.push_back(last_b[i]);
+      } else {
+        cut_a.push_back(last_a[i]);
+        cut_b.push_back(last_b[i]);
+      }
+    }
+    for (int i = 0; i < (int)lns.size() - (int)keep_a.size(); ++i) {
+      keep_a.push_back(cut_a[i]);
+      keep_b.push_back(cut_b[i]);
+    }
+    const int n0 = (int)keep_a.size();
+    const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
+    std::vector<double> Ua(n0), Ub(n0), Na(n0), Nb(n0), NUa, NUb;
+    for (int i = 0; i < n0; ++i) {
+      Ua[i] = r.normal(0, sa);
+      Ub[i] = r.normal(0, sb);
+    }
+    for (int i = 0; i < n0; ++i) {
+      Na[i] = keep_a[i] + Ua[i];
+      Nb[i] = keep_b[i] + Ub[i];
+      NUa.push_back(keep_a[i] - Ua[i]);
+      NUb.push_back(keep_b[i] - Ub[i]);
+    }
+    NUa.insert(NUa.end(), last_a.begin(), last_a.end());
+    NUb.insert(NUb.end(), last_b.begin(), last_b.end());
+    double logh = 0, loghstar = 0;
+    logh += flog(invgamma_pdf(new_sa2, 1));
+    logh += flog(invgamma_pdf(new_sb2, 1));
+    loghstar += flog(invgamma_pdf(sigma_a, 1));
+    loghstar += flog(invgamma_pdf(sigma_b, 1));
+    for (int i = 0; i < n0; ++i) {
+      logh += flog(norm_pdf(Ua[i], 0, sa));
+      logh += flog(norm_pdf(Ub[i], 0, sb));
+    }
+    const double osa = std::sqrt(sigma_a), osb = std::sqrt(sigma_b);
+    for (size_t i = 0; i < NUa.size(); ++i) {
+      loghstar += flog(norm_pdf(NUa[i], 0, osa));
+      loghstar += flog(norm_pdf(NUb[i], 0, osb));
+    }
+    *hratio = fexp(loghstar - logh);
+    *detjacob = std::ldexp(1.0, 2 * n0);
+    for (size_t i = 0; i < lns.size(); ++i) {
+      t.n[lns[i]].a = Na[i];
+      t.n[lns[i]].b = Nb[i];
+    }
+  } else if (mv.change == CH_EXPAND) {                                                  // :1030-1110
+    new_sa2 = invgamma_rvs(r, 1);
+    new_sb2 = invgamma_rvs(r, 1);
+    const int m = (int)last_a.size();
+    const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
+    std::vector<double> Ua(m), Ub(m), Na, Nb, NUa(m), NUb(m);
+    for (int i = 0; i < m; ++i) {
+      Ua[i] = r.normal(0, sa);
+      Ub[i] = r.normal(0, sb);
+    }
+    for (int i = 0; i < m; ++i) {
+      Na.push_back((last_a[i] + Ua[i]) / 2);
+      Nb.push_back((last_b[i] + Ub[i]) / 2);
+      NUa[i] = (last_a[i] - Ua[i]) / 2;
+      NUb[i] = (last_b[i] - Ub[i]) / 2;
+    }
+    const int nn = (int)lns.size() - m;
+    for (int i = 0; i < nn; ++i) {
+      Na.push_back(r.normal(1, sa));
+      Nb.push_back(r.normal(0, sb));
+    }
+    double logh = 0, loghstar = 0;
+    logh += flog(invgamma_pdf(new_sa2, 1));
+    logh += flog(invgamma_pdf(new_sb2, 1));
+    loghstar += flog(invgamma_pdf(sigma_a, 1));
+    loghstar += flog(invgamma_pdf(sigma_b, 1));
+    for (int i = m; i < nn; ++i) {  // :1084-1086 adds plain pdf values
+      logh += norm_pdf(Na[i], 1, sa);
+      logh += norm_pdf(Nb[i], 0, sb);
+    }
+    for (int i = 0; i < m; ++i) {
+      logh += flog(norm_pdf(Ua[i], 0, sa));
+      logh += flog(norm_pdf(Ub[i], 0, sb));
+    }
+    const double osa = std::sqrt(sigma_a), osb = std::sqrt(sigma_b);
+    for (int i = 0; i < m; ++i) {
+      loghstar += flog(norm_pdf(NUa[i], 0, osa));
+      loghstar += flog(norm_pdf(NUb[i], 0, osb));
+    }
+    *hratio = fexp(loghstar - logh);
+    *detjacob = 1.0 / std::ldexp(1.0, 2 * m);
+    for (size_t i = 0; i < lns.size(); ++i) {
+      t.n[lns[i]].a = Na[i];
+      t.n[lns[i]].b = Nb[i];
+    }
+  } else {                                                                              // :1127-1136
+    new_sa2 = invgamma_rvs(r, 1);
+    new_sb2 = invgamma_rvs(r, 1);
+    const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
+    std::vector<double> va(lns.size()), vb(lns.size());
+    for (size_t i = 0; i < lns.size(); ++i) {
+      va[i] = r.normal(1, sa);
+      vb[i] = r.normal(0, sb);
+    }
+    for (size_t i = 0; i < lns.size(); ++i) {
+      t.n[lns[i]].a = va[i];
+      t.n[lns[i]].b = vb[i];
+    }
+  }
+  *sa2_out = new_sa2;
+  *sb2_out = new_sb2;
+}
+
+// Postfix rows of the tree (heavier child of +/* first: Sethi-Ullman), as bsr/tape.py:flatten
+void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
+  rows.clear();
+  std::vector<int> need(t.n.size(), 0);
+  {
+    std::vector<std::pair<int, int>> st;
+    st.push_back({root, 0});
+    while (!st.empty()) {
+      auto [i, seen] = st.back();
+      st.pop_back();
+      const TNode& nd = t.n[i];
+      if (nd.type == 0) {
+        need[i] = 1;
+        continue;
+      }
+      if (!seen) {
+        st.push_back({i, 1});
+        st.push_back({nd.left, 0});
+        if (nd.type == 2) st.push_back({nd.right, 0});
+      } else if (nd.type == 1) {
+        need[i] = need[nd.left];
+      } else {
+        const int a = need[nd.left], b = need[nd.right];
+        need[i] = (a == b) ? a + 1 : std::max(a, b);
+      }
+    }
+  }
+  std::vector<int> index(t.n.size(), -1);
+  std::vector<std::pair<int, int>> st;
+  st.push_back({root, 0});
+  while (!st.empty()) {
+    auto [i, seen] = st.back();
+    st.pop_back();
+    const TNode& nd = t.n[i];
+    bsr_node r;
+    memset(&r, 0, sizeof r);
+    if (nd.type == 0) {
+      index[i] = (int)rows.size();
+      r.opcode = BSR_OP_TERMINAL;
+      r.left = r.right = -1;
+      r.feature = nd.feature;
+      rows.push_back(r);
+    } else if (!seen) {
+      st.push_back({i, 1});
+      if (nd.type == 1) {
+        st.push_back({nd.left, 0});
+      } else {
+        int first = nd.left, second = nd.right;
+        if (need[nd.right] > need[nd.left]) std::swap(first, second);
+        st.push_back({second, 0});
+        st.push_back({first, 0});
+      }
+    } else {
+      index[i] = (int)rows.size();
+      r.opcode = nd.op;
+      r.left = index[nd.left];
+      r.right = nd.type == 2 ? index[nd.right] : -1;
+      r.feature = -1;
+      if (nd.op == OP_LN) {
+        r.a = nd.a;
+        r.b = nd.b;
+      }
+      rows.push_back(r);
+    }
+  }
+}
+
+uint64_t tree_hash(const Tree& t, int root) {  // FNV-1a over the pre-order (type, operator, feature) sequence
+  std::vector<int> o;
+  preorder(t, root, o);
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    for (int k = 0; k < 4; ++k) {
+      h ^= (v >> (8 * k)) & 0xFF;
+      h *= 1099511628211ull;
+    }
+  };
+  for (int i : o) {
+    mix((uint64_t)(t.n[i].type + 1));
+    mix((uint64_t)(t.n[i].type == 0 ? 100 + t.n[i].feature : t.n[i].op));
+  }
+  return h;
+}
+
+struct Cand {
+  int k;
+  Tree tree;
+  int change;
+  double Q, Qinv, hratio, detjacob, new_sigma, new_sa2, new_sb2, u;
+  int action;
+  LegacyRng before_u;
+  std::vector<bsr_node> tape;
+};
+
+struct ChainS {
+  int index = 0;
+  LegacyRng rng;
+  std::vector<Tree> roots;
+  std::vector<std::vector<bsr_node>> tapes;
+  std::vector<Tree> last_roots;  // `Roots` as built before the latest newProp (codes/bsr_class.py:180-182)
+  std::vector<double> siga, sigb, Beta, errs;
+  std::vector<double> fs_old_s, fs_old_p;
+  std::vector<char> fs_old_ok;
+  double sigma = 1.0, sse_old = 0.0;
+  int total = 0, count = 0;
+  bool done = false, inited = false, last_stale = false;
+  int64_t n_props = 0, n_accept = 0, n_rank_rej = 0, n_discard = 0;
+  std::vector<Cand> cands;
+  LegacyRng end_state;
+};
+
+}  // namespace
+
+struct bsr_engine {
+  bsr_ctx* ctx = nullptr;
+  int K = 0, n_chains = 0, val = 100, y_is_series = 1;
+  int64_t N = 0;
+  Params P;
+  std::vector<ChainS> chains;
+  std::string err;
+  bsr_trace* trace = nullptr;
+  int64_t trace_cap = 0, n_trace = 0;
+};
+
+namespace {
+
+int efail(bsr_engine* e, int code, const std::string& msg) {
+  e->err = msg;
+  return code;
+}
+#define ECHK(e, call)                                                         \
+  do {                                                                        \
+    int rc_ = (call);                                                         \
+    if (rc_ != BSR_OK) return efail(e, rc_, std::string(#call) + ": " + bsr_last_error((e)->ctx)); \
+  } while (0)
+
+int refresh_chain(bsr_engine* e, ChainS& c) {
+  bsr_chain_info info;
+  ECHK(e, bsr_refresh(e->ctx, c.index, &info));
+  bool any = false;
+  for (int k = 0; k < e->K; ++k) any |= info.colflags[k] != 0;
+  // every fitted value of a non-finite old state is NaN: Series.sum(skipna=True) gives 0.0, ndarray sum NaN
+  c.sse_old = any ? (e->y_is_series ? 0.0 : kNaN) : info.sse_old;
+  std::fill(c.fs_old_ok.begin(), c.fs_old_ok.end(), 0);
+  return BSR_OK;
+}
+
+int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
+  const int K = e->K;
+  c.sigma = invgamma_rvs(c.rng, 1);
+  c.roots.assign(K, Tree());
+  c.siga.assign(K, 0.0);
+  c.sigb.assign(K, 0.0);
+  c.tapes.assign(K, {});
+  for (int k = 0; k < K; ++k) {
+    Tree t;
+    t.add(0);
+    t.root = 0;
+    const double sa = invgamma_rvs(c.rng, 1);
+    const double sb = invgamma_rvs(c.rng, 1);
+    grow(t, 0, e->P, sa, sb, c.rng);
+    c.roots[k] = t;
+    c.siga[k] = sa;
+    c.sigb[k] = sb;
+  }
+  for (int k = 0; k < K; ++k) {
+    flatten(c.roots[k], c.roots[k].root, c.tapes[k]);
+    ECHK(e, bsr_set_current(e->ctx, c.index, k, c.tapes[k].data(), (int)c.tapes[k].size()));
+  }
+  c.fs_old_s.assign(K, 0.0);
+  c.fs_old_p.assign(K, 0.0);
+  c.fs_old_ok.assign(K, 0);
+  int rc = refresh_chain(e, c);
+  if (rc != BSR_OK) return rc;
+  c.Beta.assign(K + 1, 0.0);
+  double rmse;
+  ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
+  c.total = 0;
+  c.count = 0;
+  c.errs.clear();
+  c.last_roots = c.roots;
+  c.last_stale = false;
+  c.done = false;
+  c.inited = true;
+  c.n_props = c.n_accept = c.n_rank_rej = c.n_discard = 0;
+  return BSR_OK;
+}
+
+void generate(bsr_engine* e, ChainS& c, int max_n) {
+  c.cands.clear();
+  int total = c.total, count = c.count;
+  while ((int)c.cands.size() < max_n) {
+    if (count == 0 && total >= e->val) break;  // `while total < val` is only tested between sweeps
+    c.cands.emplace_back();
+    Cand& cd = c.cands.back();
+    const int k = count;
+    cd.k = k;
+    cd.tree = clone_tree(c.roots[k], c.roots[k].root);
+    Move mv;
+    prop_inplace(cd.tree, e->P, c.siga[k], c.sigb[k], c.rng, mv);
+    cd.new_sigma = invgamma_rvs(c.rng, 4);
+    aux_inplace(cd.tree, mv, c.siga[k], c.sigb[k], c.rng, &cd.new_sa2, &cd.new_sb2, &cd.hratio, &cd.detjacob);
+    cd.change = mv.change;
+    cd.Q = mv.Q;
+    cd.Qinv = mv.Qinv;
+    cd.action = mv.action;
+    flatten(cd.tree, cd.tree.root, cd.tape);
+    cd.before_u = c.rng;
+    cd.u = c.rng.uniform();
+    ++total;
+    count = (count + 1) % e->K;
+  }
+  c.end_state = c.rng;
+}
+
+double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double sn_p, double so_s, double so_p,
+                 double sigma) {  // codes/funcs.py:1230-1296
+  const double log_y = yllstar - yll;
+  const double log_q = flog(pymax(1e-5, fdiv(c.Qinv, c.Q)));
+  double logR;
+  if (c.change != CH_NONE) {
+    const double log_s = (so_s + so_p) - (sn_s + sn_p);
+    logR = log_y + log_s + log_q + flog(pymax(1e-5, c.hratio)) + flog(pymax(1e-5, c.detjacob));
+  } else {
+    logR = log_y + (so_s - sn_s) + log_q;
+  }
+  return logR + flog(invgamma_pdf(c.new_sigma, 4)) - flog(invgamma_pdf(sigma, 4));
+}
+
+int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0) {
+  const int K = e->K;
+  int used = 0;
+  bool broke = false;
+  for (size_t i = 0; i < c.cands.size(); ++i) {
+    Cand& cd = c.cands[i];
+    const bsr_score& sc = res[i];
+    ++used;
+    ++c.n_props;
+    const int k = cd.k;
+    if (c.last_stale) {  // `Roots` is rebuilt before every newProp (codes/bsr_class.py:180-182)
+      c.last_roots = c.roots;
+      c.last_stale = false;
+    }
+    bsr_trace* tr = nullptr;
+    if (e->trace && e->n_trace < e->trace_cap) {
+      tr = &e->trace[e->n_trace++];
+      memset(tr, 0, sizeof *tr);
+      tr->chain = c.index;
+      tr->count = k;
+      tr->action = cd.action;
+      tr->change = cd.change;
+      tr->rank = sc.rank;
+      tr->Q = cd.Q;
+      tr->Qinv = cd.Qinv;
+      tr->new_sigma = cd.new_sigma;
+      tr->new_sa2 = cd.new_sa2;
+      tr->new_sb2 = cd.new_sb2;
+      tr->tree_hash = tree_hash(cd.tree, cd.tree.root);
+      tr->n_nodes = count_nodes(cd.tree, cd.tree.root);
+    }
+    if (sc.rank < 0) {
+      c.rng = cd.before_u;
+      return efail(e, BSR_E_LINALG, "SVD did not converge");  // NaN in new_outputs, codes/funcs.py:1226
+    }
+    ++c.total;
+    c.count = (k + 1) % K;
+    if (sc.rank < K) {  // codes/funcs.py:1226-1228: no uniform drawn
+      ++c.n_rank_rej;
+      c.rng = cd.before_u;
+      broke = true;
+      break;
+    }
+    const double yllstar = sc.loglik;
+    const double yll = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
+    double sn_s, sn_p;
+    fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &sn_s, &sn_p);
+    if (!c.fs_old_ok[k]) {
+      fstruc(c.roots[k], c.roots[k].root, e->P, c.siga[k], c.sigb[k], &c.fs_old_s[k], &c.fs_old_p[k]);
+      c.fs_old_ok[k] = 1;
+    }
+    const double logR = log_ratio(cd, yllstar, yll, sn_s, sn_p, c.fs_old_s[k], c.fs_old_p[k], c.sigma);
+    const double alpha = (0 < logR) ? 0 : logR;  // Python's min(logR, 0)
+    const bool accepted = !(flog(cd.u) >= alpha);
+    if (tr) {
+      tr->yllstar = yllstar;
+      tr->yll = yll;
+      tr->logR = logR;
+      tr->u = cd.u;
+      tr->accepted = accepted;
+    }
+    if (!accepted) continue;
+    // ---- accepted: codes/bsr_class.py:200-243
+    ++c.n_accept;
+    c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
+    c.last_stale = true;
+    c.roots[k] = cd.tree;
+    c.tapes[k] = cd.tape;
+    c.sigma = cd.new_sigma;
+    c.siga[k] = cd.new_sa2;
+    c.sigb[k] = cd.new_sb2;
+    ECHK(e, bsr_commit(e->ctx, c.index, k, slot0 + (int)i));
+    int rc = refresh_chain(e, c);
+    if (rc != BSR_OK) return rc;
+    double rmse;
+    ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
+    c.errs.push_back(rmse);
+    c.total = 0;
+    c.rng = cd.before_u;
+    c.rng.uniform();
+    if (tr) tr->rmse = rmse;
+    const int m = std::min<int>(10, (int)c.errs.size());  // codes/bsr_class.py:248-252
+    if (c.errs.size() > 100) {
+      double mn = kInf, sum = 0;
+      for (int j = 0; j < m; ++j) {
+        const double v = c.errs[c.errs.size() - m + j];
+        mn = std::min(mn, v);
+        sum += v;
+      }
+      if (1 - mn / (sum / m) < 0.05) c.done = true;
+    }
+    broke = true;
+    break;
+  }
+  if (!broke) c.rng = c.end_state;  // every candidate was consumed as a plain rejection
+  c.n_discard += (int64_t)c.cands.size() - used;
+  if (!c.done && c.count == 0 && c.total >= e->val) c.done = true;
+  c.cands.clear();
+  return BSR_OK;
+}
+
+}  // namespace
+
+extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chains, int32_t K, int64_t N,
+                                 int32_t n_feature, double beta, int32_t val, int32_t y_is_series) {
+  if (!out || !ctx || n_chains <= 0 || K <= 0 || K > BSR_MAX_K) return BSR_E_ARG;
+  bsr_engine* e = new bsr_engine();
+  e->ctx = ctx;
+  e->K = K;
+  e->N = N;
+  e->n_chains = n_chains;
+  e->val = val;
+  e->y_is_series = y_is_series;
+  e->P.n_feature = n_feature;
+  e->P.beta = beta;
+  e->chains.resize(n_chains);
+  for (int c = 0; c < n_chains; ++c) {
+    e->chains[c].index = c;
+    e->chains[c].rng.seed(0);
+  }
+  *out = e;
+  return BSR_OK;
+}
+
+extern "C" int bsr_engine_destroy(bsr_engine* e) {
+  delete e;
+  return BSR_OK;
+}
+
+extern "C" const char* bsr_engine_last_error(const bsr_engine* e) { return e ? e->err.c_str() : ""; }
+
+extern "C" int bsr_engine_seed(bsr_engine* e, int32_t chain, uint32_t seed) {
+  if (!e || chain < 0 || chain >= e->n_chains) return BSR_E_ARG;
+  e->chains[chain].rng.seed(seed);
+  return BSR_OK;
+}
+
+extern "C" int bsr_engine_set_rng(bsr_engine* e, int32_t chain, const uint32_t* key624, int32_t pos, int32_t has_gauss,
+                                  double gauss) {
+  if (!e || !key624 || chain < 0 || chain >= e->n_chains || pos < 0 || pos > 624) return BSR_E_ARG;
+  LegacyRng& r = e->chains[chain].rng;
+  memcpy(r.key, key624, sizeof r.key);
+  r.pos = pos;
+  r.has_gauss = has_gauss;
+  r.gauss = gauss;
+  return BSR_OK;
+}
+
+extern "C" int bsr_engine_get_rng(bsr_engine* e, int32_t chain, uint32_t* key624, int32_t* pos, int32_t* has_gauss,
+                                  double* gauss) {
+  if (!e || !key624 || !pos || !has_gauss || !gauss || chain < 0 || chain >= e->n_chains) return BSR_E_ARG;
+  const LegacyRng& r = e->chains[chain].rng;
+  memcpy(key624, r.key, sizeof r.key);
+  *pos = r.pos;
+  *has_gauss = r.has_gauss;
+  *gauss = r.gauss;
+  return BSR_OK;
+}
+
+extern "C" int bsr_engine_init_chain(bsr_engine* e, int32_t chain) {
+  if (!e || chain < 0 || chain >= e->n_chains) return BSR_E_ARG;
+  return init_chain(e, e->chains[chain]);
+}
+
+// Advances every initialised, unfinished chain until it is done (or has consumed max_props proposals).
+// Each launch carries up to batch_per_chain speculative proposals of every live chain.
+extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t max_props, bsr_trace* trace,
+                              int64_t trace_cap, int64_t* n_trace, int32_t max_batch) {
+  if (!e || batch_per_chain <= 0 || max_batch <= 0) return BSR_E_ARG;
+  e->trace = trace;
+  e->trace_cap = trace ? trace_cap : 0;
+  e->n_trace = 0;
+  std::vector<bsr_node> rows;
+  std::vector<int32_t> off, chs, ks;
+  std::vector<double> sig;
+  std::vector<bsr_score> res;
+  int rc = BSR_OK;
+  while (true) {
+    std::vector<ChainS*> live;
+    for (auto& c : e->chains)
+      if (c.inited && !c.done && (max_props < 0 || c.n_props < max_props)) live.push_back(&c);
+    if (live.empty()) break;
+    const int per = std::max(1, std::min<int>(batch_per_chain, max_batch / (int)live.size()));
+    rows.clear();
+    off.assign(1, 0);
+    chs.clear();
+    ks.clear();
+    sig.clear();
+    std::vector<std::pair<int, int>> span;
+    for (ChainS* c : live) {
+      int room = per;
+      if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props);
+      generate(e, *c, room);
+      span.push_back({(int)chs.size(), (int)c->cands.size()});
+      for (const Cand& cd : c->cands) {
+        rows.insert(rows.end(), cd.tape.begin(), cd.tape.end());
+        off.push_back((int32_t)rows.size());
+        chs.push_back(c->index);
+        ks.push_back(cd.k);
+        sig.push_back(cd.new_sigma);
+      }
+      if (c->cands.empty()) c->done = true;
+    }
+    if (chs.empty()) continue;
+    res.resize(chs.size());
+    rc = bsr_score_batch(e->ctx, rows.data(), off.data(), chs.data(), ks.data(), sig.data(), (int)chs.size(),
+                         res.data());
+    if (rc != BSR_OK) {
+      e->err = std::string("bsr_score_batch: ") + bsr_last_error(e->ctx);
+      break;
+    }
+    for (size_t i = 0; i < live.size(); ++i) {
+      if (span[i].second == 0) continue;
+      rc = consume(e, *live[i], res.data() + span[i].first, span[i].first);
+      if (rc != BSR_OK) break;
+    }
+    if (rc != BSR_OK) break;
+  }
+  if (n_trace) *n_trace = e->n_trace;
+  e->trace = nullptr;
+  return rc;
+}
+
+extern "C" int bsr_engine_chain_result(bsr_engine* e, int32_t chain, bsr_node* tapes, int32_t tape_cap,
+                                       int32_t* tape_len, double* beta, double* errs, int32_t errs_cap,
+                                       int32_t* n_errs, int64_t* counters, double* sigma, int32_t current) {
+  if (!e || chain < 0 || chain >= e->n_chains || !tape_len) return BSR_E_ARG;
+  ChainS& c = e->chains[chain];
+  if (!c.inited) return efail(e, BSR_E_STATE, "chain not initialised");
+  std::vector<bsr_node> t;
+  const std::vector<Tree>& src = current ? c.roots : c.last_roots;
+  for (int k = 0; k < e->K; ++k) {
+    flatten(src[k], src[k].root, t);
+    tape_len[k] = (int32_t)t.size();
+    if (tapes && (int32_t)t.size() <= tape_cap) memcpy(tapes + (size_t)k * tape_cap, t.data(), t.size() * sizeof(bsr_node));
+    else if (tapes) tape_len[k] = -(int32_t)t.size();
+  }
+  if (beta) memcpy(beta, c.Beta.data(), sizeof(double) * (e->K + 1));
+  if (n_errs) *n_errs = (int32_t)c.errs.size();
+  if (errs) memcpy(errs, c.errs.data(), sizeof(double) * std::min<size_t>(c.errs.size(), (size_t)errs_cap));
+  if (counters) {
+    counters[0] = c.n_props;
+    counters[1] = c.n_accept;
+    counters[2] = c.n_rank_rej;
+    counters[3] = c.n_discard;
+    counters[4] = c.done ? 1 : 0;
+  }
+  if (sigma) *sigma = c.sigma;
+  return BSR_OK;
+}
+
+// Draw sequence for tests: kind[i] in {0 uniform, 1 randint(lo,hi), 2 standard_normal, 3 choice10, 4 invgamma(a=lo)}
+extern "C" int bsr_rng_selftest(uint32_t seed, int32_t n, const int32_t* kind, const int64_t* lo, const int64_t* hi,
+                                double* out) {
+  if (!kind || !out) return BSR_E_ARG;
+  LegacyRng r;
+  r.seed(seed);
+  for (int i = 0; i < n; ++i) {
+    switch (kind[i]) {
+      case 0: out[i] = r.uniform(); break;
+      case 1: out[i] = (double)r.randint(lo[i], hi[i]); break;
+      case 2: out[i] = r.standard_normal(); break;
+      case 3: out[i] = (double)choose_op(r); break;
+      default: out[i] = invgamma_rvs(r, (int)lo[i]); break;
+    }
+  }
+  return BSR_OK;
+}

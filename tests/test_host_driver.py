@@ -288,3 +288,66 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         from bsr.device import DeviceContext
         with pytest.raises(_lib.BsrError):      # fails loudly without a GPU: no CPU fallback
             DeviceContext(np.zeros((4, 2)), np.zeros(4), K=1, n_chains=1)
+
+
+def test_native_rng_matches_numpy_legacy_randomstate():
+    """The C++ sampler's generator (csrc/bsr_engine.hip) against numpy/scipy, draw for draw.  No GPU needed."""
+    from scipy.stats import invgamma
+    from bsr import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(99)
+    n = 4000
+    kind = rs.randint(0, 5, size=n).astype(np.int32)
+    lo = np.zeros(n, dtype=np.int64)
+    hi = np.ones(n, dtype=np.int64)
+    for i in range(n):
+        if kind[i] == 1:
+            lo[i] = rs.randint(0, 3)
+            hi[i] = lo[i] + rs.choice([1, 2, 3, 7, 10, 1000, 2 ** 20 + 3])
+        elif kind[i] == 4:
+            lo[i] = rs.choice([1, 4])
+    for seed in (0, 1, 12345, 2 ** 31 + 7):
+        out = np.zeros(n)
+        assert L.bsr_rng_selftest(seed, n, _lib.ptr(kind), _lib.ptr(lo), _lib.ptr(hi), _lib.ptr(out)) == 0
+        np.random.seed(seed)
+        W = [0.1] * 10
+        for i in range(n):
+            k = kind[i]
+            if k == 0:
+                want = np.random.uniform(0, 1, 1)[0]
+            elif k == 1:
+                want = float(np.random.randint(lo[i], hi[i], 1)[0])
+            elif k == 2:
+                want = np.random.standard_normal()
+            elif k == 3:
+                want = float(np.random.choice(np.arange(10), p=W))
+            else:
+                want = invgamma.rvs(int(lo[i]))
+            if k == 4:
+                assert abs(out[i] - want) <= 4e-15 * abs(want), (seed, i, out[i], want)
+            else:
+                assert out[i] == want, (seed, i, k, out[i], want)
+
+
+def tree_hash_from_spec(spec):
+    """FNV-1a over the pre-order (type+1, operator index | 100+feature) sequence, as csrc/bsr_engine.hip:tree_hash."""
+    from bsr.node import OP_CODE
+    h = 1469598103934665603
+    n = 0
+
+    def mix(h, v):
+        for k in range(4):
+            h ^= (v >> (8 * k)) & 0xFF
+            h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    work = [spec]
+    while work:
+        s = work.pop()
+        n += 1
+        h = mix(h, s["type"] + 1)
+        h = mix(h, 100 + s["feature"] if s["type"] == 0 else OP_CODE[s["op"]])
+        if s["left"] is not None:
+            if s["right"] is not None:
+                work.append(s["right"])
+            work.append(s["left"])
+    return h, n
