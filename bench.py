@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=15.0,
                     help="seconds of CPU oracle work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = synchronous calls)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight, 1..4 (1 = synchronous calls)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +117,7 @@ def main():
         r = packed[i]
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
     kern_us = np.zeros(5)
-    depth = max(1, min(2, args.depth))
+    depth = max(1, min(4, args.depth))
     barrier()
     t0 = time.perf_counter()
     # two batches in flight: the host stages batch i+1 while the GPU scores batch i (different chain groups in a

@@ -149,9 +149,12 @@ int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off,
                     const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out);
 
 /* Asynchronous form of bsr_score_batch: submit enqueues upload + kernels + download and returns at once with a
- * ticket (0 or 1); wait blocks until that batch is done and copies its B results.  Two batches may be in flight, so
- * the host can stage batch i+1 while the GPU scores batch i (chains of batch i+1 must not depend on accepts of
- * batch i).  bsr_commit refers to the batch most recently waited for. */
+ * ticket; wait blocks until that batch is done and copies its B results.  Up to BSR_MAX_INFLIGHT batches may be in
+ * flight (tickets are handed out round-robin; wait for them in submission order), each on its own HIP stream, so the
+ * host stages batch i+1 and the small per-proposal kernels of batch i overlap the row pass of batch i+1.  Chains of
+ * a batch must not depend on accepts of a batch still in flight.  bsr_commit refers to the batch most recently
+ * waited for. */
+#define BSR_MAX_INFLIGHT 4
 int bsr_score_submit(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                      const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket);
 int bsr_score_wait(bsr_ctx* ctx, int32_t ticket, bsr_score* out);
@@ -206,6 +209,9 @@ int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chains, int32_t 
                       double beta, int32_t val, int32_t y_is_series);
 int bsr_engine_destroy(bsr_engine* e);
 const char* bsr_engine_last_error(const bsr_engine* e);
+/* reject = 0 (default): a NaN candidate aborts the run with BSR_E_LINALG, as the reference's matrix_rank call raises
+ * (codes/funcs.py:1226); reject != 0: it is handled like a rank-gate rejection (documented divergence). */
+int bsr_engine_set_nan_policy(bsr_engine* e, int32_t reject);
 int bsr_engine_seed(bsr_engine* e, int32_t chain, uint32_t seed);   /* == np.random.seed(seed) for that chain */
 int bsr_engine_set_rng(bsr_engine* e, int32_t chain, const uint32_t* key624, int32_t pos, int32_t has_gauss,
                        double gauss);                                /* == np.random.set_state(...) */

@@ -43,6 +43,10 @@ class NativeEngine:
             msg = self._L.bsr_engine_last_error(self._h)
             raise _lib.BsrError(rc, msg.decode() if msg else "")
 
+    def set_nan_policy(self, reject):
+        """False (default): NaN candidates raise LinAlgError like the reference; True: they are rejected."""
+        self._check(self._L.bsr_engine_set_nan_policy(self._h, 1 if reject else 0))
+
     def seed(self, chain, seed):
         self._check(self._L.bsr_engine_seed(self._h, chain, int(seed) & 0xFFFFFFFF))
 

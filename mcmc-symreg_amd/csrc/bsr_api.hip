@@ -29,6 +29,14 @@ struct BatchSlot {
   size_t code_words = 0, feat_words = 0, ln_words = 0;
   bsr_score* d_out = nullptr;
   bsr_score* h_out = nullptr;
+  hipStream_t stream = nullptr;   // each slot has its own stream: the small solve/residual/finalise kernels of one
+                                  // batch overlap the row pass of the other
+  PropCoef* d_coef = nullptr;
+  double* part1 = nullptr;
+  double* part2 = nullptr;
+  size_t part_cap = 0;   // in (proposal,row block) records
+  void* spill = nullptr;
+  size_t spill_cap = 0;  // bytes
   hipEvent_t done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int P = 0;
@@ -64,15 +72,9 @@ struct bsr_ctx {
   std::vector<ChainFitOut> h_fit;
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
-  BatchSlot slot[2];
+  BatchSlot slot[BSR_MAX_INFLIGHT];
   int next_slot = 0;
   int last_waited = -1;
-  PropCoef* d_coef = nullptr;
-  double* part1 = nullptr;
-  double* part2 = nullptr;
-  size_t part_cap = 0;   // in (proposal,row block) records
-  void* spill = nullptr;
-  size_t spill_cap = 0;  // bytes
   double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
   // tuning
@@ -136,14 +138,20 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
-  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_coef, c->part1, c->part2, c->spill,
-                 c->d_stage, c->comm_buf};
+  for (BatchSlot& s : c->slot)
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (BatchSlot& s : c->slot) {
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.d_coef) (void)hipFree(s.d_coef);
+    if (s.part1) (void)hipFree(s.part1);
+    if (s.part2) (void)hipFree(s.part2);
+    if (s.spill) (void)hipFree(s.spill);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.done) (void)hipEventDestroy(s.done);
     for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
   }
@@ -237,8 +245,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
   c->h_fit.resize(n_chains + 1);
-  CK(hipMalloc((void**)&c->d_coef, sizeof(PropCoef) * (max_batch + 1)));
   for (BatchSlot& s : c->slot) {
+    CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
     s.off_desc = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
     CK(hipMalloc((void**)&s.d_out, sizeof(bsr_score) * (max_batch + 1)));
@@ -306,26 +315,26 @@ static LaunchGeom geometry(const bsr_ctx* c, const BatchSlot& s, int P) {
   return g;
 }
 
-static int ensure_partials(bsr_ctx* c, const LaunchGeom& g, int P, int spill_slots) {
+static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P, int spill_slots) {
   const size_t recs = (size_t)P * g.n_rb;
-  if (recs > c->part_cap) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // a batch in flight may still use the old buffers
-    if (c->part1) HIPCHK(c, hipFree(c->part1));
-    if (c->part2) HIPCHK(c, hipFree(c->part2));
-    c->part1 = c->part2 = nullptr;
+  if (recs > s.part_cap) {
+    HIPCHK(c, hipStreamSynchronize(s.stream));
+    if (s.part1) HIPCHK(c, hipFree(s.part1));
+    if (s.part2) HIPCHK(c, hipFree(s.part2));
+    s.part1 = s.part2 = nullptr;
     const size_t cap = recs + recs / 2;
-    HIPCHK(c, hipMalloc((void**)&c->part1, cap * BSR_P1_WORDS * sizeof(double)));
-    HIPCHK(c, hipMalloc((void**)&c->part2, cap * BSR_P2_WORDS * sizeof(double)));
-    c->part_cap = cap;
+    HIPCHK(c, hipMalloc((void**)&s.part1, cap * BSR_P1_WORDS * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double)));
+    s.part_cap = cap;
   }
   if (spill_slots > 0) {
     const size_t need = (size_t)((g.n_rb + 7) / 8 * 8) * g.n_pg * BSR_WG_WAVES * spill_slots * BSR_WAVE * 8 * c->esz;
-    if (need > c->spill_cap) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (c->spill) HIPCHK(c, hipFree(c->spill));
-      c->spill = nullptr;
-      HIPCHK(c, hipMalloc(&c->spill, need));
-      c->spill_cap = need;
+    if (need > s.spill_cap) {
+      HIPCHK(c, hipStreamSynchronize(s.stream));
+      if (s.spill) HIPCHK(c, hipFree(s.spill));
+      s.spill = nullptr;
+      HIPCHK(c, hipMalloc(&s.spill, need));
+      s.spill_cap = need;
     }
   }
   return BSR_OK;
@@ -460,12 +469,12 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
   a->feats = feats;
   a->lnp = reinterpret_cast<const double*>(feats + s.feat_words);
   a->desc = desc;
-  a->coef = c->d_coef;
+  a->coef = s.d_coef;
   a->P = P;
   a->feat_list = s.use_lds ? s.d_feat() : nullptr;
   a->nF = s.nF;
-  a->part = residual ? c->part2 : c->part1;
-  a->spill = spill_slots ? c->spill : nullptr;
+  a->part = residual ? s.part2 : s.part1;
+  a->spill = spill_slots ? s.spill : nullptr;
   a->spill_slots = spill_slots;
   a->rows_per_lane = c->rows_per_lane;
 }
@@ -475,11 +484,11 @@ static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const
   if (c->dtype == BSR_DTYPE_F64) {
     RowPassArgs<double> a;
     fill_row_args<double>(c, s, g, &a, desc, P, spill_slots, residual);
-    launch_rows<double>(c->stream, a, nq, residual);
+    launch_rows<double>(s.stream, a, nq, residual);
   } else {
     RowPassArgs<float> a;
     fill_row_args<float>(c, s, g, &a, desc, P, spill_slots, residual);
-    launch_rows<float>(c->stream, a, nq, residual);
+    launch_rows<float>(s.stream, a, nq, residual);
   }
 }
 
@@ -489,25 +498,26 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   int spill_slots = 0;
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
   const LaunchGeom g = geometry(c, s, P);
-  int rc = ensure_partials(c, g, P, spill_slots);
+  int rc = ensure_partials(c, s, g, P, spill_slots);
   if (rc != BSR_OK) return rc;
+  hipStream_t st = s.stream;
   const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
-  HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, st));
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
-  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[0], c->stream));
-  launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
-  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[1], c->stream));
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
   const double rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
-  launch_solve(c->stream, s.d_desc(), c->d_ck, P, g.n_rb, c->part1, c->N, c->d_coef, s.d_out, rank_floor);
-  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[2], c->stream));
+  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[0], st));
+  launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
+  if (c->prof) HIPCHK(c, hipEventRecord(s.ev[1], st));
+  launch_solve(st, s.d_desc(), c->d_ck, P, g.n_rb, s.part1, c->N, s.d_coef, s.d_out, rank_floor);
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[2], st));
   if (scoring) launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1);
-  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[3], c->stream));
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[3], st));
   if (scoring)
-    launch_finalize(c->stream, s.d_desc(), c->d_ck, c->d_coef, P, g.n_rb, c->part2, c->N, s.d_out, rank_floor);
-  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[4], c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out, sizeof(bsr_score) * P, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(s.done, c->stream));
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.d_out, rank_floor);
+  if (c->prof > 1) HIPCHK(c, hipEventRecord(s.ev[4], st));
+  HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out, sizeof(bsr_score) * P, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(s.done, st));
   s.P = P;
   s.pending = true;
   return BSR_OK;
@@ -564,6 +574,7 @@ extern "C" int bsr_eval_tapes(bsr_ctx* c, const bsr_node* rows, const int32_t* t
   if (out_cols) {
     rc = ensure_zbuf(c);
     if (rc != BSR_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // zbuf's memset ran on the main stream
   }
   for (int i = 0; i < n_tapes; ++i)
     fill_eval_desc(c, &s.h_desc()[i], loc[i], out_cols ? col_ptr(c, c->zbuf, i) : nullptr);
@@ -578,17 +589,17 @@ extern "C" int bsr_eval_tapes(bsr_ctx* c, const bsr_node* rows, const int32_t* t
   if (out_cols) {
     if (c->dtype == BSR_DTYPE_F64) {
       HIPCHK(c, hipMemcpy2DAsync(out_cols, (size_t)c->N * 8, c->zbuf, (size_t)c->ld * 8, (size_t)c->N * 8, n_tapes,
-                                 hipMemcpyDeviceToHost, c->stream));
+                                 hipMemcpyDeviceToHost, s.stream));
     } else {
       if (!c->d_stage) HIPCHK(c, hipMalloc((void**)&c->d_stage, (size_t)c->ld * 8));
       for (int i = 0; i < n_tapes; ++i) {
-        launch_convert_out<float>(c->stream, (const float*)col_ptr(c, c->zbuf, i), c->d_stage, c->N);
+        launch_convert_out<float>(s.stream, (const float*)col_ptr(c, c->zbuf, i), c->d_stage, c->N);
         HIPCHK(c, hipMemcpyAsync(out_cols + (size_t)i * c->N, c->d_stage, (size_t)c->N * 8, hipMemcpyDeviceToHost,
-                                 c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+                                 s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
       }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(s.stream));
   }
   return BSR_OK;
 }
@@ -640,11 +651,14 @@ extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   D.s = 1.0;
   const int at = c->max_batch;
   s.h_desc()[at] = D;
-  HIPCHK(c, hipMemcpyAsync(s.d_desc() + at, &s.h_desc()[at], sizeof(PropDesc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.d_desc() + at, &s.h_desc()[at], sizeof(PropDesc), hipMemcpyHostToDevice, s.stream));
   const LaunchGeom g = geometry(c, s, 1);
-  rc = ensure_partials(c, g, 1, D.spill_need);
+  rc = ensure_partials(c, s, g, 1, D.spill_need);
   if (rc != BSR_OK) return rc;
   launch_row_pass(c, s, g, s.d_desc() + at, 1, D.spill_need, 0, 0);
+  // the refresh that follows runs on the main stream: order it behind this column write
+  HIPCHK(c, hipEventRecord(s.done, s.stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
   return BSR_OK;
@@ -706,7 +720,7 @@ extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t*
   }
   const int si = c->next_slot;
   BatchSlot& s = c->slot[si];
-  if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: both batch slots are in flight (wait first)");
+  if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
   std::vector<TapeLoc> loc;
   int rc = stage_tapes(c, s, rows, tape_off, B, &loc);
   if (rc != BSR_OK) return rc;
@@ -729,12 +743,12 @@ extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t*
   rc = enqueue(c, s, B, true);
   if (rc != BSR_OK) return rc;
   *ticket = si;
-  c->next_slot = si ^ 1;
+  c->next_slot = (si + 1) % BSR_MAX_INFLIGHT;
   return BSR_OK;
 }
 
 extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
-  if (!c || !out || ticket < 0 || ticket > 1) return BSR_E_ARG;
+  if (!c || !out || ticket < 0 || ticket >= BSR_MAX_INFLIGHT) return BSR_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   BatchSlot& s = c->slot[ticket];
   if (!s.scored) return fail(c, BSR_E_STATE, "bsr_score_wait: nothing submitted under this ticket");
@@ -771,7 +785,7 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
       }
       // restore the batch's own descriptors (host and device) so bsr_commit sees the original order
       memcpy(s.h_desc(), keep.data(), sizeof(PropDesc) * B);
-      HIPCHK(c, hipMemcpyAsync(s.d_desc(), s.h_desc(), sizeof(PropDesc) * B, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(s.d_desc(), s.h_desc(), sizeof(PropDesc) * B, hipMemcpyHostToDevice, s.stream));
       s.P = B;
       memcpy(c->last_us, timing, sizeof timing);
     }

@@ -882,6 +882,7 @@ struct ChainS {
   int total = 0, count = 0;
   bool done = false, inited = false, last_stale = false;
   int64_t n_props = 0, n_accept = 0, n_rank_rej = 0, n_discard = 0;
+  double run_ema = 1e9;  // typical number of proposals consumed per batch (speculation length that pays off)
   std::vector<Cand> cands;
   LegacyRng end_state;
 };
@@ -891,6 +892,7 @@ struct ChainS {
 struct bsr_engine {
   bsr_ctx* ctx = nullptr;
   int K = 0, n_chains = 0, val = 100, y_is_series = 1;
+  int nan_reject = 0;  // 0: a NaN candidate aborts like the reference (LinAlgError); 1: treat it as a rank-gate rejection
   int64_t N = 0;
   Params P;
   std::vector<ChainS> chains;
@@ -1035,7 +1037,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0) {
       tr->tree_hash = tree_hash(cd.tree, cd.tree.root);
       tr->n_nodes = count_nodes(cd.tree, cd.tree.root);
     }
-    if (sc.rank < 0) {
+    if (sc.rank < 0 && !e->nan_reject) {
       c.rng = cd.before_u;
       return efail(e, BSR_E_LINALG, "SVD did not converge");  // NaN in new_outputs, codes/funcs.py:1226
     }
@@ -1100,6 +1102,8 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0) {
   }
   if (!broke) c.rng = c.end_state;  // every candidate was consumed as a plain rejection
   c.n_discard += (int64_t)c.cands.size() - used;
+  if (broke) c.run_ema = (c.run_ema > 1e8) ? used : 0.7 * c.run_ema + 0.3 * used;
+  else if (c.run_ema < 1e8) c.run_ema = 0.7 * c.run_ema + 0.3 * (2.0 * used);
   if (!c.done && c.count == 0 && c.total >= e->val) c.done = true;
   c.cands.clear();
   return BSR_OK;
@@ -1135,6 +1139,12 @@ extern "C" int bsr_engine_destroy(bsr_engine* e) {
 
 extern "C" const char* bsr_engine_last_error(const bsr_engine* e) { return e ? e->err.c_str() : ""; }
 
+extern "C" int bsr_engine_set_nan_policy(bsr_engine* e, int32_t reject) {
+  if (!e) return BSR_E_ARG;
+  e->nan_reject = reject ? 1 : 0;
+  return BSR_OK;
+}
+
 extern "C" int bsr_engine_seed(bsr_engine* e, int32_t chain, uint32_t seed) {
   if (!e || chain < 0 || chain >= e->n_chains) return BSR_E_ARG;
   e->chains[chain].rng.seed(seed);
@@ -1169,58 +1179,120 @@ extern "C" int bsr_engine_init_chain(bsr_engine* e, int32_t chain) {
 }
 
 // Advances every initialised, unfinished chain until it is done (or has consumed max_props proposals).
-// Each launch carries up to batch_per_chain speculative proposals of every live chain.
+// Chains are dealt into up to BSR_MAX_INFLIGHT groups; each group's batch (up to batch_per_chain speculative
+// proposals per chain) is one asynchronous submission, so proposal generation and result handling of one group
+// overlap the GPU work of the others.  A chain belongs to one group only, hence never depends on a batch in flight.
 extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t max_props, bsr_trace* trace,
                               int64_t trace_cap, int64_t* n_trace, int32_t max_batch) {
   if (!e || batch_per_chain <= 0 || max_batch <= 0) return BSR_E_ARG;
   e->trace = trace;
   e->trace_cap = trace ? trace_cap : 0;
   e->n_trace = 0;
-  std::vector<bsr_node> rows;
-  std::vector<int32_t> off, chs, ks;
-  std::vector<double> sig;
-  std::vector<bsr_score> res;
-  int rc = BSR_OK;
-  while (true) {
-    std::vector<ChainS*> live;
-    for (auto& c : e->chains)
-      if (c.inited && !c.done && (max_props < 0 || c.n_props < max_props)) live.push_back(&c);
-    if (live.empty()) break;
-    const int per = std::max(1, std::min<int>(batch_per_chain, max_batch / (int)live.size()));
-    rows.clear();
-    off.assign(1, 0);
-    chs.clear();
-    ks.clear();
-    sig.clear();
+  struct Group {
+    std::vector<ChainS*> chains;
+    std::vector<bsr_node> rows;
+    std::vector<int32_t> off, chs, ks;
+    std::vector<double> sig;
+    std::vector<bsr_score> res;
     std::vector<std::pair<int, int>> span;
-    for (ChainS* c : live) {
+    int32_t ticket = -1;
+    bool inflight = false;
+  };
+  auto is_live = [&](const ChainS& c) { return c.inited && !c.done && (max_props < 0 || c.n_props < max_props); };
+  std::vector<ChainS*> live;
+  for (auto& c : e->chains)
+    if (is_live(c)) live.push_back(&c);
+  int rc = BSR_OK;
+  if (live.empty()) {
+    if (n_trace) *n_trace = 0;
+    return rc;
+  }
+  // tracing wants proposals in chain order: keep one group then
+  const int n_groups = trace ? 1 : std::max(1, std::min<int>(BSR_MAX_INFLIGHT, (int)live.size()));
+  std::vector<Group> groups(n_groups);
+  for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
+  const int per_group_cap = std::max(1, max_batch / n_groups);
+
+  auto submit = [&](Group& g) -> int {
+    g.rows.clear();
+    g.off.assign(1, 0);
+    g.chs.clear();
+    g.ks.clear();
+    g.sig.clear();
+    g.span.clear();
+    int n_live = 0;
+    for (ChainS* c : g.chains) n_live += is_live(*c) ? 1 : 0;
+    if (n_live == 0) return BSR_OK;
+    const int per = std::max(1, std::min<int>(batch_per_chain, per_group_cap / n_live));
+    for (ChainS* c : g.chains) {
+      if (!is_live(*c)) {
+        g.span.push_back({(int)g.chs.size(), 0});
+        continue;
+      }
       int room = per;
+      // speculate only about as far as this chain's batches have recently been consumed
+      if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props);
       generate(e, *c, room);
-      span.push_back({(int)chs.size(), (int)c->cands.size()});
+      g.span.push_back({(int)g.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
-        rows.insert(rows.end(), cd.tape.begin(), cd.tape.end());
-        off.push_back((int32_t)rows.size());
-        chs.push_back(c->index);
-        ks.push_back(cd.k);
-        sig.push_back(cd.new_sigma);
+        g.rows.insert(g.rows.end(), cd.tape.begin(), cd.tape.end());
+        g.off.push_back((int32_t)g.rows.size());
+        g.chs.push_back(c->index);
+        g.ks.push_back(cd.k);
+        g.sig.push_back(cd.new_sigma);
       }
       if (c->cands.empty()) c->done = true;
     }
-    if (chs.empty()) continue;
-    res.resize(chs.size());
-    rc = bsr_score_batch(e->ctx, rows.data(), off.data(), chs.data(), ks.data(), sig.data(), (int)chs.size(),
-                         res.data());
-    if (rc != BSR_OK) {
-      e->err = std::string("bsr_score_batch: ") + bsr_last_error(e->ctx);
-      break;
+    if (g.chs.empty()) return BSR_OK;
+    g.res.resize(g.chs.size());
+    int r = bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
+                             (int)g.chs.size(), &g.ticket);
+    if (r != BSR_OK) {
+      e->err = std::string("bsr_score_submit: ") + bsr_last_error(e->ctx);
+      return r;
     }
-    for (size_t i = 0; i < live.size(); ++i) {
-      if (span[i].second == 0) continue;
-      rc = consume(e, *live[i], res.data() + span[i].first, span[i].first);
+    g.inflight = true;
+    return BSR_OK;
+  };
+  auto collect = [&](Group& g) -> int {
+    if (!g.inflight) return BSR_OK;
+    g.inflight = false;
+    int r = bsr_score_wait(e->ctx, g.ticket, g.res.data());
+    if (r != BSR_OK) {
+      e->err = std::string("bsr_score_wait: ") + bsr_last_error(e->ctx);
+      return r;
+    }
+    for (size_t i = 0; i < g.chains.size(); ++i) {
+      if (g.span[i].second == 0) continue;
+      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first);
+      if (r != BSR_OK) return r;
+    }
+    return BSR_OK;
+  };
+
+  for (Group& g : groups) {
+    rc = submit(g);
+    if (rc != BSR_OK) break;
+  }
+  while (rc == BSR_OK) {
+    bool any = false;
+    for (Group& g : groups) {
+      if (!g.inflight) continue;
+      any = true;
+      rc = collect(g);
+      if (rc != BSR_OK) break;
+      rc = submit(g);
       if (rc != BSR_OK) break;
     }
-    if (rc != BSR_OK) break;
+    if (!any) break;
+  }
+  if (rc != BSR_OK) {  // drain what is still in flight so the context stays usable
+    for (Group& g : groups)
+      if (g.inflight) {
+        g.inflight = false;
+        (void)bsr_score_wait(e->ctx, g.ticket, g.res.data());
+      }
   }
   if (n_trace) *n_trace = e->n_trace;
   e->trace = nullptr;
