@@ -70,6 +70,14 @@ struct bsr_ctx {
   std::vector<ChainK> h_ck;
   ChainFitOut* d_fit = nullptr;  // [chain] no-intercept fit (also carries per-column max/flags) + 1 scratch slot
   std::vector<ChainFitOut> h_fit;
+  ChainFitOut* d_fit_icpt = nullptr;   // [chain] intercept fit of the last refresh
+  std::vector<ChainFitOut> h_fit_icpt;
+  RefreshIn* d_rin = nullptr;          // [chain]
+  std::vector<RefreshIn> h_rin;        // host-tracked max|.| and inf/NaN flags of every current column
+  RefreshPlan* d_plan = nullptr;       // one scratch plan (refreshes are serialised on the main stream)
+  RefreshPlan* h_plan = nullptr;       // pinned
+  double* d_rpart = nullptr;
+  int fast_refresh = 1;
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
   BatchSlot slot[BSR_MAX_INFLIGHT];
@@ -140,7 +148,9 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   for (BatchSlot& s : c->slot)
     if (s.stream) (void)hipStreamSynchronize(s.stream);
-  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf};
+  void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf, c->d_fit_icpt,
+                 c->d_rin, c->d_plan, c->d_rpart};
+  if (c->h_plan) (void)hipHostFree(c->h_plan);
   for (void* p : dev) if (p) (void)hipFree(p);
   for (BatchSlot& s : c->slot) {
     if (s.d_in) (void)hipFree(s.d_in);
@@ -245,6 +255,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
   c->h_fit.resize(n_chains + 1);
+  CK(hipMalloc((void**)&c->d_fit_icpt, sizeof(ChainFitOut) * (n_chains + 1)));
+  c->h_fit_icpt.resize(n_chains + 1);
+  CK(hipMalloc((void**)&c->d_rin, sizeof(RefreshIn) * (n_chains + 1)));
+  c->h_rin.resize(n_chains + 1);
+  CK(hipMalloc((void**)&c->d_plan, sizeof(RefreshPlan)));
+  CK(hipHostMalloc((void**)&c->h_plan, sizeof(RefreshPlan)));
+  CK(hipMalloc((void**)&c->d_rpart, refresh_part_doubles(N) * sizeof(double)));
+  c->fast_refresh = env_int("BSR_FAST_REFRESH", 1);
   for (BatchSlot& s : c->slot) {
     CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
@@ -627,6 +645,8 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
   rc = enqueue(c, s, 1, false);
   if (rc == BSR_OK) rc = wait_slot(c, s);
   if (rc != BSR_OK) return rc;
+  c->h_rin[chain].colmax[k] = s.h_out[0].maxabs;
+  c->h_rin[chain].colflags[k] = s.h_out[0].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
   return BSR_OK;
@@ -659,8 +679,26 @@ extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   // the refresh that follows runs on the main stream: order it behind this column write
   HIPCHK(c, hipEventRecord(s.done, s.stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
+  c->h_rin[chain].colmax[k] = s.h_out[idx].maxabs;
+  c->h_rin[chain].colflags[k] = s.h_out[idx].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
+  return BSR_OK;
+}
+
+static int refresh_slow(bsr_ctx* c, int chain) {  // single-workgroup Gram-Schmidt path (robust for dependent siblings)
+  const int K = c->K;
+  void* cols = col_ptr(c, c->cur, (int64_t)chain * K);
+  ChainK* dck = c->d_ck + (size_t)chain * K;
+  const RefreshIn* rin = c->d_rin + chain;
+  if (c->dtype == BSR_DTYPE_F64)
+    launch_refresh_basis<double>(c->stream, (const double*)cols,
+                                 K > 1 ? (double*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
+                                 (const double*)c->y, c->ld, c->N, K, rin->colmax, rin->colflags, dck);
+  else
+    launch_refresh_basis<float>(c->stream, (const float*)cols,
+                                K > 1 ? (float*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
+                                (const float*)c->y, c->ld, c->N, K, rin->colmax, rin->colflags, dck);
   return BSR_OK;
 }
 
@@ -674,23 +712,44 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
   HIPCHK(c, hipSetDevice(c->device));
   const int K = c->K;
   ChainFitOut* dfit = c->d_fit + chain;
+  ChainFitOut* dfit_i = c->d_fit_icpt + chain;
   void* cols = col_ptr(c, c->cur, (int64_t)chain * K);
   ChainK* dck = c->d_ck + (size_t)chain * K;
-  if (c->dtype == BSR_DTYPE_F64) {
-    launch_chain_fit<double>(c->stream, (const double*)cols, (const double*)c->y, c->ld, c->N, K, 0, dfit);
-    launch_refresh_basis<double>(c->stream, (const double*)cols,
-                                 K > 1 ? (double*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
-                                 (const double*)c->y, c->ld, c->N, K, dfit->maxabs, dfit->colflags, dck);
+  HIPCHK(c, hipMemcpyAsync(c->d_rin + chain, &c->h_rin[chain], sizeof(RefreshIn), hipMemcpyHostToDevice, c->stream));
+  if (c->fast_refresh) {
+    void* Q = K > 1 ? col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr;
+    if (c->dtype == BSR_DTYPE_F64)
+      launch_refresh_fast<double>(c->stream, (const double*)cols, (double*)Q, (const double*)c->y, c->ld, c->N, K,
+                                  c->d_rin + chain, c->d_plan, c->d_rpart, dck, dfit, dfit_i);
+    else
+      launch_refresh_fast<float>(c->stream, (const float*)cols, (float*)Q, (const float*)c->y, c->ld, c->N, K,
+                                 c->d_rin + chain, c->d_plan, c->d_rpart, dck, dfit, dfit_i);
+    HIPCHK(c, hipMemcpyAsync(c->h_plan, c->d_plan, sizeof(RefreshPlan), hipMemcpyDeviceToHost, c->stream));
   } else {
-    launch_chain_fit<float>(c->stream, (const float*)cols, (const float*)c->y, c->ld, c->N, K, 0, dfit);
-    launch_refresh_basis<float>(c->stream, (const float*)cols,
-                                K > 1 ? (float*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
-                                (const float*)c->y, c->ld, c->N, K, dfit->maxabs, dfit->colflags, dck);
+    if (c->dtype == BSR_DTYPE_F64) {
+      launch_chain_fit<double>(c->stream, (const double*)cols, (const double*)c->y, c->ld, c->N, K, 0, dfit);
+      launch_chain_fit<double>(c->stream, (const double*)cols, (const double*)c->y, c->ld, c->N, K, 1, dfit_i);
+    } else {
+      launch_chain_fit<float>(c->stream, (const float*)cols, (const float*)c->y, c->ld, c->N, K, 0, dfit);
+      launch_chain_fit<float>(c->stream, (const float*)cols, (const float*)c->y, c->ld, c->N, K, 1, dfit_i);
+    }
+    refresh_slow(c, chain);
   }
   HIPCHK(c, hipMemcpyAsync(&c->h_fit[chain], dfit, sizeof(ChainFitOut), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_fit_icpt[chain], dfit_i, sizeof(ChainFitOut), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain * K], dck, sizeof(ChainK) * K, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
+  if (c->fast_refresh) {
+    bool fb = false;
+    for (int k = 0; k < K; ++k) fb |= c->h_plan->fallback[k] != 0;
+    if (fb) {  // (nearly) dependent siblings: Cholesky-QR is not accurate enough, rebuild with Gram-Schmidt
+      refresh_slow(c, chain);
+      HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain * K], dck, sizeof(ChainK) * K, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipGetLastError());
+    }
+  }
   c->ready[chain] = 1;
   if (info) {
     const ChainFitOut& f = c->h_fit[chain];
@@ -698,9 +757,9 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
     info->sse_old = f.sse;
     info->scale_old = f.scale;
     for (int k = 0; k < K; ++k) {
-      info->maxabs[k] = f.maxabs[k];
+      info->maxabs[k] = c->h_rin[chain].colmax[k];
       info->beta_old[k] = f.beta[k];
-      info->colflags[k] = f.colflags[k];
+      info->colflags[k] = c->h_rin[chain].colflags[k];
     }
     info->rank_old = -2;
   }
@@ -807,19 +866,11 @@ extern "C" int bsr_fit_beta(bsr_ctx* c, int32_t chain, double* beta_out, double*
   int rc = chain_ok(c, chain, 0);
   if (rc != BSR_OK) return rc;
   if (!c->has_y) return fail(c, BSR_E_STATE, "bsr_fit_beta: context has no y");
-  for (int k = 0; k < c->K; ++k)
-    if (!c->col_set[(size_t)chain * c->K + k]) return fail(c, BSR_E_STATE, "bsr_fit_beta: a current column was never set");
-  HIPCHK(c, hipSetDevice(c->device));
-  ChainFitOut* dfit = c->d_fit + c->n_chains;  // scratch slot
-  void* cols = col_ptr(c, c->cur, (int64_t)chain * c->K);
-  if (c->dtype == BSR_DTYPE_F64)
-    launch_chain_fit<double>(c->stream, (const double*)cols, (const double*)c->y, c->ld, c->N, c->K, 1, dfit);
-  else
-    launch_chain_fit<float>(c->stream, (const float*)cols, (const float*)c->y, c->ld, c->N, c->K, 1, dfit);
-  ChainFitOut& h = c->h_fit[c->n_chains];
-  HIPCHK(c, hipMemcpyAsync(&h, dfit, sizeof(ChainFitOut), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipGetLastError());
+  if (!c->ready[chain]) {  // the intercept fit is produced by the refresh pipeline
+    rc = bsr_refresh(c, chain, nullptr);
+    if (rc != BSR_OK) return rc;
+  }
+  const ChainFitOut& h = c->h_fit_icpt[chain];
   for (int j = 0; j <= c->K; ++j) beta_out[j] = h.beta_unscaled[j];
   *rmse_out = std::sqrt(h.sse / (double)c->N);
   return BSR_OK;

@@ -70,6 +70,24 @@ struct ChainFitOut {
   uint32_t pad;
 };
 
+// ---- fast chain refresh (bsr_refresh.hip)
+#define BSR_RF_ROWS 1024
+struct RefreshIn {   // per chain, written by the host: what it already knows about the K current columns
+  double colmax[BSR_MAX_K];
+  uint32_t colflags[BSR_MAX_K];
+};
+struct RefreshPlan {  // per chain, device scratch handed from one refresh kernel to the next
+  uint32_t anyflags, pad;
+  double scale_fit;
+  double beta_fit[BSR_MAX_K], coef_fit[BSR_MAX_K], beta_icpt[BSR_MAX_K + 1];
+  double s_k[BSR_MAX_K], m_other[BSR_MAX_K];
+  uint32_t flags_k[BSR_MAX_K];
+  int32_t fallback[BSR_MAX_K];
+  double R1[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX], T1[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX];
+  double T2[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX];
+  double qy[BSR_MAX_K][BSR_NQ_MAX];
+};
+
 struct LaunchGeom {
   int rb_rows;      // rows per row block (multiple of 256)
   int n_rb;         // row blocks
@@ -115,3 +133,8 @@ template <typename T>
 void launch_convert_out(hipStream_t st, const T* src, double* dst, int64_t n);
 template <typename T>
 void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n);
+template <typename T>
+void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N, int K,
+                         const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
+                         ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt);
+size_t refresh_part_doubles(int64_t N);

@@ -6,6 +6,6 @@ out="$here/../bsr/libbsr_hip.so"
 ROCM="${ROCM_PATH:-/opt/rocm}"
 "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
   -Wall -Wno-unused-function \
-  "$here/bsr_kernels.hip" "$here/bsr_api.hip" "$here/bsr_engine.hip" \
+  "$here/bsr_kernels.hip" "$here/bsr_api.hip" "$here/bsr_engine.hip" "$here/bsr_refresh.hip" \
   -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" -o "$out"
 echo "built $out"
