@@ -10,6 +10,9 @@
 #define BSR_NQ_MAX (BSR_MAX_K - 1)  // basis columns per proposal
 #define BSR_WAVE 64
 #define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
+#ifndef BSR_ROWS_MIN_WAVES
+#define BSR_ROWS_MIN_WAVES 4         // occupancy floor requested from the compiler for the row pass
+#endif
 #define BSR_REG_STACK 3             // interpreter stack slots held in VGPRs (plus the accumulator)
 #define BSR_ROW_ALIGN 4096          // device columns are padded to a multiple of this many rows
 #define BSR_P1_WORDS 12             // doubles per (proposal,row block) partial of pass 1

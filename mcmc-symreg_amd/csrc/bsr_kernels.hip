@@ -338,7 +338,7 @@ __device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* 
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
 
 template <typename T, int NQ, int U, bool LDS, int MODE>
-__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE) void k_rows(
+__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_rows(
     const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const uint64_t* __restrict__ codes,
     const uint64_t* __restrict__ feats, const double* __restrict__ lnp, const PropDesc* __restrict__ desc,
     const PropCoef* __restrict__ coef, int P, int rb_rows, int pg, int n_rb, int n_pg,

@@ -1,11 +1,13 @@
-run() { python bench.py --steps 60 --warmup 5 --cpu-sample 0 --batch ${B:-64} > gpurun_out/x.json; python -c "
-import json,sys; d=json.load(open('gpurun_out/x.json')); print('$1', round(d['value']), round(d['ms_per_step']*1000,1), round(d["roofline"]["kernel_us"],1))"; }
-BSR_P1_U=2 run lds_u2
-BSR_P1_U=4 run lds_u4
-BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2
-BSR_NO_LDS=1 BSR_P1_U=4 run glb_u4
-BSR_RB_ROWS=256 BSR_P1_U=2 run lds_u2_rb256
-BSR_RB_ROWS=1024 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_rb1024
-BSR_RB_ROWS=256 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_rb256
-BSR_TARGET_WGS=4096 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_wgs4096
-BSR_TARGET_WGS=1024 BSR_NO_LDS=1 BSR_P1_U=2 run glb_u2_wgs1024
+# Row-pass variants on the bench workload (run on the GPU box).  Prints: tag, proposals/s, us/step, kernel us (isolated)
+run() { python bench.py --steps 60 --warmup 5 --cpu-sample 0 --batch ${B:-64} --depth ${D:-3} > gpurun_out/x.json; python -c "
+import json,sys; d=json.load(open('gpurun_out/x.json')); print('$1', round(d['value']), round(d['ms_per_step']*1000,1), round(d['roofline']['kernel_us'],1))"; }
+BSR_P1_U=2 run glb_u2
+BSR_P1_U=4 run glb_u4
+BSR_P1_U=8 run glb_u8
+BSR_NO_LDS=0 BSR_P1_U=2 run lds_u2
+BSR_NO_LDS=0 BSR_P1_U=4 BSR_RB_ROWS=256 run lds_u4_rb256
+BSR_RB_ROWS=1024 run glb_u2_rb1024
+BSR_RB_ROWS=256 run glb_u2_rb256
+BSR_TARGET_WGS=4096 run glb_u2_wgs4096
+BSR_TARGET_WGS=1024 run glb_u2_wgs1024
+BSR_TARGET_WGS=8192 BSR_RB_ROWS=256 run glb_u2_rb256_wgs8192
