@@ -497,7 +497,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Per-proposal K x K algebra.  One wave per proposal; lane (i,j) = (lane>>3, lane&7) owns element [i][j].
+// Per-proposal K x K algebra.  One wave per proposal.
 //
 // With s*O_siblings = Q R (cached) and the candidate s*z = Q c + w (w orthogonal to Q, |w| = rho):
 //   s * new_outputs = [Q, w/rho] S,   S = [[R, c], [0, rho]]   (columns: siblings ascending, then the candidate)
@@ -508,50 +508,6 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
 // where S = U Sigma V^T comes from a one-sided Jacobi sweep.  Everything is K-dimensional; the only O(N) inputs
 // are c, |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2
 // would cancel (candidate nearly inside the sibling span).
-__device__ __forceinline__ double col_reduce(double v) {  // sum over the 8 rows of a column (lane bits 3..5)
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-__device__ __forceinline__ double row_reduce(double v) {  // sum over the 8 columns of a row (lane bits 0..2)
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  return v;
-}
-
-// One-sided Jacobi: on return W = S V has mutually orthogonal columns (W[:,j] = sigma_j u_j) and V is accumulated.
-__device__ __forceinline__ void jacobi_svd(double& W, double& V, int K, int lane) {
-  const int j = lane & 7;
-  const int base = lane & ~7;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    double off = 0.0;
-    for (int a = 0; a < K - 1; ++a) {
-      for (int b = a + 1; b < K; ++b) {
-        const double wa = __shfl(W, base + a), wb = __shfl(W, base + b);  // my row's entries of columns a,b
-        const double va = __shfl(V, base + a), vb = __shfl(V, base + b);
-        const double alpha = col_reduce(wa * wa), beta = col_reduce(wb * wb), gamma = col_reduce(wa * wb);
-        const double lim = sqrt(alpha) * sqrt(beta);
-        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {  // wave-uniform
-          off = fmax(off, fabs(gamma) / lim);
-          const double zeta = (beta - alpha) / (2.0 * gamma);
-          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-          if (j == a) {
-            W = cs * wa - sn * wb;
-            V = cs * va - sn * vb;
-          } else if (j == b) {
-            W = sn * wa + cs * wb;
-            V = sn * va + cs * vb;
-          }
-        }
-      }
-    }
-    if (off <= 1e-15) break;
-  }
-}
-
 struct SolveIn {
   const ChainK* ck;
   const double* c;   // LDS: projections of s*z on the basis (nq values)
@@ -564,75 +520,9 @@ struct SolveIn {
   double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
 };
 
-// Completes one proposal: singular values -> rank, Beta, SSE, log-likelihood.  Called by all 64 lanes.
-__device__ __forceinline__ void solve_complete(const SolveIn& in, int lane, bsr_score* out) {
-  const int K = in.K, nq = in.nq, k = in.k;
-  const int i = lane >> 3, j = lane & 7;
-  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
-  double W = 0.0;
-  if (i < K && j < K) {
-    if (j < nq) W = (i <= j) ? in.ck->R[i * BSR_NQ_MAX + j] : 0.0;
-    else W = (i < nq) ? in.c[i] : rho;  // j == nq == K-1
-  }
-  double V = (i == j) ? 1.0 : 0.0;
-  jacobi_svd(W, V, K, lane);
-  const double sv = sqrt(col_reduce(W * W));                       // sigma_j, identical in every row of column j
-  double h = 0.0;                                                   // h_i for the lane's row
-  if (i < nq) h = in.ck->qy[i];
-  else if (i == nq) h = (rho > 0.0) ? in.wy / rho : 0.0;
-  const double hh = col_reduce(((j == 0) ? h : 0.0) * h);          // |h|^2 (column 0 lanes carry one copy)
-  const double hh_all = __shfl(hh, 0);
-  const double tj = col_reduce(W * h);                             // sigma_j * (u_j . h)
-  const double aj = (sv > 0.0 && j < K) ? tj / sv : 0.0;          // u_j . h
-  const double dj = (in.tau * sv) * (in.tau * sv);
-  const double eps = 1e-6;
-  const double wj = eps / (dj + eps);
-  // sums over the K columns, taken from row 0's lanes in a fixed order
-  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
-  int rank = 0;
-  for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a));
-  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
-  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);  // numpy matrix_rank default
-  for (int a = 0; a < K; ++a) {
-    const double sva = __shfl(sv, a), aa = __shfl(aj, a), wa = __shfl(wj, a);
-    smin = fmin(smin, sva);
-    rank += (sva > tol) ? 1 : 0;
-    if (sva > 0.0) {
-      misfit = fma(wa * wa, aa * aa, misfit);
-      seen = fma(aa, aa, seen);
-    }
-  }
-  misfit += fmax(0.0, hh_all - seen);                              // directions with sigma == 0 keep all of h
-  const double hz = __shfl(h, nq * 8);                             // w.y / rho
-  const double sse = fmax(0.0, in.ck->yperp2 - hz * hz) + misfit;
-  // Beta' = V diag(tau sigma / (tau^2 sigma^2 + eps)) (U^T h), in S column order -> original tree order
-  const double coef = (j < K) ? (in.tau * sv) / (dj + eps) * aj : 0.0;
-  const double bi = row_reduce(V * coef);                          // Beta'_i, identical in every column of row i
-  const double sigma = in.sigma;
-  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
-  if (lane == 0) {
-    out->loglik = ll;
-    out->sse = sse;
-    out->scale = in.scale;
-    out->maxabs = in.maxabs;
-    out->smin = smin / in.s;
-    out->smax = smax / in.s;
-    out->rank = rank;
-    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
-  }
-  if (j == 0 && i < BSR_MAX_K) {
-    if (i < K) {
-      const int tree = (i == nq) ? k : ((i < k) ? i : i + 1);
-      out->beta[tree] = bi;
-    }
-  }
-  if (lane >= K && lane < BSR_MAX_K) out->beta[lane] = 0.0;
-}
-
-// Same algebra as solve_complete for K <= 4, with the K x K factor, its Jacobi SVD and the ridge formulas held
-// entirely in registers (K is a template parameter: every index is static).  All lanes compute the same values, so
-// there is no cross-lane traffic at all: the cooperative version above spends its time in ds_bpermute latency
-// (~26 dependent shuffles per Jacobi rotation).
+// K <= 4: the K x K factor, its one-sided Jacobi SVD (W = S V ends with mutually orthogonal columns
+// W[:,j] = sigma_j u_j) and the ridge formulas held entirely in registers (K is a template parameter: every index is
+// static).  All lanes compute the same values, so there is no cross-lane traffic at all.
 template <int K>
 __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out) {
   constexpr int NQ = K - 1;
@@ -744,13 +634,141 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
   }
 }
 
+// K = 5..8: eight lanes per proposal, lane j = lane & 7 owns column j of the K x K factor W and of V in registers
+// (the 8 lane groups of the wave hold identical copies).  One-sided Jacobi with the XOR tournament ordering: in round
+// r = 1..7 column j pairs with column j ^ r, so the four rotations of a round run side by side and a sweep is 7
+// dependent steps instead of 28; the only cross-lane traffic is the partner's column (2K shuffles per round), every
+// dot product is lane-local.  Both lanes of a pair evaluate the same expressions on the same operands, so they apply
+// bit-identical rotation coefficients.
+template <int K>
+__device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out) {
+  constexpr int NQ = K - 1;
+  const int j = lane & 7;
+  const int k = in.k;
+  const ChainK* ck = in.ck;
+  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
+  const int jr = (j < NQ) ? j : 0;
+  double W[K], V[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const double r = ck->R[i * BSR_NQ_MAX + jr];
+    const double cand = (i < NQ) ? in.c[i < NQ ? i : 0] : rho;
+    W[i] = (j < NQ) ? ((i <= j) ? r : 0.0) : ((j == NQ) ? cand : 0.0);
+    V[i] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const int hb = (r >= 4) ? 4 : ((r >= 2) ? 2 : 1);
+      const bool low = (j & hb) == 0;  // j < (j ^ r)
+      double Wp[K], Vp[K];
+      double mine = 0.0, theirs = 0.0, gamma = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        Wp[i] = __shfl_xor(W[i], r);
+        Vp[i] = __shfl_xor(V[i], r);
+      }
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        mine = fma(W[i], W[i], mine);
+        theirs = fma(Wp[i], Wp[i], theirs);
+        gamma = fma(W[i], Wp[i], gamma);
+      }
+      const double alpha = low ? mine : theirs, beta = low ? theirs : mine;
+      const double lim = sqrt(alpha) * sqrt(beta);
+      if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {
+        off = fmax(off, fabs(gamma) / lim);
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        const double sp = low ? -sn : sn;  // low column: cs*W - sn*Wp ; high column: sn*Wp + cs*W
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          W[i] = cs * W[i] + sp * Wp[i];
+          V[i] = cs * V[i] + sp * Vp[i];
+        }
+      }
+    }
+    off = fmax(off, __shfl_xor(off, 1));
+    off = fmax(off, __shfl_xor(off, 2));
+    off = fmax(off, __shfl_xor(off, 4));
+    if (off <= 1e-15) break;  // wave-uniform: the lane groups are copies of each other
+  }
+  double h[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) h[i] = (i < NQ) ? ck->qy[i < NQ ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  double hh = 0.0, n2 = 0.0, tj = 0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    hh = fma(h[i], h[i], hh);
+    n2 = fma(W[i], W[i], n2);
+    tj = fma(W[i], h[i], tj);
+  }
+  const double eps = 1e-6;
+  const double sv = sqrt(n2);                                   // sigma_j
+  const double aj = (sv > 0.0 && j < K) ? tj / sv : 0.0;        // u_j . h
+  const double dj = (in.tau * sv) * (in.tau * sv);
+  const double wj = eps / (dj + eps);
+  const double coef = (j < K) ? (in.tau * sv) / (dj + eps) * aj : 0.0;
+  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
+#pragma unroll
+  for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a, 8));
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);  // numpy matrix_rank default
+  int rank = 0;
+#pragma unroll
+  for (int a = 0; a < K; ++a) {
+    const double sva = __shfl(sv, a, 8), aa = __shfl(aj, a, 8), wa = __shfl(wj, a, 8);
+    smin = fmin(smin, sva);
+    rank += (sva > tol) ? 1 : 0;
+    if (sva > 0.0) {
+      misfit = fma(wa * wa, aa * aa, misfit);
+      seen = fma(aa, aa, seen);
+    }
+  }
+  misfit += fmax(0.0, hh - seen);                               // directions with sigma == 0 keep all of h
+  const double sse = fmax(0.0, ck->yperp2 - h[NQ] * h[NQ]) + misfit;
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  double bt[K];                                                 // Beta'_i = sum_j V[i][j] coef_j
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double b = V[i] * coef;
+    b += __shfl_xor(b, 1);
+    b += __shfl_xor(b, 2);
+    b += __shfl_xor(b, 4);
+    bt[i] = b;
+  }
+  if (lane == 0) {
+    out->loglik = ll;
+    out->sse = sse;
+    out->scale = in.scale;
+    out->maxabs = in.maxabs;
+    out->smin = smin / in.s;
+    out->smax = smax / in.s;
+    out->rank = rank;
+    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+#pragma unroll
+    for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tree = (i == NQ) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bt[i];
+    }
+  }
+}
+
 __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score* out) {
   switch (in.K) {
     case 1: solve_regs<1>(in, lane, out); break;
     case 2: solve_regs<2>(in, lane, out); break;
     case 3: solve_regs<3>(in, lane, out); break;
     case 4: solve_regs<4>(in, lane, out); break;
-    default: solve_complete(in, lane, out); break;
+    case 5: solve_cols<5>(in, lane, out); break;
+    case 6: solve_cols<6>(in, lane, out); break;
+    case 7: solve_cols<7>(in, lane, out); break;
+    default: solve_cols<8>(in, lane, out); break;
   }
 }
 

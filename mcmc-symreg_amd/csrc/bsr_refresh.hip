@@ -60,76 +60,44 @@ __device__ __forceinline__ int gidx(int i, int j, int K) {  // packed upper tria
 }  // namespace
 
 // r1 ---------------------------------------------------------------------------------------------------------------
-template <typename T>
+// K is a template parameter: the K(K+1)/2 + 2K + 2 accumulators live in registers with static indices and the rows
+// are read once (the runtime-K version re-read them once per 8 words: 7 passes and a select chain per word at K = 8).
+// word list = G(i,j) i<=j (packed rows), then g_i = v_i.y, then u_i = v_i.1, then yy, sy
+template <typename T, int K>
 __global__ __launch_bounds__(RF_THREADS) void k_rf_gram(const T* __restrict__ cols, const T* __restrict__ y, int64_t ld,
-                                                        int64_t N, int K, int rows_per_block,
+                                                        int64_t N, int rows_per_block,
                                                         const RefreshIn* __restrict__ in, double* __restrict__ part) {
-  __shared__ double sh[4 * 8];
-  __shared__ double outv[8];
+  constexpr int nG = K * (K + 1) / 2;
+  constexpr int nW = nG + 2 * K + 2;
+  __shared__ double sh[4 * nW];
+  __shared__ double outv[nW];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
-  double sc[RF_MAXK];
+  double sc[K];
 #pragma unroll
-  for (int j = 0; j < RF_MAXK; ++j) sc[j] = (j < K && !(in->colflags[j] & (BSR_F_INF | BSR_F_NAN))) ? rf_pow2_prescale(in->colmax[j]) : 0.0;
-  // accumulate in chunks of 8 words to bound register use: word list = G(i,j) i<=j, then g_i, then u_i, then yy, sy
-  const int nG = K * (K + 1) / 2;
-  const int nW = nG + 2 * K + 2;
-  double* o = part + (size_t)blockIdx.x * RF_GW;
-  for (int w0 = 0; w0 < nW; w0 += 8) {
-    double acc[8];
+  for (int j = 0; j < K; ++j) sc[j] = !(in->colflags[j] & (BSR_F_INF | BSR_F_NAN)) ? rf_pow2_prescale(in->colmax[j]) : 0.0;
+  double acc[nW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-      double v[RF_MAXK];
+  for (int q = 0; q < nW; ++q) acc[q] = 0.0;
+  for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
+    double v[K];
 #pragma unroll
-      for (int j = 0; j < RF_MAXK; ++j) v[j] = (j < K && sc[j] != 0.0) ? sc[j] * (double)cols[(int64_t)j * ld + n] : 0.0;
-      const double yv = (double)y[n];
+    for (int j = 0; j < K; ++j) v[j] = (sc[j] != 0.0) ? sc[j] * (double)cols[(int64_t)j * ld + n] : 0.0;
+    const double yv = (double)y[n];
+    int w = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int w = w0 + q;
-        if (w >= nW) continue;
-        double a, b;
-        if (w < nG) {  // unpack (i,j)
-          int i = 0, rem = w;
-          while (rem >= K - i) {
-            rem -= K - i;
-            ++i;
-          }
-          const int j = i + rem;
-          double vi = 0.0, vj = 0.0;
+    for (int i = 0; i < K; ++i)
 #pragma unroll
-          for (int t = 0; t < RF_MAXK; ++t) {
-            vi = (t == i) ? v[t] : vi;
-            vj = (t == j) ? v[t] : vj;
-          }
-          a = vi;
-          b = vj;
-        } else if (w < nG + K) {
-          double vi = 0.0;
+      for (int j = i; j < K; ++j, ++w) acc[w] = fma(v[i], v[j], acc[w]);
 #pragma unroll
-          for (int t = 0; t < RF_MAXK; ++t) vi = (t == w - nG) ? v[t] : vi;
-          a = vi;
-          b = yv;
-        } else if (w < nG + 2 * K) {
-          double vi = 0.0;
+    for (int i = 0; i < K; ++i) acc[nG + i] = fma(v[i], yv, acc[nG + i]);
 #pragma unroll
-          for (int t = 0; t < RF_MAXK; ++t) vi = (t == w - nG - K) ? v[t] : vi;
-          a = vi;
-          b = 1.0;
-        } else if (w == nG + 2 * K) {
-          a = yv;
-          b = yv;
-        } else {
-          a = yv;
-          b = 1.0;
-        }
-        acc[q] = fma(a, b, acc[q]);
-      }
-    }
-    rf_block_sum<8>(acc, sh, outv);
-    if (threadIdx.x < 8 && w0 + (int)threadIdx.x < nW) o[w0 + threadIdx.x] = outv[threadIdx.x];
-    __syncthreads();
+    for (int i = 0; i < K; ++i) acc[nG + K + i] = fma(v[i], 1.0, acc[nG + K + i]);
+    acc[nG + 2 * K] = fma(yv, yv, acc[nG + 2 * K]);
+    acc[nG + 2 * K + 1] = fma(yv, 1.0, acc[nG + 2 * K + 1]);
   }
+  rf_block_sum<nW>(acc, sh, outv);
+  if (threadIdx.x < nW) part[(size_t)blockIdx.x * RF_GW + threadIdx.x] = outv[threadIdx.x];
 }
 
 // Gauss-Jordan inverse with partial pivoting of the M x M matrix in shA (leading dimension LDM), result in shI.
@@ -348,103 +316,91 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan(const RefreshIn* __restr
 // r3 ---------------------------------------------------------------------------------------------------------------
 // per block and k: words = nq(nq+1)/2 (Gram of Q1) + nq (Q1^T y); plus 2 words for the two direct residuals
 #define RF_AW 40
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(RF_THREADS) void k_rf_apply1(const T* __restrict__ cols, T* __restrict__ Qc,
-                                                          const T* __restrict__ y, int64_t ld, int64_t N, int K,
+                                                          const T* __restrict__ y, int64_t ld, int64_t N,
                                                           int rows_per_block, const RefreshPlan* __restrict__ plan,
                                                           double* __restrict__ part) {
-  __shared__ double sh[4 * 8];
-  __shared__ double outv[8];
-  const int nq = K - 1;
+  constexpr int K = NQ + 1;
+  constexpr int nGq = NQ * (NQ + 1) / 2;
+  constexpr int nW = nGq + NQ;
+  constexpr int nS = (nW > 2) ? nW : 2;
+  __shared__ double sh[4 * nS];
+  __shared__ double outv[nS];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
   double* o = part + (size_t)blockIdx.x * (RF_MAXK * RF_AW + 8);
   const bool fits = plan->anyflags == 0;
   // direct residuals of the two fits
   {
-    double acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    double acc[2] = {0.0, 0.0};
     if (fits) {
+      double cf[K], ci[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        cf[j] = plan->coef_fit[j];
+        ci[j] = plan->beta_icpt[j + 1];
+      }
+      const double c0 = plan->beta_icpt[0];
       for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-        double f0 = 0.0, f1 = plan->beta_icpt[0];
+        double f0 = 0.0, f1 = c0;
+#pragma unroll
         for (int j = 0; j < K; ++j) {
           const double v = (double)cols[(int64_t)j * ld + n];
-          f0 = fma(plan->coef_fit[j], v, f0);
-          f1 = fma(plan->beta_icpt[j + 1], v, f1);
+          f0 = fma(cf[j], v, f0);
+          f1 = fma(ci[j], v, f1);
         }
         const double yv = (double)y[n];
         acc[0] = fma(yv - f0, yv - f0, acc[0]);
         acc[1] = fma(yv - f1, yv - f1, acc[1]);
       }
     }
-    rf_block_sum<8>(acc, sh, outv);
+    rf_block_sum<2>(acc, sh, outv);
     if (threadIdx.x < 2) o[RF_MAXK * RF_AW + threadIdx.x] = outv[threadIdx.x];
     __syncthreads();
   }
-  for (int k = 0; k < K; ++k) {
-    if (nq == 0 || plan->flags_k[k] || plan->fallback[k]) continue;
-    const double sk = plan->s_k[k];
-    T* Q = Qc + (int64_t)k * nq * ld;
-    const int nGq = nq * (nq + 1) / 2;
-    const int nW = nGq + nq;
-    for (int w0 = 0; w0 < nW; w0 += 8) {
-      double acc[8];
+  if constexpr (NQ > 0) {
+    for (int k = 0; k < K; ++k) {
+      if (plan->flags_k[k] || plan->fallback[k]) continue;
+      const double sk = plan->s_k[k];
+      T* Q = Qc + (int64_t)k * NQ * ld;
+      double t1[nGq];  // upper triangle of T1 (uniform: scalar registers)
+      {
+        int w = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        for (int a_ = 0; a_ < NQ; ++a_)
+#pragma unroll
+          for (int b_ = a_; b_ < NQ; ++b_, ++w) t1[w] = plan->T1[k][a_ * RF_NQ + b_];
+      }
+      double acc[nW];
+#pragma unroll
+      for (int q = 0; q < nW; ++q) acc[q] = 0.0;
       for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-        double v[RF_NQ], q1[RF_NQ];
+        double v[NQ], q1[NQ];
 #pragma unroll
-        for (int a = 0; a < RF_NQ; ++a) {
-          const int ja = (a < k) ? a : a + 1;
-          v[a] = (a < nq) ? sk * (double)cols[(int64_t)ja * ld + n] : 0.0;
+        for (int a_ = 0; a_ < NQ; ++a_) {
+          const int ja = (a_ < k) ? a_ : a_ + 1;
+          v[a_] = sk * (double)cols[(int64_t)ja * ld + n];
         }
 #pragma unroll
-        for (int b = 0; b < RF_NQ; ++b) {
+        for (int b_ = 0; b_ < NQ; ++b_) {
           double t = 0.0;
 #pragma unroll
-          for (int a = 0; a < RF_NQ; ++a)
-            if (a <= b && b < nq) t = fma(v[a], plan->T1[k][a * RF_NQ + b], t);
-          q1[b] = t;
-        }
-        if (w0 == 0) {
-#pragma unroll
-          for (int b = 0; b < RF_NQ; ++b)
-            if (b < nq) Q[(int64_t)b * ld + n] = (T)q1[b];
+          for (int a_ = 0; a_ <= b_; ++a_) t = fma(v[a_], t1[a_ * NQ - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
+          q1[b_] = t;
+          Q[(int64_t)b_ * ld + n] = (T)t;
         }
         const double yv = (double)y[n];
+        int w = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int w = w0 + q;
-          if (w >= nW) continue;
-          double a_, b_;
-          if (w < nGq) {
-            int i = 0, rem = w;
-            while (rem >= nq - i) {
-              rem -= nq - i;
-              ++i;
-            }
-            const int j = i + rem;
-            double vi = 0.0, vj = 0.0;
+        for (int i = 0; i < NQ; ++i)
 #pragma unroll
-            for (int t = 0; t < RF_NQ; ++t) {
-              vi = (t == i) ? q1[t] : vi;
-              vj = (t == j) ? q1[t] : vj;
-            }
-            a_ = vi;
-            b_ = vj;
-          } else {
-            double vi = 0.0;
+          for (int j = i; j < NQ; ++j, ++w) acc[w] = fma(q1[i], q1[j], acc[w]);
 #pragma unroll
-            for (int t = 0; t < RF_NQ; ++t) vi = (t == w - nGq) ? q1[t] : vi;
-            a_ = vi;
-            b_ = yv;
-          }
-          acc[q] = fma(a_, b_, acc[q]);
-        }
+        for (int i = 0; i < NQ; ++i) acc[nGq + i] = fma(q1[i], yv, acc[nGq + i]);
       }
-      rf_block_sum<8>(acc, sh, outv);
-      if (threadIdx.x < 8 && w0 + (int)threadIdx.x < nW) o[k * RF_AW + w0 + threadIdx.x] = outv[threadIdx.x];
+      rf_block_sum<nW>(acc, sh, outv);
+      if (threadIdx.x < nW) o[k * RF_AW + threadIdx.x] = outv[threadIdx.x];
       __syncthreads();
     }
   }
@@ -527,46 +483,55 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan2(int K, int64_t N, int n
 }
 
 // r5 ---------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(RF_THREADS) void k_rf_apply2(T* __restrict__ Qc, const T* __restrict__ y, int64_t ld,
-                                                          int64_t N, int K, int rows_per_block,
+                                                          int64_t N, int rows_per_block,
                                                           const RefreshPlan* __restrict__ plan,
                                                           double* __restrict__ part) {
+  constexpr int K = NQ + 1;
+  constexpr int nGq = (NQ > 0) ? NQ * (NQ + 1) / 2 : 1;
   __shared__ double sh[4 * 8];
   __shared__ double outv[8];
-  const int nq = K - 1;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
   double acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+#pragma unroll 1
   for (int k = 0; k < K; ++k) {
     const bool skip = plan->flags_k[k] || plan->fallback[k];
-    T* Q = Qc + (int64_t)k * nq * ld;
+    T* Q = Qc + (int64_t)k * NQ * ld;
     double a_k = 0.0;
-    for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-      double r = (double)y[n];
-      if (!skip && nq > 0) {
-        double q1[RF_NQ], q2[RF_NQ];
+    if (skip || NQ == 0) {
+      for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
+        const double r = (double)y[n];
+        a_k = fma(r, r, a_k);
+      }
+    } else {
+      double t2[nGq], qy[NQ > 0 ? NQ : 1];
+      int w = 0;
 #pragma unroll
-        for (int a = 0; a < RF_NQ; ++a) q1[a] = (a < nq) ? (double)Q[(int64_t)a * ld + n] : 0.0;
+      for (int a_ = 0; a_ < NQ; ++a_)
 #pragma unroll
-        for (int b = 0; b < RF_NQ; ++b) {
+        for (int b_ = a_; b_ < NQ; ++b_, ++w) t2[w] = plan->T2[k][a_ * RF_NQ + b_];
+#pragma unroll
+      for (int b_ = 0; b_ < NQ; ++b_) qy[b_] = plan->qy[k][b_];
+      for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
+        double r = (double)y[n];
+        double q1[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int a_ = 0; a_ < NQ; ++a_) q1[a_] = (double)Q[(int64_t)a_ * ld + n];
+#pragma unroll
+        for (int b_ = 0; b_ < NQ; ++b_) {
           double t = 0.0;
 #pragma unroll
-          for (int a = 0; a < RF_NQ; ++a)
-            if (a <= b && b < nq) t = fma(q1[a], plan->T2[k][a * RF_NQ + b], t);
-          q2[b] = t;
+          for (int a_ = 0; a_ <= b_; ++a_) t = fma(q1[a_], t2[a_ * NQ - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
+          const T qs = (T)t;
+          Q[(int64_t)b_ * ld + n] = qs;
+          r = fma(-qy[b_], (double)qs, r);
         }
-#pragma unroll
-        for (int b = 0; b < RF_NQ; ++b)
-          if (b < nq) {
-            const T qs = (T)q2[b];
-            Q[(int64_t)b * ld + n] = qs;
-            r = fma(-plan->qy[k][b], (double)qs, r);
-          }
+        a_k = fma(r, r, a_k);
       }
-      a_k = fma(r, r, a_k);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = (q == k) ? a_k : acc[q];
@@ -586,21 +551,33 @@ __global__ __launch_bounds__(64) void k_rf_final(int K, int n_blocks, const doub
   }
 }
 
+template <typename T, int K>
+static void refresh_fast_k(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N,
+                           const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
+                           ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt) {
+  const int rows = BSR_RF_ROWS;
+  const int nb = (int)((N + rows - 1) / rows);
+  hipLaunchKernelGGL((k_rf_gram<T, K>), dim3(nb), dim3(RF_THREADS), 0, st, cols, y, ld, N, rows, d_in, d_part);
+  hipLaunchKernelGGL(k_rf_plan, dim3(1), dim3(RF_THREADS), 0, st, d_in, K, N, nb, d_part, d_plan);
+  double* part2 = d_part + (size_t)nb * RF_GW;
+  hipLaunchKernelGGL((k_rf_apply1<T, K - 1>), dim3(nb), dim3(RF_THREADS), 0, st, cols, Q, y, ld, N, rows, d_plan, part2);
+  hipLaunchKernelGGL(k_rf_plan2, dim3(1), dim3(RF_THREADS), 0, st, K, N, nb, part2, d_plan, ck, fit_noicpt, fit_icpt,
+                     d_in);
+  double* part3 = part2 + (size_t)nb * (RF_MAXK * RF_AW + 8);
+  hipLaunchKernelGGL((k_rf_apply2<T, K - 1>), dim3(nb), dim3(RF_THREADS), 0, st, Q, y, ld, N, rows, d_plan, part3);
+  hipLaunchKernelGGL(k_rf_final, dim3(1), dim3(64), 0, st, K, nb, part3, d_plan, ck);
+}
+
 template <typename T>
 void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N, int K,
                          const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
                          ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt) {
-  const int rows = BSR_RF_ROWS;
-  const int nb = (int)((N + rows - 1) / rows);
-  hipLaunchKernelGGL((k_rf_gram<T>), dim3(nb), dim3(RF_THREADS), 0, st, cols, y, ld, N, K, rows, d_in, d_part);
-  hipLaunchKernelGGL(k_rf_plan, dim3(1), dim3(RF_THREADS), 0, st, d_in, K, N, nb, d_part, d_plan);
-  double* part2 = d_part + (size_t)nb * RF_GW;
-  hipLaunchKernelGGL((k_rf_apply1<T>), dim3(nb), dim3(RF_THREADS), 0, st, cols, Q, y, ld, N, K, rows, d_plan, part2);
-  hipLaunchKernelGGL(k_rf_plan2, dim3(1), dim3(RF_THREADS), 0, st, K, N, nb, part2, d_plan, ck, fit_noicpt, fit_icpt,
-                     d_in);
-  double* part3 = part2 + (size_t)nb * (RF_MAXK * RF_AW + 8);
-  hipLaunchKernelGGL((k_rf_apply2<T>), dim3(nb), dim3(RF_THREADS), 0, st, Q, y, ld, N, K, rows, d_plan, part3);
-  hipLaunchKernelGGL(k_rf_final, dim3(1), dim3(64), 0, st, K, nb, part3, d_plan, ck);
+#define RF_CASE(KK) \
+  case KK: refresh_fast_k<T, KK>(st, cols, Q, y, ld, N, d_in, d_plan, d_part, ck, fit_noicpt, fit_icpt); break;
+  switch (K) {
+    RF_CASE(1) RF_CASE(2) RF_CASE(3) RF_CASE(4) RF_CASE(5) RF_CASE(6) RF_CASE(7) RF_CASE(8)
+  }
+#undef RF_CASE
 }
 
 size_t refresh_part_doubles(int64_t N) {
