@@ -11,9 +11,11 @@
 // randint on 32-bit draws, polar-method standard_normal with a cached second value, choice via cdf search, and
 // scipy's invgamma.rvs(a) = 1 / gammainccinv(a, U).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -899,9 +901,14 @@ struct bsr_engine {
   std::string err;
   bsr_trace* trace = nullptr;
   int64_t trace_cap = 0, n_trace = 0;
+  double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;  // seconds, reported when BSR_ENGINE_PROF is set
 };
 
 namespace {
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int efail(bsr_engine* e, int code, const std::string& msg) {
   e->err = msg;
@@ -1233,7 +1240,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       // speculate only about as far as this chain's batches have recently been consumed
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props);
+      const double tg0 = now_s();
       generate(e, *c, room);
+      e->t_gen += now_s() - tg0;
       g.span.push_back({(int)g.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
         g.rows.insert(g.rows.end(), cd.tape.begin(), cd.tape.end());
@@ -1246,8 +1255,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     }
     if (g.chs.empty()) return BSR_OK;
     g.res.resize(g.chs.size());
+    const double ts0 = now_s();
     int r = bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
                              (int)g.chs.size(), &g.ticket);
+    e->t_submit += now_s() - ts0;
     if (r != BSR_OK) {
       e->err = std::string("bsr_score_submit: ") + bsr_last_error(e->ctx);
       return r;
@@ -1258,7 +1269,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   auto collect = [&](Group& g) -> int {
     if (!g.inflight) return BSR_OK;
     g.inflight = false;
+    const double tw0 = now_s();
     int r = bsr_score_wait(e->ctx, g.ticket, g.res.data());
+    const double tw1 = now_s();
+    e->t_wait += tw1 - tw0;
     if (r != BSR_OK) {
       e->err = std::string("bsr_score_wait: ") + bsr_last_error(e->ctx);
       return r;
@@ -1268,6 +1282,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first);
       if (r != BSR_OK) return r;
     }
+    e->t_consume += now_s() - tw1;
     return BSR_OK;
   };
 
@@ -1296,6 +1311,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   }
   if (n_trace) *n_trace = e->n_trace;
   e->trace = nullptr;
+  if (getenv("BSR_ENGINE_PROF"))
+    fprintf(stderr, "bsr_engine_run: generate %.3f s, submit %.3f s, wait %.3f s, consume %.3f s\n", e->t_gen,
+            e->t_submit, e->t_wait, e->t_consume);
   return rc;
 }
 

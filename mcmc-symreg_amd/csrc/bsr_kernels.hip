@@ -474,7 +474,9 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       // census after the fact: max|z| is +inf iff an inf is present (fmax ignores NaN); the sum of squares is
       // NaN iff a NaN is present (squares are non-negative, so no inf-inf)
       const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
-      if (lane == 0) {
+      // every lane holds the wave totals and stores them to the same addresses: no lane-divergent branch anywhere
+      // in the kernel, so the uniform node loop above is left alone by the CFG structurizer
+      {
         double* o = part + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
 #pragma unroll
         for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = (i < NQ) ? c[i < NQ ? i : 0] : 0.0;
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
     } else {
       a0 = wave_sum(a0);
       a1 = wave_sum(a1);
-      if (lane == 0) {
+      {
         double* o = part + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
         o[0] = a0;
         o[1] = a1;
