@@ -16,6 +16,8 @@ static thread_local std::string g_create_error;
 
 struct TapeLoc {
   int code_off, n_nodes, feat_off, ln_off, max_sp;
+  int n_stream;  // opcode-stream entries after fusing `terminal, +|*` pairs
+  int cost;      // rough relative cost of one sweep of the tape (orders the work queue: heaviest first)
 };
 
 // Everything one batch in flight owns.  Two slots let the host stage batch i+1 while the GPU scores batch i.
@@ -37,6 +39,9 @@ struct BatchSlot {
   size_t part_cap = 0;   // in (proposal,row block) records
   void* spill = nullptr;
   size_t spill_cap = 0;  // bytes
+  int32_t* queue = nullptr;  // ring of work-queue counter sets for the projection pass (zeroed once; every launch
+                             // takes the next set and clears the one half a ring ahead)
+  uint32_t queue_seq = 0;
   hipEvent_t done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int P = 0;
@@ -59,6 +64,8 @@ struct bsr_ctx {
   hipStream_t stream = nullptr;
   int64_t N = 0, ld = 0;
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
+  int n_cu = 256;
+  std::vector<int> order_tmp;
   size_t esz = 8;
   bool has_y = false;
   void* Xt = nullptr;
@@ -158,6 +165,7 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.d_coef) (void)hipFree(s.d_coef);
+    if (s.queue) (void)hipFree(s.queue);
     if (s.part1) (void)hipFree(s.part1);
     if (s.part2) (void)hipFree(s.part2);
     if (s.spill) (void)hipFree(s.spill);
@@ -212,10 +220,13 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   c->has_y = (y != nullptr);
   c->rows_per_lane = env_int("BSR_P1_U", 2);
   if (c->rows_per_lane != 2 && c->rows_per_lane != 4 && c->rows_per_lane != 8) c->rows_per_lane = 2;
-  c->rb_rows = env_int("BSR_RB_ROWS", 512);
+  // rows per task: 1024 amortises the per-task setup and reductions (~1 us) once there are enough row blocks to go
+  // round (measured: +5..13 % at N = 100k..1M); small inputs keep shorter blocks so fewer masked rows are evaluated
+  const int rb_default = (N >= 65536) ? 1024 : ((N > 256) ? 512 : 256);
+  c->rb_rows = env_int("BSR_RB_ROWS", rb_default);
   if (c->rb_rows < 256 || c->rb_rows > BSR_ROW_ALIGN || (BSR_ROW_ALIGN % c->rb_rows) != 0 ||
       (c->rb_rows % (64 * c->rows_per_lane)) != 0)
-    c->rb_rows = 512;
+    c->rb_rows = rb_default;
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
   c->slot_of.assign(d, -1);
@@ -234,6 +245,10 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     }                                                  \
   } while (0)
   CK(hipSetDevice(device));
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+  }
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t colb = (size_t)c->ld * c->esz;
   CK(hipMalloc(&c->Xt, colb * d));
@@ -266,6 +281,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   for (BatchSlot& s : c->slot) {
     CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
+    CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
+    CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     s.off_desc = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
     CK(hipMalloc((void**)&s.d_out, sizeof(bsr_score) * (max_batch + 1)));
@@ -330,6 +347,10 @@ static LaunchGeom geometry(const bsr_ctx* c, const BatchSlot& s, int P) {
   pg = std::max(1, std::min(pg, P));
   g.pg = pg;
   g.n_pg = (P + pg - 1) / pg;
+  // work-queue launch: one resident set of workgroups (5 per CU fit at <= 102 VGPRs), never more than there are tasks
+  const int64_t tasks = (int64_t)P * g.n_rb;
+  const int64_t want = std::min<int64_t>((int64_t)c->n_cu * 5, (tasks + BSR_WG_WAVES - 1) / BSR_WG_WAVES);
+  g.dyn_wgs = (int)std::max<int64_t>(8, (want + 7) / 8 * 8);
   return g;
 }
 
@@ -346,7 +367,8 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
     s.part_cap = cap;
   }
   if (spill_slots > 0) {
-    const size_t need = (size_t)((g.n_rb + 7) / 8 * 8) * g.n_pg * BSR_WG_WAVES * spill_slots * BSR_WAVE * 8 * c->esz;
+    const size_t wgs = std::max((size_t)((g.n_rb + 7) / 8 * 8) * g.n_pg, (size_t)g.dyn_wgs);
+    const size_t need = wgs * BSR_WG_WAVES * spill_slots * BSR_WAVE * 8 * c->esz;
     if (need > s.spill_cap) {
       HIPCHK(c, hipStreamSynchronize(s.stream));
       if (s.spill) HIPCHK(c, hipFree(s.spill));
@@ -360,7 +382,8 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
 
 // Validates the tapes, chooses LDS staging, and writes the compact streams the interpreter reads into the slot's
 // pinned input block:
-//   opcode stream  : 4 bits per node, 16 nodes per 64-bit word, one padding word per tape
+//   opcode stream  : 4 bits per entry, 16 per 64-bit word, one padding word per tape; an entry is a tape node, or a
+//                    `terminal, +|*` pair fused into BSR_SOP_ADD_T / BSR_SOP_MUL_T
 //   column stream  : 16 bits per terminal in tape order (LDS slot when staging, else the X column), 4 per word,
 //                    padded with a valid id so the kernel may request one terminal past the end
 //   ln stream      : (a,b) per ln node in tape order plus one padding pair
@@ -424,24 +447,44 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   double* hl = reinterpret_cast<double*>(hf + fw);
   memset(hc, 0, (cw + fw) * 8);
   for (int i = 0; i < n; ++i) {
-    const TapeLoc& L = (*loc)[i];
+    const TapeLoc L = (*loc)[i];
     uint64_t* pc = hc + L.code_off;
     uint64_t* pf = hf + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
-    int nt = 0, nl = 0;
+    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 8;
     for (int j = 0; j < L.n_nodes; ++j) {
       const bsr_node& r = rows[tape_off[i] + j];
-      pc[j >> 4] |= (uint64_t)(r.opcode & 15) << (4 * (j & 15));
+      int code = r.opcode & 15;
       if (r.opcode == BSR_OP_TERMINAL) {
         const uint64_t id = (uint64_t)(s.use_lds ? c->slot_of[r.feature] : r.feature);
         pf[nt >> 2] |= id << (16 * (nt & 3));
         ++nt;
+        // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
+        // one stream entry: acc = acc op X[:,f], no push/pop
+        const int nxt = (j + 1 < L.n_nodes) ? rows[tape_off[i] + j + 1].opcode : -1;
+        if (j > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
+          code = (nxt == BSR_OP_ADD) ? BSR_SOP_ADD_T : BSR_SOP_MUL_T;
+          ++j;
+        } else {
+          ++sp;
+        }
       } else if (r.opcode == BSR_OP_LN) {
         pl[2 * nl] = r.a;
         pl[2 * nl + 1] = r.b;
         ++nl;
+      } else if (r.opcode >= BSR_OP_ADD) {
+        --sp;
       }
+      mx = std::max(mx, sp);
+      pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
+      ++ns;
+      // measured per-visit costs (tools/stamps.py), in units of ~150 cycles: plain op 1, column read 4, exp/inv 3, sin/cos 8
+      cost += (r.opcode == BSR_OP_TERMINAL) ? 4 : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 8
+              : (r.opcode == BSR_OP_EXP || r.opcode == BSR_OP_INV) ? 3 : 1;
     }
+    (*loc)[i].n_stream = ns;
+    (*loc)[i].cost = cost;
+    (*loc)[i].max_sp = mx;
     pl[2 * nl] = 1.0;
     pl[2 * nl + 1] = 0.0;
     if (!s.use_lds) {  // padding ids must name a valid column: repeat the first terminal's
@@ -456,10 +499,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
 static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
   memset(D, 0, sizeof *D);
   D->code_off = L.code_off;
-  D->n_nodes = L.n_nodes;
+  D->n_nodes = L.n_stream;
   D->feat_off = L.feat_off;
   D->ln_off = L.ln_off;
   D->spill_need = std::max(0, L.max_sp - 1 - 2);  // sized for the smallest register stack (2 slots at 8 rows/lane)
+  D->cost = L.cost;
 }
 
 static void fill_eval_desc(bsr_ctx* c, PropDesc* D, const TapeLoc& L, void* zout) {
@@ -495,6 +539,13 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
   a->spill = spill_slots ? s.spill : nullptr;
   a->spill_slots = spill_slots;
   a->rows_per_lane = c->rows_per_lane;
+  if (!residual) {
+    const uint32_t q = s.queue_seq++;
+    a->queue = s.queue + (size_t)(q % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
+    a->queue_clear = s.queue + (size_t)((q + BSR_QUEUE_SETS / 2) % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
+  } else {
+    a->queue = a->queue_clear = nullptr;
+  }
 }
 
 static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const PropDesc* desc, int P,
@@ -518,6 +569,11 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   const LaunchGeom g = geometry(c, s, P);
   int rc = ensure_partials(c, s, g, P, spill_slots);
   if (rc != BSR_OK) return rc;
+  // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
+  c->order_tmp.resize(P);
+  for (int i = 0; i < P; ++i) c->order_tmp[i] = i;
+  std::stable_sort(c->order_tmp.begin(), c->order_tmp.end(), [&](int a, int b) { return hd[a].cost > hd[b].cost; });
+  for (int i = 0; i < P; ++i) hd[i].order = c->order_tmp[i];
   hipStream_t st = s.stream;
   const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
   HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, st));
@@ -669,6 +725,7 @@ extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   D.qbase = nullptr;
   D.zout = col_ptr(c, c->cur, (int64_t)chain * c->K + k);
   D.s = 1.0;
+  D.order = 0;
   const int at = c->max_batch;
   s.h_desc()[at] = D;
   HIPCHK(c, hipMemcpyAsync(s.d_desc() + at, &s.h_desc()[at], sizeof(PropDesc), hipMemcpyHostToDevice, s.stream));

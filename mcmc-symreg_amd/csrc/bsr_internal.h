@@ -10,6 +10,12 @@
 #define BSR_NQ_MAX (BSR_MAX_K - 1)  // basis columns per proposal
 #define BSR_WAVE 64
 #define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
+// opcode-stream-only codes (never in a bsr_node): acc = acc + X[:,f] / acc * X[:,f] with f from the column stream
+#define BSR_QUEUE_SETS 16                             // ring of counter sets per batch slot
+#define BSR_QUEUE_SUB 16                              // ticket counters per XCD (power of two, <= 32)
+#define BSR_QUEUE_SET_INTS (8 * BSR_QUEUE_SUB * 32)   // one counter per 128-byte line
+#define BSR_SOP_ADD_T 11
+#define BSR_SOP_MUL_T 12
 #ifndef BSR_ROWS_MIN_WAVES
 #define BSR_ROWS_MIN_WAVES 4         // occupancy floor requested from the compiler for the row pass
 #endif
@@ -44,7 +50,8 @@ struct PropDesc {
   int32_t K;
   int32_t ck;           // index into the ChainK array (chain*K + k)
   int32_t spill_need;   // stack slots beyond the register stack
-  int32_t pad0, pad1;
+  int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
+  int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
   const void* qbase;    // first basis column (nq columns, stride ld)
   void* zout;           // where the candidate column goes (ld values) or nullptr
   double s;             // prescale applied to the candidate column in all accumulations
@@ -96,6 +103,7 @@ struct LaunchGeom {
   int n_rb;         // row blocks
   int pg;           // proposals per workgroup
   int n_pg;         // proposal groups
+  int dyn_wgs;      // workgroups of the work-queue (projection) launch
 };
 
 // kernels (bsr_kernels.hip)
@@ -117,6 +125,8 @@ struct RowPassArgs {
   void* spill;
   int spill_slots;
   int rows_per_lane;          // 2, 4 or 8 (rb_rows must be a multiple of 64*rows_per_lane)
+  int32_t* queue;             // work queue of the projection pass: 8 x BSR_QUEUE_SUB ticket counters, 128 B apart
+  int32_t* queue_clear;       // the counter set this launch zeroes for a later one
 };
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);

@@ -36,8 +36,14 @@ __device__ __forceinline__ const T CONSTANT_AS* as_const(const T* p) {
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  int l2, h2;
+  if constexpr (ROW_MASK == 0xF) {  // every lane is written: no need to initialise the destination
+    l2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    h2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+  } else {
+    l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  }
   return __hiloint2double(h2, l2);
 }
 __device__ __forceinline__ double readlane63(double v) {
@@ -45,6 +51,15 @@ __device__ __forceinline__ double readlane63(double v) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
+// max(a, |b|) in one instruction.  fmax() costs three here: LLVM canonicalises both operands (v_max_f64 x, x) before
+// the real maximum to quiet signalling NaNs.  v_max_f64 already returns the other operand when one is a NaN, which is
+// the fmax behaviour the census relies on (a NaN row never becomes the maximum; it is flagged through the sum).
+__device__ __forceinline__ double max_abs(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_abs(float a, float b) { return fmaxf(a, fabsf(b)); }
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0xB1, 0xF>(v);
   v += dpp_f64<0x4E, 0xF>(v);
@@ -56,6 +71,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return readlane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {  // inputs are non-negative (|z| maxima): 0 is neutral
+  // plain fmax here: its first step also re-materialises v through an ordinary VALU instruction, so the DPP reads below
+  // never follow the inline-asm write of max_abs directly (the hazard recogniser cannot see into inline asm)
+  v = fmax(v, 0.0);
   v = fmax(v, dpp_f64<0xB1, 0xF>(v));
   v = fmax(v, dpp_f64<0x4E, 0xF>(v));
   v = fmax(v, dpp_f64<0x141, 0xF>(v));
@@ -210,7 +228,8 @@ __device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg) {
 }
 
 // Evaluates one tape on the lane's U rows.  The tape arrives as three compact streams built by the host from the
-// bsr_node rows (bsr_api.hip: build_streams): 4-bit opcodes (16 per 64-bit word), 16-bit column ids of the terminals
+// bsr_node rows (bsr_api.hip: stage_tapes): 4-bit opcodes (16 per 64-bit word; `terminal, +|*` pairs arrive fused as
+// BSR_SOP_ADD_T / BSR_SOP_MUL_T), 16-bit column ids of the terminals
 // in tape order (4 per word) and the (a,b) pairs of the ln nodes.  They are read through the constant address space
 // (scalar loads) a whole word at a time, so the node loop itself is register-only: opcode, stack pointer and every
 // branch are wave-uniform, and the only memory operation on the critical path is the terminal read, which is
@@ -243,11 +262,19 @@ __device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* 
     }
     const int op = (int)(code & 15u);
     code >>= 4;
-    if (op == BSR_OP_TERMINAL) {
-      st.push(sp, acc);
-      ++sp;
+    if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
+      if (op == BSR_OP_TERMINAL) {
+        st.push(sp, acc);
+        ++sp;
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[u] = pre[u];
+        for (int u = 0; u < U; ++u) acc[u] = pre[u];
+      } else if (op == BSR_SOP_ADD_T) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
+      } else {  // BSR_SOP_MUL_T
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
+      }
       fhead >>= 16;
       if (++nt == 4) {
         fhead = fnext;
@@ -337,23 +364,44 @@ __device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* 
 //   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
 
+// In-kernel timing stamps (debug builds only: -DBSR_STAMPS): shader-clock samples of the first waves of the PROJECT
+// pass, read back with bsr_debug_stamps().  tools/stamps.py prints the per-phase cycle budget of a wave.
+#ifdef BSR_STAMPS
+#define BSR_STAMP_WAVES 16384
+#define BSR_STAMP_SLOTS 48
+__device__ unsigned long long bsr_dbg_stamps[BSR_STAMP_WAVES * BSR_STAMP_SLOTS];
+#define STAMP(i)                                                                                         \
+  do {                                                                                                   \
+    const int si_ = (i);                                                                                 \
+    if (MODE == MODE_PROJECT && gwave < BSR_STAMP_WAVES && si_ < BSR_STAMP_SLOTS && lane == 0)           \
+      bsr_dbg_stamps[gwave * BSR_STAMP_SLOTS + si_] = clock64();                                         \
+  } while (0)
+extern "C" int bsr_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr_dbg_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <typename T, int NQ, int U, bool LDS, int MODE>
 __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_rows(
     const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const uint64_t* __restrict__ codes,
     const uint64_t* __restrict__ feats, const double* __restrict__ lnp, const PropDesc* __restrict__ desc,
     const PropCoef* __restrict__ coef, int P, int rb_rows, int pg, int n_rb, int n_pg,
     const int32_t* __restrict__ feat_list, int nF, double* __restrict__ part, T* __restrict__ spill,
-    int spill_slots) {
+    int spill_slots, int32_t* __restrict__ queue, int32_t* __restrict__ queue_clear) {
+  constexpr bool DYN = !LDS && MODE == MODE_PROJECT;
   constexpr int S = (U >= 8) ? 2 : BSR_REG_STACK;
   constexpr int VEC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [nF][rb_rows] then y[rb_rows]   (LDS variant only)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const WorkItem wi = map_work(n_rb, n_pg);
-  if (!wi.valid) return;
-  const int rb = wi.rb;
-  const int64_t row_base = (int64_t)rb * rb_rows;
+  WorkItem wi = {0, 0, true};
+  if constexpr (!DYN) {
+    wi = map_work(n_rb, n_pg);
+    if (!wi.valid) return;
+  }
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   const PropCoef CONSTANT_AS* cf = as_const(coef);
   if (MODE == MODE_RESIDUAL) {  // nothing to do for this group? leave before staging anything
@@ -371,7 +419,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       const int f = idx / nvec, v = idx - f * nvec;
       const T* src = (f < nF) ? Xt + (int64_t)feat_list[f] * ld : y;
       V4 val = {0.f, 0.f, 0.f, 0.f};
-      if (src) val = *reinterpret_cast<const V4*>(src + row_base + (int64_t)v * VEC);
+      if (src) val = *reinterpret_cast<const V4*>(src + (int64_t)wi.rb * rb_rows + (int64_t)v * VEC);
       *reinterpret_cast<V4*>(sx + (size_t)f * rb_rows + (size_t)v * VEC) = val;
     }
     __syncthreads();
@@ -380,11 +428,16 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   const int sweeps = rb_rows / (BSR_WAVE * U);
   const int gwave = blockIdx.x * BSR_WG_WAVES + wave;
   T* my_spill = spill ? spill + (size_t)gwave * spill_slots * (BSR_WAVE * 8) : nullptr;
+  int stamp_i = 0;
+  (void)stamp_i;
+  STAMP(stamp_i++);  // wave start
+#ifdef BSR_STAMPS
+  if (MODE == MODE_PROJECT && gwave < BSR_STAMP_WAVES && lane == 0)
+    bsr_dbg_stamps[gwave * BSR_STAMP_SLOTS + 46] = wall_clock64();  // constant-rate reference (100 MHz)
+#endif
 
-  for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
-    const int p = wi.pgi * pg + pi;
-    if (p >= P) break;
-    if (MODE == MODE_RESIDUAL && cf[p].skip) continue;
+  // one task: tape p over row block rb (all its sweeps), partial sums stored for k_solve
+  auto run_task = [&](const int p, const int rb, const int64_t row_base) {
     const T* qbase = (const T*)dsc[p].qbase;
     T* zout = (T*)dsc[p].zout;
     const double s = dsc[p].s;
@@ -397,6 +450,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
 #pragma unroll
     for (int i = 0; i < NQ; ++i) c[i] = (MODE == MODE_RESIDUAL) ? cf[p].c[i] : 0.0;
     double a0 = 0.0, a1 = 0.0, amax = 0.0;  // PROJECT: |s z|^2, s z.y   RESIDUAL: |w|^2, w.y
+    STAMP(stamp_i++);  // proposal start (descriptor fields requested)
 
     for (int sw = 0; sw < sweeps; ++sw) {
       const int off = sw * (BSR_WAVE * U) + 2 * lane;  // lane's pair 0 inside the row block
@@ -441,7 +495,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
         const double zd = (double)z;
         const double zs = zd * s;
         if (MODE == MODE_PROJECT) {
-          amax = fmax(amax, fabs(zd));
+          amax = max_abs(amax, zd);
           a0 = fma(zs, zs, a0);
           a1 = fma(zs, (double)yv[u], a1);
 #pragma unroll
@@ -456,6 +510,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
           }
         }
       }
+      STAMP(stamp_i++);  // sweep done
       if (MODE == MODE_PROJECT && zout) {
         T* zo = zout + row_base + off;
 #pragma unroll
@@ -474,8 +529,9 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       // census after the fact: max|z| is +inf iff an inf is present (fmax ignores NaN); the sum of squares is
       // NaN iff a NaN is present (squares are non-negative, so no inf-inf)
       const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
-      // every lane holds the wave totals and stores them to the same addresses: no lane-divergent branch anywhere
-      // in the kernel, so the uniform node loop above is left alone by the CFG structurizer
+      STAMP(stamp_i++);  // reductions done
+      // every lane holds the wave totals and stores them to the same addresses: the task body has no lane-divergent
+      // branch, so its uniform node loop is left alone by the CFG structurizer
       {
         double* o = part + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
 #pragma unroll
@@ -495,7 +551,89 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
         o[1] = a1;
       }
     }
+  };
+
+  if constexpr (DYN) {
+    // Work queue: every workgroup pulls (four tapes, row block) tickets until none are left.  Tapes differ several-fold in cost, a
+    // launch is only 2-3 tasks per resident wave, and the SIMD favours its oldest waves, so a static split leaves the
+    // chip waiting for a few late, lonely waves (measured with tools/stamps.py: waves of one launch end anywhere
+    // between 6 and 28 us).  Here the heaviest tapes go first (desc[i].order) and the tail is one task long.
+    //  * Ticket counters are per XCD (blockIdx & 7, the hardware's round-robin placement): an XCD works on its own
+    //    eighth of the row blocks, like the static mapping, and bumps its counters with L2-local atomics (no sc1: a
+    //    device-scope atomic is executed memory-side, ~35 ns each once thousands of waves hit one address).  Should a
+    //    counter ever be touched from two XCDs, each L2 counts through its own copy: tasks may be repeated (the same
+    //    values stored again), never skipped.
+    //  * Even in L2 one address takes an atomic only every ~8 ns, so an XCD's tasks are spread over BSR_QUEUE_SUB
+    //    counters (row block j of the XCD belongs to counter j % BSR_QUEUE_SUB).  A workgroup drains its own counter,
+    //    then reads all of them at once (one lane each, through the atomic unit so the values are fresh) and moves to
+    //    one that still has tickets; which one depends on the workgroup, so the last counters are not stormed.
+    //  * A ticket is one row block x four neighbouring tapes of the cost order, one per wave: the four waves of a
+    //    workgroup stay on one row block (its y, basis and X lines are shared through the CU's L1, as in the static
+    //    mapping; per-wave tickets scattered them and made every sweep 1.8x slower) and finish at about the same time.
+    //  * The next ticket is requested before the current task runs, so its round trip hides under the task.
+    //  * Counters live 128 B apart; the launcher hands out a fresh, zeroed set per launch and this launch clears the
+    //    set that comes up again half a ring later.
+    const int x = blockIdx.x & 7;
+    if (blockIdx.x == 0 && threadIdx.x < 8 * BSR_QUEUE_SUB) queue_clear[threadIdx.x * 32] = 0;
+    __shared__ int s_tk[2], s_next;
+    const int nrb_x = (n_rb - x + 7) >> 3;
+    int32_t* qx = queue + x * (BSR_QUEUE_SUB * 32);
+    const int wgid = (int)(blockIdx.x >> 3);
+    const int nquad = (P + BSR_WG_WAVES - 1) / BSR_WG_WAVES;  // a ticket = one row block x four neighbouring tapes
+    const int my_c = lane & (BSR_QUEUE_SUB - 1);
+    const int my_n = ((nrb_x - my_c + BSR_QUEUE_SUB - 1) / BSR_QUEUE_SUB) * nquad;  // tickets behind counter my_c
+    int cq = wgid & (BSR_QUEUE_SUB - 1);
+    int par = 0;
+    for (int round = 0;; ++round) {
+      const int nj = (nrb_x - cq + BSR_QUEUE_SUB - 1) / BSR_QUEUE_SUB;  // row blocks cq, cq+SUB, ... of this XCD
+      const int n_tasks = nj * nquad;
+      if (n_tasks > 0) {
+        int32_t* q = qx + cq * 32;
+        if (threadIdx.x == 0) s_tk[par] = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        for (;;) {
+          const int t = __builtin_amdgcn_readfirstlane(s_tk[par]);
+          if (t >= n_tasks) break;
+          int tn = 0;
+          if (threadIdx.x == 0) tn = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // row-block-major: neighbouring tickets are different tapes on one row block (tape-major order put every wave
+          // of the chip on the same two or three X columns at once and doubled the sweep time)
+          const int jj = t / nquad;
+          const int pi = (t - jj * nquad) * BSR_WG_WAVES + wave;
+          const int rb = x + 8 * (cq + BSR_QUEUE_SUB * jj);
+          if (pi < P) run_task(dsc[pi].order, rb, (int64_t)rb * rb_rows);
+          if (threadIdx.x == 0) s_tk[par ^ 1] = tn;
+          par ^= 1;
+          __syncthreads();
+        }
+      }
+      if (wave == 0) {
+        int seen = 0x7fffffff;
+        if (lane < BSR_QUEUE_SUB)
+          seen = __hip_atomic_fetch_add(qx + my_c * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t open = (uint32_t)__ballot(lane < BSR_QUEUE_SUB && seen < my_n);
+        // rotate by a workgroup- and round-dependent amount and take the first open counter from there
+        const int rot = (wgid * 5 + round * 7) & (BSR_QUEUE_SUB - 1);
+        const uint32_t m16 = (1u << BSR_QUEUE_SUB) - 1u;
+        const uint32_t r = ((open >> rot) | (open << (BSR_QUEUE_SUB - rot))) & m16;
+        if (lane == 0) s_next = open ? ((rot + __builtin_ctz(r | 0x10000u)) & (BSR_QUEUE_SUB - 1)) : -1;
+      }
+      __syncthreads();
+      cq = __builtin_amdgcn_readfirstlane(s_next);
+      if (cq < 0) break;
+    }
+  } else {
+    for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
+      const int p = wi.pgi * pg + pi;
+      if (p >= P) break;
+      if (MODE == MODE_RESIDUAL && cf[p].skip) continue;
+      run_task(p, wi.rb, (int64_t)wi.rb * rb_rows);
+    }
   }
+#ifdef BSR_STAMPS
+  if (MODE == MODE_PROJECT && gwave < BSR_STAMP_WAVES && lane == 0)
+    bsr_dbg_stamps[gwave * BSR_STAMP_SLOTS + 47] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1297,15 +1435,16 @@ template <typename T, int NQ, int MODE, int U>
 static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   const LaunchGeom& g = a.g;
   dim3 grid((unsigned)(((g.n_rb + 7) / 8) * 8 * g.n_pg)), block(BSR_WG_WAVES * BSR_WAVE);
+  if (!a.feat_list && MODE == MODE_PROJECT) grid.x = (unsigned)g.dyn_wgs;  // work-queue launch
   if (a.feat_list) {
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
     hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
-                       (T*)a.spill, a.spill_slots);
+                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
   } else {
     hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
-                       (T*)a.spill, a.spill_slots);
+                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
   }
 }
 template <typename T, int NQ, int MODE>
