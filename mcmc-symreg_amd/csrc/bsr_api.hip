@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "bsr_internal.h"
@@ -50,6 +51,8 @@ struct BatchSlot {
   int rb_rows = 512;
   bool pending = false;
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
+  std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
+  std::vector<int> order_tmp;    // scratch of the cost sort
 
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
   PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
@@ -65,7 +68,6 @@ struct bsr_ctx {
   int64_t N = 0, ld = 0;
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
   int n_cu = 256;
-  std::vector<int> order_tmp;
   size_t esz = 8;
   bool has_y = false;
   void* Xt = nullptr;
@@ -90,8 +92,8 @@ struct bsr_ctx {
   BatchSlot slot[BSR_MAX_INFLIGHT];
   int next_slot = 0;
   int last_waited = -1;
+  std::mutex mu;  // commit / refresh / fit share the main stream and one set of staging buffers (bsr_internal_lock)
   double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
-  std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
   // tuning
   int rb_rows = 512;
   int target_wgs = 2048;
@@ -229,7 +231,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     c->rb_rows = rb_default;
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
-  c->slot_of.assign(d, -1);
+  for (BatchSlot& s : c->slot) s.slot_of.assign(d, -1);
   int rc = BSR_OK;
   auto bail = [&](int code) {
     g_create_error = c->err;
@@ -394,7 +396,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
   loc->resize(n);
   size_t cw = 0, fw = 0, lw = 0;
-  std::fill(c->slot_of.begin(), c->slot_of.end(), -1);
+  std::fill(s.slot_of.begin(), s.slot_of.end(), -1);
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
@@ -404,7 +406,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
       if (rows[j].opcode == BSR_OP_TERMINAL) {
         ++nt;
-        c->slot_of[rows[j].feature] = 0;
+        s.slot_of[rows[j].feature] = 0;
       } else if (rows[j].opcode == BSR_OP_LN) {
         ++nl;
       }
@@ -423,8 +425,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   s.nF = 0;
   int32_t* hfeat = s.h_feat();
   for (int f = 0; f < c->d; ++f)
-    if (c->slot_of[f] == 0) {
-      c->slot_of[f] = s.nF;
+    if (s.slot_of[f] == 0) {
+      s.slot_of[f] = s.nF;
       hfeat[s.nF++] = f;
     }
   const size_t lds_budget = 64 * 1024;
@@ -456,7 +458,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const bsr_node& r = rows[tape_off[i] + j];
       int code = r.opcode & 15;
       if (r.opcode == BSR_OP_TERMINAL) {
-        const uint64_t id = (uint64_t)(s.use_lds ? c->slot_of[r.feature] : r.feature);
+        const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[r.feature] : r.feature);
         pf[nt >> 2] |= id << (16 * (nt & 3));
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
@@ -570,10 +572,10 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   int rc = ensure_partials(c, s, g, P, spill_slots);
   if (rc != BSR_OK) return rc;
   // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
-  c->order_tmp.resize(P);
-  for (int i = 0; i < P; ++i) c->order_tmp[i] = i;
-  std::stable_sort(c->order_tmp.begin(), c->order_tmp.end(), [&](int a, int b) { return hd[a].cost > hd[b].cost; });
-  for (int i = 0; i < P; ++i) hd[i].order = c->order_tmp[i];
+  s.order_tmp.resize(P);
+  for (int i = 0; i < P; ++i) s.order_tmp[i] = i;
+  std::stable_sort(s.order_tmp.begin(), s.order_tmp.end(), [&](int a, int b) { return hd[a].cost > hd[b].cost; });
+  for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
   hipStream_t st = s.stream;
   const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
   HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, st));
@@ -710,11 +712,21 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
 
 extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   if (!c) return BSR_E_ARG;
+  if (c->last_waited < 0) return fail(c, BSR_E_STATE, "bsr_commit: no scored batch to commit from");
+  return bsr_internal_commit(c, c->last_waited, chain, k, idx);
+}
+
+void bsr_internal_lock(bsr_ctx* c) { c->mu.lock(); }
+void bsr_internal_unlock(bsr_ctx* c) { c->mu.unlock(); }
+
+// Commits candidate `idx` of the batch last scored on slot `si`.  Callers on several threads hold bsr_internal_lock
+// across commit + refresh + fit (they share the main stream).
+int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t idx) {
   int rc = chain_ok(c, chain, k);
   if (rc != BSR_OK) return rc;
-  if (c->last_waited < 0 || !c->slot[c->last_waited].scored)
+  if (si < 0 || si >= BSR_MAX_INFLIGHT || !c->slot[si].scored)
     return fail(c, BSR_E_STATE, "bsr_commit: no scored batch to commit from");
-  BatchSlot& s = c->slot[c->last_waited];
+  BatchSlot& s = c->slot[si];
   if (idx < 0 || idx >= s.P) return fail(c, BSR_E_STATE, "bsr_commit: index is not part of the last scored batch");
   HIPCHK(c, hipSetDevice(c->device));
   // Candidate columns are not kept by the scoring pass: re-run the still-staged tape straight into the chain cache.
@@ -823,9 +835,10 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
   return BSR_OK;
 }
 
-extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
-                                const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket) {
-  if (!c || !chain || !which_k || !sigma || !ticket) return BSR_E_ARG;
+// Stages and enqueues one batch on slot `si` (bsr_score_submit picks the slots round-robin; the native sampler's
+// worker threads each own one).
+int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                        const int32_t* which_k, const double* sigma, int32_t B) {
   if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
   HIPCHK(c, hipSetDevice(c->device));
   const int K = c->K;
@@ -834,7 +847,6 @@ extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t*
     if (rc != BSR_OK) return rc;
     if (!c->ready[chain[i]]) return fail(c, BSR_E_STATE, "bsr_score_submit: chain not refreshed");
   }
-  const int si = c->next_slot;
   BatchSlot& s = c->slot[si];
   if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
   std::vector<TapeLoc> loc;
@@ -856,22 +868,37 @@ extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t*
     D->sigma = sigma[i];
   }
   s.scored = true;
-  rc = enqueue(c, s, B, true);
+  return enqueue(c, s, B, true);
+}
+
+extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                                const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket) {
+  if (!c || !chain || !which_k || !sigma || !ticket) return BSR_E_ARG;
+  const int si = c->next_slot;
+  int rc = bsr_internal_submit(c, si, rows, tape_off, chain, which_k, sigma, B);
   if (rc != BSR_OK) return rc;
   *ticket = si;
   c->next_slot = (si + 1) % BSR_MAX_INFLIGHT;
   return BSR_OK;
 }
 
-extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
-  if (!c || !out || ticket < 0 || ticket >= BSR_MAX_INFLIGHT) return BSR_E_ARG;
+// Waits for slot `ticket` only and copies its scores out; touches no other slot and no context-wide state (K > 1).
+int bsr_internal_wait(bsr_ctx* c, int ticket, bsr_score* out) {
   HIPCHK(c, hipSetDevice(c->device));
   BatchSlot& s = c->slot[ticket];
   if (!s.scored) return fail(c, BSR_E_STATE, "bsr_score_wait: nothing submitted under this ticket");
   int rc = wait_slot(c, s);
   if (rc != BSR_OK) return rc;
+  memcpy(out, s.h_out, sizeof(bsr_score) * s.P);
+  return BSR_OK;
+}
+
+extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
+  if (!c || !out || ticket < 0 || ticket >= BSR_MAX_INFLIGHT) return BSR_E_ARG;
+  int rc = bsr_internal_wait(c, ticket, out);
+  if (rc != BSR_OK) return rc;
+  BatchSlot& s = c->slot[ticket];
   const int B = s.P;
-  memcpy(out, s.h_out, sizeof(bsr_score) * B);
   c->last_waited = ticket;
   if (c->K == 1) {
     // no sibling column fixes the accumulation scale: rescore candidates whose |z|^2 left the double range

@@ -18,10 +18,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bsr_hip.h"
+#include "bsr_internal.h"
 
 namespace {
 
@@ -902,6 +906,7 @@ struct bsr_engine {
   bsr_trace* trace = nullptr;
   int64_t trace_cap = 0, n_trace = 0;
   double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;  // seconds, reported when BSR_ENGINE_PROF is set
+  std::mutex mu;        // guards err (worker threads)
 };
 
 namespace {
@@ -911,6 +916,7 @@ double now_s() {
 }
 
 int efail(bsr_engine* e, int code, const std::string& msg) {
+  std::lock_guard<std::mutex> lk(e->mu);
   e->err = msg;
   return code;
 }
@@ -1013,7 +1019,9 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
   return logR + flog(invgamma_pdf(c.new_sigma, 4)) - flog(invgamma_pdf(sigma, 4));
 }
 
-int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0) {
+// batch_slot < 0: the batch was scored through the public ticket API (one thread); otherwise by a worker thread that
+// owns that batch slot, and the accept path takes the context lock (commit, refresh and fit share the main stream)
+int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot) {
   const int K = e->K;
   int used = 0;
   bool broke = false;
@@ -1084,11 +1092,19 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0) {
     c.sigma = cd.new_sigma;
     c.siga[k] = cd.new_sa2;
     c.sigb[k] = cd.new_sb2;
-    ECHK(e, bsr_commit(e->ctx, c.index, k, slot0 + (int)i));
-    int rc = refresh_chain(e, c);
-    if (rc != BSR_OK) return rc;
     double rmse;
-    ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
+    {
+      struct CtxLock {
+        bsr_ctx* c;
+        explicit CtxLock(bsr_ctx* c_) : c(c_) { if (c) bsr_internal_lock(c); }
+        ~CtxLock() { if (c) bsr_internal_unlock(c); }
+      } lk(batch_slot >= 0 ? e->ctx : nullptr);
+      if (batch_slot >= 0) ECHK(e, bsr_internal_commit(e->ctx, batch_slot, c.index, k, slot0 + (int)i));
+      else ECHK(e, bsr_commit(e->ctx, c.index, k, slot0 + (int)i));
+      int rc = refresh_chain(e, c);
+      if (rc != BSR_OK) return rc;
+      ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
+    }
     c.errs.push_back(rmse);
     c.total = 0;
     c.rng = cd.before_u;
@@ -1203,7 +1219,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::vector<bsr_score> res;
     std::vector<std::pair<int, int>> span;
     int32_t ticket = -1;
+    int slot = -1;  // >= 0: this group's worker thread owns that batch slot
     bool inflight = false;
+    double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
   };
   auto is_live = [&](const ChainS& c) { return c.inited && !c.done && (max_props < 0 || c.n_props < max_props); };
   std::vector<ChainS*> live;
@@ -1216,8 +1234,15 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   }
   // tracing wants proposals in chain order: keep one group then
   const int n_groups = trace ? 1 : std::max(1, std::min<int>(BSR_MAX_INFLIGHT, (int)live.size()));
+  // One worker thread per group (each with its own batch slot and HIP stream): proposal generation, staging and the
+  // 6-8 HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single
+  // host thread leaves the GPU two thirds idle.  K == 1 keeps the single-threaded ticket path (its rescoring step
+  // drains every slot).
+  static const int want_threads = getenv("BSR_ENGINE_THREADS") ? atoi(getenv("BSR_ENGINE_THREADS")) : 1;
+  const bool threaded = n_groups > 1 && e->K > 1 && want_threads != 0;
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
+  for (int gi = 0; gi < n_groups; ++gi) groups[gi].slot = threaded ? gi : -1;
   const int per_group_cap = std::max(1, max_batch / n_groups);
 
   auto submit = [&](Group& g) -> int {
@@ -1242,7 +1267,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props);
       const double tg0 = now_s();
       generate(e, *c, room);
-      e->t_gen += now_s() - tg0;
+      g.t_gen += now_s() - tg0;
       g.span.push_back({(int)g.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
         g.rows.insert(g.rows.end(), cd.tape.begin(), cd.tape.end());
@@ -1256,13 +1281,15 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     if (g.chs.empty()) return BSR_OK;
     g.res.resize(g.chs.size());
     const double ts0 = now_s();
-    int r = bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
-                             (int)g.chs.size(), &g.ticket);
-    e->t_submit += now_s() - ts0;
-    if (r != BSR_OK) {
-      e->err = std::string("bsr_score_submit: ") + bsr_last_error(e->ctx);
-      return r;
-    }
+    int r;
+    if (g.slot >= 0)
+      r = bsr_internal_submit(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
+                              (int)g.chs.size());
+    else
+      r = bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
+                           (int)g.chs.size(), &g.ticket);
+    g.t_submit += now_s() - ts0;
+    if (r != BSR_OK) return efail(e, r, std::string("bsr_score_submit: ") + bsr_last_error(e->ctx));
     g.inflight = true;
     return BSR_OK;
   };
@@ -1270,50 +1297,80 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     if (!g.inflight) return BSR_OK;
     g.inflight = false;
     const double tw0 = now_s();
-    int r = bsr_score_wait(e->ctx, g.ticket, g.res.data());
+    int r = (g.slot >= 0) ? bsr_internal_wait(e->ctx, g.slot, g.res.data())
+                          : bsr_score_wait(e->ctx, g.ticket, g.res.data());
     const double tw1 = now_s();
-    e->t_wait += tw1 - tw0;
-    if (r != BSR_OK) {
-      e->err = std::string("bsr_score_wait: ") + bsr_last_error(e->ctx);
-      return r;
-    }
+    g.t_wait += tw1 - tw0;
+    if (r != BSR_OK) return efail(e, r, std::string("bsr_score_wait: ") + bsr_last_error(e->ctx));
     for (size_t i = 0; i < g.chains.size(); ++i) {
       if (g.span[i].second == 0) continue;
-      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first);
+      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first, g.slot);
       if (r != BSR_OK) return r;
     }
-    e->t_consume += now_s() - tw1;
+    g.t_consume += now_s() - tw1;
     return BSR_OK;
   };
 
-  for (Group& g : groups) {
-    rc = submit(g);
-    if (rc != BSR_OK) break;
-  }
-  while (rc == BSR_OK) {
-    bool any = false;
+  if (threaded) {
+    std::atomic<int> first_rc{BSR_OK};
+    auto worker = [&](Group& g) {
+      int r = BSR_OK;
+      while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK) {
+        r = submit(g);
+        if (r != BSR_OK || !g.inflight) break;
+        r = collect(g);
+      }
+      if (r == BSR_OK && g.inflight) r = collect(g);
+      if (g.inflight) {  // left in flight by an error elsewhere: drain so the context stays usable
+        g.inflight = false;
+        (void)bsr_internal_wait(e->ctx, g.slot, g.res.data());
+      }
+      if (r != BSR_OK) {
+        int expect = BSR_OK;
+        first_rc.compare_exchange_strong(expect, r);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int gi = 1; gi < n_groups; ++gi) th.emplace_back(worker, std::ref(groups[gi]));
+    worker(groups[0]);
+    for (auto& t : th) t.join();
+    rc = first_rc.load();
+  } else {
     for (Group& g : groups) {
-      if (!g.inflight) continue;
-      any = true;
-      rc = collect(g);
-      if (rc != BSR_OK) break;
       rc = submit(g);
       if (rc != BSR_OK) break;
     }
-    if (!any) break;
-  }
-  if (rc != BSR_OK) {  // drain what is still in flight so the context stays usable
-    for (Group& g : groups)
-      if (g.inflight) {
-        g.inflight = false;
-        (void)bsr_score_wait(e->ctx, g.ticket, g.res.data());
+    while (rc == BSR_OK) {
+      bool any = false;
+      for (Group& g : groups) {
+        if (!g.inflight) continue;
+        any = true;
+        rc = collect(g);
+        if (rc != BSR_OK) break;
+        rc = submit(g);
+        if (rc != BSR_OK) break;
       }
+      if (!any) break;
+    }
+    if (rc != BSR_OK) {  // drain what is still in flight so the context stays usable
+      for (Group& g : groups)
+        if (g.inflight) {
+          g.inflight = false;
+          (void)bsr_score_wait(e->ctx, g.ticket, g.res.data());
+        }
+    }
+  }
+  for (const Group& g : groups) {
+    e->t_gen += g.t_gen;
+    e->t_submit += g.t_submit;
+    e->t_wait += g.t_wait;
+    e->t_consume += g.t_consume;
   }
   if (n_trace) *n_trace = e->n_trace;
   e->trace = nullptr;
   if (getenv("BSR_ENGINE_PROF"))
-    fprintf(stderr, "bsr_engine_run: generate %.3f s, submit %.3f s, wait %.3f s, consume %.3f s\n", e->t_gen,
-            e->t_submit, e->t_wait, e->t_consume);
+    fprintf(stderr, "bsr_engine_run (%s): generate %.3f s, submit %.3f s, wait %.3f s, consume %.3f s (thread-seconds)\n",
+            threaded ? "worker threads" : "one thread", e->t_gen, e->t_submit, e->t_wait, e->t_consume);
   return rc;
 }
 

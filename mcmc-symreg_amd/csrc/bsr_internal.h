@@ -106,6 +106,15 @@ struct LaunchGeom {
   int dyn_wgs;      // workgroups of the work-queue (projection) launch
 };
 
+// slot-explicit entry points behind bsr_score_submit / bsr_score_wait / bsr_commit (bsr_api.hip), used by the native
+// sampler's worker threads: each thread owns one batch slot, and holds the context lock across commit + refresh + fit
+__attribute__((visibility("hidden"))) int bsr_internal_submit(bsr_ctx* c, int slot, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                        const int32_t* which_k, const double* sigma, int32_t B);
+__attribute__((visibility("hidden"))) int bsr_internal_wait(bsr_ctx* c, int slot, bsr_score* out);
+__attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int slot, int32_t chain, int32_t k, int32_t idx);
+__attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
+__attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
+
 // kernels (bsr_kernels.hip)
 template <typename T>
 struct RowPassArgs {
