@@ -201,8 +201,10 @@ def main():
         }
         # HBM traffic per launch of that kernel from the committed rocprofv3 PMC run of this same command
         # (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 on gfx950)
-        tpath = os.path.join(ROOT, "profiles", "r01d_traffic_%s_B%d.json" % (args.workload, B))
-        if C == 1 and args.dtype == "f64" and os.path.exists(tpath):
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s_B%d.json" % (args.workload, B))))
+        tpath = tpaths[-1] if tpaths else ""          # the latest committed run of this workload
+        if C == 1 and args.dtype == "f64" and tpath:
             for kname, rec in json.load(open(tpath)).items():
                 if "k_rows" in kname:
                     out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
