@@ -1238,7 +1238,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // 6-8 HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single
   // host thread leaves the GPU two thirds idle.  K == 1 keeps the single-threaded ticket path (its rescoring step
   // drains every slot).
-  static const int want_threads = getenv("BSR_ENGINE_THREADS") ? atoi(getenv("BSR_ENGINE_THREADS")) : 1;
+  const int want_threads = getenv("BSR_ENGINE_THREADS") ? atoi(getenv("BSR_ENGINE_THREADS")) : 1;
   const bool threaded = n_groups > 1 && e->K > 1 && want_threads != 0;
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);

@@ -190,3 +190,32 @@ def test_parallel_chains_equal_single_chain_runs(engine):
         else:                       # the C++ sampler's invgamma quantile differs from scipy's in the last ulps
             assert np.allclose(one.betas_[0], par.betas_[c], rtol=1e-5, atol=1e-9), c
             assert np.allclose(one.train_err_[0], par.train_err_[c], rtol=1e-7), c
+
+
+def test_native_engine_worker_threads_do_not_change_results(monkeypatch):
+    """The native sampler with one worker thread per chain group gives bit-identical chains to the one-thread run."""
+    from bsr.device import DeviceContext
+    from bsr.native import NativeEngine
+    from bsr.node import Express
+    rs = np.random.RandomState(21)
+    N, d, K, C = 20000, 5, 3, 8
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    runs = []
+    for threads in ("1", "0"):
+        monkeypatch.setenv("BSR_ENGINE_THREADS", threads)
+        ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=32 * C)
+        eng = NativeEngine(ctx, C, d, val=10 ** 9)
+        eng.set_nan_policy(True)
+        for c in range(C):
+            eng.seed(c, 500 + c)
+            eng.init_chain(c)
+        eng.run(batch_per_chain=32, max_props=1500)
+        res = [eng.result(c, current=True) for c in range(C)]
+        runs.append([([Express(t) for t in r["roots"]], r["beta"].tobytes(), np.asarray(r["errs"]).tobytes(),
+                      r["n_props"], r["n_accept"], r["n_rank_rejects"], eng.get_numpy_state(c)[1].tobytes())
+                     for c, r in enumerate(res)])
+        eng.close()
+        ctx.close()
+    assert runs[0] == runs[1]
+    assert sum(r[4] for r in runs[0]) > 0          # some proposals were accepted on the way

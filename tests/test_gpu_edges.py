@@ -1,0 +1,194 @@
+"""Edge cases of the HIP path through the C ABI: ragged and tiny row counts, deep trees (stack spill), the largest
+tapes, error returns, and independence of a proposal's result from the batch it is scored in.  Needs an MI355X."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import node_from_spec, spec_from_node
+
+pytestmark = pytest.mark.gpu
+
+import bsr_oracle as O
+
+
+def _ctx(*a, **k):
+    from bsr.device import DeviceContext
+    return DeviceContext(*a, **k)
+
+
+def _leaf(f):
+    from bsr.node import Node
+    n = Node(1)
+    n.type = 0
+    n.feature = np.array([f])
+    return n
+
+
+def _un(op, c, a=None, b=None):
+    from bsr.node import Node
+    n = Node(0)
+    n.type, n.operator, n.left, n.a, n.b = 1, op, c, a, b
+    c.parent = n
+    return n
+
+
+def _bi(op, l, r):
+    from bsr.node import Node
+    n = Node(0)
+    n.type, n.operator, n.left, n.right = 2, op, l, r
+    l.parent = r.parent = n
+    return n
+
+
+def _oracle_col(tree, X):
+    with np.errstate(all="ignore"):
+        return O.allcal(O.tree_from_json(spec_from_node(tree)), pd.DataFrame(X))[:, 0]
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 63, 64, 65, 127, 129, 255, 256, 257, 1023, 1025, 2049, 4097])
+def test_ragged_and_tiny_row_counts(N):
+    """Row counts around every tiling boundary (lane pair, wave sweep, row block, column padding): columns, max|z| and
+    the scored quantities must not see the padding rows."""
+    from bsr.tape import flatten
+    rs = np.random.RandomState(N)
+    d, K = 3, 2
+    X = rs.uniform(-2, 2, size=(N, d))
+    y = X[:, 0] * X[:, 1] + 0.3 * X[:, 2] + 0.05 * rs.standard_normal(N)
+    ctx = _ctx(X, y, K=K, n_chains=1, max_batch=8)
+    cur = [_bi("*", _leaf(0), _leaf(1)), _un("ln", _leaf(2), 0.7, -0.2)]
+    for k in range(K):
+        ctx.set_current(0, k, flatten(cur[k]))
+    ctx.refresh(0)
+    cands = [_bi("+", _leaf(0), _leaf(2)), _un("square", _leaf(1)), _un("inv", _un("ln", _leaf(0), 1.0, 3.5)),
+             _bi("*", _un("neg", _leaf(2)), _bi("+", _leaf(0), _leaf(1))), _leaf(1)]
+    tapes = [flatten(t) for t in cands]
+    cols, maxabs, flags = ctx.eval_tapes(tapes)
+    for i, t in enumerate(cands):
+        want = _oracle_col(t, X)
+        assert np.array_equal(cols[i], want), (N, i)            # exact opcodes only: bit for bit
+        assert maxabs[i] == np.max(np.abs(want)) and flags[i] == 0
+    ks = np.array([0, 1, 0, 1, 0], dtype=np.int32)
+    sig = np.full(len(cands), 0.8)
+    res = ctx.score_batch(tapes, np.zeros(len(cands), np.int32), ks, sig)
+    cur_cols = np.stack([_oracle_col(t, X) for t in cur], axis=1)
+    for i, t in enumerate(cands):
+        want = O.score_proposal(cur_cols, int(ks[i]), _oracle_col(t, X), y, sig[i])
+        assert (res["rank"][i] == K) == (want["rank"] == K), (N, i, res[i], want)
+        if want["rank"] == K:
+            assert abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]), (N, i, res[i], want)
+    ctx.close()
+
+
+def _perfect(depth, op, next_feature, d):
+    if depth == 0:
+        return _leaf(next(next_feature) % d)
+    return _bi(op, _perfect(depth - 1, op, next_feature, d), _perfect(depth - 1, op, next_feature, d))
+
+
+@pytest.mark.parametrize("depth", [4, 5, 6, 8, 12])
+def test_deep_trees_spill_the_register_stack(depth):
+    """A perfect binary tree of depth D needs D+1 live values: beyond 4 the interpreter spills to its per-wave global
+    area.  Depth 12 is BASELINE config 5's bound (8 191 nodes).  Sums of terminals are exact in any operand order."""
+    import itertools
+    from bsr.tape import flatten
+    N, d = 700, 5
+    rs = np.random.RandomState(depth)
+    X = rs.randint(-8, 9, size=(N, d)).astype(np.float64)      # small integers: every partial sum is exact
+    y = rs.standard_normal(N)
+    ctx = _ctx(X, y, K=2, n_chains=1, max_batch=4)
+    tree = _perfect(depth, "+", itertools.count(), d)
+    tape = flatten(tree)
+    assert len(tape) == 2 ** (depth + 1) - 1
+    mixed = _bi("*", _perfect(min(depth, 6), "+", itertools.count(3), d), _un("ln", _perfect(3, "+", itertools.count(1), d), 0.5, 1.0))
+    cols, maxabs, flags = ctx.eval_tapes([tape, flatten(mixed)])
+    assert np.array_equal(cols[0], _oracle_col(tree, X))
+    assert np.array_equal(cols[1], _oracle_col(mixed, X))
+    # the same deep tree as a scored candidate (projection pass + solve) against the oracle
+    cur = [_leaf(0), _un("square", _leaf(1))]
+    for k in range(2):
+        ctx.set_current(0, k, flatten(cur[k]))
+    ctx.refresh(0)
+    res = ctx.score_batch([tape], np.zeros(1, np.int32), np.array([1], np.int32), np.array([1.3]))
+    cur_cols = np.stack([_oracle_col(t, X) for t in cur], axis=1)
+    want = O.score_proposal(cur_cols, 1, _oracle_col(tree, X), y, 1.3)
+    assert int(res["rank"][0]) == want["rank"] == 2
+    assert abs(res["loglik"][0] - want["loglik"]) <= 1e-9 * abs(want["loglik"])
+    ctx.close()
+
+
+def test_error_returns_do_not_poison_the_context():
+    """Malformed input is refused with the documented codes and the context keeps working afterwards."""
+    from bsr import _lib
+    from bsr.tape import NODE_DTYPE, flatten
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-1, 1, size=(300, 2))
+    y = rs.standard_normal(300)
+    with pytest.raises((_lib.BsrError, ValueError)):
+        _ctx(np.zeros((0, 2)), np.zeros(0), K=2, n_chains=1, max_batch=4)      # no rows
+    ctx = _ctx(X, y, K=2, n_chains=1, max_batch=4)
+    good = flatten(_bi("+", _leaf(0), _leaf(1)))
+    bad_feature = good.copy()
+    bad_feature["feature"][0] = 7
+    with pytest.raises(_lib.BsrError) as e:
+        ctx.eval_tapes([bad_feature])
+    assert _lib.ERRORS[e.value.code] == "BSR_E_TAPE" and "feature" in str(e.value)
+    dangling = good[:2].copy()                                                   # two values left on the stack
+    with pytest.raises(_lib.BsrError):
+        ctx.eval_tapes([dangling])
+    unknown = good.copy()
+    unknown["opcode"][2] = 11                                                    # stream-only code, not a node opcode
+    with pytest.raises(_lib.BsrError):
+        ctx.eval_tapes([unknown])
+    too_long = np.zeros(16385 * 2 + 1, dtype=NODE_DTYPE)                         # > BSR_MAX_TAPE nodes
+    with pytest.raises(_lib.BsrError):
+        ctx.eval_tapes([too_long])
+    with pytest.raises(_lib.BsrError):
+        ctx.eval_tapes([good] * 5)                                               # more than max_batch
+    with pytest.raises(_lib.BsrError):
+        ctx.score_batch([good], np.zeros(1, np.int32), np.zeros(1, np.int32), np.ones(1))   # chain never set/refreshed
+    cols, _, _ = ctx.eval_tapes([good])
+    assert np.array_equal(cols[0], X[:, 0] + X[:, 1])
+    ctx.close()
+
+
+def test_a_proposal_scores_the_same_in_any_batch():
+    """Bit-identical results whether a candidate is scored alone, in a small batch or in a full one, in any position,
+    sync or pipelined: the native sampler's worker threads and the bench's batching rely on it."""
+    from bsr.tape import flatten, pack
+    N, d, K, B = 5000, 6, 3, 64
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    ctx = _ctx(X, y, K=K, n_chains=1, max_batch=B)
+    np.random.seed(5)
+    trees = []
+    while len(trees) < K + B:
+        root = O.ONode(0)
+        O.grow(root, d, list(O.OPS), list(O.OP_WEIGHTS), list(O.OP_ARITY), -1, 1.0, 1.0)
+        if O.count_nodes(root) < 60:
+            trees.append(node_from_spec(spec_from_node(root)))
+    for k in range(K):
+        ctx.set_current(0, k, flatten(trees[k]))
+    ctx.refresh(0)
+    tapes = [flatten(t) for t in trees[K:]]
+    ks = (np.arange(B) % K).astype(np.int32)
+    sig = rs.uniform(0.5, 2.0, size=B)
+    zeros = np.zeros(B, np.int32)
+    full = ctx.score_batch(tapes, zeros, ks, sig).copy()
+    for i in (0, 7, 31, 63):
+        one = ctx.score_batch([tapes[i]], zeros[:1], ks[i:i + 1], sig[i:i + 1])
+        assert one[0].tobytes() == full[i].tobytes(), i
+    perm = rs.permutation(B)
+    shuffled = ctx.score_batch([tapes[j] for j in perm], zeros, ks[perm], sig[perm])
+    assert shuffled.tobytes() == full[perm].tobytes()
+    # pipelined: four half batches in flight
+    halves = [perm[:16], perm[16:32], perm[32:48], perm[48:]]
+    tickets = []
+    for h in halves:
+        rows, off = pack([tapes[j] for j in h])
+        tickets.append((ctx.score_submit(rows, off, zeros[:len(h)], ks[h], sig[h]), h, (rows, off)))
+    for t, h, _keep in tickets:
+        out = np.zeros(len(h), dtype=full.dtype)
+        ctx.score_wait(t, out)
+        assert out.tobytes() == full[h].tobytes()
+    ctx.close()
