@@ -19,7 +19,9 @@
 #ifndef BSR_ROWS_MIN_WAVES
 #define BSR_ROWS_MIN_WAVES 4         // occupancy floor requested from the compiler for the row pass
 #endif
+#ifndef BSR_REG_STACK
 #define BSR_REG_STACK 3             // interpreter stack slots held in VGPRs (plus the accumulator)
+#endif
 #define BSR_ROW_ALIGN 4096          // device columns are padded to a multiple of this many rows
 #define BSR_P1_WORDS 12             // doubles per (proposal,row block) partial of pass 1
 #define BSR_P2_WORDS 2              // doubles per (proposal,row block) partial of pass 2
