@@ -68,6 +68,81 @@ class BSR(BaseEstimator, RegressorMixin):
         XX = np.concatenate((np.ones((X.shape[0], 1)), cols.T), axis=1)
         return np.matmul(XX, self.betas_[-last_ind])
 
+    # ---- beyond the reference: every chain's prediction in one pass, and a stable model file
+    def predict_all(self, test_data):
+        """Predictions of every fitted chain: array (n_chains, n_rows).  Row -i equals predict(test_data, last_ind=i)[:, 0].
+        All chains' trees are evaluated in batches on one device context (the reference evaluates one chain per call)."""
+        from .device import DeviceContext
+        from .tape import flatten
+        X = np.ascontiguousarray(np.asarray(test_data, dtype=np.float64))
+        K = self.treeNum
+        tapes = [flatten(self.roots_[c][k]) for c in range(len(self.roots_)) for k in range(K)]
+        out = np.empty((len(self.roots_), X.shape[0]), dtype=np.float64)
+        per = max(K, (256 // K) * K)                       # whole chains per launch
+        ctx = DeviceContext(X, None, max_batch=per, device=self.device, dtype=self.dtype)
+        try:
+            for lo in range(0, len(tapes), per):
+                cols, _, _ = ctx.eval_tapes(tapes[lo:lo + per])
+                for j in range(0, cols.shape[0], K):
+                    c = (lo + j) // K
+                    XX = np.concatenate((np.ones((X.shape[0], 1)), cols[j:j + K].T), axis=1)
+                    out[c] = np.matmul(XX, self.betas_[c])[:, 0]
+        finally:
+            ctx.close()
+        return out
+
+    def save(self, path):
+        """Writes the fitted chains (trees as postfix tapes, Beta, RMSE history) and the constructor arguments as JSON.
+        The reference offers only pickling of Node graphs; this file does not depend on Python object layout."""
+        import json
+        from .tape import flatten
+
+        def enc(v):
+            v = float(v)
+            return v if np.isfinite(v) else ("nan" if np.isnan(v) else ("inf" if v > 0 else "-inf"))
+        chains = []
+        for c in range(len(self.roots_)):
+            trees = []
+            for root in self.roots_[c]:
+                t = flatten(root)
+                trees.append([[int(r["opcode"]), int(r["left"]), int(r["right"]), int(r["feature"]), enc(r["a"]), enc(r["b"])]
+                              for r in t])
+            chains.append({"trees": trees, "beta": [enc(b) for b in np.asarray(self.betas_[c]).reshape(-1)],
+                           "train_err": [enc(e) for e in self.train_err_[c]]})
+        doc = {"format": "bsr-hip-model", "version": 1,
+               "operators": ["inv", "ln", "neg", "sin", "cos", "exp", "square", "cubic", "+", "*"],
+               "node_fields": ["opcode (index into operators, 10 = terminal)", "left", "right", "feature", "a", "b"],
+               "params": {k: getattr(self, k) for k in ("treeNum", "itrNum", "alpha1", "alpha2", "beta", "val")},
+               "chains": chains}
+        with open(path, "w") as f:
+            json.dump(doc, f)
+
+    @classmethod
+    def load(cls, path, **kwargs):
+        """Rebuilds an estimator written by save(): model(), complexity(), predict(), predict_all() work at once."""
+        import json
+        from .tape import NODE_DTYPE, unflatten
+
+        def dec(v):
+            return float(v)                                # "nan" / "inf" / "-inf" parse as floats
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("format") != "bsr-hip-model" or doc.get("version") != 1:
+            raise ValueError("not a bsr-hip-model v1 file: %r" % path)
+        est = cls(**dict(doc["params"], **kwargs))
+        est.roots_, est.betas_, est.train_err_ = [], [], []
+        for ch in doc["chains"]:
+            roots = []
+            for rows in ch["trees"]:
+                t = np.zeros(len(rows), dtype=NODE_DTYPE)
+                for i, r in enumerate(rows):
+                    t[i] = (r[0], r[1], r[2], r[3], dec(r[4]), dec(r[5]))
+                roots.append(unflatten(t))
+            est.roots_.append(roots)
+            est.betas_.append(np.array([dec(b) for b in ch["beta"]], dtype=np.float64).reshape(-1, 1))
+            est.train_err_.append([dec(e) for e in ch["train_err"]])
+        return est
+
     # ---- codes/bsr_class.py:77-278
     def fit(self, train_data, train_y):
         self.roots_, self.betas_, self.train_err_ = [], [], []

@@ -219,3 +219,29 @@ def test_native_engine_worker_threads_do_not_change_results(monkeypatch):
         ctx.close()
     assert runs[0] == runs[1]
     assert sum(r[4] for r in runs[0]) > 0          # some proposals were accepted on the way
+
+
+def test_predict_all_and_model_file_on_device(tmp_path):
+    """predict_all() row -i == predict(last_ind=i); a saved and reloaded model predicts bit-identically."""
+    from bsr import BSR
+    rs = np.random.RandomState(8)
+    X = rs.uniform(-3, 3, size=(300, 3))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(300)
+    est = BSR(treeNum=3, itrNum=5, val=40, chain_seeds=[11, 12, 13, 14, 15], chains_per_launch=5, batch=16)
+    est.fit(X, y)
+    Xt = rs.uniform(-3, 3, size=(77, 3))
+    allp = est.predict_all(Xt)
+    assert allp.shape == (5, 77)
+    for i in range(1, 6):
+        assert np.array_equal(allp[-i], est.predict(Xt, last_ind=i)[:, 0]), i
+    path = str(tmp_path / "m.json")
+    est.save(path)
+    back = BSR.load(path)
+    assert back.model() == est.model()
+    assert np.array_equal(back.predict_all(Xt), allp)
+    with np.errstate(all="ignore"):
+        import pandas as pd
+        cols = np.stack([O.allcal(O.tree_from_json(__import__("conftest").spec_from_node(t)), pd.DataFrame(Xt))[:, 0]
+                         for t in est.roots_[-1]], axis=1)
+    want = np.concatenate((np.ones((77, 1)), cols), axis=1) @ est.betas_[-1]
+    assert np.allclose(allp[-1], want[:, 0], rtol=1e-9, atol=1e-9)

@@ -351,3 +351,30 @@ def tree_hash_from_spec(spec):
                 work.append(s["right"])
             work.append(s["left"])
     return h, n
+
+
+def test_model_file_roundtrip(tmp_path):
+    """BSR.save / BSR.load: trees (structure, operand order, ln parameters incl. non-finite), Beta and RMSE history."""
+    from bsr import BSR
+    from bsr.node import Express, getNum
+    g = load_golden("g2_grow.json")
+    trees = [node_from_spec(c["tree"]) for c in g["cases"][:12]]
+    est = BSR(treeNum=3, itrNum=4, val=77)
+    est.roots_ = [trees[0:3], trees[3:6], trees[6:9], trees[9:12]]
+    est.betas_ = [np.arange(4, dtype=np.float64).reshape(-1, 1) * (c + 0.5) for c in range(4)]
+    est.betas_[2][1, 0] = np.nan
+    est.train_err_ = [[1.0, 0.5], [], [float("inf")], [0.25]]
+    path = str(tmp_path / "model.json")
+    est.save(path)
+    back = BSR.load(path)
+    assert (back.treeNum, back.itrNum, back.val) == (3, 4, 77)
+    for c in range(4):
+        assert [Express(t) for t in back.roots_[c]] == [Express(t) for t in est.roots_[c]]
+        assert [getNum(t) for t in back.roots_[c]] == [getNum(t) for t in est.roots_[c]]
+        assert np.array_equal(back.betas_[c], est.betas_[c], equal_nan=True) and back.betas_[c].shape == (4, 1)
+        assert back.train_err_[c] == est.train_err_[c]
+    assert back.model() == est.model() and back.complexity() == est.complexity()
+    assert back.model(last_ind=3) == est.model(last_ind=3)
+    with pytest.raises(ValueError):
+        (tmp_path / "other.json").write_text('{"format": "something else"}')
+        BSR.load(str(tmp_path / "other.json"))
