@@ -304,6 +304,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
 #undef CK
   rc = (dtype == BSR_DTYPE_F64) ? upload_data<double>(c, X, y) : upload_data<float>(c, X, y);
   if (rc != BSR_OK) return bail(rc);
+  // every buffer initialised above (null-stream and main-stream memsets) is complete before any slot stream runs
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(c, BSR_E_HIP, "hipDeviceSynchronize after setup"));
   *out = c;
   return BSR_OK;
 }

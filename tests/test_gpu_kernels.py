@@ -98,7 +98,8 @@ def _rand_trees(rs_seed, n, d, min_nodes=1):
 
 
 @pytest.mark.parametrize("N,d,K,B,seed", [(3000, 6, 3, 48, 1), (1000, 4, 8, 40, 2), (777, 3, 1, 24, 3),
-                                          (5000, 10, 2, 64, 4), (130, 2, 3, 64, 5)])
+                                          (5000, 10, 2, 64, 4), (130, 2, 3, 64, 5), (800, 4, 4, 32, 6),
+                                          (800, 5, 5, 32, 7), (600, 4, 6, 32, 8), (600, 5, 7, 32, 9)])
 def test_score_batch_vs_oracle(N, d, K, B, seed):
     """Random current trees + random candidate trees: rank gate, SSE, log-likelihood and Beta against the oracle."""
     from bsr.tape import flatten
@@ -132,7 +133,7 @@ def test_score_batch_vs_oracle(N, d, K, B, seed):
     res2 = ctx.score_batch(tapes, chains, ks, sig)  # eval_tapes reuses the candidate slots: rescore
     assert res.tobytes() == res2.tobytes()           # deterministic, bit for bit
     dev_cur = [ctx.get_current(c).T for c in range(2)]
-    n_full = 0
+    n_full = n_chaotic = 0
     for i in range(B):
         with np.errstate(all="ignore"):
             col = O.allcal(cands[i], Xdf)[:, 0]
@@ -142,8 +143,18 @@ def test_score_batch_vs_oracle(N, d, K, B, seed):
         assert (res["rank"][i] == K) == (want["rank"] == K), (tag, res[i])
         if want["rank"] == K:
             n_full += 1
-            # (1) north-star bound against the oracle end to end: 1e-6 relative on the log-likelihood
-            assert abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]), (tag, res[i], want)
+            # (1) north-star bound against the oracle end to end: 1e-6 relative on the log-likelihood.  Exception: trees
+            #     that are chaotic at the ulp level (cos(exp(x^6)): the value depends on the libm build) -- the oracle's own
+            #     value must then move under a one-ulp perturbation of X, and such candidates stay rare
+            if not abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]):
+                vals = []
+                for eps in (2.0 ** -52, -2.0 ** -52, 2.0 ** -51):
+                    with np.errstate(all="ignore"):
+                        colp = O.allcal(cands[i], pd.DataFrame(X * (1.0 + eps)))[:, 0]
+                    vals.append(O.score_proposal(cur_cols[chains[i]], ks[i], colp, y, sig[i])["loglik"])
+                spread = max(abs(v - want["loglik"]) for v in vals)
+                assert spread > 1e-7 * abs(want["loglik"]), (tag, res[i], want, vals)
+                n_chaotic += 1
             assert abs(res["scale"][i] - want["scale"]) <= 1e-12 * want["scale"], tag
             # (2) solver in isolation: oracle fed with the device's own columns (removes libm ulp differences
             #     that ill-conditioned trees such as sin(exp(1/x)) amplify)
@@ -154,7 +165,7 @@ def test_score_batch_vs_oracle(N, d, K, B, seed):
             assert abs(res["loglik"][i] - w2["loglik"]) <= tol * abs(w2["loglik"]), (tag, cond, res[i], w2)
             assert abs(res["sse"][i] - w2["sse"]) <= tol * abs(w2["sse"]) + 1e-12 * float(y @ y), (tag, cond, res[i], w2)
             assert np.all(np.abs(res["beta"][i][:K] - w2["beta"]) <= 1e-6 * np.max(np.abs(w2["beta"])) * max(1.0, cond * 1e-6)), (tag, res[i], w2)
-    assert n_full > 0
+    assert n_full > 0 and n_chaotic <= max(1, B // 20), (n_full, n_chaotic)
     # accept the first full-rank proposal: commit == set_current of the same tape
     i = int(np.argmax(res["rank"] == K))
     ctx.commit(int(chains[i]), int(ks[i]), i)

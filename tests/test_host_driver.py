@@ -186,7 +186,8 @@ def _ulp_sensitive(rec, X, y, rtol):
     return bool(spread > 0.1 * rtol * abs(vals[0])) or not np.all(np.isfinite(base))
 
 
-TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr"]
+TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr",
+          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24"]
 
 
 def replay_trace(name, make_scorer, batch, ll_rtol):

@@ -88,7 +88,8 @@ def test_g3_yloglike():
         assert sc["rank"] == c["rank"], c["name"]
 
 
-TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr"]
+TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr",
+          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24"]
 
 
 @pytest.mark.parametrize("name", TRACES)

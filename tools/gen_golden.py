@@ -394,6 +394,16 @@ def g5():
     trace_fit("synth_K2_s11_yarr", X, np.asarray(y), K=2, seed=11, max_props=300)
 
 
+def g5b():
+    """More tree counts (K = 4..7 take the other register / lane-group solver instantiations on the device)."""
+    X, y = data_synth(400, 4, seed=3)
+    trace_fit("synth_K4_s21", X, y, K=4, seed=21, max_props=220)
+    trace_fit("synth_K5_s22", X, y, K=5, seed=22, max_props=220)
+    X, y = data_synth(600, 6, seed=4)
+    trace_fit("synth_K6_s23", X, y, K=6, seed=23, max_props=200)
+    trace_fit("synth_K7_s24", X, y, K=7, seed=24, max_props=200)
+
+
 def g6():
     np.random.seed(0)
     X, y = data_f1(100)
@@ -462,6 +472,6 @@ def g7():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g5b", "g6", "g7"]
     for t in todo:
         globals()[t]()
