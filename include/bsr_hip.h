@@ -148,8 +148,9 @@ int bsr_refresh(bsr_ctx* ctx, int32_t chain, bsr_chain_info* info);
 int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                     const int32_t* which_k, const double* sigma, int32_t B, bsr_score* out);
 
-/* Asynchronous form of bsr_score_batch: submit enqueues upload + kernels + download and returns at once with a
- * ticket; wait blocks until that batch is done and copies its B results.  Up to BSR_MAX_INFLIGHT batches may be in
+/* Asynchronous form of bsr_score_batch: submit enqueues the tape upload and the kernels (which write their results
+ * into pinned host memory) and returns at once with a ticket; wait blocks until that batch is done and copies its B
+ * results.  Up to BSR_MAX_INFLIGHT batches may be in
  * flight (tickets are handed out round-robin; wait for them in submission order), each on its own HIP stream, so the
  * host stages batch i+1 and the small per-proposal kernels of batch i overlap the row pass of batch i+1.  Chains of
  * a batch must not depend on accepts of a batch still in flight.  bsr_commit refers to the batch most recently

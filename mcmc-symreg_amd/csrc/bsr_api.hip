@@ -632,7 +632,7 @@ static int wait_slot(bsr_ctx* c, BatchSlot& s) {
   return BSR_OK;
 }
 
-// The evaluate-only entry points are synchronous: they drain both slots and run in slot 0.
+// The evaluate-only entry points are synchronous: they drain every slot and run in slot 0.
 static int drain(bsr_ctx* c) {
   for (BatchSlot& s : c->slot) {
     int rc = wait_slot(c, s);
