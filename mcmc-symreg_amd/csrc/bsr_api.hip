@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -94,6 +95,7 @@ struct bsr_ctx {
   int next_slot = 0;
   int last_waited = -1;
   std::mutex mu;  // commit / refresh / fit share the main stream and one set of staging buffers (bsr_internal_lock)
+  std::mutex err_mu;  // the error text may be written by worker threads
   double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
   // tuning
   int rb_rows = 512;
@@ -109,26 +111,35 @@ struct bsr_ctx {
   std::string err;
 };
 
+struct bsr_ctx;
+static void set_err(bsr_ctx* c, const char* msg);
 #define HIPCHK(ctx, call)                                                                       \
   do {                                                                                          \
     hipError_t e_ = (call);                                                                     \
     if (e_ != hipSuccess) {                                                                     \
       char b_[512];                                                                             \
       snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      (ctx)->err = b_;                                                                          \
+      set_err((ctx), b_);                                                                       \
       return BSR_E_HIP;                                                                         \
     }                                                                                           \
   } while (0)
 
 // host-side cost of a submission, printed by bsr_ctx_destroy when BSR_HOST_PROF is set
-static double g_t_stage = 0, g_t_desc = 0, g_t_enq = 0;
-static long g_n_sub = 0;
-static inline double host_now() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+static std::atomic<long long> g_ns_stage{0}, g_ns_desc{0}, g_ns_enq{0}, g_n_sub{0};  // worker threads submit too
+static const bool g_host_prof = getenv("BSR_HOST_PROF") != nullptr;
+static inline long long host_now() {
+  return g_host_prof ? std::chrono::duration_cast<std::chrono::nanoseconds>(
+                           std::chrono::steady_clock::now().time_since_epoch()).count()
+                     : 0;
+}
+
+static void set_err(bsr_ctx* c, const char* msg) {
+  std::lock_guard<std::mutex> lk(c->err_mu);
+  c->err = msg;
 }
 
 static int fail(bsr_ctx* ctx, int code, const char* msg) {
-  if (ctx) ctx->err = msg; else g_create_error = msg;
+  if (ctx) set_err(ctx, msg); else g_create_error = msg;
   return code;
 }
 
@@ -159,9 +170,11 @@ static int env_int(const char* name, int dflt) {
 }
 
 extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
-  if (getenv("BSR_HOST_PROF") && g_n_sub > 0)
-    fprintf(stderr, "bsr host cost per submission: stage %.2f us, descriptors %.2f us, enqueue (sort + HIP calls) %.2f us over %ld\n",
-            g_t_stage / g_n_sub * 1e6, g_t_desc / g_n_sub * 1e6, g_t_enq / g_n_sub * 1e6, g_n_sub);
+  if (g_host_prof && g_n_sub.load() > 0) {
+    const double n = (double)g_n_sub.load();
+    fprintf(stderr, "bsr host cost per submission: stage %.2f us, descriptors %.2f us, enqueue (sort + HIP calls) %.2f us over %.0f\n",
+            g_ns_stage.load() / n * 1e-3, g_ns_desc.load() / n * 1e-3, g_ns_enq.load() / n * 1e-3, n);
+  }
   if (!c) return BSR_E_ARG;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -862,10 +875,10 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
   BatchSlot& s = c->slot[si];
   if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
   std::vector<TapeLoc> loc;
-  const double th0 = host_now();
+  const long long th0 = host_now();
   int rc = stage_tapes(c, s, rows, tape_off, B, &loc);
   if (rc != BSR_OK) return rc;
-  const double th1 = host_now();
+  const long long th1 = host_now();
   PropDesc* hd = s.h_desc();
   for (int i = 0; i < B; ++i) {
     PropDesc* D = &hd[i];
@@ -882,12 +895,14 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
     D->sigma = sigma[i];
   }
   s.scored = true;
-  const double th2 = host_now();
+  const long long th2 = host_now();
   rc = enqueue(c, s, B, true);
-  g_t_stage += th1 - th0;
-  g_t_desc += th2 - th1;
-  g_t_enq += host_now() - th2;
-  ++g_n_sub;
+  if (g_host_prof) {
+    g_ns_stage.fetch_add(th1 - th0, std::memory_order_relaxed);
+    g_ns_desc.fetch_add(th2 - th1, std::memory_order_relaxed);
+    g_ns_enq.fetch_add(host_now() - th2, std::memory_order_relaxed);
+    g_n_sub.fetch_add(1, std::memory_order_relaxed);
+  }
   return rc;
 }
 
