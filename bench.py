@@ -89,7 +89,7 @@ def main():
     # every step still stages, uploads and scores its batch in full -- nothing is cached between steps
     n_unique = min(n_batches, max(64, args.warmup + 44))
     packed = []
-    feats = set()
+    feat_counts = []           # |F| of each launch: distinct X columns its tapes reference
     n_nodes = n_trans = 0
     for _ in range(n_unique):
         tapes, chs, ks, sig = [], [], [], []
@@ -101,10 +101,12 @@ def main():
                 sig.append(cd.new_sigma)
             ch.rng_state = ch._end_state      # keep drawing new proposals from the same frozen state
         rows, off = pack(tapes)
+        feats = set()
         for t in tapes:
             n_nodes += len(t)
             n_trans += int(np.isin(t["opcode"], (0, 3, 4, 5)).sum())
             feats.update(int(f) for f in t["feature"][t["opcode"] == 10])
+        feat_counts.append(len(feats))
         packed.append((rows, off, np.array(chs, np.int32), np.array(ks, np.int32), np.array(sig, np.float64),
                        np.zeros(len(tapes), dtype=_lib.SCORE_DTYPE), tapes))
     P = len(packed[0][2])
@@ -196,7 +198,8 @@ def main():
         # bytes = s * N * (|F| + 1 + C_r + C_w): features referenced, y, K-1 cached sibling columns per chain,
         # C_w = 0 (candidate columns are scratch; reported separately)
         s = 8 if args.dtype == "f64" else 4
-        alg_bytes = s * N * (len(feats) + 1 + C * (K - 1))
+        n_feat = float(np.mean(feat_counts))          # per launch, averaged over the batches of the run
+        alg_bytes = int(s * N * (n_feat + 1 + C * (K - 1)))
         p1 = kern_iso * 1e-6
         out = {
             "metric": "MH proposals scored/sec (N=100k,d=10,K=3) at 1/2/4/8 MI355X; HBM GB/s",
@@ -211,7 +214,7 @@ def main():
                          "frac": alg_bytes / p1 / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_rows<PROJECT> (tree-eval + projection)", "kernel_us": kern_iso,
                          "kernel_us_in_timed_region": kern_us[0],
-                         "algorithmic_bytes": alg_bytes},
+                         "algorithmic_bytes": alg_bytes, "features_per_launch": n_feat},
             "batches_in_flight": depth,
         }
         # HBM traffic per launch of that kernel from the committed rocprofv3 PMC run of this same command
