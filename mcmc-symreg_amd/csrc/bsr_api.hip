@@ -70,6 +70,7 @@ struct bsr_ctx {
   int64_t N = 0, ld = 0;
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
   int n_cu = 256;
+  int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the row pass is sized for (f64 kernels: 92 VGPRs -> 5)
   size_t esz = 8;
   bool has_y = false;
   void* Xt = nullptr;
@@ -253,6 +254,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       (c->rb_rows % (64 * c->rows_per_lane)) != 0)
     c->rb_rows = rb_default;
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
+  c->wgs_per_cu = std::max(1, std::min(8, env_int("BSR_WGS_PER_CU", 5)));
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
   for (BatchSlot& s : c->slot) s.slot_of.assign(d, -1);
   int rc = BSR_OK;
@@ -375,7 +377,7 @@ static LaunchGeom geometry(const bsr_ctx* c, const BatchSlot& s, int P) {
   g.n_pg = (P + pg - 1) / pg;
   // work-queue launch: one resident set of workgroups (5 per CU fit at <= 102 VGPRs), never more than there are tasks
   const int64_t tasks = (int64_t)P * g.n_rb;
-  const int64_t want = std::min<int64_t>((int64_t)c->n_cu * 5, (tasks + BSR_WG_WAVES - 1) / BSR_WG_WAVES);
+  const int64_t want = std::min<int64_t>((int64_t)c->n_cu * c->wgs_per_cu, (tasks + BSR_WG_WAVES - 1) / BSR_WG_WAVES);
   g.dyn_wgs = (int)std::max<int64_t>(8, (want + 7) / 8 * 8);
   return g;
 }
