@@ -192,3 +192,33 @@ def test_a_proposal_scores_the_same_in_any_batch():
         ctx.score_wait(t, out)
         assert out.tobytes() == full[h].tobytes()
     ctx.close()
+
+
+def test_exact_opcode_trees_are_bit_identical_to_the_oracle():
+    """300 random trees over the opcodes whose device arithmetic is exactly numpy's (terminal, inv, ln, neg, square, +, *):
+    every column bit for bit.  Exercises the fused terminal+binary stream entries in all positions and stack depths."""
+    from bsr.tape import flatten
+    rs = np.random.RandomState(77)
+    N, d = 257, 4
+    X = rs.uniform(-2, 2, size=(N, d))
+    X[::17, 1] = 0.0                                           # exact zeros: inv(0) = 0
+    ctx = _ctx(X, None, K=1, n_chains=1, max_batch=64)
+
+    def rand_tree(depth):
+        r = rs.uniform()
+        if depth == 0 or r < 0.25:
+            return _leaf(rs.randint(d))
+        if r < 0.6:
+            op = ["inv", "ln", "neg", "square"][rs.randint(4)]
+            return _un(op, rand_tree(depth - 1), rs.normal(1, 0.5), rs.normal(0, 0.5)) if op == "ln" else _un(op, rand_tree(depth - 1))
+        return _bi("+*"[rs.randint(2)], rand_tree(depth - 1), rand_tree(depth - 1))
+    trees = [rand_tree(rs.randint(1, 7)) for _ in range(300)]
+    for lo in range(0, len(trees), 60):
+        chunk = trees[lo:lo + 60]
+        cols, maxabs, flags = ctx.eval_tapes([flatten(t) for t in chunk])
+        for i, t in enumerate(chunk):
+            want = _oracle_col(t, X)
+            same = (cols[i] == want) | (np.isnan(cols[i]) & np.isnan(want))
+            assert same.all(), (lo + i, int((~same).sum()))
+            assert bool(flags[i] & 1) == bool(np.isinf(want).any()) and bool(flags[i] & 2) == bool(np.isnan(want).any())
+    ctx.close()
