@@ -245,3 +245,26 @@ def test_predict_all_and_model_file_on_device(tmp_path):
                          for t in est.roots_[-1]], axis=1)
     want = np.concatenate((np.ones((77, 1)), cols), axis=1) @ est.betas_[-1]
     assert np.allclose(allp[-1], want[:, 0], rtol=1e-9, atol=1e-9)
+
+
+def test_rccl_gather_through_the_c_abi_single_rank():
+    """bsr_comm_unique_id / init / allgather with a one-rank communicator: the RCCL path of the accepted-tree gather
+    (the multi-rank exchange itself is covered with gloo in tests/test_dist_gloo.py and by the driver's N>1 bench runs)."""
+    from bsr import dist
+    from bsr.device import DeviceContext
+    from bsr.node import Express
+    rs = np.random.RandomState(2)
+    X = rs.uniform(-3, 3, size=(500, 3))
+    y = X[:, 0] * X[:, 1] + 0.1 * rs.standard_normal(500)
+    ctx = DeviceContext(X, y, K=2, n_chains=1, max_batch=4)
+    uid = DeviceContext.comm_unique_id()
+    g = dist.RcclGather(ctx, 1, 0, uid)
+    g2 = load_golden("g2_grow.json")
+    trees = [node_from_spec(c["tree"]) for c in g2["cases"][:2]]
+    rec = dist.pack_record(5, trees, np.array([[0.5], [1.5], [-2.0]]), 0.9, [1.0, 0.75], 10, 2)
+    got = dist.gather_chains(g, [rec], 2)
+    assert len(got) == 1 and got[0]["chain"] == 5
+    assert [Express(t) for t in got[0]["roots"]] == [Express(t) for t in trees]
+    assert np.array_equal(got[0]["beta"].reshape(-1), [0.5, 1.5, -2.0])
+    assert (got[0]["n_props"], got[0]["n_accept"], got[0]["n_errs"]) == (10, 2, 2)
+    ctx.close()
