@@ -125,4 +125,5 @@ def device_count():
 
 
 def ptr(a):
-    return a.ctypes.data_as(C.c_void_p)
+    """Address of a numpy array for a c_void_p argument (a plain int: half the cost of ctypes.data_as)."""
+    return a.ctypes.data

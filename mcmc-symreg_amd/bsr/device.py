@@ -94,6 +94,21 @@ class DeviceContext:
         _lib.check(rc, self._h)
         return t.value
 
+    def prepare(self, rows, off, chains, ks, sig):
+        """Pins down the five input arrays of a batch once (addresses resolved, references kept) for callers that submit
+        the same pre-packed batch many times or want the submission itself as cheap as possible."""
+        arrs = (np.ascontiguousarray(rows), np.ascontiguousarray(off, dtype=np.int32),
+                np.ascontiguousarray(chains, dtype=np.int32), np.ascontiguousarray(ks, dtype=np.int32),
+                np.ascontiguousarray(sig, dtype=np.float64))
+        return tuple(a.ctypes.data for a in arrs) + (len(arrs[2]), arrs)
+
+    def score_submit_prepared(self, prep):
+        t = C.c_int32(-1)
+        rc = self._L.bsr_score_submit(self._h, prep[0], prep[1], prep[2], prep[3], prep[4], prep[5], C.byref(t))
+        if rc:
+            _lib.check(rc, self._h)
+        return t.value
+
     def score_wait(self, ticket, out):
         _lib.check(self._L.bsr_score_wait(self._h, ticket, _lib.ptr(out)), self._h)
         return out
