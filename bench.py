@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: MH proposals scored per second (N=100k, d=10, K=3) on N MI355X + kernel roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chains C] [--workload c2|c3|c5]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chains C] [--workload c2|c3|c4|c5]
+
+With --gpus N > 1 and no launcher variables in the environment, this process starts N fresh child processes (one per
+GPU, RANK/LOCAL_RANK/WORLD_SIZE set) before anything touches the GPU, relays rank 0's JSON line and exits with the
+worst child exit code.  Under an external launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`) each process is one rank already.  Ranks meet through a rendezvous directory for the 128-byte RCCL unique
+id; barrier, max-over-ranks timing and the gather of accepted trees are RCCL all-gathers through the C ABI
+(bsr_comm_allgather).  No PyTorch anywhere.
 
 A "step" is one bsr_score_batch call: B speculative proposals per chain, drawn by the real move mix (all seven
 actions, codes/funcs.py:475-480) from a seeded chain state, are scored against the chain's current trees: tree
 evaluation over all N rows, rank gate, OLS fit, Gaussian log-likelihood (codes/funcs.py:1212-1235).  X, y and the
 chain caches are resident in HBM; the call still uploads the tapes (KBs) and downloads the B result records, because
-that is what the C ABI boundary hands over.  Independent chains shard one per rank with no data-path collective
-(weak scaling); the only exchange is the RCCL all-gather of the chains' accepted trees after the timed region.
+that is what the C ABI boundary hands over.  Independent chains shard over the ranks with no data-path collective
+(weak scaling).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -22,85 +29,135 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mcmc-symreg_amd"))
 
-import numpy as np
-
 WORKLOADS = {
-    "c2": dict(N=100_000, d=10, K=3, desc="N=100k, d=10, K=3, 1 chain per GPU (BASELINE configs[1])"),
-    "c3": dict(N=100_000, d=10, K=8, desc="N=100k, d=10, K=8, batched multi-proposal (BASELINE configs[2])"),
-    "c5": dict(N=1_000_000, d=50, K=3, desc="N=1M, d=50, K=3 (BASELINE configs[4])"),
+    "c2": dict(N=100_000, d=10, K=3, chains=1, batch=64,
+               desc="N=100k, d=10, K=3, 1 chain per GPU (BASELINE configs[1])"),
+    "c3": dict(N=100_000, d=10, K=8, chains=1, batch=64,
+               desc="N=100k, d=10, K=8, batched multi-proposal (BASELINE configs[2])"),
+    "c4": dict(N=100_000, d=10, K=3, chains=8, batch=32,
+               desc="N=100k, d=10, K=3, 8 chains per GPU (per-GPU share of BASELINE configs[3])"),
+    "c5": dict(N=1_000_000, d=50, K=3, chains=1, batch=64,
+               desc="N=1M, d=50, K=3 (BASELINE configs[4])"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+MIN_TIMED_S = 1.0       # the timed region is repeated (whole multiples of --steps) until it lasts this long
 
 
 def synth(N, d, seed=0):
     """SURVEY 8d recipe: X~U(-3,3), y = 1.35 x0 x1 + 5.5 sin((x0-1)(x1-1)) + 0.1 N(0,1)."""
+    import numpy as np
     rs = np.random.RandomState(seed)
     X = rs.uniform(-3, 3, size=(N, d))
     y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
     return X, y
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=64, help="speculative proposals per chain and step")
-    ap.add_argument("--chains", type=int, default=1, help="chains per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="speculative proposals per chain and step (0: workload default)")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (0: workload default)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--burnin", type=int, default=300, help="real MCMC proposals run before freezing the state")
     ap.add_argument("--cpu-sample", type=float, default=15.0,
                     help="seconds of CPU oracle work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--depth", type=int, default=4, help="batches in flight, 1..4 (1 = synchronous calls)")
-    args = ap.parse_args()
+    ap.add_argument("--extras", type=int, default=-1,
+                    help="1: also run short legs of the other configs (c3, c5, c4's per-GPU share, native-engine chain "
+                         "throughput) and report them under 'extra'; 0: headline only; -1: on for the default workload")
+    ap.add_argument("--min-time", type=float, default=MIN_TIMED_S)
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+def launch_children(args):
+    """--gpus N without a launcher: N fresh child processes, one per device.  Nothing here touches HIP."""
+    from bsr.launch import spawn
+    argv = [os.path.abspath(__file__)] + sys.argv[1:]
+    codes, text = spawn(args.gpus, argv)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank exit codes %r\n" % (codes,))
+        return max(abs(c) for c in bad) or 1
+    return 0
+
+
+class Ranks:
+    """This rank's view of the job: device, gather (RCCL all-gather through the C ABI) and the helpers built on it."""
+
+    def __init__(self):
+        from bsr.launch import rank_env
+        self.rank, self.world, self.local = rank_env()
+        self.gather = None
+        self.via = None
+
+    def device(self):
+        if os.environ.get("BSR_SHARE_DEVICE") == "1":
+            return 0
+        return self.local if self.world > 1 else 0
+
+    def connect(self):
+        """One small context per rank that lives as long as the process and owns the RCCL communicator."""
+        import numpy as np
+        from bsr import dist as D
+        from bsr.device import DeviceContext
+        self.comm_ctx = DeviceContext(np.zeros((1, 1)), None, K=0, n_chains=0, max_batch=1, device=self.device())
+        self.gather, _ = D.connect(self.comm_ctx, self.rank, self.world)
+        self.via = {"RcclGather": "bsr_comm_allgather (RCCL via C ABI)", "SoloGather": None,
+                    "FileGather": "rendezvous directory (BSR_SHARE_DEVICE=1 test mode: ranks share one GPU)"}[
+                        type(self.gather).__name__]
+
+    def barrier(self):
+        from bsr import dist as D
+        if self.world > 1:
+            D.barrier(self.gather)
+
+    def max(self, v):
+        from bsr import dist as D
+        return D.allreduce_max(self.gather, v) if self.world > 1 else v
+
+
+def build_workload(name, args, ranks, n_unique_min=64):
+    """Uploads the data, burns the chains in and pre-generates the step inputs of one workload."""
+    import numpy as np
     from bsr import _lib
     from bsr.chain import Chain, DeviceScorer, run_chains
     from bsr.tape import pack
-
-    W = WORKLOADS[args.workload]
+    W = WORKLOADS[name]
     N, d, K = W["N"], W["d"], W["K"]
-    B, C = args.batch, args.chains
+    B = args.batch or W["batch"]
+    C = args.chains or W["chains"]
     X, y = synth(N, d, seed=0)
-    scorer = DeviceScorer(X, y, K, n_chains=C, max_batch=B * C, device=local if world > 1 else 0, dtype=args.dtype)
+    scorer = DeviceScorer(X, y, K, n_chains=C, max_batch=B * C, device=ranks.device(), dtype=args.dtype)
     ctx = scorer.ctx
-
-    # chain states: seeded chains advanced by a short real run, then frozen
     chains = []
     for c in range(C):
-        np.random.seed(1000 + rank * C + c)
+        np.random.seed(1000 + ranks.rank * C + c)
         chains.append(Chain(c, scorer, N, d, K, val=10 ** 9))
     run_chains(chains, scorer, batch_per_chain=B, max_props=args.burnin)
+    return dict(name=name, W=W, N=N, d=d, K=K, B=B, C=C, X=X, y=y, scorer=scorer, ctx=ctx, chains=chains,
+                pack=pack, lib=_lib)
 
-    # pre-generate the step inputs: every step scores a fresh batch drawn from the frozen states
-    n_batches = args.warmup + args.steps
-    # distinct pre-generated batches (the Python sampler needs ~60 ms per batch of 64): long runs cycle through them;
-    # every step still stages, uploads and scores its batch in full -- nothing is cached between steps
-    n_unique = min(n_batches, max(64, args.warmup + 44))
-    packed = []
-    feat_counts = []           # |F| of each launch: distinct X columns its tapes reference
+
+def generate_batches(wl, n_unique):
+    """Distinct pre-generated batches (the Python sampler needs ~60 ms per batch of 64): long runs cycle through them;
+    every step still stages, uploads and scores its batch in full -- nothing is cached between steps."""
+    import numpy as np
+    packed, feat_counts = [], []
     n_nodes = n_trans = 0
+    B, ctx, _lib = wl["B"], wl["ctx"], wl["lib"]
     for _ in range(n_unique):
         tapes, chs, ks, sig = [], [], [], []
-        for ch in chains:
+        for ch in wl["chains"]:
             for cd in ch.generate(B):
                 tapes.append(cd.tape)
                 chs.append(ch.index)
                 ks.append(cd.k)
                 sig.append(cd.new_sigma)
             ch.rng_state = ch._end_state      # keep drawing new proposals from the same frozen state
-        rows, off = pack(tapes)
+        rows, off = wl["pack"](tapes)
         feats = set()
         for t in tapes:
             n_nodes += len(t)
@@ -110,152 +167,268 @@ def main():
         rec = (rows, off, np.array(chs, np.int32), np.array(ks, np.int32), np.array(sig, np.float64),
                np.zeros(len(tapes), dtype=_lib.SCORE_DTYPE), tapes)
         packed.append(rec + (ctx.prepare(*rec[:5]),))     # input addresses resolved once: the batch is host-resident
-    P = len(packed[0][2])
+    wl.update(packed=packed, feat_counts=feat_counts, n_nodes=n_nodes, n_trans=n_trans, P=len(packed[0][2]))
+    return wl
 
-    def barrier():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+def timed_region(wl, ranks, steps, warmup, depth, min_time):
+    """W warm-up steps, then R x `steps` timed steps between barriers (R chosen so the region lasts >= min_time),
+    several batches in flight; HIP events bracket the row pass of every 4th batch on the stream it runs on."""
+    import numpy as np
+    ctx, packed = wl["ctx"], wl["packed"]
+    n_unique = len(packed)
+    for i in range(warmup):
         r = packed[i % n_unique]
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
     kern_us = np.zeros(5)
-    n_timed = 0
-    depth = max(1, min(4, args.depth))
-    TIMED_EVERY = 4            # HIP events bracket the row pass of every 4th batch of the timed region (two more HIP
-                               # calls, ~6 us of host time, on a submission path that is host-bound at B=64)
-    barrier()
-    t0 = time.perf_counter()
-    # several batches in flight: the host stages batch i+1 while the GPU scores batch i (different chain groups in a
-    # real run; here every batch is drawn from frozen chain states, so there is no dependency between batches)
-    tickets = []
-    for i in range(args.warmup, n_batches):
-        r = packed[i % n_unique]
-        timed = (i - args.warmup) % TIMED_EVERY == 0
-        if timed:
-            ctx.set_profiling(1)
-        tickets.append((ctx.score_submit_prepared(r[7]), r, timed))
-        if timed:
-            ctx.set_profiling(0)
-        if len(tickets) >= depth:
+    n_timed = [0]
+    depth = max(1, min(4, depth))
+    TIMED_EVERY = 4
+
+    def run_steps(n, first):
+        """n pipelined steps: the host stages batch i+1 while the GPU scores batch i (different chain groups in a real
+        run; here every batch is drawn from frozen chain states, so batches do not depend on each other)."""
+        tickets = []
+        for i in range(n):
+            r = packed[(first + i) % n_unique]
+            timed = i % TIMED_EVERY == 0
+            if timed:
+                ctx.set_profiling(1)
+            tickets.append((ctx.score_submit_prepared(r[7]), r, timed))
+            if timed:
+                ctx.set_profiling(0)
+            if len(tickets) >= depth:
+                t, rr, tm = tickets.pop(0)
+                ctx.score_wait(t, rr[5])
+                if tm:
+                    kern_us[:] += ctx.last_timing()
+                    n_timed[0] += 1
+        while tickets:
             t, rr, tm = tickets.pop(0)
             ctx.score_wait(t, rr[5])
             if tm:
-                kern_us += ctx.last_timing()
-                n_timed += 1
-    while tickets:
-        t, rr, tm = tickets.pop(0)
-        ctx.score_wait(t, rr[5])
-        if tm:
-            kern_us += ctx.last_timing()
-            n_timed += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_us /= max(1, n_timed)
+                kern_us[:] += ctx.last_timing()
+                n_timed[0] += 1
+
+    repeats = 1
+    if min_time > 0:
+        # untimed probe of the pipelined step time (more warm-up, in effect) sizes the timed region
+        n_probe = max(4, min(steps, 40))
+        t_w = time.perf_counter()
+        run_steps(n_probe, warmup)
+        per_step = (time.perf_counter() - t_w) / n_probe
+        repeats = int(math.ceil(ranks.max(min_time * 1.15 / max(1e-7, per_step * steps))))
+        repeats = max(1, min(repeats, 20000))
+    n_steps = steps * repeats
+    kern_us[:] = 0.0
+    n_timed[0] = 0
+    ranks.barrier()
+    t0 = time.perf_counter()
+    run_steps(n_steps, warmup)
+    ranks.barrier()
+    elapsed = ranks.max(time.perf_counter() - t0)
+    kern_us /= max(1, n_timed[0])
     # the same kernel with nothing else on the GPU (one batch at a time): with several batches in flight the events of
     # the timed region also span time the kernel shares the chip with the other streams' small kernels, and
     # rocprofv3 serialises dispatches, so this is the figure its kernel stats reproduce
-    n_iso = min(args.steps, 50)
+    n_iso = min(steps, 50)
     kern_iso = 0.0
     ctx.set_profiling(1)
-    for i in range(args.warmup, args.warmup + n_iso):
-        r = packed[i % n_unique]
+    for i in range(n_iso):
+        r = packed[(warmup + i) % n_unique]
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
         kern_iso += ctx.last_timing()[0]
-    kern_iso /= n_iso
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ctx.set_profiling(0)
+    kern_iso /= max(1, n_iso)
+    return dict(elapsed=elapsed, n_steps=n_steps, repeats=repeats, kern_us_region=float(kern_us[0]),
+                kern_us=float(kern_iso))
 
-    # the one exchange of the path: gather every chain's current (accepted) trees over RCCL (outside the timed region)
-    gathered = None
-    gather_via = None
-    if dist is not None:
-        import torch
-        from bsr.dist import pack_chain_record, RECORD_BYTES, TorchGather
-        rec = np.concatenate([pack_chain_record(ch) for ch in chains])
-        try:     # RCCL communicator owned by the C ABI (bsr_comm_*), unique id handed out through the launcher's group
-            uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.from_numpy(ctx.comm_unique_id()))
-            dist.broadcast(uid, 0)
-            ctx.comm_init(world, rank, uid.cpu().numpy())
-            gathered = ctx.comm_allgather(rec)
-            gather_via = "bsr_comm_allgather (RCCL via C ABI)"
-        except Exception as exc:   # keep the bench line: fall back to the launcher's own RCCL group
-            sys.stderr.write("C-ABI gather failed (%r); using torch.distributed all_gather\n" % (exc,))
-            gathered = TorchGather(device="cuda").allgather(rec)
-            gather_via = "torch.distributed all_gather (RCCL)"
-        assert gathered.shape == (world, RECORD_BYTES * C)
 
-    if rank == 0:
-        total_props = world * P * args.steps
-        value = total_props / elapsed
-        # roofline of the dominant kernel (tree-eval + projection pass), SURVEY 8d formula:
-        # bytes = s * N * (|F| + 1 + C_r + C_w): features referenced, y, K-1 cached sibling columns per chain,
-        # C_w = 0 (candidate columns are scratch; reported separately)
-        s = 8 if args.dtype == "f64" else 4
-        n_feat = float(np.mean(feat_counts))          # per launch, averaged over the batches of the run
-        alg_bytes = int(s * N * (n_feat + 1 + C * (K - 1)))
-        p1 = kern_iso * 1e-6
-        out = {
-            "metric": "MH proposals scored/sec (N=100k,d=10,K=3) at 1/2/4/8 MI355X; HBM GB/s",
-            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": W["desc"], "N": N, "d": d, "K": K, "chains_per_gpu": C,
-                       "proposals_per_step_per_gpu": P, "speculative_batch": B, "parallelism": "chains x%d" % world,
-                       "avg_nodes_per_tape": n_nodes / (n_unique * P),
-                       "transcendental_node_frac": n_trans / max(1, n_nodes)},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / p1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / p1 / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_rows<PROJECT> (tree-eval + projection)", "kernel_us": kern_iso,
-                         "kernel_us_in_timed_region": kern_us[0],
-                         "algorithmic_bytes": alg_bytes, "features_per_launch": n_feat},
-            "batches_in_flight": depth,
-        }
-        # HBM traffic per launch of that kernel from the committed rocprofv3 PMC run of this same command
-        # (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 on gfx950)
-        import glob
-        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s_B%d.json" % (args.workload, B))))
-        tpath = tpaths[-1] if tpaths else ""          # the latest committed run of this workload
-        if C == 1 and args.dtype == "f64" and tpath:
-            for kname, rec in json.load(open(tpath)).items():
-                if "k_rows" in kname:
-                    out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
-        if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(X, y, K, chains, packed[args.warmup:], args.cpu_sample)
-        if gathered is not None:
-            out["gathered_records"] = int(gathered.shape[0] * C)
-            out["gather"] = gather_via
+def summarize(wl, tr, ranks, args):
+    """Throughput and the roofline object of the dominant kernel (tree-eval + projection pass), SURVEY 8d formula:
+    bytes = s * N * (|F| + 1 + C_r + C_w): features referenced, y, cached basis columns per chain, C_w = 0."""
+    import numpy as np
+    N, K, C, P = wl["N"], wl["K"], wl["C"], wl["P"]
+    s = 8 if args.dtype == "f64" else 4
+    n_feat = float(np.mean(wl["feat_counts"]))
+    alg_bytes = int(s * N * (n_feat + 1 + C * (K - 1)))
+    p1 = tr["kern_us"] * 1e-6
+    total_props = ranks.world * P * tr["n_steps"]
+    n_unique = len(wl["packed"])
+    return {
+        "value": total_props / tr["elapsed"],
+        "ms_per_step": 1e3 * tr["elapsed"] / tr["n_steps"],
+        "timed_repeats": tr["repeats"], "timed_region_s": tr["elapsed"],
+        "config": {"workload": wl["W"]["desc"], "N": N, "d": wl["d"], "K": K, "chains_per_gpu": C,
+                   "proposals_per_step_per_gpu": P, "speculative_batch": wl["B"],
+                   "parallelism": "chains x%d" % ranks.world,
+                   "avg_nodes_per_tape": wl["n_nodes"] / (n_unique * P),
+                   "transcendental_node_frac": wl["n_trans"] / max(1, wl["n_nodes"])},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / p1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / p1 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "row pass (tree-eval + projection)", "kernel_us": tr["kern_us"],
+                     "kernel_us_in_timed_region": tr["kern_us_region"],
+                     "algorithmic_bytes": alg_bytes, "features_per_launch": n_feat},
+    }
+
+
+def attach_traffic(out, name, B, C, dtype):
+    """HBM traffic per launch of the row pass from the committed rocprofv3 PMC run of this same command
+    (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 on gfx950)."""
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s_B%d.json" % (name, B))))
+    tpath = tpaths[-1] if tpaths else ""
+    if C == WORKLOADS[name]["chains"] and dtype == "f64" and tpath:
+        for kname, rec in json.load(open(tpath)).items():
+            if "k_rows" in kname or "k_tile" in kname:
+                out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
+                break
+
+
+def gather_trees(wl, ranks):
+    """The one exchange of the path: every chain's current (accepted) trees, all-gathered over RCCL."""
+    import numpy as np
+    from bsr.dist import pack_chain_record, RECORD_BYTES
+    if ranks.world <= 1:
+        return None
+    rec = np.concatenate([pack_chain_record(ch) for ch in wl["chains"]])
+    got = ranks.gather.allgather(rec)
+    assert got.shape == (ranks.world, RECORD_BYTES * wl["C"]), got.shape
+    return int(got.shape[0] * wl["C"])
+
+
+def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
+    """End-to-end chain throughput of config 4's per-GPU share: the native sampler drives `chains` chains on this
+    rank's GPU (consumed MH proposals per second, host proposal generation and accept path included), then the
+    accepted trees of all ranks are gathered."""
+    import numpy as np
+    from bsr import dist as D
+    from bsr.chain import DeviceScorer
+    from bsr.native import NativeEngine
+    W = WORKLOADS["c4"]
+    X, y = synth(W["N"], W["d"], seed=0)
+    scorer = DeviceScorer(X, y, W["K"], n_chains=chains, max_batch=chains * batch, device=ranks.device(),
+                          dtype=args.dtype)
+    eng = NativeEngine(scorer.ctx, chains, W["d"], val=10 ** 9)
+    eng.set_nan_policy(True)     # a throughput leg: a NaN candidate is a rejection, not the reference's LinAlgError
+    try:
+        for c in range(chains):
+            eng.seed(c, 1000 + ranks.rank * chains + c)
+            eng.init_chain(c)
+        eng.run(batch_per_chain=batch, max_props=200)            # warm-up
+        done0 = sum(eng.result(c)["n_props"] for c in range(chains))
+        ranks.barrier()
+        t0 = time.perf_counter()
+        target = 200
+        while time.perf_counter() - t0 < seconds:
+            target += 4000
+            eng.run(batch_per_chain=batch, max_props=target)
+        ranks.barrier()
+        dt = ranks.max(time.perf_counter() - t0)
+        res = [eng.result(c, current=True) for c in range(chains)]
+        done = sum(r["n_props"] for r in res) - done0
+        recs = [D.pack_record(ranks.rank * chains + c, None, r["beta"], r["sigma"], r["errs"], r["n_props"],
+                              r["n_accept"], r["n_rank_rejects"], r["n_discarded"], tapes_in=r["tapes"])
+                for c, r in enumerate(res)]
+        n_gathered = None
+        total = done
+        if ranks.world > 1:
+            n_gathered = int(D.gather_raw(ranks.gather, recs, chains).shape[0])
+            total = float(np.sum(ranks.gather.allgather(np.array([done], dtype=np.float64).view(np.uint8))
+                                 .reshape(-1).view(np.float64)))
+        return {"metric": "consumed MH proposals/s, native sampler, %d chains x batch %d per GPU" % (chains, batch),
+                "value": total / dt, "seconds": dt, "chains_total": chains * ranks.world,
+                "gathered_records": n_gathered,
+                "discarded_fraction": sum(r["n_discarded"] for r in res) /
+                max(1, sum(r["n_discarded"] + r["n_props"] for r in res))}
+    finally:
+        eng.close()
+        scorer.close()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_children(args)
+    ranks = Ranks()
+    if args.gpus != ranks.world:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); start it as `python bench.py --gpus N` "
+                         "or under a launcher with --nproc-per-node N\n" % (args.gpus, ranks.world))
+        return 2
+    extras = args.extras if args.extras >= 0 else int(args.workload == "c2" and not args.batch and not args.chains
+                                                     and args.dtype == "f64")
+    cpu_mp = None
+    if ranks.rank == 0 and args.cpu_sample > 0 and (args.workload == "c4" or (args.chains or 0) > 1):
+        cpu_mp = cpu_baseline_multiproc(args.cpu_sample / 2)      # before this process creates a GPU context
+
+    ranks.connect()
+    wl = build_workload(args.workload, args, ranks)
+    n_unique = min(args.warmup + args.steps, max(64, args.warmup + 44))
+    generate_batches(wl, n_unique)
+    tr = timed_region(wl, ranks, args.steps, args.warmup, args.depth, args.min_time)
+    out = {"metric": "MH proposals scored/sec (N=100k,d=10,K=3) at 1/2/4/8 MI355X; HBM GB/s",
+           "value": None, "unit": "proposals/s", "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic"}
+    out.update(summarize(wl, tr, ranks, args))
+    out["batches_in_flight"] = max(1, min(4, args.depth))
+    attach_traffic(out, args.workload, wl["B"], wl["C"], args.dtype)
+    n_g = gather_trees(wl, ranks)
+    if n_g is not None:
+        out["gathered_records"] = n_g
+        out["gather"] = ranks.via
+    if ranks.rank == 0 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(wl["X"], wl["y"], wl["K"], wl["chains"], wl["packed"][args.warmup:],
+                                           args.cpu_sample)
+        if cpu_mp is not None:
+            out["cpu_baseline"]["multiprocess"] = cpu_mp
+    wl["scorer"].close()
+
+    if extras:
+        ex = {}
+        short = argparse.Namespace(**vars(args))
+        short.batch, short.chains = 0, 0
+        legs = ["c3", "c5", "c4"] if ranks.world == 1 else ["c4"]
+        for name in legs:
+            try:
+                w2 = build_workload(name, short, ranks)
+                steps2 = max(10, min(args.steps, 60))
+                generate_batches(w2, min(args.warmup + steps2, 40))
+                t2 = timed_region(w2, ranks, steps2, min(args.warmup, 10), args.depth, min(args.min_time, 0.5))
+                s2 = summarize(w2, t2, ranks, args)
+                s2["unit"] = "proposals/s"
+                s2["steps"] = steps2
+                attach_traffic(s2, name, w2["B"], w2["C"], args.dtype)
+                if ranks.world > 1:
+                    s2["gathered_records"] = gather_trees(w2, ranks)
+                ex[name] = s2
+                w2["scorer"].close()
+            except Exception as exc:                               # an extra leg never costs the headline line
+                ex[name] = {"error": repr(exc)}
+        try:
+            ex["c4_native_engine"] = engine_leg(args, ranks)
+        except Exception as exc:
+            ex["c4_native_engine"] = {"error": repr(exc)}
+        out["extra"] = ex
+    if ranks.rank == 0:
         print(json.dumps(out))
-    scorer.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(X, y, K, chains, batches, budget_s):
-    """Times the oracle's reference-faithful restatement of the same scoring work on the host CPU (1 thread):
-    per proposal K+1 tree evaluations with per-element exp/inv loops, SVD rank gate, two ylogLike passes
-    (codes/funcs.py:1212-1235).  Bounded sample: proposals of the timed batches, in order, for ~budget_s seconds."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pandas as pd
-    import bsr_oracle as O
+def _onode(O, n):
+    m = O.ONode(n.depth)
+    m.type, m.operator, m.op_ind, m.feature, m.a, m.b = n.type, n.operator, n.op_ind, n.feature, n.a, n.b
+    m.left = _onode(O, n.left) if n.left is not None else None
+    m.right = _onode(O, n.right) if n.right is not None else None
+    return m
+
+
+def _cpu_faithful(O, Xdf, ys, y, K, chains, batches, budget_s):
+    """Reference-faithful flavour: per proposal K+1 tree evaluations with per-element exp/inv loops, SVD rank gate,
+    two ylogLike passes (codes/funcs.py:1212-1235)."""
+    import numpy as np
     from bsr.tape import unflatten
-
-    def onode(n):
-        m = O.ONode(n.depth)
-        m.type, m.operator, m.op_ind, m.feature, m.a, m.b = n.type, n.operator, n.op_ind, n.feature, n.a, n.b
-        m.left = onode(n.left) if n.left is not None else None
-        m.right = onode(n.right) if n.right is not None else None
-        return m
-    Xdf = pd.DataFrame(X)
-    ys = pd.Series(y)
     t0 = time.perf_counter()
     done = 0
     for batch in batches:
@@ -268,10 +441,10 @@ def cpu_baseline(X, y, K, chains, batches, budget_s):
             with np.errstate(all="ignore"):
                 for j in range(K):
                     if j == k:
-                        new_o[:, j] = O.allcal(onode(unflatten(tapes[i])), Xdf, faithful=True)[:, 0]
-                        old_o[:, j] = O.allcal(onode(ch.roots[j]), Xdf, faithful=True)[:, 0]
+                        new_o[:, j] = O.allcal(_onode(O, unflatten(tapes[i])), Xdf, faithful=True)[:, 0]
+                        old_o[:, j] = O.allcal(_onode(O, ch.roots[j]), Xdf, faithful=True)[:, 0]
                     else:
-                        col = O.allcal(onode(ch.roots[j]), Xdf, faithful=True)[:, 0]
+                        col = O.allcal(_onode(O, ch.roots[j]), Xdf, faithful=True)[:, 0]
                         new_o[:, j] = col
                         old_o[:, j] = col
                 try:
@@ -283,19 +456,42 @@ def cpu_baseline(X, y, K, chains, batches, budget_s):
                     O.yloglike(ys, old_o, ch.sigma)
             done += 1
             if time.perf_counter() - t0 > budget_s:
-                break
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
+                return done, time.perf_counter() - t0
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(X, y, K, chains, batches, budget_s):
+    """Times the oracle's restatement of the same scoring work on the host CPU.  Bounded sample: proposals of the
+    timed batches, in order.  Three figures: reference-faithful with the BLAS pool at its default size (the headline
+    `value`; the reference is one CPython thread whose numpy calls may thread), the same with the BLAS pool limited
+    to one thread, and the vectorised-fair flavour."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import pandas as pd
+    import bsr_oracle as O
+    from bsr.tape import unflatten
+    Xdf = pd.DataFrame(X)
+    ys = pd.Series(y)
+    cores = os.cpu_count() or 1
+    done, dt = _cpu_faithful(O, Xdf, ys, y, K, chains, batches, budget_s * 0.45)
     out = {"value": done / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+           "blas_threads": "default (%d logical cores visible)" % cores,
            "sample": "%d proposals of the timed batches in order, oracle reference-faithful flavour "
                      "(K+1 allcal with per-element exp/inv loops + matrix_rank + 2 ylogLike), %.1f s" % (done, dt)}
-    # second flavour: the same CPU path written the way a numpy user would -- vectorised exp/inv, the
-    # sibling columns and the old log-likelihood cached per chain -- so the ratio is not only "a Python loop removed"
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            d1, t1 = _cpu_faithful(O, Xdf, ys, y, K, chains, batches, budget_s * 0.3)
+        out["blas_1_thread"] = {"value": d1 / t1, "unit": "proposals/s",
+                                "sample": "%d proposals, same flavour, BLAS/OpenMP pools limited to 1 thread, %.1f s" % (d1, t1)}
+    except Exception as exc:
+        out["blas_1_thread"] = {"error": repr(exc)}
+    # vectorised-fair flavour (SURVEY 8d): the same CPU path written the way a numpy user would -- vectorised exp/inv,
+    # the sibling columns and the old log-likelihood cached per chain -- so the ratio is not only "a Python loop removed"
     t1 = time.perf_counter()
     fair = 0
     cache = {}
-    budget2 = budget_s / 3.0
+    budget2 = budget_s * 0.25
     for batch in batches:
         tapes, chs, ks, sig = batch[6], batch[2], batch[3], batch[4]
         for i in range(len(tapes)):
@@ -303,10 +499,10 @@ def cpu_baseline(X, y, K, chains, batches, budget_s):
             k = int(ks[i])
             with np.errstate(all="ignore"):
                 if ch.index not in cache:
-                    cols = np.stack([O.allcal(onode(ch.roots[j]), Xdf, faithful=False)[:, 0] for j in range(K)], axis=1)
+                    cols = np.stack([O.allcal(_onode(O, ch.roots[j]), Xdf, faithful=False)[:, 0] for j in range(K)], axis=1)
                     cache[ch.index] = (cols, O.yloglike(ys, cols, ch.sigma) if np.all(np.isfinite(cols)) else None)
                 new_o = cache[ch.index][0].copy()
-                new_o[:, k] = O.allcal(onode(unflatten(tapes[i])), Xdf, faithful=False)[:, 0]
+                new_o[:, k] = O.allcal(_onode(O, unflatten(tapes[i])), Xdf, faithful=False)[:, 0]
                 try:
                     full = np.linalg.matrix_rank(new_o) == K
                 except np.linalg.LinAlgError:
@@ -325,5 +521,58 @@ def cpu_baseline(X, y, K, chains, batches, budget_s):
     return out
 
 
+def _mp_worker(args):
+    """One CPU process = one chain of the oracle's reference-faithful newProp loop (host driver + scoring)."""
+    seed, budget_s = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    import bsr_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    W = WORKLOADS["c4"]
+    X, y = synth(W["N"], W["d"], seed=0)
+    np.random.seed(seed)
+    t0 = time.perf_counter()
+    n = [0]
+    t_last = [t0]
+
+    class Stop(Exception):
+        pass
+
+    def on_prop(tr):
+        n[0] += 1
+        t_last[0] = time.perf_counter()
+        if t_last[0] - t0 > budget_s:
+            raise Stop()
+    try:
+        with np.errstate(all="ignore"):
+            O.run_chain(X, y, K=W["K"], val=10 ** 9, faithful=True, on_proposal=on_prop)
+    except Stop:
+        pass
+    except Exception:        # e.g. LinAlgError on a NaN candidate, as in the reference: the chain ends there
+        pass
+    return n[0], t_last[0] - t0
+
+
+def cpu_baseline_multiproc(budget_s):
+    """independent chains are the only CPU parallelism the reference offers -- min(64, cores) processes,
+    one chain each, the oracle's faithful newProp loop at config 4's sizes."""
+    import multiprocessing as mp
+    procs = max(1, min(64, os.cpu_count() or 1))
+    try:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            res = pool.map(_mp_worker, [(1000 + c, budget_s) for c in range(procs)])
+        rate = sum(n / max(t, 1e-9) for n, t in res if n > 0)
+        return {"value": rate, "unit": "proposals/s", "cores": procs,
+                "sample": "%d processes x 1 chain, oracle faithful newProp loop (N=100k, d=10, K=3), ~%.1f s each; "
+                          "%d proposals in all" % (procs, budget_s, sum(n for n, _ in res))}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

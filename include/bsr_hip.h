@@ -111,8 +111,10 @@ int bsr_device_count(int* count);
 /* Uploads the training data once.  X is row-major (N,d) as in a C-order numpy
  * array / DataFrame.values (the `indata` of codes/funcs.py:175); it is stored
  * feature-major on the device.  y may be NULL for an evaluate-only context
- * (allcal / predict).  K, n_chains, max_batch size the chain caches and the
- * per-batch scratch (candidate columns: max_batch * N values). */
+ * (allcal / predict).  K and n_chains size the chain caches (current columns and their orthonormal basis);
+ * max_batch bounds the proposals / tapes of one call and sizes the per-batch descriptor, partial-sum and result
+ * blocks (O(max_batch * N / 1024) doubles).  Candidate columns are not stored by the scoring pass; the
+ * max_batch * N column buffer of bsr_eval_tapes is allocated on its first use. */
 int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor,
                    const double* y, int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype);
 int bsr_ctx_destroy(bsr_ctx* ctx);
@@ -154,7 +156,7 @@ int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off,
  * flight (tickets are handed out round-robin; wait for them in submission order), each on its own HIP stream, so the
  * host stages batch i+1 and the small per-proposal kernels of batch i overlap the row pass of batch i+1.  Chains of
  * a batch must not depend on accepts of a batch still in flight.  bsr_commit refers to the batch most recently
- * waited for. */
+ * waited for and returns BSR_E_STATE once that batch's slot has been submitted to again. */
 #define BSR_MAX_INFLIGHT 4
 int bsr_score_submit(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                      const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket);

@@ -10,6 +10,10 @@ reference's meaning.  Extra keyword-only options (defaults preserve the referenc
                          reference; a list of ints: chain c is seeded with chain_seeds[c] and chains advance
                          together, several per launch (independent restarts are the reference's only parallelism,
                          codes/bsr_class.py:99)
+  devices                None: everything runs in this process on `device`.  A list of GPU indices: the chains are
+                         sharded over one fresh process per listed GPU (chain c -> devices[c % len], seeded
+                         chain_seeds[c], default 1000 + c), each rank drives its share with the native sampler and
+                         the outcomes are gathered over RCCL (bsr.sharded; SURVEY 8e, BASELINE configs[3])
 """
 import numpy as np
 
@@ -30,7 +34,8 @@ except Exception:  # pragma: no cover
 
 class BSR(BaseEstimator, RegressorMixin):
     def __init__(self, treeNum=3, itrNum=5000, alpha1=0.4, alpha2=0.4, beta=-1, disp=False, val=100,
-                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8, engine="native"):
+                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8, engine="native",
+                 devices=None):
         self.treeNum = treeNum
         self.itrNum = itrNum
         self.alpha1 = alpha1
@@ -44,6 +49,7 @@ class BSR(BaseEstimator, RegressorMixin):
         self.chain_seeds = chain_seeds
         self.chains_per_launch = chains_per_launch
         self.engine = engine
+        self.devices = devices
 
     # ---- codes/bsr_class.py:37-51
     def model(self, last_ind=1):
@@ -151,6 +157,8 @@ class BSR(BaseEstimator, RegressorMixin):
         y = np.ascontiguousarray(np.asarray(train_y, dtype=np.float64).reshape(-1))
         N, d = X.shape
         K = self.treeNum
+        if self.devices is not None:
+            return self._fit_sharded(X, y, K, y_is_series)
         T = P.default_table()
         seeds = self.chain_seeds
         n_slots = 1 if seeds is None else max(1, min(self.chains_per_launch, len(seeds), self.itrNum))
@@ -186,6 +194,25 @@ class BSR(BaseEstimator, RegressorMixin):
         finally:
             scorer.close()
         for r in results:
+            self.roots_.append(r["roots"])
+            self.betas_.append(r["beta"])
+            self.train_err_.append(r["errs"])
+            self.stats_["proposals"] += r["n_props"]
+            self.stats_["accepts"] += r["n_accept"]
+            self.stats_["rank_rejects"] += r["n_rank_rejects"]
+            self.stats_["discarded"] += r["n_discarded"]
+        return
+
+    def _fit_sharded(self, X, y, K, y_is_series):
+        """One process per GPU of `devices`; this process touches no GPU (codes/bsr_class.py:99, 270-276 sharded)."""
+        from .sharded import fit_sharded
+        seeds = self.chain_seeds if self.chain_seeds is not None else [1000 + c for c in range(self.itrNum)]
+        seeds = [int(v) for v in seeds[:self.itrNum]]
+        recs = fit_sharded(X, y, K=K, seeds=seeds, devices=list(self.devices), batch=self.batch, val=self.val,
+                           beta=self.beta, chains_per_launch=self.chains_per_launch, dtype=self.dtype,
+                           y_is_series=y_is_series)
+        self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
+        for r in recs:
             self.roots_.append(r["roots"])
             self.betas_.append(r["beta"])
             self.train_err_.append(r["errs"])

@@ -1,0 +1,152 @@
+"""One process per GPU without a launcher framework: spawn, rendezvous and the host-side exchange of the 128-byte
+RCCL unique id.
+
+Two ways a rank comes to life:
+  * `spawn(n, argv)`: the caller (which must not have touched the GPU itself) starts n fresh Python processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / BSR_RDV_DIR in their environment, relays their
+    output and returns their exit codes.  `bench.py --gpus N` and `BSR(devices=[...]).fit` use it.
+  * an external launcher (e.g. `python -m torch.distributed.run`) that sets the same RANK / WORLD_SIZE variables.
+
+Either way the ranks meet through `Rendezvous`: a directory on the node's file system (one node is the whole scope
+of the multi-GPU path) in which rank 0 publishes small blobs by atomic rename and the others poll.  It carries the
+unique id that `bsr_comm_init` needs and nothing else on the product path; every later exchange (barrier, timing
+reduction, the gather of accepted trees) is an RCCL all-gather through the C ABI (`bsr.dist.RcclGather`).
+"""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+import time
+
+
+def rank_env():
+    """(rank, world, local_rank) of this process; (0, 1, 0) when no launcher variables are set."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
+    """Starts `nprocs` children running `sys.executable argv...`, one per GPU (LOCAL_RANK = rank).  Rank 0's stdout
+    is returned (and echoed when relay_rank0_stdout); every child's stderr goes to this process's stderr.
+    Returns (exit codes, rank-0 stdout).  The caller must not have initialised HIP: children are fresh processes."""
+    rdv = tempfile.mkdtemp(prefix="bsr_rdv_")
+    port = free_port()
+    procs = []
+    for r in range(nprocs):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "BSR_RDV_DIR": rdv, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        codes = []
+        for p in procs:
+            left = None if deadline is None else max(1.0, deadline - time.time())
+            codes.append(p.wait(timeout=left))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        codes = [p.wait() for p in procs]
+    finally:
+        for name in os.listdir(rdv):
+            try:
+                os.unlink(os.path.join(rdv, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(rdv)
+        except OSError:
+            pass
+    text = out0.decode(errors="replace")
+    if relay_rank0_stdout and text:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    return codes, text
+
+
+class Rendezvous:
+    """File-system meeting point of the ranks of one node."""
+
+    def __init__(self, rank, world, directory=None, timeout=300.0):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        d = directory or os.environ.get("BSR_RDV_DIR")
+        self.own_dir = False
+        if not d:
+            # external launcher: every rank is a child of the same agent process, and the port is unique per job
+            d = os.path.join(tempfile.gettempdir(), "bsr_rdv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+            self.own_dir = True
+        self.dir = d
+        self.t_start = time.time()
+        os.makedirs(d, exist_ok=True)
+        self.seq = 0
+
+    def _path(self, name):
+        return os.path.join(self.dir, name)
+
+    def publish(self, name, blob):
+        tmp = self._path(".%s.%d.tmp" % (name, self.rank))
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, self._path(name))
+
+    def fetch(self, name, nbytes=None):
+        t_end = time.time() + self.timeout
+        p = self._path(name)
+        while True:
+            try:
+                # a blob older than this job (same agent pid and port reused after a crash) is not ours
+                if os.path.getmtime(p) >= self.t_start - 600.0:
+                    with open(p, "rb") as f:
+                        b = f.read()
+                    if nbytes is None or len(b) == nbytes:
+                        return b
+            except OSError:
+                pass
+            if time.time() > t_end:
+                raise TimeoutError("rendezvous: %s did not appear in %s within %.0f s" % (name, self.dir, self.timeout))
+            time.sleep(0.002)
+
+    def broadcast(self, name, make_blob, nbytes=None):
+        """Rank 0 creates the blob (make_blob()), everyone returns it."""
+        if self.rank == 0:
+            blob = bytes(make_blob())
+            self.publish(name, blob)
+            return blob
+        return self.fetch(name, nbytes)
+
+    def allgather(self, blob):
+        """Host-side all-gather of equal-size blobs through the directory.  Not the product's gather (that is RCCL,
+        bsr.dist.RcclGather): used by tests that run several ranks on one device, where RCCL refuses to start."""
+        seq = self.seq
+        self.seq += 1
+        self.publish("ag%d_%d" % (seq, self.rank), bytes(blob))
+        return [self.fetch("ag%d_%d" % (seq, r), len(blob)) for r in range(self.world)]
+
+    def close(self):
+        """Rank 0 removes what it published (call after a collective that proves everyone has read it)."""
+        if self.rank != 0:
+            return
+        try:
+            os.unlink(self._path("uid"))
+        except OSError:
+            pass
+        if self.own_dir:
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass

@@ -51,6 +51,8 @@ struct BatchSlot {
   bool use_lds = false;
   int rb_rows = 512;
   bool pending = false;
+  uint32_t gen = 0;         // bumped by every submission on this slot
+  uint32_t waited_gen = 0;  // generation whose results the last wait on this slot handed out
   int timed = 0;        // profiling level the pending batch was enqueued with
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
@@ -253,6 +255,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   if (c->rb_rows < 256 || c->rb_rows > BSR_ROW_ALIGN || (BSR_ROW_ALIGN % c->rb_rows) != 0 ||
       (c->rb_rows % (64 * c->rows_per_lane)) != 0)
     c->rb_rows = rb_default;
+  if (c->rb_rows % (64 * c->rows_per_lane) != 0) c->rows_per_lane = 2;  // a row block is a whole number of sweeps
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
   c->wgs_per_cu = std::max(1, std::min(8, env_int("BSR_WGS_PER_CU", 5)));
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
@@ -754,6 +757,8 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
   if (si < 0 || si >= BSR_MAX_INFLIGHT || !c->slot[si].scored)
     return fail(c, BSR_E_STATE, "bsr_commit: no scored batch to commit from");
   BatchSlot& s = c->slot[si];
+  if (s.pending || s.waited_gen != s.gen)
+    return fail(c, BSR_E_STATE, "bsr_commit: the slot of the last waited batch has been resubmitted since (commit before the next submit on it)");
   if (idx < 0 || idx >= s.P) return fail(c, BSR_E_STATE, "bsr_commit: index is not part of the last scored batch");
   HIPCHK(c, hipSetDevice(c->device));
   // Candidate columns are not kept by the scoring pass: re-run the still-staged tape straight into the chain cache.
@@ -897,6 +902,7 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
     D->sigma = sigma[i];
   }
   s.scored = true;
+  ++s.gen;
   const long long th2 = host_now();
   rc = enqueue(c, s, B, true);
   if (g_host_prof) {
@@ -926,6 +932,7 @@ int bsr_internal_wait(bsr_ctx* c, int ticket, bsr_score* out) {
   if (!s.scored) return fail(c, BSR_E_STATE, "bsr_score_wait: nothing submitted under this ticket");
   int rc = wait_slot(c, s);
   if (rc != BSR_OK) return rc;
+  s.waited_gen = s.gen;
   memcpy(out, s.h_out, sizeof(bsr_score) * s.P);
   return BSR_OK;
 }
@@ -946,6 +953,7 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
       rc = drain(c);
       if (rc != BSR_OK) return rc;
       std::vector<PropDesc> keep(s.h_desc(), s.h_desc() + B);
+      std::vector<bsr_score> batch_scores(s.h_out, s.h_out + B);  // the rescoring run reuses entries 0..redo-1
       double timing[5];
       memcpy(timing, c->last_us, sizeof timing);
       for (size_t j = 0; j < redo.size(); ++j) {
@@ -962,8 +970,11 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
       for (size_t j = 0; j < redo.size(); ++j) {
         out[redo[j]] = s.h_out[j];
         out[redo[j]].flags &= ~BSR_F_SCALE_RETRY;
+        batch_scores[redo[j]] = out[redo[j]];
       }
-      // restore the batch's own descriptors (host and device) so bsr_commit sees the original order
+      // the slot's result block goes back to batch order (bsr_commit reads max|z| and the flags of the accepted
+      // candidate from it), and so do the batch's own descriptors, host and device
+      memcpy(s.h_out, batch_scores.data(), sizeof(bsr_score) * B);
       memcpy(s.h_desc(), keep.data(), sizeof(PropDesc) * B);
       HIPCHK(c, hipMemcpyAsync(s.d_desc(), s.h_desc(), sizeof(PropDesc) * B, hipMemcpyHostToDevice, s.stream));
       s.P = B;

@@ -1,0 +1,116 @@
+"""BASELINE configs[3] on the GPU box: config 4's per-GPU share (8 chains, N=100k, d=10, K=3, native sampler with
+its worker threads) against single-chain runs and the CPU oracle; the sharded product entry; bench.py's own
+multi-process launch.  The box has one GPU: several ranks share it with BSR_SHARE_DEVICE=1, which swaps only the
+transport of the gather (RCCL refuses two ranks on one device) -- the RCCL calls themselves are covered with a
+one-rank communicator here and with N ranks by the driver's scaling run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import spec_from_node
+
+pytestmark = pytest.mark.gpu
+
+import bsr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _c4_data(N=100_000, d=10):
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    return X, y
+
+
+def _summ(rec):
+    from bsr.node import Express
+    return ([Express(t) for t in rec["roots"]], rec["n_props"], rec["n_accept"], rec["n_rank_rejects"])
+
+
+def test_config4_share_equals_single_chain_runs_and_the_oracle():
+    """8 chains advanced together (worker threads on, 32 speculative proposals each per launch) give exactly the
+    chains that run one at a time; chain 0 is the oracle's chain under the same seed (codes/bsr_class.py:99-273)."""
+    from bsr import dist as D
+    from bsr.sharded import run_rank
+    X, y = _c4_data()
+    K, val = 3, 40
+    seeds = [1000 + c for c in range(8)]
+    raw, stats = run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=val, chains_per_launch=8)
+    together = [D.unpack_record(raw[i]) for i in range(raw.shape[0])]
+    assert [r["chain"] for r in together] == list(range(8))
+    assert stats["proposals"] == sum(r["n_props"] for r in together) and stats["chains"] == 8
+    for c in range(8):
+        raw1, _ = run_rank(X, y, K, [seeds[c]], rank=0, world=1, device=0, batch=32, val=val, chains_per_launch=1)
+        one = D.unpack_record(raw1[0])
+        assert _summ(one) == _summ(together[c]), c
+        assert np.array_equal(one["beta"], together[c]["beta"]), c          # same arithmetic whatever shares the launch
+        assert one["errs"] == together[c]["errs"], c
+    # the oracle's chain 0 (vectorised flavour: same values as the faithful one, see tests/test_oracle_golden.py)
+    np.random.seed(seeds[0])
+    with np.errstate(all="ignore"):
+        ref = O.run_chain(pd.DataFrame(X), pd.Series(y), K=K, val=val, faithful=False)
+    got = together[0]
+    assert [O.express(t) for t in ref["roots"]] == _summ(got)[0]
+    assert ref["n_props"] == got["n_props"]
+    assert len(ref["errs"]) == len(got["errs"]) == got["n_accept"]
+    assert np.allclose(ref["errs"], got["errs"], rtol=1e-6)
+    assert np.allclose(ref["beta"].reshape(-1), got["beta"].reshape(-1), rtol=1e-5, atol=1e-8)
+
+
+def test_sharded_fit_product_entry_matches_in_process_fit():
+    """BSR(devices=[0]) -- one child process per listed GPU, native sampler, gather -- returns what the in-process
+    fit with the same per-chain seeds returns (roots_, betas_, train_err_ of codes/bsr_class.py:270-276)."""
+    from bsr import BSR
+    from bsr.node import Express
+    X, y = _c4_data(N=5000, d=4)
+    seeds = [2000 + c for c in range(5)]
+    here = BSR(treeNum=3, itrNum=5, val=40, chain_seeds=seeds, chains_per_launch=4, batch=16)
+    here.fit(X, y)
+    far = BSR(treeNum=3, itrNum=5, val=40, chain_seeds=seeds, chains_per_launch=4, batch=16, devices=[0])
+    far.fit(X, y)
+    assert len(far.roots_) == 5
+    for c in range(5):
+        assert [Express(t) for t in far.roots_[c]] == [Express(t) for t in here.roots_[c]], c
+        assert np.array_equal(far.betas_[c], here.betas_[c]), c
+        assert far.train_err_[c] == here.train_err_[c], c
+    assert far.stats_["proposals"] == here.stats_["proposals"] and far.model() == here.model()
+    assert np.array_equal(far.predict(X[:50]), here.predict(X[:50]))
+
+
+def test_two_ranks_sharing_the_device_give_the_one_rank_result():
+    """World 2 (chains c % 2, both ranks on this box's only GPU, gather through the rendezvous directory) == world 1."""
+    from bsr.node import Express
+    from bsr.sharded import fit_sharded
+    X, y = _c4_data(N=4000, d=3)
+    seeds = [3000 + c for c in range(5)]
+    one = fit_sharded(X, y, K=3, seeds=seeds, devices=[0], batch=16, val=30, chains_per_launch=3)
+    two = fit_sharded(X, y, K=3, seeds=seeds, devices=[0, 0], batch=16, val=30, chains_per_launch=3,
+                      env_extra={"BSR_SHARE_DEVICE": "1"})
+    assert [r["chain"] for r in two] == [0, 1, 2, 3, 4]
+    for a, b in zip(one, two):
+        assert [Express(t) for t in a["roots"]] == [Express(t) for t in b["roots"]]
+        assert np.array_equal(a["beta"], b["beta"]) and a["errs"] == b["errs"] and a["n_props"] == b["n_props"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: two child ranks, one JSON line with n_gpus 2 and the gathered
+    record count; the parent never touches the GPU."""
+    env = dict(os.environ, BSR_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--cpu-sample", "0", "--extras", "0", "--min-time", "0", "--burnin", "60"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gathered_records"] == 2 and out["steps"] == 8
+    assert out["config"]["proposals_per_step_per_gpu"] == 64 and out["value"] > 0
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel_us"] > 0

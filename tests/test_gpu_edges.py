@@ -222,3 +222,51 @@ def test_exact_opcode_trees_are_bit_identical_to_the_oracle():
             assert same.all(), (lo + i, int((~same).sum()))
             assert bool(flags[i] & 1) == bool(np.isinf(want).any()) and bool(flags[i] & 2) == bool(np.isnan(want).any())
     ctx.close()
+
+
+def test_k1_rescored_candidates_keep_the_batch_order_for_commit():
+    """treeNum = 1: a candidate whose |z|^2 leaves the double range is rescored with a matched prescale
+    (BSR_F_SCALE_RETRY).  The rescoring run must not disturb the other candidates' records: committing index 0 of a
+    batch whose index 3 was rescored adopts candidate 0's max|z| and flags, and the refreshed chain state is the
+    oracle's (codes/funcs.py:1147-1174 on the single column)."""
+    from bsr import _lib
+    from bsr.tape import flatten
+    N, d = 3000, 3
+    rs = np.random.RandomState(4)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 2.0 * X[:, 1] + 0.3 * X[:, 0] ** 2 + 0.1 * rs.standard_normal(N)
+    ctx = _ctx(X, y, K=1, n_chains=1, max_batch=8)
+    ctx.set_current(0, 0, flatten(_un("sin", _leaf(0))))
+    ctx.refresh(0)
+    huge = _un("cubic", _un("exp", _un("ln", _leaf(0), 60.0, 0.0)))          # up to (e^180)^3 ~ 3e234 > 2^400
+    cands = [_leaf(1), _un("square", _leaf(2)), _bi("+", _leaf(0), _leaf(1)), huge, _un("neg", _leaf(2))]
+    res = ctx.score_batch([flatten(t) for t in cands], np.zeros(5, np.int32), np.zeros(5, np.int32), np.full(5, 0.9))
+    assert not (res["flags"] & _lib.F_SCALE_RETRY).any()
+    cols = [_oracle_col(t, X) for t in cands]
+    for i, col in enumerate(cols):
+        want = O.score_proposal(np.zeros((N, 1)), 0, col, y, 0.9)
+        assert int(res["rank"][i]) == want["rank"] == 1, i
+        assert abs(res["loglik"][i] - want["loglik"]) <= 1e-9 * abs(want["loglik"]), i
+        assert res["maxabs"][i] == np.max(np.abs(col)), i
+    assert res["maxabs"][3] > 2.0 ** 400
+    ctx.commit(0, 0, 0)
+    info = ctx.refresh(0)
+    assert info["maxabs"][0] == np.max(np.abs(X[:, 1]))
+    ll, sse, scale, beta = O.yloglike_parts(y, cols[0].reshape(-1, 1), 1.0)
+    assert abs(info["sse_old"] - sse) <= 1e-9 * sse
+    beta_i, rmse = ctx.fit_beta(0)
+    want_b, want_rmse = O.intercept_fit(pd.Series(y), cols[0].reshape(-1, 1))
+    assert np.allclose(beta_i.reshape(-1), np.asarray(want_b).reshape(-1), rtol=1e-8) and abs(rmse - want_rmse) <= 1e-9 * want_rmse
+    # a commit that refers to a batch whose slot has been submitted to again is refused
+    t = [ctx.score_submit(*__import__("bsr.tape", fromlist=["pack"]).pack([flatten(cands[0])]), np.zeros(1, np.int32),
+                          np.zeros(1, np.int32), np.ones(1)) for _ in range(4)]
+    out = np.zeros(1, dtype=_lib.SCORE_DTYPE)
+    ctx.score_wait(t[0], out)
+    t.append(ctx.score_submit(*__import__("bsr.tape", fromlist=["pack"]).pack([flatten(cands[1])]), np.zeros(1, np.int32),
+                              np.zeros(1, np.int32), np.ones(1)))            # reuses the slot of t[0]
+    with pytest.raises(_lib.BsrError) as e:
+        ctx.commit(0, 0, 0)
+    assert _lib.ERRORS[e.value.code] == "BSR_E_STATE"
+    for tk in t[1:]:
+        ctx.score_wait(tk, out)
+    ctx.close()
