@@ -78,10 +78,10 @@ struct bsr_ctx {
   void* Xt = nullptr;
   void* y = nullptr;
   void* cur = nullptr;   // [chain][k][ld]
-  void* Q = nullptr;     // [chain][k][K-1][ld]
+  void* Q = nullptr;     // [chain][K][ld]: one orthonormal basis of the chain's K current columns
   void* zbuf = nullptr;  // [max_batch][ld], allocated on the first bsr_eval_tapes that wants columns
-  ChainK* d_ck = nullptr;
-  std::vector<ChainK> h_ck;
+  ChainB* d_ck = nullptr;        // [chain]
+  std::vector<ChainB> h_ck;
   ChainFitOut* d_fit = nullptr;  // [chain] no-intercept fit (also carries per-column max/flags) + 1 scratch slot
   std::vector<ChainFitOut> h_fit;
   ChainFitOut* d_fit_icpt = nullptr;   // [chain] intercept fit of the last refresh
@@ -288,13 +288,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   if (K > 0 && n_chains > 0) {
     CK(hipMalloc(&c->cur, colb * n_chains * K));
     CK(hipMemsetAsync(c->cur, 0, colb * n_chains * K, c->stream));
-    if (K > 1) {
-      CK(hipMalloc(&c->Q, colb * n_chains * K * (K - 1)));
-      CK(hipMemsetAsync(c->Q, 0, colb * n_chains * K * (K - 1), c->stream));
-    }
-    CK(hipMalloc((void**)&c->d_ck, sizeof(ChainK) * n_chains * K));
-    CK(hipMemsetAsync(c->d_ck, 0, sizeof(ChainK) * n_chains * K, c->stream));
-    c->h_ck.resize((size_t)n_chains * K);
+    CK(hipMalloc(&c->Q, colb * n_chains * K));
+    CK(hipMemsetAsync(c->Q, 0, colb * n_chains * K, c->stream));
+    CK(hipMalloc((void**)&c->d_ck, sizeof(ChainB) * n_chains));
+    CK(hipMemsetAsync(c->d_ck, 0, sizeof(ChainB) * n_chains, c->stream));
+    c->h_ck.resize((size_t)n_chains);
     c->ready.assign(n_chains, 0);
     c->col_set.assign((size_t)n_chains * K, 0);
   }
@@ -790,15 +788,13 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
 static int refresh_slow(bsr_ctx* c, int chain) {  // single-workgroup Gram-Schmidt path (robust for dependent siblings)
   const int K = c->K;
   void* cols = col_ptr(c, c->cur, (int64_t)chain * K);
-  ChainK* dck = c->d_ck + (size_t)chain * K;
+  ChainB* dck = c->d_ck + (size_t)chain;
   const RefreshIn* rin = c->d_rin + chain;
   if (c->dtype == BSR_DTYPE_F64)
-    launch_refresh_basis<double>(c->stream, (const double*)cols,
-                                 K > 1 ? (double*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
+    launch_refresh_basis<double>(c->stream, (const double*)cols, (double*)col_ptr(c, c->Q, (int64_t)chain * K),
                                  (const double*)c->y, c->ld, c->N, K, rin->colmax, rin->colflags, dck);
   else
-    launch_refresh_basis<float>(c->stream, (const float*)cols,
-                                K > 1 ? (float*)col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr,
+    launch_refresh_basis<float>(c->stream, (const float*)cols, (float*)col_ptr(c, c->Q, (int64_t)chain * K),
                                 (const float*)c->y, c->ld, c->N, K, rin->colmax, rin->colflags, dck);
   return BSR_OK;
 }
@@ -815,10 +811,10 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
   ChainFitOut* dfit = c->d_fit + chain;
   ChainFitOut* dfit_i = c->d_fit_icpt + chain;
   void* cols = col_ptr(c, c->cur, (int64_t)chain * K);
-  ChainK* dck = c->d_ck + (size_t)chain * K;
+  ChainB* dck = c->d_ck + (size_t)chain;
   HIPCHK(c, hipMemcpyAsync(c->d_rin + chain, &c->h_rin[chain], sizeof(RefreshIn), hipMemcpyHostToDevice, c->stream));
   if (c->fast_refresh) {
-    void* Q = K > 1 ? col_ptr(c, c->Q, (int64_t)chain * K * (K - 1)) : nullptr;
+    void* Q = col_ptr(c, c->Q, (int64_t)chain * K);
     if (c->dtype == BSR_DTYPE_F64)
       launch_refresh_fast<double>(c->stream, (const double*)cols, (double*)Q, (const double*)c->y, c->ld, c->N, K,
                                   c->d_rin + chain, c->d_plan, c->d_rpart, dck, dfit, dfit_i);
@@ -838,15 +834,13 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
   }
   HIPCHK(c, hipMemcpyAsync(&c->h_fit[chain], dfit, sizeof(ChainFitOut), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_fit_icpt[chain], dfit_i, sizeof(ChainFitOut), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain * K], dck, sizeof(ChainK) * K, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain], dck, sizeof(ChainB), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   if (c->fast_refresh) {
-    bool fb = false;
-    for (int k = 0; k < K; ++k) fb |= c->h_plan->fallback[k] != 0;
-    if (fb) {  // (nearly) dependent siblings: Cholesky-QR is not accurate enough, rebuild with Gram-Schmidt
+    if (c->h_plan->fallback != 0) {  // (nearly) dependent columns: Cholesky-QR is not accurate enough, rebuild with Gram-Schmidt
       refresh_slow(c, chain);
-      HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain * K], dck, sizeof(ChainK) * K, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(&c->h_ck[(size_t)chain], dck, sizeof(ChainB), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipGetLastError());
     }
@@ -890,15 +884,14 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
   for (int i = 0; i < B; ++i) {
     PropDesc* D = &hd[i];
     fill_desc_tape(D, loc[i]);
-    const int ckidx = chain[i] * K + which_k[i];
     D->mode = BSR_MODE_SCORE;
-    D->nq = K - 1;
+    D->nq = K;
     D->k = which_k[i];
     D->K = K;
-    D->ck = ckidx;
-    D->qbase = (K > 1) ? col_ptr(c, c->Q, (int64_t)ckidx * (K - 1)) : nullptr;
+    D->ck = chain[i];
+    D->qbase = col_ptr(c, c->Q, (int64_t)chain[i] * K);
     D->zout = nullptr;
-    D->s = c->h_ck[ckidx].s;
+    D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
   }
   s.scored = true;

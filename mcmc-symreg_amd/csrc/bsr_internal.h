@@ -7,7 +7,7 @@
 
 #include "../../include/bsr_hip.h"
 
-#define BSR_NQ_MAX (BSR_MAX_K - 1)  // basis columns per proposal
+#define BSR_NQ_MAX BSR_MAX_K        // basis columns per chain (one orthonormal column per current tree output)
 #define BSR_WAVE 64
 #define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
 // opcode-stream-only codes (never in a bsr_node): acc = acc + X[:,f] / acc * X[:,f] with f from the column stream
@@ -28,16 +28,17 @@
 
 enum { BSR_MODE_SCORE = 0, BSR_MODE_EVAL = 1 };
 
-// Cached factors of one (chain, k): leave-one-out basis of the K-1 sibling columns, scaled by the
-// power of two `s`:  s * O_j = Q R  (j != k ascending).  See DESIGN.md "rank gate and OLS".
-struct ChainK {
+// Cached factors of one chain: ONE orthonormal basis of its K current columns, each prescaled by its own power of
+// two d_j:  O_j d_j = sum_i Q_i R_ij  (R upper triangular).  A proposal that replaces tree k uses R with column k
+// removed; see DESIGN.md "rank gate and OLS".  Non-finite columns enter as zero columns (d_j = 0).
+struct ChainB {
   double R[BSR_NQ_MAX * BSR_NQ_MAX];     // upper triangular, row-major [row][col]
   double qy[BSR_NQ_MAX];                 // Q^T y
   double yperp2;                         // |y - Q Q^T y|^2, measured directly
-  double s;                              // power-of-two prescale
-  double m_other;                        // max |sibling columns| (unscaled)
-  uint32_t flags;                        // BSR_F_INF / BSR_F_NAN of the sibling columns
-  uint32_t pad;
+  double d[BSR_NQ_MAX];                  // per-column power-of-two prescale (0: column holds inf/NaN)
+  double s_k[BSR_MAX_K];                 // prescale of a candidate for tree k: pow2 of max |sibling columns|
+  double m_other[BSR_MAX_K];             // max |columns j != k| (unscaled)
+  uint32_t flags_k[BSR_MAX_K];           // BSR_F_INF / BSR_F_NAN of the columns j != k
 };
 
 // Device-side descriptor of one tape to run in the row passes.
@@ -47,10 +48,10 @@ struct PropDesc {
   int32_t feat_off;     // first 64-bit word of the tape's terminal-column stream
   int32_t ln_off;       // first (a,b) pair of the tape's ln-parameter stream
   int32_t mode;         // BSR_MODE_*
-  int32_t nq;           // basis columns (K-1), 0 in eval mode
+  int32_t nq;           // basis columns (K), 0 in eval mode
   int32_t k;            // tree index being replaced
   int32_t K;
-  int32_t ck;           // index into the ChainK array (chain*K + k)
+  int32_t ck;           // index into the ChainB array (chain)
   int32_t spill_need;   // stack slots beyond the register stack
   int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
   int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
@@ -94,10 +95,10 @@ struct RefreshPlan {  // per chain, device scratch handed from one refresh kerne
   double beta_fit[BSR_MAX_K], coef_fit[BSR_MAX_K], beta_icpt[BSR_MAX_K + 1];
   double s_k[BSR_MAX_K], m_other[BSR_MAX_K];
   uint32_t flags_k[BSR_MAX_K];
-  int32_t fallback[BSR_MAX_K];
-  double R1[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX], T1[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX];
-  double T2[BSR_MAX_K][BSR_NQ_MAX * BSR_NQ_MAX];
-  double qy[BSR_MAX_K][BSR_NQ_MAX];
+  int32_t fallback, pad2;      // the Cholesky-QR factors are not accurate enough: rebuild with Gram-Schmidt
+  double R1[BSR_NQ_MAX * BSR_NQ_MAX], T1[BSR_NQ_MAX * BSR_NQ_MAX], T2[BSR_NQ_MAX * BSR_NQ_MAX];
+  double qy[BSR_NQ_MAX];
+  double dcol[BSR_NQ_MAX];
 };
 
 struct LaunchGeom {
@@ -141,13 +142,13 @@ struct RowPassArgs {
 };
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
-void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
+void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor);
-void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
+void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor);
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
-                          const double* col_maxabs, const uint32_t* col_flags, ChainK* ck_chain);
+                          const double* col_maxabs, const uint32_t* col_flags, ChainB* cb);
 template <typename T>
 void launch_chain_fit(hipStream_t st, const T* cols, const T* y, int64_t ld, int64_t N, int K, int intercept,
                       ChainFitOut* out);
@@ -159,6 +160,6 @@ template <typename T>
 void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n);
 template <typename T>
 void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N, int K,
-                         const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
+                         const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainB* ck,
                          ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt);
 size_t refresh_part_doubles(int64_t N);

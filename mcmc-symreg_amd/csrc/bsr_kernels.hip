@@ -2,7 +2,7 @@
 //
 // Row pass (the O(N) work; one launch covers a whole batch of proposals):
 //   k_rows<MODE_PROJECT>  : postfix stack-machine over each candidate tape (allcal, codes/funcs.py:175-220) fused
-//                           with the projections of the candidate column on the cached orthonormal sibling basis,
+//                           with the projections of the candidate column on the chain's cached orthonormal basis,
 //                           |z|^2, z.y, max|z| and the inf/NaN census.  Candidate columns are NOT stored: the few
 //                           consumers (near-dependent candidates, an accepted proposal) re-run the tape instead.
 //   k_rows<MODE_RESIDUAL> : same interpreter; direct residual of the candidate against the sibling basis
@@ -12,7 +12,7 @@
 //                ridge OLS (codes/funcs.py:1151-1155), SSE and log-likelihood (codes/funcs.py:1162-1173).
 //   k_finalize : the same algebra for the proposals that needed the residual pass.
 // Rare path (initialisation / accepted proposal), one workgroup each:
-//   k_refresh_basis : leave-one-out orthonormal bases of the chain's current columns.
+//   k_refresh_basis : orthonormal basis of the chain's K current columns (Gram-Schmidt fallback).
 //   k_chain_fit     : ridge OLS of y on the K current columns, with or without intercept
 //                     (codes/funcs.py:1235 old state; codes/bsr_class.py:147-163, 211-233).
 //
@@ -536,11 +536,10 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
         double* o = part + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
 #pragma unroll
         for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = (i < NQ) ? c[i < NQ ? i : 0] : 0.0;
-        o[7] = a0;
-        o[8] = a1;
-        o[9] = amax;
-        o[10] = (double)fl;
-        o[11] = 0.0;
+        o[8] = a0;
+        o[9] = a1;
+        o[10] = amax;
+        o[11] = (double)fl;
       }
     } else {
       a0 = wave_sum(a0);
@@ -637,46 +636,78 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Per-proposal K x K algebra.  One wave per proposal.
+// Per-proposal small algebra.  One wave per proposal.
 //
-// With s*O_siblings = Q R (cached) and the candidate s*z = Q c + w (w orthogonal to Q, |w| = rho):
-//   s * new_outputs = [Q, w/rho] S,   S = [[R, c], [0, rho]]   (columns: siblings ascending, then the candidate)
-// so the singular values of S are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with
-// XX = new_outputs/scale = [Q, w/rho] (tau S), tau = 1/(s*scale), h = [Q^T y, w.y/rho]:
+// The chain keeps ONE orthonormal basis of its K current columns, O_j d_j = sum_i Q_i R_ij (d_j: power-of-two column
+// prescales).  A proposal replaces tree k by the candidate z.  With s the candidate's prescale, c = Q^T (s z),
+// w = s z - Q c (orthogonal to Q, |w| = rho):
+//   s * new_outputs = [Q, w/rho] S,   S = [[R_{-k} (s/d), c], [0, rho]]      ((K+1) x K: R without column k)
+// (columns: siblings ascending, then the candidate).  [Q, w/rho] has orthonormal columns, so the singular values of S
+// are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with XX = new_outputs/scale = [Q, w/rho] (tau S),
+// tau = 1/(s*scale), h = [Q^T y, w.y/rho], S = U Sigma V^T (one-sided Jacobi on the K columns of length K+1):
 //   Beta = V (tau Sigma)/(tau^2 Sigma^2 + 1e-6) U^T h                  (ridge OLS, codes/funcs.py:1151-1155)
-//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + sum_j (1e-6/(tau^2 sigma_j^2 + 1e-6))^2 (u_j^T h)^2   (codes/funcs.py:1162)
-// where S = U Sigma V^T comes from a one-sided Jacobi sweep.  Everything is K-dimensional; the only O(N) inputs
-// are c, |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2
-// would cancel (candidate nearly inside the sibling span).
+//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + | h - U diag(d_m/(d_m + 1e-6)) U^T h |^2,  d_m = tau^2 sigma_m^2
+// (codes/funcs.py:1162): the first term is what lies outside the (K+1)-dimensional frame, the second the misfit
+// inside it -- the ridge shrinkage plus the one frame direction the new columns do not span (the old column k's own
+// contribution), measured as a residual vector, never as a difference of squares.  The only O(N) inputs are c,
+// |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2 would
+// cancel (candidate nearly inside the span of the current columns).
 struct SolveIn {
-  const ChainK* ck;
-  const double* c;   // LDS: projections of s*z on the basis (nq values)
+  const ChainB* ck;
+  const double* c;   // LDS: projections of s*z on the basis (K values)
   double rho2;       // |w|^2
   double wy;         // w . y
+  double zz;         // |s z|^2
   double tau, s, sigma, scale, maxabs;
-  int K, k, nq;
+  int K, k;
   int64_t N;
   uint32_t flags;
   double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
 };
 
-// K <= 4: the K x K factor, its one-sided Jacobi SVD (W = S V ends with mutually orthogonal columns
-// W[:,j] = sigma_j u_j) and the ridge formulas held entirely in registers (K is a template parameter: every index is
-// static).  All lanes compute the same values, so there is no cross-lane traffic at all.
+// entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
+__device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
+  if (m == K - 1) return (i < K) ? in.c[i < K ? i : 0] : rho;
+  const int j = (m < in.k) ? m : m + 1;            // sibling tree
+  if (i > j || i >= K) return 0.0;
+  const double dj = in.ck->d[j];
+  return (dj != 0.0) ? in.ck->R[i * BSR_NQ_MAX + j] * (in.s / dj) : 0.0;
+}
+
+__device__ __forceinline__ void store_score(const SolveIn& in, int K, bsr_score* out, double ll, double sse, double smin,
+                                            double smax, int rank, const double* bt) {
+  out->loglik = ll;
+  out->sse = sse;
+  out->scale = in.scale;
+  out->maxabs = in.maxabs;
+  out->smin = smin / in.s;
+  out->smax = smax / in.s;
+  out->rank = rank;
+  out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+}
+
+// K <= 4: the factor, its one-sided Jacobi SVD (W = S V ends with mutually orthogonal columns W[:,m] = sigma_m u_m)
+// and the ridge formulas held entirely in registers (K is a template parameter: every index is static).  All lanes
+// compute the same values, so there is no cross-lane traffic at all.
 template <int K>
 __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out) {
-  constexpr int NQ = K - 1;
+  constexpr int M = K + 1;
   const int k = in.k;
-  const ChainK* ck = in.ck;
-  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
-  double W[K][K], V[K][K];
+  const ChainB* ck = in.ck;
+  // a residual at the rounding level of s z (a candidate that reproduces a vector of the span, e.g. the old column
+  // itself) carries no direction: w = 0.  The cut is half of numpy's rank tolerance relative to |s z|, so it moves
+  // every singular value of the factor by less than half that tolerance.
+  const double rel_w = 0.5 * (double)((in.N > (int64_t)K) ? in.N : (int64_t)K) * 2.220446049250313e-16;
+  const double rho = (in.rho2 > fmax(1e-30, rel_w * rel_w) * in.zz) ? sqrt(in.rho2) : 0.0;
+  double W[M][K], V[K][K];
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) W[i][j] = factor_entry(in, K, i, j, rho);
 #pragma unroll
   for (int i = 0; i < K; ++i)
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      W[i][j] = (j < NQ) ? ((i <= j) ? ck->R[i * BSR_NQ_MAX + j] : 0.0) : ((i < NQ) ? in.c[i < NQ ? i : 0] : rho);
-      V[i][j] = (i == j) ? 1.0 : 0.0;
-    }
+    for (int j = 0; j < K; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0;
 #pragma unroll
@@ -685,7 +716,7 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
       for (int b = a + 1; b < K; ++b) {
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
+        for (int i = 0; i < M; ++i) {
           alpha = fma(W[i][a], W[i][a], alpha);
           beta = fma(W[i][b], W[i][b], beta);
           gamma = fma(W[i][a], W[i][b], gamma);
@@ -697,10 +728,14 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
           const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
           const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
 #pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const double wa = W[i][a], wb = W[i][b], va = V[i][a], vb = V[i][b];
+          for (int i = 0; i < M; ++i) {
+            const double wa = W[i][a], wb = W[i][b];
             W[i][a] = cs * wa - sn * wb;
             W[i][b] = sn * wa + cs * wb;
+          }
+#pragma unroll
+          for (int i = 0; i < K; ++i) {
+            const double va = V[i][a], vb = V[i][b];
             V[i][a] = cs * va - sn * vb;
             V[i][b] = sn * va + cs * vb;
           }
@@ -709,42 +744,41 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
     }
     if (off <= 1e-15) break;
   }
-  double h[K];
+  double h[M];
 #pragma unroll
-  for (int i = 0; i < K; ++i) h[i] = (i < NQ) ? ck->qy[i < NQ ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
-  double hh = 0.0;
-#pragma unroll
-  for (int i = 0; i < K; ++i) hh = fma(h[i], h[i], hh);
+  for (int i = 0; i < M; ++i) h[i] = (i < K) ? ck->qy[i < K ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
   const double eps = 1e-6;
-  double sv[K], coefj[K];
-  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
+  double sv[K], coefj[K], r[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) r[i] = h[i];
+  double smax = 0.0, smin = INFINITY;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     double n2 = 0.0, tj = 0.0;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
+    for (int i = 0; i < M; ++i) {
       n2 = fma(W[i][j], W[i][j], n2);
       tj = fma(W[i][j], h[i], tj);
     }
     sv[j] = sqrt(n2);
-    const double aj = (sv[j] > 0.0) ? tj / sv[j] : 0.0;
+    const double aj = (sv[j] > 0.0) ? tj / sv[j] : 0.0;                // u_j . h
     const double dj = (in.tau * sv[j]) * (in.tau * sv[j]);
-    const double wj = eps / (dj + eps);
     coefj[j] = (in.tau * sv[j]) / (dj + eps) * aj;
+    const double gj = (sv[j] > 0.0) ? dj / (dj + eps) * aj / sv[j] : 0.0;  // fitted share along u_j, per unit of W[:,j]
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(-gj, W[i][j], r[i]);
     smax = fmax(smax, sv[j]);
     smin = fmin(smin, sv[j]);
-    if (sv[j] > 0.0) {
-      misfit = fma(wj * wj, aj * aj, misfit);
-      seen = fma(aj, aj, seen);
-    }
   }
-  misfit += fmax(0.0, hh - seen);
+  double misfit = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) misfit = fma(r[i], r[i], misfit);
   const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
   const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);
   int rank = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) rank += (sv[j] > tol) ? 1 : 0;
-  const double sse = fmax(0.0, ck->yperp2 - h[NQ] * h[NQ]) + misfit;
+  const double sse = fmax(0.0, ck->yperp2 - h[K] * h[K]) + misfit;
   const double sigma = in.sigma;
   const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
   double bt[K];
@@ -756,61 +790,53 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
     bt[i] = bi;
   }
   if (lane == 0) {
-    out->loglik = ll;
-    out->sse = sse;
-    out->scale = in.scale;
-    out->maxabs = in.maxabs;
-    out->smin = smin / in.s;
-    out->smax = smax / in.s;
-    out->rank = rank;
-    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+    store_score(in, K, out, ll, sse, smin, smax, rank, bt);
 #pragma unroll
     for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int tree = (i == NQ) ? k : ((i < k) ? i : i + 1);
+      const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
       out->beta[tree] = bt[i];
     }
   }
 }
 
-// K = 5..8: eight lanes per proposal, lane j = lane & 7 owns column j of the K x K factor W and of V in registers
+// K = 5..8: eight lanes per proposal, lane j = lane & 7 owns column j of the (K+1) x K factor W and of V in registers
 // (the 8 lane groups of the wave hold identical copies).  One-sided Jacobi with the XOR tournament ordering: in round
 // r = 1..7 column j pairs with column j ^ r, so the four rotations of a round run side by side and a sweep is 7
-// dependent steps instead of 28; the only cross-lane traffic is the partner's column (2K shuffles per round), every
+// dependent steps instead of 28; the only cross-lane traffic is the partner's column (2K+1 shuffles per round), every
 // dot product is lane-local.  Both lanes of a pair evaluate the same expressions on the same operands, so they apply
 // bit-identical rotation coefficients.
 template <int K>
 __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out) {
-  constexpr int NQ = K - 1;
+  constexpr int M = K + 1;
   const int j = lane & 7;
   const int k = in.k;
-  const ChainK* ck = in.ck;
-  const double rho = (in.rho2 > 0.0) ? sqrt(in.rho2) : 0.0;
-  const int jr = (j < NQ) ? j : 0;
-  double W[K], V[K];
+  const ChainB* ck = in.ck;
+  // a residual at the rounding level of s z (a candidate that reproduces a vector of the span, e.g. the old column
+  // itself) carries no direction: w = 0.  The cut is half of numpy's rank tolerance relative to |s z|, so it moves
+  // every singular value of the factor by less than half that tolerance.
+  const double rel_w = 0.5 * (double)((in.N > (int64_t)K) ? in.N : (int64_t)K) * 2.220446049250313e-16;
+  const double rho = (in.rho2 > fmax(1e-30, rel_w * rel_w) * in.zz) ? sqrt(in.rho2) : 0.0;
+  double W[M], V[K];
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const double r = ck->R[i * BSR_NQ_MAX + jr];
-    const double cand = (i < NQ) ? in.c[i < NQ ? i : 0] : rho;
-    W[i] = (j < NQ) ? ((i <= j) ? r : 0.0) : ((j == NQ) ? cand : 0.0);
-    V[i] = (i == j) ? 1.0 : 0.0;
-  }
+  for (int i = 0; i < M; ++i) W[i] = (j < K) ? factor_entry(in, K, i, (j < K) ? j : 0, rho) : 0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) V[i] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0;
 #pragma unroll
     for (int r = 1; r < 8; ++r) {
       const int hb = (r >= 4) ? 4 : ((r >= 2) ? 2 : 1);
       const bool low = (j & hb) == 0;  // j < (j ^ r)
-      double Wp[K], Vp[K];
+      double Wp[M], Vp[K];
       double mine = 0.0, theirs = 0.0, gamma = 0.0;
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        Wp[i] = __shfl_xor(W[i], r);
-        Vp[i] = __shfl_xor(V[i], r);
-      }
+      for (int i = 0; i < M; ++i) Wp[i] = __shfl_xor(W[i], r);
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
+      for (int i = 0; i < K; ++i) Vp[i] = __shfl_xor(V[i], r);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
         mine = fma(W[i], W[i], mine);
         theirs = fma(Wp[i], Wp[i], theirs);
         gamma = fma(W[i], Wp[i], gamma);
@@ -824,10 +850,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
         const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
         const double sp = low ? -sn : sn;  // low column: cs*W - sn*Wp ; high column: sn*Wp + cs*W
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-          W[i] = cs * W[i] + sp * Wp[i];
-          V[i] = cs * V[i] + sp * Vp[i];
-        }
+        for (int i = 0; i < M; ++i) W[i] = cs * W[i] + sp * Wp[i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) V[i] = cs * V[i] + sp * Vp[i];
       }
     }
     off = fmax(off, __shfl_xor(off, 1));
@@ -835,13 +860,12 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
     off = fmax(off, __shfl_xor(off, 4));
     if (off <= 1e-15) break;  // wave-uniform: the lane groups are copies of each other
   }
-  double h[K];
+  double h[M];
 #pragma unroll
-  for (int i = 0; i < K; ++i) h[i] = (i < NQ) ? ck->qy[i < NQ ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
-  double hh = 0.0, n2 = 0.0, tj = 0.0;
+  for (int i = 0; i < M; ++i) h[i] = (i < K) ? ck->qy[i < K ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  double n2 = 0.0, tj = 0.0;
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    hh = fma(h[i], h[i], hh);
+  for (int i = 0; i < M; ++i) {
     n2 = fma(W[i], W[i], n2);
     tj = fma(W[i], h[i], tj);
   }
@@ -849,9 +873,20 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
   const double sv = sqrt(n2);                                   // sigma_j
   const double aj = (sv > 0.0 && j < K) ? tj / sv : 0.0;        // u_j . h
   const double dj = (in.tau * sv) * (in.tau * sv);
-  const double wj = eps / (dj + eps);
   const double coef = (j < K) ? (in.tau * sv) / (dj + eps) * aj : 0.0;
-  double smax = 0.0, smin = INFINITY, misfit = 0.0, seen = 0.0;
+  const double gj = (sv > 0.0 && j < K) ? dj / (dj + eps) * aj / sv : 0.0;
+  // residual inside the frame: r = h - sum_j u_j (d_j/(d_j+eps)) (u_j . h), summed over the 8 column lanes
+  double misfit = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double t = gj * W[i];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
+    const double ri = h[i] - t;
+    misfit = fma(ri, ri, misfit);
+  }
+  double smax = 0.0, smin = INFINITY;
 #pragma unroll
   for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a, 8));
   const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
@@ -859,16 +894,11 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
   int rank = 0;
 #pragma unroll
   for (int a = 0; a < K; ++a) {
-    const double sva = __shfl(sv, a, 8), aa = __shfl(aj, a, 8), wa = __shfl(wj, a, 8);
+    const double sva = __shfl(sv, a, 8);
     smin = fmin(smin, sva);
     rank += (sva > tol) ? 1 : 0;
-    if (sva > 0.0) {
-      misfit = fma(wa * wa, aa * aa, misfit);
-      seen = fma(aa, aa, seen);
-    }
   }
-  misfit += fmax(0.0, hh - seen);                               // directions with sigma == 0 keep all of h
-  const double sse = fmax(0.0, ck->yperp2 - h[NQ] * h[NQ]) + misfit;
+  const double sse = fmax(0.0, ck->yperp2 - h[K] * h[K]) + misfit;
   const double sigma = in.sigma;
   const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
   double bt[K];                                                 // Beta'_i = sum_j V[i][j] coef_j
@@ -881,19 +911,12 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
     bt[i] = b;
   }
   if (lane == 0) {
-    out->loglik = ll;
-    out->sse = sse;
-    out->scale = in.scale;
-    out->maxabs = in.maxabs;
-    out->smin = smin / in.s;
-    out->smax = smax / in.s;
-    out->rank = rank;
-    out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+    store_score(in, K, out, ll, sse, smin, smax, rank, bt);
 #pragma unroll
     for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int tree = (i == NQ) ? k : ((i < k) ? i : i + 1);
+      const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
       out->beta[tree] = bt[i];
     }
   }
@@ -912,29 +935,29 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
   }
 }
 
-__global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainK* __restrict__ cks,
+__global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
                                                     double rank_floor) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
-  __shared__ double sh_c[8];
+  __shared__ double sh_c[BSR_NQ_MAX];
 
-  double sum[9];
+  double sum[BSR_NQ_MAX + 2];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) sum[i] = 0.0;
+  for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = 0.0;
   double amax = 0.0;
   uint32_t fl = 0;
   for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
     const double* q = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sum[i] += q[i];
-    amax = fmax(amax, q[9]);
-    fl |= (uint32_t)q[10];
+    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += q[i];
+    amax = fmax(amax, q[10]);
+    fl |= (uint32_t)q[11];
   }
 #pragma unroll
-  for (int i = 0; i < 9; ++i) sum[i] = wave_sum(sum[i]);
+  for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = wave_sum(sum[i]);
   amax = wave_max(amax);
   fl = wave_or(fl);
   if (fl & BSR_F_INF) amax = INFINITY;
@@ -953,9 +976,9 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   }
   const int K = dsc[p].K, k = dsc[p].k, nq = dsc[p].nq;
   const double s = dsc[p].s;
-  const ChainK* ck = cks + dsc[p].ck;
-  const uint32_t flags = fl | ck->flags;
-  const double scale_ref = fmax(ck->m_other, amax);
+  const ChainB* ck = cks + dsc[p].ck;
+  const uint32_t flags = fl | ck->flags_k[k];
+  const double scale_ref = fmax(ck->m_other[k], amax);
   if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
     if (lane == 0) {
       cf->skip = 1;
@@ -970,9 +993,9 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
     if (lane < BSR_MAX_K) out->beta[lane] = NAN;
     return;
   }
-  const double zz = sum[7], zy = sum[8];
-  if (nq == 0) {
-    // K == 1: no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
+  const double zz = sum[BSR_NQ_MAX], zy = sum[BSR_NQ_MAX + 1];
+  if (K == 1) {
+    // no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
     const double as = amax * s;
     if (as > 0.0 && (as > 0x1p400 || as < 0x1p-400)) {
       if (lane == 0) {
@@ -999,7 +1022,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
     }
   }
   const double rho2 = zz - cc;
-  // the candidate is (nearly) inside the sibling span: |w|^2 and w.y come from the direct residual pass instead
+  // the candidate is (nearly) inside the span of the current columns: |w|^2 and w.y come from the direct residual pass
   const bool ambiguous = (nq > 0) && !(rho2 > 1e-6 * zz);
   if (ambiguous) {
     if (lane < BSR_NQ_MAX) cf->c[lane] = (lane < nq) ? sh_c[lane] : 0.0;
@@ -1019,6 +1042,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   in.ck = ck;
   in.c = sh_c;
   in.rho2 = rho2;
+  in.zz = zz;
   in.wy = zy - cqy;
   in.tau = 1.0 / (s * scale_ref);
   in.s = s;
@@ -1027,7 +1051,6 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   in.maxabs = amax;
   in.K = K;
   in.k = k;
-  in.nq = nq;
   in.N = N;
   in.flags = flags;
   in.rank_floor = rank_floor;
@@ -1037,7 +1060,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // finalize (only proposals flagged by k_solve): same algebra with the directly measured |w|^2 and w.y
 __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
-                                                       const ChainK* __restrict__ cks,
+                                                       const ChainB* __restrict__ cks,
                                                        const PropCoef* __restrict__ coef, int P, int n_rb,
                                                        const double* __restrict__ part2, int64_t N,
                                                        bsr_score* __restrict__ outv, double rank_floor) {
@@ -1046,7 +1069,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   const PropCoef* cf = coef + p;
   if (cf->skip) return;
-  __shared__ double sh_c[8];
+  __shared__ double sh_c[BSR_NQ_MAX];
   double ww = 0.0, wy = 0.0;
   for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
     const double* q = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
@@ -1055,12 +1078,13 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   }
   ww = wave_sum(ww);
   wy = wave_sum(wy);
-  if (lane < 8) sh_c[lane] = (lane < BSR_NQ_MAX) ? cf->c[lane] : 0.0;
+  if (lane < BSR_NQ_MAX) sh_c[lane] = cf->c[lane];
   __syncthreads();
   SolveIn in;
   in.ck = cks + dsc[p].ck;
   in.c = sh_c;
   in.rho2 = ww;
+  in.zz = cf->zz;
   in.wy = wy;
   in.tau = cf->tau;
   in.s = cf->s;
@@ -1069,7 +1093,6 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   in.maxabs = cf->maxabs;
   in.K = dsc[p].K;
   in.k = dsc[p].k;
-  in.nq = dsc[p].nq;
   in.N = N;
   in.flags = cf->flags;
   in.rank_floor = rank_floor;
@@ -1111,117 +1134,114 @@ __device__ __forceinline__ double pow2_prescale(double m) {
   return ldexp(1.0, -e);
 }
 
-// Leave-one-out bases.  grid.x = K (which column is left out), block = 1024 threads.
-// s * O_j = Q R for the siblings j != kk in ascending order; Gram-Schmidt with three orthogonalisation sweeps.
+// The chain's basis by Gram-Schmidt (fallback of the Cholesky-QR pipeline in bsr_refresh.hip: dependent or
+// non-finite columns).  grid = 1 block of 1024 threads.  O_m d_m = Q R over all K current columns, three
+// orthogonalisation sweeps per column; a column that holds inf/NaN enters as a zero column, a column that is exactly
+// dependent on its predecessors ends as a zero basis vector with R_mm = 0.
 template <typename T>
-__global__ __launch_bounds__(BSR_BLK) void k_refresh_basis(const T* __restrict__ cur, T* __restrict__ Qc,
+__global__ __launch_bounds__(BSR_BLK) void k_refresh_basis(const T* __restrict__ cur, T* __restrict__ Q,
                                                            const T* __restrict__ y, int64_t ld, int64_t N, int K,
                                                            const double* __restrict__ col_maxabs,
                                                            const uint32_t* __restrict__ col_flags,
-                                                           ChainK* __restrict__ ck_chain) {
-  const int kk = blockIdx.x;
-  const int nq = K - 1;
-  T* Q = Qc + (int64_t)kk * nq * ld;
-  ChainK* ck = ck_chain + kk;
-  __shared__ double sh[(BSR_BLK_WAVES + 1) * 8];
+                                                           ChainB* __restrict__ cb) {
+  __shared__ double sh[(BSR_BLK_WAVES + 1) * 9];
   __shared__ double shR[BSR_NQ_MAX * BSR_NQ_MAX];
   __shared__ double shqy[BSR_NQ_MAX];
+  __shared__ double shd[BSR_NQ_MAX];
 
-  double m_other = 0.0;
-  uint32_t flags = 0;
-  for (int j = 0; j < K; ++j) {
-    if (j == kk) continue;
-    m_other = fmax(m_other, col_maxabs[j]);
-    flags |= col_flags[j];
-  }
-  if (flags & BSR_F_INF) m_other = INFINITY;
-  const double s = pow2_prescale(m_other);
   if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) shR[threadIdx.x] = 0.0;
-  if (threadIdx.x < BSR_NQ_MAX) shqy[threadIdx.x] = 0.0;
+  if (threadIdx.x < BSR_NQ_MAX) {
+    shqy[threadIdx.x] = 0.0;
+    const int j = threadIdx.x;
+    shd[j] = (j < K && !(col_flags[j] & (BSR_F_INF | BSR_F_NAN))) ? pow2_prescale(col_maxabs[j]) : 0.0;
+    // per-k census of the sibling columns
+    double m_other = 0.0;
+    uint32_t fl = 0;
+    for (int i = 0; i < K; ++i) {
+      if (i == j) continue;
+      m_other = fmax(m_other, col_maxabs[i]);
+      fl |= col_flags[i] & (BSR_F_INF | BSR_F_NAN);
+    }
+    if (fl & BSR_F_INF) m_other = INFINITY;
+    cb->s_k[j] = (j < K) ? pow2_prescale(m_other) : 1.0;
+    cb->m_other[j] = (j < K) ? m_other : 0.0;
+    cb->flags_k[j] = (j < K) ? fl : 0u;
+  }
   __syncthreads();
 
-  if (!(flags & (BSR_F_INF | BSR_F_NAN))) {
-    for (int m = 0; m < nq; ++m) {
-      const int jm = (m < kk) ? m : m + 1;
-      const T* src = cur + (int64_t)jm * ld;
-      T* v = Q + (int64_t)m * ld;
-      double h[8];
-      // sweep 0: v = s * O_jm ; h = Q^T v
+  for (int m = 0; m < K; ++m) {
+    const T* src = cur + (int64_t)m * ld;
+    T* v = Q + (int64_t)m * ld;
+    const double dm = shd[m];
+    double h[9];
+    // sweep 0: v = d_m * O_m ; h = Q^T v
 #pragma unroll
-      for (int i = 0; i < 8; ++i) h[i] = 0.0;
+    for (int i = 0; i < 9; ++i) h[i] = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+      const double x = (dm != 0.0) ? dm * (double)src[n] : 0.0;
+      v[n] = (T)x;
+      const double xv = (double)v[n];
+#pragma unroll
+      for (int i = 0; i < BSR_NQ_MAX; ++i)
+        if (i < m) h[i] = fma((double)Q[(int64_t)i * ld + n], xv, h[i]);
+      h[8] = fma(xv, xv, h[8]);
+    }
+    block_sum<9>(h, sh);
+    // three orthogonalisation sweeps: v -= Q h ; h = Q^T v
+    for (int sweep = 0; sweep < 3; ++sweep) {
+      if (m == 0) break;
+      if (threadIdx.x < BSR_NQ_MAX && (int)threadIdx.x < m) shR[threadIdx.x * BSR_NQ_MAX + m] += h[threadIdx.x];
+      double hn[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) hn[i] = 0.0;
       for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
-        const double x = s * (double)src[n];
+        double x = (double)v[n];
+#pragma unroll
+        for (int i = 0; i < BSR_NQ_MAX; ++i)
+          if (i < m) x = fma(-h[i], (double)Q[(int64_t)i * ld + n], x);
         v[n] = (T)x;
         const double xv = (double)v[n];
 #pragma unroll
         for (int i = 0; i < BSR_NQ_MAX; ++i)
-          if (i < m) h[i] = fma((double)Q[(int64_t)i * ld + n], xv, h[i]);
+          if (i < m) hn[i] = fma((double)Q[(int64_t)i * ld + n], xv, hn[i]);
+        hn[8] = fma(xv, xv, hn[8]);
       }
-      block_sum<8>(h, sh);
-      // three orthogonalisation sweeps: v -= Q h ; h = Q^T v
-      for (int sweep = 0; sweep < 3; ++sweep) {
-        if (threadIdx.x < BSR_NQ_MAX && (int)threadIdx.x < m) shR[threadIdx.x * BSR_NQ_MAX + m] += h[threadIdx.x];
-        double hn[8];
+      block_sum<9>(hn, sh);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hn[i] = 0.0;
-        for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
-          double x = (double)v[n];
-#pragma unroll
-          for (int i = 0; i < BSR_NQ_MAX; ++i)
-            if (i < m) x = fma(-h[i], (double)Q[(int64_t)i * ld + n], x);
-          v[n] = (T)x;
-          const double xv = (double)v[n];
-#pragma unroll
-          for (int i = 0; i < BSR_NQ_MAX; ++i)
-            if (i < m) hn[i] = fma((double)Q[(int64_t)i * ld + n], xv, hn[i]);
-          hn[7] = fma(xv, xv, hn[7]);
-        }
-        block_sum<8>(hn, sh);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = hn[i];
-        if (m == 0) break;
-      }
-      const double r = sqrt(h[7]);
-      const double inv = (r > 0.0) ? 1.0 / r : 0.0;
-      double qy[1] = {0.0};
-      for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
-        const double x = (double)v[n] * inv;
-        v[n] = (T)x;
-        qy[0] = fma((double)v[n], (double)y[n], qy[0]);
-      }
-      block_sum<1>(qy, sh);
-      if (threadIdx.x == 0) {
-        shR[m * BSR_NQ_MAX + m] = r;
-        shqy[m] = qy[0];
-      }
-      __syncthreads();
+      for (int i = 0; i < 9; ++i) h[i] = hn[i];
     }
+    const double r = sqrt(h[8]);
+    const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+    double qy[1] = {0.0};
+    for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+      const double x = (double)v[n] * inv;
+      v[n] = (T)x;
+      qy[0] = fma((double)v[n], (double)y[n], qy[0]);
+    }
+    block_sum<1>(qy, sh);
+    if (threadIdx.x == 0) {
+      shR[m * BSR_NQ_MAX + m] = r;
+      shqy[m] = qy[0];
+    }
+    __syncthreads();
   }
   __syncthreads();
-  // |y - Q Q^T y|^2 measured directly (with no finite basis: |y|^2)
+  // |y - Q Q^T y|^2 measured directly
   double yp[1] = {0.0};
-  {
-    const bool useq = !(flags & (BSR_F_INF | BSR_F_NAN));
-    for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
-      double r = (double)y[n];
-      if (useq) {
+  for (int64_t n = threadIdx.x; n < N; n += BSR_BLK) {
+    double r = (double)y[n];
 #pragma unroll
-        for (int i = 0; i < BSR_NQ_MAX; ++i)
-          if (i < nq) r = fma(-shqy[i], (double)Q[(int64_t)i * ld + n], r);
-      }
-      yp[0] = fma(r, r, yp[0]);
-    }
+    for (int i = 0; i < BSR_NQ_MAX; ++i)
+      if (i < K) r = fma(-shqy[i], (double)Q[(int64_t)i * ld + n], r);
+    yp[0] = fma(r, r, yp[0]);
   }
   block_sum<1>(yp, sh);
-  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) ck->R[threadIdx.x] = shR[threadIdx.x];
-  if (threadIdx.x < BSR_NQ_MAX) ck->qy[threadIdx.x] = shqy[threadIdx.x];
-  if (threadIdx.x == 0) {
-    ck->yperp2 = yp[0];
-    ck->s = s;
-    ck->m_other = m_other;
-    ck->flags = flags;
-    ck->pad = 0;
+  if (threadIdx.x < BSR_NQ_MAX * BSR_NQ_MAX) cb->R[threadIdx.x] = shR[threadIdx.x];
+  if (threadIdx.x < BSR_NQ_MAX) {
+    cb->qy[threadIdx.x] = shqy[threadIdx.x];
+    cb->d[threadIdx.x] = shd[threadIdx.x];
   }
+  if (threadIdx.x == 0) cb->yperp2 = yp[0];
 }
 
 // Ridge OLS of y on [1?, O_0..O_{K-1}] exactly as codes/funcs.py:1148-1162 / codes/bsr_class.py:147-163.
@@ -1463,23 +1483,23 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
     else launch_rows_nq<T, n, MODE_PROJECT>(st, a);        \
     break;
   switch (nq) {
-    BSR_CASE(0) BSR_CASE(1) BSR_CASE(2) BSR_CASE(3) BSR_CASE(4) BSR_CASE(5) BSR_CASE(6) BSR_CASE(7)
+    BSR_CASE(0) BSR_CASE(1) BSR_CASE(2) BSR_CASE(3) BSR_CASE(4) BSR_CASE(5) BSR_CASE(6) BSR_CASE(7) BSR_CASE(8)
   }
 #undef BSR_CASE
 }
-void launch_solve(hipStream_t st, const PropDesc* desc, const ChainK* ck, int P, int n_rb, const double* part1,
+void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor) {
   hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor);
 }
-void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainK* ck, const PropCoef* coef, int P, int n_rb,
+void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor) {
   hipLaunchKernelGGL(k_finalize, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out, rank_floor);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
-                          const double* col_maxabs, const uint32_t* col_flags, ChainK* ck_chain) {
-  hipLaunchKernelGGL((k_refresh_basis<T>), dim3(K), dim3(BSR_BLK), 0, st, cur, Q, y, ld, N, K, col_maxabs,
-                     col_flags, ck_chain);
+                          const double* col_maxabs, const uint32_t* col_flags, ChainB* cb) {
+  hipLaunchKernelGGL((k_refresh_basis<T>), dim3(1), dim3(BSR_BLK), 0, st, cur, Q, y, ld, N, K, col_maxabs,
+                     col_flags, cb);
 }
 template <typename T>
 void launch_chain_fit(hipStream_t st, const T* cols, const T* y, int64_t ld, int64_t N, int K, int intercept,
@@ -1504,7 +1524,7 @@ void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t n) {
 #define BSR_INSTANTIATE(T)                                                                                          \
   template void launch_rows<T>(hipStream_t, const RowPassArgs<T>&, int, int);                                       \
   template void launch_refresh_basis<T>(hipStream_t, const T*, T*, const T*, int64_t, int64_t, int, const double*,  \
-                                        const uint32_t*, ChainK*);                                                  \
+                                        const uint32_t*, ChainB*);                                                  \
   template void launch_chain_fit<T>(hipStream_t, const T*, const T*, int64_t, int64_t, int, int, ChainFitOut*);     \
   template void launch_transpose_in<T>(hipStream_t, const double*, T*, int64_t, int, int64_t);                      \
   template void launch_convert_out<T>(hipStream_t, const T*, double*, int64_t);                                     \

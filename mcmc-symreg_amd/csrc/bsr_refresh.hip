@@ -4,16 +4,19 @@
 //   r1 k_rf_gram    (row blocks)  Gram of the K current columns, y and the constant, each column prescaled by its
 //                                 own power of two
 //   r2 k_rf_plan    (1 block)     old-state ridge OLS (codes/funcs.py:1148-1155) and intercept ridge OLS
-//                                 (codes/bsr_class.py:147-163); for every k the Cholesky factor R1 of the
-//                                 leave-one-out sub-Gram and T1 = R1^-1
-//   r3 k_rf_apply1  (row blocks)  Q1_(k) = (s_k O_(k)) T1, its Gram and Q1^T y; direct residual SSE of both fits
+//                                 (codes/bsr_class.py:147-163); Cholesky factor R1 of the Gram of the K prescaled
+//                                 columns and T1 = R1^-1
+//   r3 k_rf_apply1  (row blocks)  Q1 = (O D) T1, its Gram and Q1^T y; direct residual SSE of both fits
 //   r4 k_rf_plan2   (1 block)     second Cholesky (CholeskyQR2): T2, R = R2 R1, Q^T y; fit results
-//   r5 k_rf_apply2  (row blocks)  Q_(k) = Q1_(k) T2 in place; |y - Q Q^T y|^2
-//   r6 k_rf_final   (1 block)     reduce, publish ChainK
+//   r5 k_rf_apply2  (row blocks)  Q = Q1 T2 in place; |y - Q Q^T y|^2
+//   r6 k_rf_final   (1 block)     reduce, publish ChainB
 //
-// CholeskyQR2 is as accurate as Gram-Schmidt while cond(O_(k)) < ~1e5; a basis whose first Cholesky shows a pivot
-// ratio below 1e-10 (or a non-positive pivot: dependent siblings, e.g. two identical initial trees) is flagged and
-// rebuilt by the single-workgroup Gram-Schmidt kernel k_refresh_basis (bsr_kernels.hip).
+// ONE basis of all K current columns per chain (a proposal for tree k uses R with column k removed, bsr_kernels.hip
+// k_solve): K basis columns to keep, read and rebuild instead of K(K-1) leave-one-out ones.
+// CholeskyQR2 is as accurate as Gram-Schmidt while cond(O D) < ~1e5; a chain whose first Cholesky shows a pivot
+// ratio below 1e-10 (or a non-positive pivot: dependent columns, e.g. two identical initial trees, or a column
+// holding inf/NaN) is flagged and rebuilt by the single-workgroup Gram-Schmidt kernel k_refresh_basis
+// (bsr_kernels.hip).
 #include "bsr_internal.h"
 
 #define RF_THREADS 256
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan(const RefreshIn* __restr
                                                         RefreshPlan* __restrict__ plan) {
   __shared__ double G[RF_GW];
   __shared__ double shA[RF_LDM * RF_LDM], shI[RF_LDM * RF_LDM];
-  __shared__ double sub[RF_MAXK][RF_NQ * RF_NQ], Rk[RF_MAXK][RF_NQ * RF_NQ], Tk[RF_MAXK][RF_NQ * RF_NQ];
+  __shared__ double sub[RF_NQ * RF_NQ], Rk[RF_NQ * RF_NQ], Tk[RF_NQ * RF_NQ];
   __shared__ double sc[RF_MAXK];
   __shared__ int shpiv;
   const int nG = K * (K + 1) / 2;
@@ -279,10 +282,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan(const RefreshIn* __restr
     plan->beta_icpt[threadIdx.x] = NAN;
   }
   __syncthreads();
-  // ---- leave-one-out factors: thread k handles basis k
+  // ---- per-k candidate prescale / sibling census (thread k), Cholesky of the whole prescaled Gram (thread 0)
   if ((int)threadIdx.x < K) {
     const int k = threadIdx.x;
-    const int nq = K - 1;
     double m_other = 0.0;
     uint32_t fl = 0;
     for (int j = 0; j < K; ++j) {
@@ -291,45 +293,39 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan(const RefreshIn* __restr
       fl |= in->colflags[j] & (BSR_F_INF | BSR_F_NAN);
     }
     if (fl & BSR_F_INF) m_other = INFINITY;
-    const double sk = rf_pow2_prescale(m_other);
-    plan->s_k[k] = sk;
+    plan->s_k[k] = rf_pow2_prescale(m_other);
     plan->m_other[k] = m_other;
     plan->flags_k[k] = fl;
-    int fallback = 0;
-    if (!fl && nq > 0) {
-      for (int a = 0; a < nq; ++a)
-        for (int b = 0; b < nq; ++b) {
-          const int ja = (a < k) ? a : a + 1, jb = (b < k) ? b : b + 1;
-          sub[k][a * RF_NQ + b] = Gs(ja, jb) * (sk / sc[ja]) * (sk / sc[jb]);
-        }
-      const double ratio = rf_chol_inv(sub[k], nq, Rk[k], Tk[k]);
-      if (!(ratio > 1e-10)) fallback = 1;
-    }
-    plan->fallback[k] = fallback;
+    plan->dcol[k] = sc[k];
+  }
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < K; ++a)
+      for (int b = 0; b < K; ++b) sub[a * RF_NQ + b] = Gs(a, b);
+    const double ratio = rf_chol_inv(sub, K, Rk, Tk);
+    plan->fallback = (ratio > 1e-10) ? 0 : 1;
+    plan->pad2 = 0;
     for (int i = 0; i < RF_NQ * RF_NQ; ++i) {
-      plan->R1[k][i] = (!fl && nq > 0) ? Rk[k][i] : 0.0;
-      plan->T1[k][i] = (!fl && nq > 0) ? Tk[k][i] : 0.0;
+      plan->R1[i] = Rk[i];
+      plan->T1[i] = Tk[i];
     }
   }
 }
 
 // r3 ---------------------------------------------------------------------------------------------------------------
-// per block and k: words = nq(nq+1)/2 (Gram of Q1) + nq (Q1^T y); plus 2 words for the two direct residuals
-#define RF_AW 40
-template <typename T, int NQ>
-__global__ __launch_bounds__(RF_THREADS) void k_rf_apply1(const T* __restrict__ cols, T* __restrict__ Qc,
+// per block: words = K(K+1)/2 (Gram of Q1) + K (Q1^T y); plus 2 words for the two direct residuals
+#define RF_AW 48
+template <typename T, int K>
+__global__ __launch_bounds__(RF_THREADS) void k_rf_apply1(const T* __restrict__ cols, T* __restrict__ Q,
                                                           const T* __restrict__ y, int64_t ld, int64_t N,
                                                           int rows_per_block, const RefreshPlan* __restrict__ plan,
                                                           double* __restrict__ part) {
-  constexpr int K = NQ + 1;
-  constexpr int nGq = NQ * (NQ + 1) / 2;
-  constexpr int nW = nGq + NQ;
-  constexpr int nS = (nW > 2) ? nW : 2;
-  __shared__ double sh[4 * nS];
-  __shared__ double outv[nS];
+  constexpr int nGq = K * (K + 1) / 2;
+  constexpr int nW = nGq + K;
+  __shared__ double sh[4 * nW];
+  __shared__ double outv[nW];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
-  double* o = part + (size_t)blockIdx.x * (RF_MAXK * RF_AW + 8);
+  double* o = part + (size_t)blockIdx.x * (RF_AW + 8);
   const bool fits = plan->anyflags == 0;
   // direct residuals of the two fits
   {
@@ -356,67 +352,59 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_apply1(const T* __restrict__ 
       }
     }
     rf_block_sum<2>(acc, sh, outv);
-    if (threadIdx.x < 2) o[RF_MAXK * RF_AW + threadIdx.x] = outv[threadIdx.x];
+    if (threadIdx.x < 2) o[RF_AW + threadIdx.x] = outv[threadIdx.x];
     __syncthreads();
   }
-  if constexpr (NQ > 0) {
-    for (int k = 0; k < K; ++k) {
-      if (plan->flags_k[k] || plan->fallback[k]) continue;
-      const double sk = plan->s_k[k];
-      T* Q = Qc + (int64_t)k * NQ * ld;
-      double t1[nGq];  // upper triangle of T1 (uniform: scalar registers)
-      {
-        int w = 0;
+  if (plan->fallback) return;
+  double t1[nGq], dc[K];  // upper triangle of T1 and the column prescales (uniform: scalar registers)
+  {
+    int w = 0;
 #pragma unroll
-        for (int a_ = 0; a_ < NQ; ++a_)
+    for (int a_ = 0; a_ < K; ++a_)
 #pragma unroll
-          for (int b_ = a_; b_ < NQ; ++b_, ++w) t1[w] = plan->T1[k][a_ * RF_NQ + b_];
-      }
-      double acc[nW];
+      for (int b_ = a_; b_ < K; ++b_, ++w) t1[w] = plan->T1[a_ * RF_NQ + b_];
 #pragma unroll
-      for (int q = 0; q < nW; ++q) acc[q] = 0.0;
-      for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-        double v[NQ], q1[NQ];
-#pragma unroll
-        for (int a_ = 0; a_ < NQ; ++a_) {
-          const int ja = (a_ < k) ? a_ : a_ + 1;
-          v[a_] = sk * (double)cols[(int64_t)ja * ld + n];
-        }
-#pragma unroll
-        for (int b_ = 0; b_ < NQ; ++b_) {
-          double t = 0.0;
-#pragma unroll
-          for (int a_ = 0; a_ <= b_; ++a_) t = fma(v[a_], t1[a_ * NQ - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
-          q1[b_] = t;
-          Q[(int64_t)b_ * ld + n] = (T)t;
-        }
-        const double yv = (double)y[n];
-        int w = 0;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i)
-#pragma unroll
-          for (int j = i; j < NQ; ++j, ++w) acc[w] = fma(q1[i], q1[j], acc[w]);
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) acc[nGq + i] = fma(q1[i], yv, acc[nGq + i]);
-      }
-      rf_block_sum<nW>(acc, sh, outv);
-      if (threadIdx.x < nW) o[k * RF_AW + threadIdx.x] = outv[threadIdx.x];
-      __syncthreads();
-    }
+    for (int j = 0; j < K; ++j) dc[j] = plan->dcol[j];
   }
+  double acc[nW];
+#pragma unroll
+  for (int q = 0; q < nW; ++q) acc[q] = 0.0;
+  for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
+    double v[K], q1[K];
+#pragma unroll
+    for (int a_ = 0; a_ < K; ++a_) v[a_] = (dc[a_] != 0.0) ? dc[a_] * (double)cols[(int64_t)a_ * ld + n] : 0.0;
+#pragma unroll
+    for (int b_ = 0; b_ < K; ++b_) {
+      double t = 0.0;
+#pragma unroll
+      for (int a_ = 0; a_ <= b_; ++a_) t = fma(v[a_], t1[a_ * K - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
+      q1[b_] = t;
+      Q[(int64_t)b_ * ld + n] = (T)t;
+    }
+    const double yv = (double)y[n];
+    int w = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int j = i; j < K; ++j, ++w) acc[w] = fma(q1[i], q1[j], acc[w]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[nGq + i] = fma(q1[i], yv, acc[nGq + i]);
+  }
+  rf_block_sum<nW>(acc, sh, outv);
+  if (threadIdx.x < nW) o[threadIdx.x] = outv[threadIdx.x];
 }
 
 // r4 ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RF_THREADS) void k_rf_plan2(int K, int64_t N, int n_blocks, const double* __restrict__ part,
-                                                         RefreshPlan* __restrict__ plan, ChainK* __restrict__ ck,
+                                                         RefreshPlan* __restrict__ plan, ChainB* __restrict__ cb,
                                                          ChainFitOut* __restrict__ fit_noicpt,
                                                          ChainFitOut* __restrict__ fit_icpt,
                                                          const RefreshIn* __restrict__ in) {
-  __shared__ double W[RF_MAXK * RF_AW + 8];
-  __shared__ double sub[RF_MAXK][RF_NQ * RF_NQ], Rk[RF_MAXK][RF_NQ * RF_NQ], Tk[RF_MAXK][RF_NQ * RF_NQ];
-  const int stride = RF_MAXK * RF_AW + 8;
+  __shared__ double W[RF_AW + 8];
+  __shared__ double sub[RF_NQ * RF_NQ], Rk[RF_NQ * RF_NQ], Tk[RF_NQ * RF_NQ];
+  const int stride = RF_AW + 8;
   {
-    __shared__ double red[4][RF_MAXK * RF_AW + 8];
+    __shared__ double red[4][RF_AW + 8];
     const int slice = threadIdx.x >> 6;
     for (int w = threadIdx.x & 63; w < stride; w += 64) {
       double t = 0.0;
@@ -428,13 +416,12 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan2(int K, int64_t N, int n
     for (int w = threadIdx.x; w < stride; w += RF_THREADS) W[w] = ((red[0][w] + red[1][w]) + red[2][w]) + red[3][w];
   }
   __syncthreads();
-  const int nq = K - 1;
   if (threadIdx.x == 0) {
     const bool ok = plan->anyflags == 0;
-    fit_noicpt->sse = ok ? W[RF_MAXK * RF_AW] : NAN;
+    fit_noicpt->sse = ok ? W[RF_AW] : NAN;
     fit_noicpt->scale = plan->scale_fit;
     fit_noicpt->anyflags = plan->anyflags;
-    fit_icpt->sse = ok ? W[RF_MAXK * RF_AW + 1] : NAN;
+    fit_icpt->sse = ok ? W[RF_AW + 1] : NAN;
     fit_icpt->scale = fmax(1.0, plan->scale_fit);
     fit_icpt->anyflags = plan->anyflags;
     for (int j = 0; j < K; ++j) {
@@ -443,137 +430,119 @@ __global__ __launch_bounds__(RF_THREADS) void k_rf_plan2(int K, int64_t N, int n
       fit_noicpt->colflags[j] = in->colflags[j];
     }
     for (int j = 0; j <= K; ++j) fit_icpt->beta_unscaled[j] = plan->beta_icpt[j];
-  }
-  if ((int)threadIdx.x < K) {
-    const int k = threadIdx.x;
-    ChainK* c = ck + k;
-    c->s = plan->s_k[k];
-    c->m_other = plan->m_other[k];
-    c->flags = plan->flags_k[k];
-    c->pad = 0;
-    for (int i = 0; i < RF_NQ * RF_NQ; ++i) c->R[i] = 0.0;
-    for (int i = 0; i < RF_NQ; ++i) c->qy[i] = 0.0;
-    if (nq > 0 && !plan->flags_k[k] && !plan->fallback[k]) {
-      const int nGq = nq * (nq + 1) / 2;
-      const double* w = W + k * RF_AW;
-      for (int a = 0; a < nq; ++a)
-        for (int b = a; b < nq; ++b) {
-          const double v = w[gidx(a, b, nq)];
-          sub[k][a * RF_NQ + b] = v;
-          sub[k][b * RF_NQ + a] = v;
+    for (int k = 0; k < RF_MAXK; ++k) {
+      cb->s_k[k] = (k < K) ? plan->s_k[k] : 1.0;
+      cb->m_other[k] = (k < K) ? plan->m_other[k] : 0.0;
+      cb->flags_k[k] = (k < K) ? plan->flags_k[k] : 0u;
+      cb->d[k] = (k < K) ? plan->dcol[k] : 0.0;
+      cb->qy[k] = 0.0;
+    }
+    for (int i = 0; i < RF_NQ * RF_NQ; ++i) cb->R[i] = 0.0;
+    if (!plan->fallback) {
+      const int nGq = K * (K + 1) / 2;
+      for (int a = 0; a < K; ++a)
+        for (int b = a; b < K; ++b) {
+          const double v = W[gidx(a, b, K)];
+          sub[a * RF_NQ + b] = v;
+          sub[b * RF_NQ + a] = v;
         }
-      const double ratio = rf_chol_inv(sub[k], nq, Rk[k], Tk[k]);
-      if (!(ratio > 1e-6)) plan->fallback[k] = 1;  // Q1 was far from orthonormal: the first factor was too inaccurate
-      for (int i = 0; i < RF_NQ * RF_NQ; ++i) plan->T2[k][i] = Tk[k][i];
+      const double ratio = rf_chol_inv(sub, K, Rk, Tk);
+      if (!(ratio > 1e-6)) plan->fallback = 1;  // Q1 was far from orthonormal: the first factor was too inaccurate
+      for (int i = 0; i < RF_NQ * RF_NQ; ++i) plan->T2[i] = Tk[i];
       // R = R2 R1 ; q^T y = T2^T (Q1^T y)
-      for (int a = 0; a < nq; ++a)
-        for (int b = a; b < nq; ++b) {
+      for (int a = 0; a < K; ++a)
+        for (int b = a; b < K; ++b) {
           double t = 0.0;
-          for (int m = a; m <= b; ++m) t += Rk[k][a * RF_NQ + m] * plan->R1[k][m * RF_NQ + b];
-          c->R[a * RF_NQ + b] = t;
+          for (int m = a; m <= b; ++m) t += Rk[a * RF_NQ + m] * plan->R1[m * RF_NQ + b];
+          cb->R[a * RF_NQ + b] = t;
         }
-      for (int b = 0; b < nq; ++b) {
+      for (int b = 0; b < K; ++b) {
         double t = 0.0;
-        for (int a = 0; a <= b; ++a) t += Tk[k][a * RF_NQ + b] * w[nGq + a];
-        c->qy[b] = t;
-        plan->qy[k][b] = t;
+        for (int a = 0; a <= b; ++a) t += Tk[a * RF_NQ + b] * W[nGq + a];
+        cb->qy[b] = t;
+        plan->qy[b] = t;
       }
     }
   }
 }
 
 // r5 ---------------------------------------------------------------------------------------------------------------
-template <typename T, int NQ>
-__global__ __launch_bounds__(RF_THREADS) void k_rf_apply2(T* __restrict__ Qc, const T* __restrict__ y, int64_t ld,
+template <typename T, int K>
+__global__ __launch_bounds__(RF_THREADS) void k_rf_apply2(T* __restrict__ Q, const T* __restrict__ y, int64_t ld,
                                                           int64_t N, int rows_per_block,
                                                           const RefreshPlan* __restrict__ plan,
                                                           double* __restrict__ part) {
-  constexpr int K = NQ + 1;
-  constexpr int nGq = (NQ > 0) ? NQ * (NQ + 1) / 2 : 1;
-  __shared__ double sh[4 * 8];
-  __shared__ double outv[8];
+  constexpr int nGq = K * (K + 1) / 2;
+  __shared__ double sh[4];
+  __shared__ double outv[1];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
-  double acc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-#pragma unroll 1
-  for (int k = 0; k < K; ++k) {
-    const bool skip = plan->flags_k[k] || plan->fallback[k];
-    T* Q = Qc + (int64_t)k * NQ * ld;
-    double a_k = 0.0;
-    if (skip || NQ == 0) {
-      for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-        const double r = (double)y[n];
-        a_k = fma(r, r, a_k);
-      }
-    } else {
-      double t2[nGq], qy[NQ > 0 ? NQ : 1];
-      int w = 0;
-#pragma unroll
-      for (int a_ = 0; a_ < NQ; ++a_)
-#pragma unroll
-        for (int b_ = a_; b_ < NQ; ++b_, ++w) t2[w] = plan->T2[k][a_ * RF_NQ + b_];
-#pragma unroll
-      for (int b_ = 0; b_ < NQ; ++b_) qy[b_] = plan->qy[k][b_];
-      for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
-        double r = (double)y[n];
-        double q1[NQ > 0 ? NQ : 1];
-#pragma unroll
-        for (int a_ = 0; a_ < NQ; ++a_) q1[a_] = (double)Q[(int64_t)a_ * ld + n];
-#pragma unroll
-        for (int b_ = 0; b_ < NQ; ++b_) {
-          double t = 0.0;
-#pragma unroll
-          for (int a_ = 0; a_ <= b_; ++a_) t = fma(q1[a_], t2[a_ * NQ - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
-          const T qs = (T)t;
-          Q[(int64_t)b_ * ld + n] = qs;
-          r = fma(-qy[b_], (double)qs, r);
-        }
-        a_k = fma(r, r, a_k);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = (q == k) ? a_k : acc[q];
+  double acc[1] = {0.0};
+  if (plan->fallback) {  // the Gram-Schmidt kernel rebuilds everything, including |y_perp|^2
+    if (threadIdx.x == 0) part[blockIdx.x] = 0.0;
+    return;
   }
-  rf_block_sum<8>(acc, sh, outv);
-  if (threadIdx.x < 8) part[(size_t)blockIdx.x * 8 + threadIdx.x] = outv[threadIdx.x];
+  double t2[nGq], qy[K];
+  int w = 0;
+#pragma unroll
+  for (int a_ = 0; a_ < K; ++a_)
+#pragma unroll
+    for (int b_ = a_; b_ < K; ++b_, ++w) t2[w] = plan->T2[a_ * RF_NQ + b_];
+#pragma unroll
+  for (int b_ = 0; b_ < K; ++b_) qy[b_] = plan->qy[b_];
+  for (int64_t n = r0 + threadIdx.x; n < r1; n += RF_THREADS) {
+    double r = (double)y[n];
+    double q1[K];
+#pragma unroll
+    for (int a_ = 0; a_ < K; ++a_) q1[a_] = (double)Q[(int64_t)a_ * ld + n];
+#pragma unroll
+    for (int b_ = 0; b_ < K; ++b_) {
+      double t = 0.0;
+#pragma unroll
+      for (int a_ = 0; a_ <= b_; ++a_) t = fma(q1[a_], t2[a_ * K - (a_ * (a_ - 1)) / 2 + (b_ - a_)], t);
+      const T qs = (T)t;
+      Q[(int64_t)b_ * ld + n] = qs;
+      r = fma(-qy[b_], (double)qs, r);
+    }
+    acc[0] = fma(r, r, acc[0]);
+  }
+  rf_block_sum<1>(acc, sh, outv);
+  if (threadIdx.x == 0) part[blockIdx.x] = outv[0];
 }
 
 // r6 ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rf_final(int K, int n_blocks, const double* __restrict__ part,
-                                                 const RefreshPlan* __restrict__ plan, ChainK* __restrict__ ck) {
-  if ((int)threadIdx.x < K) {
+__global__ __launch_bounds__(64) void k_rf_final(int n_blocks, const double* __restrict__ part, ChainB* __restrict__ cb) {
+  if (threadIdx.x == 0) {
     double t = 0.0;
 #pragma unroll 8
-    for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * 8 + threadIdx.x];
-    ck[threadIdx.x].yperp2 = t;
+    for (int b = 0; b < n_blocks; ++b) t += part[b];
+    cb->yperp2 = t;
   }
 }
 
 template <typename T, int K>
 static void refresh_fast_k(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N,
-                           const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
+                           const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainB* cb,
                            ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt) {
   const int rows = BSR_RF_ROWS;
   const int nb = (int)((N + rows - 1) / rows);
   hipLaunchKernelGGL((k_rf_gram<T, K>), dim3(nb), dim3(RF_THREADS), 0, st, cols, y, ld, N, rows, d_in, d_part);
   hipLaunchKernelGGL(k_rf_plan, dim3(1), dim3(RF_THREADS), 0, st, d_in, K, N, nb, d_part, d_plan);
   double* part2 = d_part + (size_t)nb * RF_GW;
-  hipLaunchKernelGGL((k_rf_apply1<T, K - 1>), dim3(nb), dim3(RF_THREADS), 0, st, cols, Q, y, ld, N, rows, d_plan, part2);
-  hipLaunchKernelGGL(k_rf_plan2, dim3(1), dim3(RF_THREADS), 0, st, K, N, nb, part2, d_plan, ck, fit_noicpt, fit_icpt,
+  hipLaunchKernelGGL((k_rf_apply1<T, K>), dim3(nb), dim3(RF_THREADS), 0, st, cols, Q, y, ld, N, rows, d_plan, part2);
+  hipLaunchKernelGGL(k_rf_plan2, dim3(1), dim3(RF_THREADS), 0, st, K, N, nb, part2, d_plan, cb, fit_noicpt, fit_icpt,
                      d_in);
-  double* part3 = part2 + (size_t)nb * (RF_MAXK * RF_AW + 8);
-  hipLaunchKernelGGL((k_rf_apply2<T, K - 1>), dim3(nb), dim3(RF_THREADS), 0, st, Q, y, ld, N, rows, d_plan, part3);
-  hipLaunchKernelGGL(k_rf_final, dim3(1), dim3(64), 0, st, K, nb, part3, d_plan, ck);
+  double* part3 = part2 + (size_t)nb * (RF_AW + 8);
+  hipLaunchKernelGGL((k_rf_apply2<T, K>), dim3(nb), dim3(RF_THREADS), 0, st, Q, y, ld, N, rows, d_plan, part3);
+  hipLaunchKernelGGL(k_rf_final, dim3(1), dim3(64), 0, st, nb, part3, cb);
 }
 
 template <typename T>
 void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_t ld, int64_t N, int K,
-                         const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainK* ck,
+                         const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainB* cb,
                          ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt) {
 #define RF_CASE(KK) \
-  case KK: refresh_fast_k<T, KK>(st, cols, Q, y, ld, N, d_in, d_plan, d_part, ck, fit_noicpt, fit_icpt); break;
+  case KK: refresh_fast_k<T, KK>(st, cols, Q, y, ld, N, d_in, d_plan, d_part, cb, fit_noicpt, fit_icpt); break;
   switch (K) {
     RF_CASE(1) RF_CASE(2) RF_CASE(3) RF_CASE(4) RF_CASE(5) RF_CASE(6) RF_CASE(7) RF_CASE(8)
   }
@@ -582,10 +551,10 @@ void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_
 
 size_t refresh_part_doubles(int64_t N) {
   const size_t nb = (size_t)((N + BSR_RF_ROWS - 1) / BSR_RF_ROWS);
-  return nb * (RF_GW + RF_MAXK * RF_AW + 8 + 8);
+  return nb * (RF_GW + RF_AW + 8 + 1);
 }
 
 template void launch_refresh_fast<double>(hipStream_t, const double*, double*, const double*, int64_t, int64_t, int,
-                                          const RefreshIn*, RefreshPlan*, double*, ChainK*, ChainFitOut*, ChainFitOut*);
+                                          const RefreshIn*, RefreshPlan*, double*, ChainB*, ChainFitOut*, ChainFitOut*);
 template void launch_refresh_fast<float>(hipStream_t, const float*, float*, const float*, int64_t, int64_t, int,
-                                         const RefreshIn*, RefreshPlan*, double*, ChainK*, ChainFitOut*, ChainFitOut*);
+                                         const RefreshIn*, RefreshPlan*, double*, ChainB*, ChainFitOut*, ChainFitOut*);
