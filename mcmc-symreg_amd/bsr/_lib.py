@@ -38,7 +38,8 @@ class ChainInfo(C.Structure):
 
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbsr_hip.so")
+# BSR_LIB_PATH: an alternative build of the same library (kernel experiments, e.g. tools/ablate_tile.sh)
+LIB_PATH = os.environ.get("BSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbsr_hip.so")
 
 
 def lib():

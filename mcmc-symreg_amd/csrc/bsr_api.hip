@@ -30,12 +30,19 @@ struct BatchSlot {
   uint8_t* h_in = nullptr;
   uint8_t* d_in = nullptr;
   size_t in_cap = 0;
-  size_t off_desc = 0, off_streams = 0;
+  size_t off_cols = 0, off_sched = 0, off_desc = 0, off_streams = 0;
   size_t code_words = 0, feat_words = 0, ln_words = 0;
+  // tile pass (bsr_tile.hip): a second column stream with LDS slots instead of X columns sits behind the ln pairs
+  bool tile = false;
+  int tile_chains = 0;                // distinct chains of the batch (their basis columns are staged in LDS)
+  std::vector<int32_t> chain_slot;    // chain -> index among the batch's chains, -1 if absent
+  std::vector<int32_t> batch_chains;  // the batch's chains in first-seen order
+  std::vector<double> wave_load;      // scratch of the tile schedule
   bsr_score* h_out = nullptr;
   hipStream_t stream = nullptr;   // each slot has its own stream: the small solve/residual/finalise kernels of one
                                   // batch overlap the row pass of the other
   PropCoef* d_coef = nullptr;
+  int32_t* d_flagged = nullptr;  // [0] count, [1..] proposals k_solve hands to the residual pass; k_finalize empties it
   double* part1 = nullptr;
   double* part2 = nullptr;
   size_t part_cap = 0;   // in (proposal,row block) records
@@ -59,6 +66,10 @@ struct BatchSlot {
   std::vector<int> order_tmp;    // scratch of the cost sort
 
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
+  const void** h_cols() const { return reinterpret_cast<const void**>(h_in + off_cols); }
+  int32_t* h_sched() const { return reinterpret_cast<int32_t*>(h_in + off_sched); }
+  const void* const* d_cols() const { return reinterpret_cast<const void* const*>(d_in + off_cols); }
+  const int32_t* d_sched() const { return reinterpret_cast<const int32_t*>(d_in + off_sched); }
   PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
   uint64_t* h_streams() const { return reinterpret_cast<uint64_t*>(h_in + off_streams); }
   const int32_t* d_feat() const { return reinterpret_cast<const int32_t*>(d_in); }
@@ -105,6 +116,13 @@ struct bsr_ctx {
   int target_wgs = 2048;
   int rows_per_lane = 2;
   int no_lds = 0;
+  // tile pass geometry, fixed for the life of the context (a proposal's partial sums must not depend on the batch)
+  int tile_on = 1;
+  int tile_multi = 0;     // allow the chunked variant (slices larger than LDS)
+  int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1;
+  int tile_sub = 1, tile_sub_blocks = 1;   // sub-slices per slice (single-chunk contexts only) and their length
+  size_t tile_sched_cap = 0;
+  unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
   // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
   int prof = 0;
   double last_us[5] = {0, 0, 0, 0, 0};
@@ -185,7 +203,7 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   for (BatchSlot& s : c->slot)
     if (s.stream) (void)hipStreamSynchronize(s.stream);
   void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf, c->d_fit_icpt,
-                 c->d_rin, c->d_plan, c->d_rpart};
+                 c->d_rin, c->d_plan, c->d_rpart, c->d_stamps};
   if (c->h_plan) (void)hipHostFree(c->h_plan);
   for (void* p : dev) if (p) (void)hipFree(p);
   for (BatchSlot& s : c->slot) {
@@ -193,6 +211,7 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.d_coef) (void)hipFree(s.d_coef);
+    if (s.d_flagged) (void)hipFree(s.d_flagged);
     if (s.queue) (void)hipFree(s.queue);
     if (s.part1) (void)hipFree(s.part1);
     if (s.part2) (void)hipFree(s.part2);
@@ -279,6 +298,50 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
   }
+  {
+    // Tile pass: one workgroup per CU.  T tape groups share the CUs: n_cu / T row slices, each served by T
+    // workgroups with different tapes.  More groups = fewer tapes per wave and longer slices (fewer lane reductions,
+    // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
+    // L2-sized.  Everything here depends on the context alone.
+    c->tile_on = env_int("BSR_TILE", 1);
+    c->tile_multi = env_int("BSR_TILE_MULTI", 0);
+    c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
+    const double data_mb = (double)N * (std::min(d, 32) + 1 + std::max(1, K)) * c->esz / 1e6;
+    int T = 1;
+    const int want = (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // groups that give every wave one tape
+    if (data_mb <= 24.0) T = std::min(4, want);
+    else if (data_mb <= 96.0) T = std::min(2, want);
+    T = std::max(1, std::min(8, T));
+    while (T > 1 && (c->n_cu % T) != 0) --T;
+    // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
+    // fit LDS whole even then (staged once, no barrier per chunk).
+    const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
+    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->n_cu / t); return (c->tile_blocks + sl - 1) / sl; };
+    auto fits_whole = [&](int t) {
+      return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
+    };
+    while (T > 1 && !fits_whole(T)) T >>= 1;
+    T = env_int("BSR_TILE_T", T);
+    T = std::max(1, std::min(8, T));
+    while (T > 1 && (c->n_cu % T) != 0) --T;
+    c->tile_T = T;
+    c->tile_slices = std::max(1, c->n_cu / T);
+    c->tile_bps = (c->tile_blocks + c->tile_slices - 1) / c->tile_slices;
+    // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
+    // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
+    c->tile_sub = 1;
+    c->tile_sub_blocks = c->tile_bps;
+    if (fits_whole(T) && c->tile_bps >= 4 && env_int("BSR_TILE_SUB", 1) > 1) {
+      c->tile_sub = 2;
+      c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
+    }
+    c->tile_sched_cap = (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64;
+    if (env_int("BSR_TILE_STAMPS", 0)) {
+      const size_t nb = (size_t)c->n_cu * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
+      if (hipMalloc((void**)&c->d_stamps, nb) == hipSuccess) (void)hipMemset(c->d_stamps, 0, nb);
+      else c->d_stamps = nullptr;
+    }
+  }
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t colb = (size_t)c->ld * c->esz;
   CK(hipMalloc(&c->Xt, colb * d));
@@ -309,10 +372,15 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   for (BatchSlot& s : c->slot) {
     CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
+    CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * (max_batch + 2)));
+    CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * (max_batch + 2)));
     CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
-    s.off_desc = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_cols = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_sched = s.off_cols + ((size_t)(d + 1 + std::max(1, n_chains) * std::max(1, K)) * sizeof(void*) + 255) / 256 * 256;
+    s.off_desc = s.off_sched + (c->tile_sched_cap * sizeof(int32_t) + 255) / 256 * 256;
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
+    s.chain_slot.assign(std::max(1, n_chains), -1);
     CK(hipHostMalloc((void**)&s.h_out, sizeof(bsr_score) * (max_batch + 1)));
     CK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     for (auto& e : s.ev) CK(hipEventCreate(&e));
@@ -417,27 +485,34 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
 //                    padded with a valid id so the kernel may request one terminal past the end
 //   ln stream      : (a,b) per ln node in tape order plus one padding pair
 static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* tape_off, int n,
-                       std::vector<TapeLoc>* loc) {
+                       std::vector<TapeLoc>* loc, int tile_chains = 0) {
   if (!rows || !tape_off || n <= 0) return fail(c, BSR_E_ARG, "null tapes / empty batch");
   if (n > c->max_batch) return fail(c, BSR_E_TOOBIG, "batch larger than max_batch");
   if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
   loc->resize(n);
   size_t cw = 0, fw = 0, lw = 0;
+  int max_fused_sp = 0;
   std::fill(s.slot_of.begin(), s.slot_of.end(), -1);
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
     int rc = check_tape(c, rows + tape_off[i], len, &L.max_sp);
     if (rc != BSR_OK) return rc;
-    int nt = 0, nl = 0;
+    int nt = 0, nl = 0, fsp = 0, fmx = 0;  // fsp: stack depth with `terminal, +|*` pairs fused (what the kernels run)
     for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
       if (rows[j].opcode == BSR_OP_TERMINAL) {
         ++nt;
         s.slot_of[rows[j].feature] = 0;
+        const int nxt = (j + 1 < tape_off[i + 1]) ? rows[j + 1].opcode : -1;
+        if (j > tape_off[i] && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
       } else if (rows[j].opcode == BSR_OP_LN) {
         ++nl;
+      } else if (rows[j].opcode >= BSR_OP_ADD) {
+        --fsp;
       }
+      fmx = std::max(fmx, fsp);
     }
+    max_fused_sp = std::max(max_fused_sp, fmx);
     L.n_nodes = len;
     L.code_off = (int)cw;
     L.feat_off = (int)fw;
@@ -446,7 +521,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     fw += (size_t)(nt + 1 + 3) / 4 + 1;
     lw += (size_t)nl + 1;
   }
-  int rc = ensure_input(c, s, cw + fw + 2 * lw);
+  int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw);
   if (rc != BSR_OK) return rc;
   // columns of X referenced by this batch -> LDS slots (ascending feature order)
   s.nF = 0;
@@ -468,17 +543,31 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       }
     }
   }
+  // tile pass: every column the batch touches (X columns, y, K basis columns per chain) must fit in LDS for at least
+  // one 128-row block, and no tape may need more value-stack slots than the register stack holds
+  s.tile = false;
+  s.tile_chains = tile_chains;
+  if (c->tile_on && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK) {
+    const size_t ncols = (size_t)s.nF + 1 + (size_t)tile_chains * c->K;
+    // the whole slice in LDS at once (single-chunk variant); the chunked variant (no double buffering yet) is slower
+    // than k_rows on data sets beyond L2 and only runs when asked for (BSR_TILE_MULTI=1)
+    const size_t blocks = c->tile_multi ? 1 : (size_t)c->tile_bps;
+    if (ncols * blocks * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024) s.tile = true;
+  }
   s.code_words = cw;
   s.feat_words = fw;
   s.ln_words = 2 * lw;
   uint64_t* hc = s.h_streams();
   uint64_t* hf = hc + cw;
   double* hl = reinterpret_cast<double*>(hf + fw);
+  uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + 2 * lw);  // tile pass: the column stream in LDS slots
   memset(hc, 0, (cw + fw) * 8);
+  if (s.tile) memset(hf2, 0, fw * 8);
   for (int i = 0; i < n; ++i) {
     const TapeLoc L = (*loc)[i];
     uint64_t* pc = hc + L.code_off;
     uint64_t* pf = hf + L.feat_off;
+    uint64_t* pf2 = hf2 + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
     int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 8;
     for (int j = 0; j < L.n_nodes; ++j) {
@@ -487,6 +576,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       if (r.opcode == BSR_OP_TERMINAL) {
         const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[r.feature] : r.feature);
         pf[nt >> 2] |= id << (16 * (nt & 3));
+        if (s.tile) pf2[nt >> 2] |= (uint64_t)s.slot_of[r.feature] << (16 * (nt & 3));
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
         // one stream entry: acc = acc op X[:,f], no push/pop
@@ -520,6 +610,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const uint64_t id0 = pf[0] & 0xFFFFu;
       const int words = (nt + 1 + 3) / 4 + 1;
       for (int t = nt; t < words * 4; ++t) pf[t >> 2] |= id0 << (16 * (t & 3));
+    }
+    if (s.tile) {
+      const uint64_t id0 = pf2[0] & 0xFFFFu;
+      const int words = (nt + 1 + 3) / 4 + 1;
+      for (int t = nt; t < words * 4; ++t) pf2[t >> 2] |= id0 << (16 * (t & 3));
     }
   }
   return BSR_OK;
@@ -573,7 +668,8 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
     a->queue = s.queue + (size_t)(q % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
     a->queue_clear = s.queue + (size_t)((q + BSR_QUEUE_SETS / 2) % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
   } else {
-    a->queue = a->queue_clear = nullptr;
+    a->queue = s.d_flagged;
+    a->queue_clear = nullptr;
   }
 }
 
@@ -595,31 +691,126 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   PropDesc* hd = s.h_desc();
   int spill_slots = 0;
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
-  const LaunchGeom g = geometry(c, s, P);
-  int rc = ensure_partials(c, s, g, P, spill_slots);
-  if (rc != BSR_OK) return rc;
+  LaunchGeom g = geometry(c, s, P);
+  const bool tile = scoring && s.tile;
+  const int n_part = tile ? c->tile_slices * c->tile_sub : g.n_rb;   // partial records per proposal that k_solve reduces
+  {
+    LaunchGeom gp = g;
+    gp.n_rb = std::max(g.n_rb, n_part);
+    int rc0 = ensure_partials(c, s, gp, P, spill_slots);
+    if (rc0 != BSR_OK) return rc0;
+  }
+  int rc = BSR_OK;
+  TileGeom tg;
+  memset(&tg, 0, sizeof tg);
+  if (tile) {
+    // geometry of this launch: the context's slices, as many blocks per chunk as the batch's columns leave room for
+    tg.T = c->tile_T;
+    tg.n_slices = c->tile_slices;
+    tg.bps = c->tile_bps;
+    tg.n_blocks = c->tile_blocks;
+    tg.ncols = s.nF + 1 + s.tile_chains * c->K;
+    tg.y_slot = s.nF;
+    const size_t per_block = (size_t)tg.ncols * BSR_TILE_BLOCK * c->esz;
+    tg.chunk_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)tg.bps, (tile_lds_bytes_max() - 1024) / per_block));
+    const int per_group = (P + tg.T - 1) / tg.T;
+    const int q_need = (per_group + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;
+    const int qb = (c->K <= 3) ? 4 : ((c->K <= 5) ? 3 : 2);
+    tg.qmax = (q_need <= 1) ? 1 : qb;
+    tg.n_pass = (q_need + tg.qmax - 1) / tg.qmax;
+    // the whole slice fits in LDS: staged once, waves pull tapes from the group's list (single-chunk variant)
+    tg.per_group = (tg.chunk_blocks >= tg.bps && env_int("BSR_TILE_SINGLE", 1)) ? per_group : 0;
+    tg.n_sub = c->tile_sub;
+    tg.sub_blocks = c->tile_sub_blocks;
+    tg.n_part = tg.n_slices * tg.n_sub;
+    if (tg.n_sub > 1 && tg.per_group == 0) return fail(c, BSR_E_STATE, "tile geometry: sub-slices need the single-chunk variant");
+    // column table: referenced X columns, y, the basis columns of the batch's chains
+    const void** hc = s.h_cols();
+    const int32_t* hfeat = s.h_feat();
+    for (int f = 0; f < s.nF; ++f) hc[f] = col_ptr(c, c->Xt, hfeat[f]);
+    hc[s.nF] = c->y;
+    for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
+      for (int k = 0; k < c->K; ++k)
+        hc[s.nF + 1 + ci * c->K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * c->K + k);
+  }
   // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
   s.order_tmp.resize(P);
   for (int i = 0; i < P; ++i) s.order_tmp[i] = i;
   std::stable_sort(s.order_tmp.begin(), s.order_tmp.end(), [&](int a, int b) { return hd[a].cost > hd[b].cost; });
   for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
+  if (tile && tg.per_group > 0) {
+    // single-chunk variant: group g's list = tapes g, g+T, ... of the cost order, heaviest first
+    const size_t n_sched = (size_t)tg.T * tg.per_group;
+    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
+    int32_t* sc = s.h_sched();
+    for (size_t i = 0; i < n_sched; ++i) sc[i] = -1;
+    for (int i = 0; i < P; ++i) sc[(size_t)(i % tg.T) * tg.per_group + i / tg.T] = s.order_tmp[i];
+  } else if (tile) {
+    // Static schedule: tapes in cost order are dealt to the T groups round-robin; inside a group each goes to the
+    // wave with the least work so far that still has a free slot (waves w, w+4, w+8, w+12 share a SIMD, but a light
+    // wave frees issue slots for its SIMD mates, so per-wave balance is what is worth having).
+    const int slots_per_wave = tg.n_pass * tg.qmax;
+    const size_t n_sched = (size_t)tg.T * tg.n_pass * BSR_TILE_WAVES * tg.qmax;
+    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
+    int32_t* sc = s.h_sched();
+    for (size_t i = 0; i < n_sched; ++i) sc[i] = -1;
+    s.wave_load.assign((size_t)tg.T * BSR_TILE_WAVES, 0.0);
+    std::vector<int>& cnt = s.order_tmp;  // reuse below after copying the order
+    std::vector<int> order(s.order_tmp.begin(), s.order_tmp.begin() + P);
+    cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
+    for (int i = 0; i < P; ++i) {
+      const int p = order[i];
+      const int grp = i % tg.T;
+      int best = -1;
+      for (int w = 0; w < BSR_TILE_WAVES; ++w) {
+        const int idx = grp * BSR_TILE_WAVES + w;
+        if (cnt[idx] >= slots_per_wave) continue;
+        if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
+      }
+      const int idx = grp * BSR_TILE_WAVES + best;
+      const int slot = cnt[idx]++;
+      const int pass = slot / tg.qmax, q = slot % tg.qmax;
+      sc[(((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q] = p;
+      s.wave_load[idx] += (double)hd[p].cost;
+    }
+  }
   hipStream_t st = s.stream;
-  const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
+  const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words * (s.tile ? 2 : 1) + s.ln_words) * 8;
   HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, st));
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
   const double rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
   s.timed = c->prof;  // the level in force when the batch was enqueued decides which events exist at wait time
   if (s.timed) HIPCHK(c, hipEventRecord(s.ev[0], st));
-  launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
+  if (tile) {
+    const uint64_t* codes = s.d_streams();
+    const uint64_t* feats = codes + s.code_words;
+    const double* lnp = reinterpret_cast<const double*>(feats + s.feat_words);
+    const uint64_t* feats_lds = reinterpret_cast<const uint64_t*>(lnp + s.ln_words);
+    if (c->dtype == BSR_DTYPE_F64) {
+      TileArgs<double> a;
+      a.g = tg; a.colsrc = (const double* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
+      a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = P; a.K = c->K;
+      a.stamps = c->d_stamps;
+      launch_tile<double>(st, a);
+    } else {
+      TileArgs<float> a;
+      a.g = tg; a.colsrc = (const float* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
+      a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = P; a.K = c->K;
+      a.stamps = c->d_stamps;
+      launch_tile<float>(st, a);
+    }
+  } else {
+    launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
+  }
   if (s.timed) HIPCHK(c, hipEventRecord(s.ev[1], st));
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, P, g.n_rb, s.part1, c->N, s.d_coef, s.h_out, rank_floor);
+  launch_solve(st, s.d_desc(), c->d_ck, P, n_part, s.part1, c->N, s.d_coef, s.h_out, rank_floor, s.d_flagged);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[2], st));
   if (scoring) launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[3], st));
   if (scoring)
-    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor);
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor, s.d_flagged);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[4], st));
   HIPCHK(c, hipEventRecord(s.done, st));
   s.P = P;
@@ -877,7 +1068,14 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
   if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
   std::vector<TapeLoc> loc;
   const long long th0 = host_now();
-  int rc = stage_tapes(c, s, rows, tape_off, B, &loc);
+  for (int32_t ch : s.batch_chains) s.chain_slot[ch] = -1;
+  s.batch_chains.clear();
+  for (int i = 0; i < B; ++i)
+    if (s.chain_slot[chain[i]] < 0) {
+      s.chain_slot[chain[i]] = (int32_t)s.batch_chains.size();
+      s.batch_chains.push_back(chain[i]);
+    }
+  int rc = stage_tapes(c, s, rows, tape_off, B, &loc, (int)s.batch_chains.size());
   if (rc != BSR_OK) return rc;
   const long long th1 = host_now();
   PropDesc* hd = s.h_desc();
@@ -891,6 +1089,7 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
     D->ck = chain[i];
     D->qbase = col_ptr(c, c->Q, (int64_t)chain[i] * K);
     D->zout = nullptr;
+    D->qslot = s.nF + 1 + s.chain_slot[chain[i]] * K;
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
   }
@@ -1068,6 +1267,23 @@ extern "C" int bsr_yloglike_host(int device, int64_t N, int32_t K, const double*
   if (rank) *rank = sc.rank;
   bsr_ctx_destroy(c);
   return BSR_OK;
+}
+
+// Diagnostics (not part of the product surface): clock samples of the last tile launch, see bsr_tile.hip.
+// out: [workgroups][16 waves][8] uint64; returns the number of workgroups, 0 if stamps are off (BSR_TILE_STAMPS unset).
+extern "C" int bsr_debug_tile_stamps(bsr_ctx* c, unsigned long long* out, int32_t max_wgs, int32_t* geom5) {
+  if (!c || !out) return BSR_E_ARG;
+  if (!c->d_stamps) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  const int n = std::min<int>(max_wgs, c->n_cu);
+  if (hipMemcpy(out, c->d_stamps, (size_t)n * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long),
+                hipMemcpyDeviceToHost) != hipSuccess) return BSR_E_HIP;
+  if (geom5) {
+    geom5[0] = c->tile_T; geom5[1] = c->tile_slices; geom5[2] = c->tile_bps; geom5[3] = c->tile_blocks;
+    geom5[4] = c->n_cu * 100 + c->tile_sub;
+  }
+  return n;
 }
 
 extern "C" int bsr_set_profiling(bsr_ctx* c, int32_t level) {

@@ -1,0 +1,413 @@
+// Device-side building blocks shared by the row-pass kernels (bsr_kernels.hip: k_rows, bsr_tile.hip: k_tile):
+// DPP wave reductions, the opcode semantics of codes/funcs.py:179-212, the register value stack and the postfix
+// stack-machine interpreter over the compact tape streams.  gfx950 only (wave64).
+#pragma once
+
+#include "bsr_internal.h"
+#include "bsr_sincos.h"
+
+#define CONSTANT_AS __attribute__((address_space(4)))
+
+template <typename T>
+__device__ __forceinline__ const T CONSTANT_AS* as_const(const T* p) {
+  return (const T CONSTANT_AS*)p;
+}
+
+// Wave-level reductions on the VALU with DPP (no LDS traffic, unlike __shfl which lowers to ds_bpermute).
+// Fixed combination order -> deterministic.  After the six steps lane 63 holds the reduction of all 64 lanes;
+// v_readlane broadcasts it.  DPP controls: quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1], 0x141 row_half_mirror,
+// 0x140 row_mirror, 0x142 row_bcast:15 (rows 1,3), 0x143 row_bcast:31 (rows 2,3).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int l2, h2;
+  if constexpr (ROW_MASK == 0xF) {  // every lane is written: no need to initialise the destination
+    l2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    h2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+  } else {
+    l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  }
+  return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double readlane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// max(a, |b|) in one instruction.  fmax() costs three here: LLVM canonicalises both operands (v_max_f64 x, x) before
+// the real maximum to quiet signalling NaNs.  v_max_f64 already returns the other operand when one is a NaN, which is
+// the fmax behaviour the census relies on (a NaN row never becomes the maximum; it is flagged through the sum).
+__device__ __forceinline__ double max_abs(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_abs(float a, float b) { return fmaxf(a, fabsf(b)); }
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0xB1, 0xF>(v);
+  v += dpp_f64<0x4E, 0xF>(v);
+  v += dpp_f64<0x141, 0xF>(v);
+  v += dpp_f64<0x140, 0xF>(v);
+  // rows not selected by the row mask receive 0 (old = 0, bound_ctrl off keeps `old`): add is a no-op there
+  v += dpp_f64<0x142, 0xA>(v);
+  v += dpp_f64<0x143, 0xC>(v);
+  return readlane63(v);
+}
+__device__ __forceinline__ double wave_max(double v) {  // inputs are non-negative (|z| maxima): 0 is neutral
+  // plain fmax here: its first step also re-materialises v through an ordinary VALU instruction, so the DPP reads below
+  // never follow the inline-asm write of max_abs directly (the hazard recogniser cannot see into inline asm)
+  v = fmax(v, 0.0);
+  v = fmax(v, dpp_f64<0xB1, 0xF>(v));
+  v = fmax(v, dpp_f64<0x4E, 0xF>(v));
+  v = fmax(v, dpp_f64<0x141, 0xF>(v));
+  v = fmax(v, dpp_f64<0x140, 0xF>(v));
+  v = fmax(v, dpp_f64<0x142, 0xA>(v));
+  v = fmax(v, dpp_f64<0x143, 0xC>(v));
+  return readlane63(v);
+}
+// Sums eight per-lane doubles over the wave at once.  v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves
+// and 16-lane rows between two registers, so one swap + one add halves the lanes of TWO quantities; the last four
+// steps are the in-row DPP butterfly.  ~45 vector instructions for eight sums instead of ~20 each with wave_sum.
+// On return the 16 lanes of row r hold total[map(r)] in lo (values 0..3) and hi (values 4..7), map = {0, 2, 1, 3}.
+// Fixed combination order: deterministic.
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double row_sum16(double v) {  // all 16 lanes of a row end with the row's sum
+  v += dpp_f64<0xB1, 0xF>(v);
+  v += dpp_f64<0x4E, 0xF>(v);
+  v += dpp_f64<0x141, 0xF>(v);
+  v += dpp_f64<0x140, 0xF>(v);
+  return v;
+}
+__device__ __forceinline__ void wave_sum8(double (&v)[8], double& lo, double& hi) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    swap32(v[i], v[i + 1]);
+    v[i] += v[i + 1];          // lanes 0-31: value i over both halves; lanes 32-63: value i+1
+  }
+  swap16(v[0], v[2]);
+  swap16(v[4], v[6]);
+  lo = row_sum16(v[0] + v[2]);  // rows: values 0, 2, 1, 3
+  hi = row_sum16(v[4] + v[6]);  // rows: values 4, 6, 5, 7
+}
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// opcode semantics (codes/funcs.py:179-212)
+template <typename T> __device__ __forceinline__ T op_exp(T x);
+// exp is evaluated unconditionally on min(x,200) and the clamp applied by a select: a lane-divergent branch around
+// it would turn the interpreter loop into a structurized region (see sin_rows below).
+template <> __device__ __forceinline__ double op_exp<double>(double x) {
+  const double e = exp(fmin(x, 200.0));
+  return (x <= 200.0) ? e : 1e10;
+}
+template <> __device__ __forceinline__ float op_exp<float>(float x) {
+  const float e = expf(fminf(x, 200.0f));
+  return (x <= 200.0f) ? e : 1e10f;
+}
+// sin/cos carry lane-divergent branches (large-argument reduction).  Inlined into the interpreter they make the whole
+// node loop a divergent region, which LLVM then structurizes into long chains of flag-guarded blocks (~150 scalar
+// instructions per node).  Kept out of line, the loop has only wave-uniform branches and stays a plain scalar
+// switch; the call costs a few dozen cycles against the ~85 fp64 instructions of the function itself.
+template <typename T, int U>
+struct VecOf;
+template <>
+struct VecOf<double, 2> { using type = double2; };
+template <>
+struct VecOf<float, 2> { using type = float2; };
+// fp64: branch-free bsr_sincos (bsr_sincos.h) unless some lane of the wave holds a huge, infinite or NaN argument --
+// a wave-uniform test -- in which case the whole wave takes the library routine.
+static __device__ __attribute__((noinline)) double2 sin_rows(double2 v) {
+  const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;  // false for NaN
+  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(sin(v.x), sin(v.y));
+  return make_double2(bsr_sincos(v.x, 0), bsr_sincos(v.y, 0));
+}
+static __device__ __attribute__((noinline)) double2 cos_rows(double2 v) {
+  const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;
+  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(cos(v.x), cos(v.y));
+  return make_double2(bsr_sincos(v.x, 1), bsr_sincos(v.y, 1));
+}
+static __device__ __attribute__((noinline)) float2 sin_rows(float2 v) { return make_float2(sinf(v.x), sinf(v.y)); }
+static __device__ __attribute__((noinline)) float2 cos_rows(float2 v) { return make_float2(cosf(v.x), cosf(v.y)); }
+
+// np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
+// Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
+template <typename T> __device__ __forceinline__ T op_cube(T x);
+template <> __device__ __forceinline__ double op_cube<double>(double x) {
+  const double x2 = x * x;
+  const double e = fma(x, x, -x2);
+  const double p = x2 * x;
+  const double pe = fma(x2, x, -p);
+  const double r = p + (pe + e * x);
+  return (isfinite(p) && isfinite(r)) ? r : p;  // keep inf/NaN and overflow behaviour of the plain product
+}
+template <> __device__ __forceinline__ float op_cube<float>(float x) {
+  const double xd = (double)x;
+  return (float)(xd * xd * xd);
+}
+
+// Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.  S slots live in VGPRs,
+// deeper entries (Strahler number of the tree > S+1, rare) go to a per-wave global spill area.
+template <typename T, int U, int S>
+struct RegStack {
+  T s[S][U];
+  T* spill;  // per-wave: slot-major [slot][64*U]
+  int lane;
+
+  __device__ __forceinline__ void push(int sp, const T (&v)[U]) {
+    if (sp < S) {
+      switch (sp) {
+#define X(i)                                                             \
+  case i:                                                                \
+    if constexpr (i < S) {                                               \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) s[i][u] = v[u];      \
+    }                                                                    \
+    break;
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+#undef X
+      }
+    } else {
+      T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+      for (int u = 0; u < U; ++u) q[u] = v[u];
+    }
+  }
+  __device__ __forceinline__ void pop(int sp, T (&v)[U]) {
+    if (sp < S) {
+      switch (sp) {
+#define X(i)                                                             \
+  case i:                                                                \
+    if constexpr (i < S) {                                               \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s[i][u];      \
+    }                                                                    \
+    break;
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+#undef X
+      }
+    } else {
+      const T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = q[u];
+    }
+  }
+};
+
+// Terminal loaders.  A lane owns U/2 pairs of adjacent rows, pair j at chunk offset j*128 + 2*lane, so every
+// 16-byte access of the wave covers 1 KiB of consecutive addresses (LDS: conflict-free ds_read_b128).
+// LdsCols reads the workgroup's staged tile [slot][rb_rows]; GlobalCols reads the feature-major matrix directly.
+template <typename T, int U>
+struct LdsCols {
+  const T* sx;
+  int rb_rows;
+  int off;  // sweep offset + 2*lane, inside the tile
+  __device__ __forceinline__ void load(int slot, T (&v)[U]) const {
+    const T* col = sx + slot * rb_rows + off;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      v[2 * j] = col[j * 128];
+      v[2 * j + 1] = col[j * 128 + 1];
+    }
+  }
+};
+template <typename T, int U>
+struct GlobalCols {
+  const T* __restrict__ Xt;
+  int64_t ld, r0;  // r0 = absolute row of the lane's first pair
+  __device__ __forceinline__ void load(int feature, T (&v)[U]) const {
+    const T* col = Xt + (int64_t)feature * ld + r0;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      v[2 * j] = col[j * 128];
+      v[2 * j + 1] = col[j * 128 + 1];
+    }
+  }
+};
+
+// XCD-aware work mapping for the row passes.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the
+// XCD's group), each with a private 4 MiB L2.  All proposal groups of one row block, and a fixed eighth of the row
+// blocks, go to the same group, so an XCD's L2 only ever holds its 1/8 slice of X, y and the cached basis columns
+// (1.7 MB at N=100k, d=10, K=3) instead of all of it.  Placement only affects speed, never results.
+struct WorkItem {
+  int rb, pgi;
+  bool valid;
+};
+__device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg) {
+  const int w = blockIdx.x;
+  const int xcd = w & 7, j = w >> 3;
+  WorkItem it;
+  it.pgi = j % n_pg;
+  it.rb = (j / n_pg) * 8 + xcd;
+  it.valid = it.rb < n_rb;
+  return it;
+}
+
+// Evaluates one tape on the lane's U rows.  The tape arrives as three compact streams built by the host from the
+// bsr_node rows (bsr_api.hip: stage_tapes): 4-bit opcodes (16 per 64-bit word; `terminal, +|*` pairs arrive fused as
+// BSR_SOP_ADD_T / BSR_SOP_MUL_T), 16-bit column ids of the terminals
+// in tape order (4 per word) and the (a,b) pairs of the ln nodes.  They are read through the constant address space
+// (scalar loads) a whole word at a time, so the node loop itself is register-only: opcode, stack pointer and every
+// branch are wave-uniform, and the only memory operation on the critical path is the terminal read, which is
+// requested one terminal ahead.  Each stream is padded so that reading one element past the end is always valid.
+// The first words of a tape's three streams (wave-uniform: they live in SGPRs).  A caller that runs one tape over many
+// row blocks loads them once (load_tape_head) instead of paying three scalar round trips per block.
+struct TapeHead {
+  uint64_t code0, code1, f0, f1;
+  double la, lb;
+};
+__device__ __forceinline__ TapeHead load_tape_head(const uint64_t* codes, const uint64_t* feats, const double* lnp) {
+  const uint64_t CONSTANT_AS* cw = as_const(codes);
+  const uint64_t CONSTANT_AS* fw = as_const(feats);
+  const double CONSTANT_AS* lp = as_const(lnp);
+  TapeHead h;
+  h.code0 = cw[0];
+  h.code1 = cw[1];
+  h.f0 = fw[0];
+  h.f1 = fw[1];
+  h.la = lp[0];
+  h.lb = lp[1];
+  return h;
+}
+
+template <typename T, int U, int S, typename Loader>
+__device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t* codes, const uint64_t* feats,
+                                              const double* lnp, int n, const Loader& ldr, T (&acc)[U], T* spill,
+                                              int lane) {
+  const uint64_t CONSTANT_AS* cw = as_const(codes);
+  const uint64_t CONSTANT_AS* fw = as_const(feats);
+  const double CONSTANT_AS* lp = as_const(lnp);
+  RegStack<T, U, S> st;
+  st.spill = spill;
+  st.lane = lane;
+  uint64_t code = hd.code0, code_next = hd.code1;
+  uint64_t fhead = hd.f0, fnext = hd.f1;
+  double la = hd.la, lb = hd.lb;
+  int ci = 1, fi = 1, li = 1, nt = 0;
+  int sp = 0;  // values on the stack below the accumulator
+  T pre[U];
+  ldr.load((int)(fhead & 0xFFFFu), acc);  // node 0 is always a terminal
+  fhead >>= 16;
+  nt = 1;
+  ldr.load((int)(fhead & 0xFFFFu), pre);  // data of the next terminal (padding repeats a valid column)
+  code >>= 4;
+#ifdef BSR_ABLATE_TAPE     // timing experiment: the tape is its first terminal (results are wrong)
+  n = 1;
+#endif
+  for (int i = 1; i < n; ++i) {
+    if ((i & 15) == 0) {
+      code = code_next;
+      ++ci;
+      code_next = cw[ci];
+    }
+    const int op = (int)(code & 15u);
+    code >>= 4;
+    if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
+      if (op == BSR_OP_TERMINAL) {
+        st.push(sp, acc);
+        ++sp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = pre[u];
+      } else if (op == BSR_SOP_ADD_T) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
+      } else {  // BSR_SOP_MUL_T
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
+      }
+      fhead >>= 16;
+      if (++nt == 4) {
+        fhead = fnext;
+        ++fi;
+        fnext = fw[fi];
+        nt = 0;
+      }
+      ldr.load((int)(fhead & 0xFFFFu), pre);
+    } else if (op >= BSR_OP_ADD) {
+      T lhs[U];
+      --sp;
+      st.pop(sp, lhs);
+      if (op == BSR_OP_ADD) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = lhs[u] + acc[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = lhs[u] * acc[u];
+      }
+    } else {
+      switch (op) {
+        case BSR_OP_INV:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
+          break;
+        case BSR_OP_LN: {
+          const T a = (T)la, b = (T)lb;
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
+          la = lp[2 * li];
+          lb = lp[2 * li + 1];
+          ++li;
+        } break;
+        case BSR_OP_NEG:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = -acc[u];
+          break;
+        case BSR_OP_SIN:
+#pragma unroll
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            r = sin_rows(v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
+          break;
+        case BSR_OP_COS:
+#pragma unroll
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            r = cos_rows(v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
+          break;
+        case BSR_OP_EXP:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_exp<T>(acc[u]);
+          break;
+        case BSR_OP_SQUARE:
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
+          break;
+        default:  // BSR_OP_CUBIC
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = op_cube<T>(acc[u]);
+          break;
+      }
+    }
+  }
+}
+
+template <typename T, int U, int S, typename Loader>
+__device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* feats, const double* lnp, int n,
+                                         const Loader& ldr, T (&acc)[U], T* spill, int lane) {
+  const TapeHead hd = load_tape_head(codes, feats, lnp);
+  run_tape_head<T, U, S>(hd, codes, feats, lnp, n, ldr, acc, spill, lane);
+}

@@ -55,6 +55,8 @@ struct PropDesc {
   int32_t spill_need;   // stack slots beyond the register stack
   int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
   int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
+  int32_t qslot;        // tile pass: LDS slot of the chain's first basis column (K consecutive slots)
+  int32_t pad;
   const void* qbase;    // first basis column (nq columns, stride ld)
   void* zout;           // where the candidate column goes (ld values) or nullptr
   double s;             // prescale applied to the candidate column in all accumulations
@@ -101,6 +103,48 @@ struct RefreshPlan {  // per chain, device scratch handed from one refresh kerne
   double dcol[BSR_NQ_MAX];
 };
 
+// ---- tile-stationary row pass (bsr_tile.hip).  Fixed per context (so that a proposal's partial sums do not depend on
+// the batch it is scored in): rows per lane and block, the number of row slices and their block ranges.
+#define BSR_TILE_WAVES 16                 // waves per workgroup (one workgroup per CU)
+#define BSR_TILE_U 2                      // rows per lane and block: a block is 64 * U = 128 rows
+#define BSR_TILE_BLOCK (BSR_WAVE * BSR_TILE_U)
+#define BSR_TILE_QMAX 4                   // tape slots per wave and pass (register accumulator sets)
+struct TileGeom {
+  int T;                // tape groups: workgroup w serves slice w % n_slices with the tapes of group w / n_slices
+  int n_slices;         // row slices (partials per proposal)
+  int bps;              // blocks per slice
+  int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
+  int chunk_blocks;     // blocks staged in LDS at a time
+  int n_pass;           // passes over the slice (tapes per wave beyond the accumulator sets)
+  int qmax;             // accumulator sets of the launched variant (1 or up to BSR_TILE_QMAX)
+  int ncols;            // LDS columns: referenced X columns, y, K basis columns per chain of the batch
+  int y_slot;           // LDS slot of y
+  int per_group;        // single-chunk variant: tapes per group (length of a group's list in `sched`)
+  int n_sub;            // single-chunk variant: a slice is cut into n_sub sub-slices of sub_blocks blocks; the unit of
+  int sub_blocks;       // work a wave pulls is (tape, sub-slice) and there is one partial record per unit
+  int n_part;           // partial records per proposal = n_slices * n_sub
+};
+template <typename T>
+struct TileArgs {
+  TileGeom g;
+  const T* const* colsrc;     // [ncols] global column pointers (device memory)
+  int64_t N;
+  const uint64_t* codes;
+  const uint64_t* feats;
+  const double* lnp;
+  const PropDesc* desc;
+  const int32_t* sched;       // multi-chunk: [T][n_pass][BSR_TILE_WAVES][qmax] tape index or -1
+                              // single-chunk: [T][per_group] tape indices, heaviest first, -1 padded
+  double* part;               // [P][n_slices][BSR_P1_WORDS]
+  int P;
+  int K;
+  unsigned long long* stamps; // diagnostics (BSR_TILE_STAMPS=1): [workgroup][wave][8] clock samples, else null
+};
+#define BSR_TILE_STAMP_WORDS 8
+template <typename T>
+void launch_tile(hipStream_t st, const TileArgs<T>& a);
+size_t tile_lds_bytes_max();
+
 struct LaunchGeom {
   int rb_rows;      // rows per row block (multiple of 256)
   int n_rb;         // row blocks
@@ -143,9 +187,9 @@ struct RowPassArgs {
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged);
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
                           const double* col_maxabs, const uint32_t* col_flags, ChainB* cb);

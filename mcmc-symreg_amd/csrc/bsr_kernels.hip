@@ -22,334 +22,7 @@
 
 #include <cstdlib>
 
-#define CONSTANT_AS __attribute__((address_space(4)))
-
-template <typename T>
-__device__ __forceinline__ const T CONSTANT_AS* as_const(const T* p) {
-  return (const T CONSTANT_AS*)p;
-}
-
-// Wave-level reductions on the VALU with DPP (no LDS traffic, unlike __shfl which lowers to ds_bpermute).
-// Fixed combination order -> deterministic.  After the six steps lane 63 holds the reduction of all 64 lanes;
-// v_readlane broadcasts it.  DPP controls: quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1], 0x141 row_half_mirror,
-// 0x140 row_mirror, 0x142 row_bcast:15 (rows 1,3), 0x143 row_bcast:31 (rows 2,3).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  int l2, h2;
-  if constexpr (ROW_MASK == 0xF) {  // every lane is written: no need to initialise the destination
-    l2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
-    h2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
-  } else {
-    l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-    h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
-  }
-  return __hiloint2double(h2, l2);
-}
-__device__ __forceinline__ double readlane63(double v) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
-}
-// max(a, |b|) in one instruction.  fmax() costs three here: LLVM canonicalises both operands (v_max_f64 x, x) before
-// the real maximum to quiet signalling NaNs.  v_max_f64 already returns the other operand when one is a NaN, which is
-// the fmax behaviour the census relies on (a NaN row never becomes the maximum; it is flagged through the sum).
-__device__ __forceinline__ double max_abs(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float max_abs(float a, float b) { return fmaxf(a, fabsf(b)); }
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0xB1, 0xF>(v);
-  v += dpp_f64<0x4E, 0xF>(v);
-  v += dpp_f64<0x141, 0xF>(v);
-  v += dpp_f64<0x140, 0xF>(v);
-  // rows not selected by the row mask receive 0 (old = 0, bound_ctrl off keeps `old`): add is a no-op there
-  v += dpp_f64<0x142, 0xA>(v);
-  v += dpp_f64<0x143, 0xC>(v);
-  return readlane63(v);
-}
-__device__ __forceinline__ double wave_max(double v) {  // inputs are non-negative (|z| maxima): 0 is neutral
-  // plain fmax here: its first step also re-materialises v through an ordinary VALU instruction, so the DPP reads below
-  // never follow the inline-asm write of max_abs directly (the hazard recogniser cannot see into inline asm)
-  v = fmax(v, 0.0);
-  v = fmax(v, dpp_f64<0xB1, 0xF>(v));
-  v = fmax(v, dpp_f64<0x4E, 0xF>(v));
-  v = fmax(v, dpp_f64<0x141, 0xF>(v));
-  v = fmax(v, dpp_f64<0x140, 0xF>(v));
-  v = fmax(v, dpp_f64<0x142, 0xA>(v));
-  v = fmax(v, dpp_f64<0x143, 0xC>(v));
-  return readlane63(v);
-}
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
-  return v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// opcode semantics (codes/funcs.py:179-212)
-template <typename T> __device__ __forceinline__ T op_exp(T x);
-// exp is evaluated unconditionally on min(x,200) and the clamp applied by a select: a lane-divergent branch around
-// it would turn the interpreter loop into a structurized region (see sin_rows below).
-template <> __device__ __forceinline__ double op_exp<double>(double x) {
-  const double e = exp(fmin(x, 200.0));
-  return (x <= 200.0) ? e : 1e10;
-}
-template <> __device__ __forceinline__ float op_exp<float>(float x) {
-  const float e = expf(fminf(x, 200.0f));
-  return (x <= 200.0f) ? e : 1e10f;
-}
-// sin/cos carry lane-divergent branches (large-argument reduction).  Inlined into the interpreter they make the whole
-// node loop a divergent region, which LLVM then structurizes into long chains of flag-guarded blocks (~150 scalar
-// instructions per node).  Kept out of line, the loop has only wave-uniform branches and stays a plain scalar
-// switch; the call costs a few dozen cycles against the ~85 fp64 instructions of the function itself.
-template <typename T, int U>
-struct VecOf;
-template <>
-struct VecOf<double, 2> { using type = double2; };
-template <>
-struct VecOf<float, 2> { using type = float2; };
-__device__ __attribute__((noinline)) double2 sin_rows(double2 v) { return make_double2(sin(v.x), sin(v.y)); }
-__device__ __attribute__((noinline)) double2 cos_rows(double2 v) { return make_double2(cos(v.x), cos(v.y)); }
-__device__ __attribute__((noinline)) float2 sin_rows(float2 v) { return make_float2(sinf(v.x), sinf(v.y)); }
-__device__ __attribute__((noinline)) float2 cos_rows(float2 v) { return make_float2(cosf(v.x), cosf(v.y)); }
-
-// np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
-// Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
-template <typename T> __device__ __forceinline__ T op_cube(T x);
-template <> __device__ __forceinline__ double op_cube<double>(double x) {
-  const double x2 = x * x;
-  const double e = fma(x, x, -x2);
-  const double p = x2 * x;
-  const double pe = fma(x2, x, -p);
-  const double r = p + (pe + e * x);
-  return (isfinite(p) && isfinite(r)) ? r : p;  // keep inf/NaN and overflow behaviour of the plain product
-}
-template <> __device__ __forceinline__ float op_cube<float>(float x) {
-  const double xd = (double)x;
-  return (float)(xd * xd * xd);
-}
-
-// Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.  S slots live in VGPRs,
-// deeper entries (Strahler number of the tree > S+1, rare) go to a per-wave global spill area.
-template <typename T, int U, int S>
-struct RegStack {
-  T s[S][U];
-  T* spill;  // per-wave: slot-major [slot][64*U]
-  int lane;
-
-  __device__ __forceinline__ void push(int sp, const T (&v)[U]) {
-    if (sp < S) {
-      switch (sp) {
-#define X(i)                                                             \
-  case i:                                                                \
-    if constexpr (i < S) {                                               \
-      _Pragma("unroll") for (int u = 0; u < U; ++u) s[i][u] = v[u];      \
-    }                                                                    \
-    break;
-        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
-#undef X
-      }
-    } else {
-      T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
-#pragma unroll
-      for (int u = 0; u < U; ++u) q[u] = v[u];
-    }
-  }
-  __device__ __forceinline__ void pop(int sp, T (&v)[U]) {
-    if (sp < S) {
-      switch (sp) {
-#define X(i)                                                             \
-  case i:                                                                \
-    if constexpr (i < S) {                                               \
-      _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s[i][u];      \
-    }                                                                    \
-    break;
-        X(0) X(1) X(2) X(3) X(4) X(5) X(6)
-#undef X
-      }
-    } else {
-      const T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = q[u];
-    }
-  }
-};
-
-// Terminal loaders.  A lane owns U/2 pairs of adjacent rows, pair j at chunk offset j*128 + 2*lane, so every
-// 16-byte access of the wave covers 1 KiB of consecutive addresses (LDS: conflict-free ds_read_b128).
-// LdsCols reads the workgroup's staged tile [slot][rb_rows]; GlobalCols reads the feature-major matrix directly.
-template <typename T, int U>
-struct LdsCols {
-  const T* sx;
-  int rb_rows;
-  int off;  // sweep offset + 2*lane, inside the tile
-  __device__ __forceinline__ void load(int slot, T (&v)[U]) const {
-    const T* col = sx + slot * rb_rows + off;
-#pragma unroll
-    for (int j = 0; j < U / 2; ++j) {
-      v[2 * j] = col[j * 128];
-      v[2 * j + 1] = col[j * 128 + 1];
-    }
-  }
-};
-template <typename T, int U>
-struct GlobalCols {
-  const T* __restrict__ Xt;
-  int64_t ld, r0;  // r0 = absolute row of the lane's first pair
-  __device__ __forceinline__ void load(int feature, T (&v)[U]) const {
-    const T* col = Xt + (int64_t)feature * ld + r0;
-#pragma unroll
-    for (int j = 0; j < U / 2; ++j) {
-      v[2 * j] = col[j * 128];
-      v[2 * j + 1] = col[j * 128 + 1];
-    }
-  }
-};
-
-// XCD-aware work mapping for the row passes.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the
-// XCD's group), each with a private 4 MiB L2.  All proposal groups of one row block, and a fixed eighth of the row
-// blocks, go to the same group, so an XCD's L2 only ever holds its 1/8 slice of X, y and the cached basis columns
-// (1.7 MB at N=100k, d=10, K=3) instead of all of it.  Placement only affects speed, never results.
-struct WorkItem {
-  int rb, pgi;
-  bool valid;
-};
-__device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg) {
-  const int w = blockIdx.x;
-  const int xcd = w & 7, j = w >> 3;
-  WorkItem it;
-  it.pgi = j % n_pg;
-  it.rb = (j / n_pg) * 8 + xcd;
-  it.valid = it.rb < n_rb;
-  return it;
-}
-
-// Evaluates one tape on the lane's U rows.  The tape arrives as three compact streams built by the host from the
-// bsr_node rows (bsr_api.hip: stage_tapes): 4-bit opcodes (16 per 64-bit word; `terminal, +|*` pairs arrive fused as
-// BSR_SOP_ADD_T / BSR_SOP_MUL_T), 16-bit column ids of the terminals
-// in tape order (4 per word) and the (a,b) pairs of the ln nodes.  They are read through the constant address space
-// (scalar loads) a whole word at a time, so the node loop itself is register-only: opcode, stack pointer and every
-// branch are wave-uniform, and the only memory operation on the critical path is the terminal read, which is
-// requested one terminal ahead.  Each stream is padded so that reading one element past the end is always valid.
-template <typename T, int U, int S, typename Loader>
-__device__ __forceinline__ void run_tape(const uint64_t* codes, const uint64_t* feats, const double* lnp, int n,
-                                         const Loader& ldr, T (&acc)[U], T* spill, int lane) {
-  const uint64_t CONSTANT_AS* cw = as_const(codes);
-  const uint64_t CONSTANT_AS* fw = as_const(feats);
-  const double CONSTANT_AS* lp = as_const(lnp);
-  RegStack<T, U, S> st;
-  st.spill = spill;
-  st.lane = lane;
-  uint64_t code = cw[0], code_next = cw[1];
-  uint64_t fhead = fw[0], fnext = fw[1];
-  double la = lp[0], lb = lp[1];
-  int ci = 1, fi = 1, li = 1, nt = 0;
-  int sp = 0;  // values on the stack below the accumulator
-  T pre[U];
-  ldr.load((int)(fhead & 0xFFFFu), acc);  // node 0 is always a terminal
-  fhead >>= 16;
-  nt = 1;
-  ldr.load((int)(fhead & 0xFFFFu), pre);  // data of the next terminal (padding repeats a valid column)
-  code >>= 4;
-  for (int i = 1; i < n; ++i) {
-    if ((i & 15) == 0) {
-      code = code_next;
-      ++ci;
-      code_next = cw[ci];
-    }
-    const int op = (int)(code & 15u);
-    code >>= 4;
-    if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
-      if (op == BSR_OP_TERMINAL) {
-        st.push(sp, acc);
-        ++sp;
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = pre[u];
-      } else if (op == BSR_SOP_ADD_T) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
-      } else {  // BSR_SOP_MUL_T
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
-      }
-      fhead >>= 16;
-      if (++nt == 4) {
-        fhead = fnext;
-        ++fi;
-        fnext = fw[fi];
-        nt = 0;
-      }
-      ldr.load((int)(fhead & 0xFFFFu), pre);
-    } else if (op >= BSR_OP_ADD) {
-      T lhs[U];
-      --sp;
-      st.pop(sp, lhs);
-      if (op == BSR_OP_ADD) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = lhs[u] + acc[u];
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = lhs[u] * acc[u];
-      }
-    } else {
-      switch (op) {
-        case BSR_OP_INV:
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
-          break;
-        case BSR_OP_LN: {
-          const T a = (T)la, b = (T)lb;
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
-          la = lp[2 * li];
-          lb = lp[2 * li + 1];
-          ++li;
-        } break;
-        case BSR_OP_NEG:
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = -acc[u];
-          break;
-        case BSR_OP_SIN:
-#pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            r = sin_rows(v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
-          }
-          break;
-        case BSR_OP_COS:
-#pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            r = cos_rows(v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
-          }
-          break;
-        case BSR_OP_EXP:
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = op_exp<T>(acc[u]);
-          break;
-        case BSR_OP_SQUARE:
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
-          break;
-        default:  // BSR_OP_CUBIC
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = op_cube<T>(acc[u]);
-          break;
-      }
-    }
-  }
-}
+#include "bsr_device.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Row pass.  grid = 8 * ceil(n_rb/8) * n_pg workgroups of 4 waves (XCD-aware mapping above); a workgroup owns one
@@ -404,14 +77,11 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   }
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   const PropCoef CONSTANT_AS* cf = as_const(coef);
-  if (MODE == MODE_RESIDUAL) {  // nothing to do for this group? leave before staging anything
-    bool any = false;
-    for (int pi = 0; pi < pg; ++pi) {
-      const int p = wi.pgi * pg + pi;
-      if (p < P && !cf[p].skip) any = true;
-    }
-    if (!any) return;
-  }
+  // RESIDUAL: the proposals to redo are the ones k_solve appended to the batch's list (queue[0] = count, queue[1..] =
+  // proposal indices); one workgroup per row block walks that list -- nothing to stage or schedule when it is empty
+  const int32_t CONSTANT_AS* flagged = as_const(queue);
+  const int n_flag = (MODE == MODE_RESIDUAL) ? flagged[0] : 0;
+  if (MODE == MODE_RESIDUAL && n_flag == 0) return;
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;
@@ -622,11 +292,14 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       if (cq < 0) break;
     }
   } else {
-    for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
-      const int p = wi.pgi * pg + pi;
-      if (p >= P) break;
-      if (MODE == MODE_RESIDUAL && cf[p].skip) continue;
-      run_task(p, wi.rb, (int64_t)wi.rb * rb_rows);
+    if (MODE == MODE_RESIDUAL) {
+      for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], wi.rb, (int64_t)wi.rb * rb_rows);
+    } else {
+      for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
+        const int p = wi.pgi * pg + pi;
+        if (p >= P) break;
+        run_task(p, wi.rb, (int64_t)wi.rb * rb_rows);
+      }
     }
   }
 #ifdef BSR_STAMPS
@@ -938,7 +611,7 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
 __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
-                                                    double rank_floor) {
+                                                    double rank_floor, int32_t* __restrict__ flagged) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
@@ -1034,6 +707,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
       cf->maxabs = amax;
       cf->flags = flags;
       cf->skip = 0;
+      // hand the proposal to the residual pass and k_finalize (the order of the list does not matter to the results)
+      flagged[1 + atomicAdd(&flagged[0], 1)] = p;
     }
     return;
   }
@@ -1059,17 +734,24 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------
 // finalize (only proposals flagged by k_solve): same algebra with the directly measured |w|^2 and w.y
-__global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
-                                                       const ChainB* __restrict__ cks,
-                                                       const PropCoef* __restrict__ coef, int P, int n_rb,
-                                                       const double* __restrict__ part2, int64_t N,
-                                                       bsr_score* __restrict__ outv, double rank_floor) {
-  const int p = blockIdx.x;
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __restrict__ desc,
+                                                           const ChainB* __restrict__ cks,
+                                                           const PropCoef* __restrict__ coef, int P, int n_rb,
+                                                           const double* __restrict__ part2, int64_t N,
+                                                           bsr_score* __restrict__ outv, double rank_floor,
+                                                           int32_t* __restrict__ flagged) {
+  // one workgroup of four waves walks the batch's list of flagged proposals, one proposal per wave at a time
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
+  __shared__ double sh_all[4][BSR_NQ_MAX];
+  double* sh_c = sh_all[wave];
+  const int n_flag = flagged[0];
+  __syncthreads();
+  if (threadIdx.x == 0) flagged[0] = 0;  // the list is consumed: empty for the slot's next batch
+  for (int fi = wave; fi < n_flag; fi += 4) {
+  const int p = flagged[1 + fi];
   const PropCoef* cf = coef + p;
-  if (cf->skip) return;
-  __shared__ double sh_c[BSR_NQ_MAX];
   double ww = 0.0, wy = 0.0;
   for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
     const double* q = part2 + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
@@ -1079,7 +761,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   ww = wave_sum(ww);
   wy = wave_sum(wy);
   if (lane < BSR_NQ_MAX) sh_c[lane] = cf->c[lane];
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
   SolveIn in;
   in.ck = cks + dsc[p].ck;
   in.c = sh_c;
@@ -1097,6 +780,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_finalize(const PropDesc* __restric
   in.flags = cf->flags;
   in.rank_floor = rank_floor;
   solve_any(in, lane, outv + p);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1456,14 +1140,16 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   const LaunchGeom& g = a.g;
   dim3 grid((unsigned)(((g.n_rb + 7) / 8) * 8 * g.n_pg)), block(BSR_WG_WAVES * BSR_WAVE);
   if (!a.feat_list && MODE == MODE_PROJECT) grid.x = (unsigned)g.dyn_wgs;  // work-queue launch
+  if (MODE == MODE_RESIDUAL) grid.x = (unsigned)(((g.n_rb + 7) / 8) * 8);   // one workgroup per row block, flagged list
+  const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
   if (a.feat_list) {
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
     hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
-                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
+                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
   } else {
     hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
-                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, g.n_pg, a.feat_list, a.nF, a.part,
+                       a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
   }
 }
@@ -1488,12 +1174,14 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 #undef BSR_CASE
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor) {
-  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged) {
+  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
+                     flagged);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor) {
-  hipLaunchKernelGGL(k_finalize, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out, rank_floor);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
+                     rank_floor, flagged);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,

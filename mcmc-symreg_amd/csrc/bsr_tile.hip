@@ -1,0 +1,386 @@
+// Tile-stationary, tape-streaming row pass for gfx950 (MI355X): the projection pass of the scoring path
+// (allcal + the O(N) part of ylogLike / the rank gate, codes/funcs.py:175-220, 1147-1174, 1212-1226).
+//
+// One workgroup of 16 waves per CU.  A workgroup owns a row slice (a fixed share of the N rows) and one group of the
+// batch's tapes.  It stages its rows of every column the batch needs -- the referenced X columns, y and the basis
+// columns of the chains in the batch -- in LDS, chunk by chunk, and each of its waves runs "its" tapes (a static,
+// cost-balanced schedule written by the host) over the staged rows: a lane owns 2 adjacent rows of every 128-row
+// block, terminals are ds_read_b128, and the per-lane sums of a tape (projections on the basis, |s z|^2, s z.y,
+// max|z|) stay in registers across blocks and chunks.  A tape is reduced over the lanes ONCE per slice, not once per
+// (tape, row block) task as in k_rows: at N = 100k that is the difference between 4-8 k and 6 k x 5 wave reductions
+// per launch, and there is no ticket queue, no per-task descriptor fetch and no exposed L2 latency per terminal.
+//
+// What is summed in which order depends only on the context (rows per lane, slice boundaries), never on the batch:
+// a proposal's partial sums -- hence its score -- are bit-identical whatever else shares the launch.
+#include "bsr_device.h"
+
+namespace {
+
+template <int KQ>
+struct TapeAcc {
+  double c[KQ > 0 ? KQ : 1];
+  double a0, a1, amax;
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) c[i] = 0.0;
+    a0 = a1 = amax = 0.0;
+  }
+};
+
+// per-lane sums of one 128-row block of one tape; z: the lane's two candidate values, yv / qv: the lane's pair of y and
+// of every basis column (read from LDS by the caller, early enough to be there when the tape has run)
+template <typename T, int KQ, bool MASK>
+__device__ __forceinline__ void accumulate_v(TapeAcc<KQ>& A, const T (&z)[BSR_TILE_U], const typename VecOf<T, 2>::type yv,
+                                             const typename VecOf<T, 2>::type (&qv)[KQ > 0 ? KQ : 1], double s,
+                                             int64_t row0, int64_t N) {
+#ifdef BSR_ABLATE_ACC      // timing experiment: one sum only (results are wrong)
+  A.a0 += (double)z[0] + (double)z[1];
+  return;
+#endif
+#pragma unroll
+  for (int u = 0; u < BSR_TILE_U; ++u) {
+    T zv = z[u];
+    if (MASK) zv = (row0 + u < N) ? zv : (T)0;
+    const double zd = (double)zv;
+    const double zs = zd * s;
+    A.amax = max_abs(A.amax, zd);
+    A.a0 = fma(zs, zs, A.a0);
+    A.a1 = fma(zs, (double)(u == 0 ? yv.x : yv.y), A.a1);
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) A.c[i] = fma((double)(u == 0 ? qv[i].x : qv[i].y), zs, A.c[i]);
+  }
+}
+template <typename T, int KQ, bool MASK>
+__device__ __forceinline__ void accumulate(TapeAcc<KQ>& A, const T (&z)[BSR_TILE_U], const T* __restrict__ sy,
+                                           const T* __restrict__ sq, int col_stride, double s, int64_t row0, int64_t N) {
+  using V2 = typename VecOf<T, 2>::type;
+  const V2 yv = *reinterpret_cast<const V2*>(sy);
+  V2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * col_stride);
+  accumulate_v<T, KQ, MASK>(A, z, yv, qv, s, row0, N);
+}
+
+// Copies rows [c0*128, (c0+nb)*128) of every column of the launch into LDS.  Unit of work = 64 lanes x 16 B of one
+// column; wave w takes units w, w+16, ... and keeps DEPTH loads in flight before it writes them to LDS.
+template <typename T, int DEPTH>
+__device__ __forceinline__ void stage_rows(T* sx, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
+                                           int nb, int wave, int lane) {
+  constexpr int VEC = 16 / sizeof(T);
+  using V4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int UPB = BSR_TILE_BLOCK / VEC / BSR_WAVE;      // units per column and block (f64: 1; f32: half a unit)
+  const int upc = (UPB > 0) ? UPB * nb : (nb + 1) / 2;      // units per column
+  const int nvec_col = nb * (BSR_TILE_BLOCK / VEC);         // 16-byte pieces per column
+  const int n_units = ncols * upc;
+  int col = 0, ub = wave;                                   // unit = (col, ub): ub-th unit of column col
+  while (ub >= upc && col < ncols) { ub -= upc; ++col; }
+  for (int u0 = wave; u0 < n_units; u0 += DEPTH * BSR_TILE_WAVES) {
+    V4 r[DEPTH];
+    int de[DEPTH];                                          // LDS element offset of each piece, -1: none
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      de[j] = -1;
+      if (col < ncols) {
+        const int piece = ub * BSR_WAVE + lane;
+        if (piece < nvec_col) {
+          const int e = piece * VEC;                        // element offset inside the staged rows of the column
+          r[j] = *reinterpret_cast<const V4*>(colsrc[col] + (int64_t)c0 * BSR_TILE_BLOCK + e);
+          de[j] = col * chunk_rows + e;
+        }
+        ub += BSR_TILE_WAVES;
+        while (ub >= upc && col < ncols) { ub -= upc; ++col; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      if (de[j] >= 0) *reinterpret_cast<V4*>(sx + de[j]) = r[j];
+  }
+}
+
+// Lane reduction of one tape's sums and the store of its (tape, slice) partial record; every lane stores the same
+// totals (no lane-divergent branch).
+template <int KQ>
+__device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, int lane) {
+#ifdef BSR_ABLATE_REDUCE   // timing experiment: no lane reduction (results are wrong)
+#pragma unroll
+  for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
+  o[8] = A.a0; o[9] = A.a1; o[10] = A.amax; o[11] = 0.0;
+  return;
+#endif
+  // words 0..7: projections, 8: |s z|^2, 9: s z.y -- ten sums in groups of eight (wave_sum8), then max|z| and flags
+  constexpr int row_map[4] = {0, 2, 1, 3};
+  const int slot = row_map[lane >> 4];
+  double g0[8], lo0, hi0;
+  if constexpr (KQ <= 6) {  // everything fits one group: c[0..KQ-1] at 0.., a0 at 6, a1 at 7
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g0[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
+    g0[6] = A.a0;
+    g0[7] = A.a1;
+    wave_sum8(g0, lo0, hi0);
+    const double amax = wave_max(A.amax);
+    const double a0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hi0), 16),
+                                       __builtin_amdgcn_readlane(__double2loint(hi0), 16));  // value 6 lives in row 1 of hi
+    const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
+    if ((lane & 15) == 0) {
+      o[slot] = lo0;                                   // values 0..3
+      const int hslot = 4 + slot;                      // values 4..7 -> words 4, 5 (projections) and 8, 9 (a0, a1)
+      o[hslot < 6 ? hslot : hslot + 2] = hi0;
+    }
+    if (lane == 0) {
+      o[6] = 0.0;
+      o[7] = 0.0;
+      o[10] = amax;
+      o[11] = (double)fl;
+    }
+  } else {
+    double g1[8], lo1, hi1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g0[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g1[i] = 0.0;
+    g1[0] = A.a0;
+    g1[1] = A.a1;
+    wave_sum8(g0, lo0, hi0);
+    wave_sum8(g1, lo1, hi1);
+    const double amax = wave_max(A.amax);
+    const double a0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lo1), 0),
+                                       __builtin_amdgcn_readlane(__double2loint(lo1), 0));
+    const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
+    if ((lane & 15) == 0) {
+      o[slot] = lo0;
+      o[4 + slot] = hi0;
+      if (slot < 2) o[8 + slot] = lo1;                 // values 0 (a0, row 0) and 1 (a1, row 2 -> slot 1)
+    }
+    if (lane == 0) {
+      o[10] = amax;
+      o[11] = (double)fl;
+    }
+  }
+}
+
+// Single-chunk variant: the workgroup's whole slice fits in LDS.  Staged once; then the waves pull tapes from the
+// group's list (heaviest first) through an LDS counter, and a wave runs its tape over all blocks of the slice with one
+// set of accumulators.  Which wave runs a tape does not matter to the sums (one wave, blocks in order).
+template <typename T, int KQ>
+__global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> a) {
+  constexpr int U = BSR_TILE_U;
+  constexpr int S = BSR_REG_STACK;
+  using V2 = typename VecOf<T, 2>::type;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
+  __shared__ int s_next;
+  const TileGeom g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
+  const int b0 = slice * g.bps;
+  const int b1 = min(g.n_blocks, b0 + g.bps);
+  const int nb = max(0, b1 - b0);
+  const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
+  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
+  const int32_t CONSTANT_AS* list = as_const(a.sched) + (size_t)tg * g.per_group;
+  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
+  const T* sy = sx + (size_t)g.y_slot * chunk_rows;
+  unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
+#define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  TSTAMP(0);
+  if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;  // the first 16 list entries go to the waves in order
+  stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
+  __syncthreads();
+  TSTAMP(1);
+  TSTAMP(2);
+  // unit of work: (tape t of the group's list, sub-slice j); units are numbered tape-major, heaviest tape first
+  const int n_items = g.per_group * g.n_sub;
+  int idx = wave;
+  while (idx < n_items) {
+    const int t = idx / g.n_sub, j = idx - t * g.n_sub;
+    const int p = list[t];
+    if (p < 0) break;
+    const int sb0 = min(nb, j * g.sub_blocks), sb1 = min(nb, sb0 + g.sub_blocks);
+    // the next unit is requested now; its round trip hides under this one
+    int nxt = 0;
+    if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t* pc = a.codes + dsc[p].code_off;
+    const uint64_t* pf = a.feats + dsc[p].feat_off;
+    const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
+    const int n_nodes = dsc[p].n_nodes;
+    const double s = dsc[p].s;
+    const T* sq = sx + (size_t)dsc[p].qslot * chunk_rows;
+    const TapeHead hd = load_tape_head(pc, pf, pl);
+    TapeAcc<KQ> A;
+    A.clear();
+    // one 128-row block: the lane's pair of rows, sums in row order
+    auto add_block = [&](const T (&zz)[U], int off, int b) {
+      const int64_t row0 = (int64_t)(b0 + b) * BSR_TILE_BLOCK + 2 * lane;
+      const V2 yv = *reinterpret_cast<const V2*>(sy + off);
+      V2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * chunk_rows + off);
+      if ((int64_t)(b0 + b + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
+      else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
+    };
+    // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.  The
+    // per-lane sums still grow block by block in row order, so the result does not depend on the pairing.
+    int b = sb0;
+#pragma unroll 1
+    for (; b + 1 < sb1; b += 2) {
+      const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
+      T z4[2 * U];
+      LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
+      run_tape_head<T, 2 * U, S>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
+      const T za[U] = {z4[0], z4[1]}, zb[U] = {z4[2], z4[3]};
+      add_block(za, off, b);
+      add_block(zb, off + BSR_TILE_BLOCK, b + 1);
+    }
+    if (b < sb1) {
+      const int off = b * BSR_TILE_BLOCK + 2 * lane;
+      T z[U];
+      LdsCols<T, U> ldr{sx, chunk_rows, off};
+      run_tape_head<T, U, S>(hd, pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
+      add_block(z, off, b);
+    }
+    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice * g.n_sub + j) * BSR_P1_WORDS, lane);
+    idx = __builtin_amdgcn_readfirstlane(nxt);
+  }
+  TSTAMP(3);
+  TSTAMP(4);
+  if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#undef TSTAMP
+}
+
+template <typename T, int KQ, int QMAX>
+__global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a) {
+  constexpr int U = BSR_TILE_U;
+  constexpr int S = BSR_REG_STACK;
+  constexpr int VEC = 16 / sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
+  const TileGeom g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
+  const int b0 = slice * g.bps;
+  const int b1 = min(g.n_blocks, b0 + g.bps);
+  const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
+  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
+  const int32_t CONSTANT_AS* sched = as_const(a.sched);
+  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
+  const T* sy = sx + (size_t)g.y_slot * chunk_rows;
+  // diagnostics: shader-clock samples per wave (0 start, 1 first chunk staged, 2 first chunk computed, 3 all chunks
+  // computed, 4 reductions stored; 7 and 6: the constant-rate 100 MHz clock at the start and at the end -- the shader
+  // clock counters of different XCDs are not aligned, only differences inside one wave mean anything)
+  unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
+#define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  TSTAMP(0);
+  if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+
+  for (int pass = 0; pass < g.n_pass; ++pass) {
+    const int32_t CONSTANT_AS* my = sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
+    TapeAcc<KQ> A[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) A[q].clear();
+
+    for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks) {
+      const int nb = min(g.chunk_blocks, b1 - c0);
+      if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
+      stage_rows<T, 4>(sx, colsrc, g.ncols, chunk_rows, c0, nb, wave, lane);
+      __syncthreads();
+      if (c0 == b0 && pass == 0) TSTAMP(1);
+#pragma unroll 1
+      for (int q = 0; q < QMAX; ++q) {
+        const int p = my[q];
+        if (p < 0) continue;
+        const uint64_t* pc = a.codes + dsc[p].code_off;
+        const uint64_t* pf = a.feats + dsc[p].feat_off;
+        const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
+        const int n_nodes = dsc[p].n_nodes;
+        const double s = dsc[p].s;
+        const T* sq = sx + (size_t)dsc[p].qslot * chunk_rows;
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+          const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk
+          const int64_t row0 = (int64_t)(c0 + b) * BSR_TILE_BLOCK + 2 * lane;
+          T z[U];
+          LdsCols<T, U> ldr{sx, chunk_rows, off};
+          run_tape<T, U, S>(pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
+          const bool full = (int64_t)(c0 + b + 1) * BSR_TILE_BLOCK <= a.N;  // wave-uniform
+#define BSR_ACC_CASE(qq)                                                                              \
+  case qq:                                                                                            \
+    if constexpr (qq < QMAX) {                                                                        \
+      if (full) accumulate<T, KQ, false>(A[qq], z, sy + off, sq + off, chunk_rows, s, row0, a.N);     \
+      else accumulate<T, KQ, true>(A[qq], z, sy + off, sq + off, chunk_rows, s, row0, a.N);           \
+    }                                                                                                 \
+    break;
+          switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) BSR_ACC_CASE(2) BSR_ACC_CASE(3) }
+#undef BSR_ACC_CASE
+        }
+      }
+      if (c0 == b0 && pass == 0) TSTAMP(2);
+    }
+    if (pass == g.n_pass - 1) TSTAMP(3);
+    // one lane reduction per (tape, slice); every lane stores the same totals (no lane-divergent branch)
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+      const int p = my[q];
+      if (p < 0) continue;
+      store_partial<KQ>(A[q], a.part + ((size_t)p * g.n_part + slice) * BSR_P1_WORDS, lane);
+    }
+  }
+  TSTAMP(4);
+  if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#undef TSTAMP
+}
+
+template <typename T, int KQ>
+void launch_kq(hipStream_t st, const TileArgs<T>& a) {
+  const TileGeom& g = a.g;
+  const dim3 grid((unsigned)(g.T * g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
+  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T);
+  if (g.per_group > 0) {
+    static bool attr0 = false;
+    if (!attr0) {
+      (void)hipFuncSetAttribute((const void*)k_tile1<T, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(tile_lds_bytes_max() - 1024));
+      attr0 = true;
+    }
+    hipLaunchKernelGGL((k_tile1<T, KQ>), grid, block, lds, st, a);
+  } else if (g.qmax == 1) {
+    static bool attr1 = false;
+    if (!attr1) {
+      (void)hipFuncSetAttribute((const void*)k_tile<T, KQ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(tile_lds_bytes_max() - 1024));
+      attr1 = true;
+    }
+    hipLaunchKernelGGL((k_tile<T, KQ, 1>), grid, block, lds, st, a);
+  } else {
+    constexpr int QB = (KQ <= 3) ? 4 : ((KQ <= 5) ? 3 : 2);
+    static bool attrb = false;
+    if (!attrb) {
+      (void)hipFuncSetAttribute((const void*)k_tile<T, KQ, QB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(tile_lds_bytes_max() - 1024));
+      attrb = true;
+    }
+    hipLaunchKernelGGL((k_tile<T, KQ, QB>), grid, block, lds, st, a);
+  }
+}
+
+}  // namespace
+
+size_t tile_lds_bytes_max() { return 160 * 1024; }
+
+template <typename T>
+void launch_tile(hipStream_t st, const TileArgs<T>& a) {
+  switch (a.K) {
+    case 1: launch_kq<T, 1>(st, a); break;
+    case 2: launch_kq<T, 2>(st, a); break;
+    case 3: launch_kq<T, 3>(st, a); break;
+    case 4: launch_kq<T, 4>(st, a); break;
+    case 5: launch_kq<T, 5>(st, a); break;
+    case 6: launch_kq<T, 6>(st, a); break;
+    case 7: launch_kq<T, 7>(st, a); break;
+    default: launch_kq<T, 8>(st, a); break;
+  }
+}
+template void launch_tile<double>(hipStream_t, const TileArgs<double>&);
+template void launch_tile<float>(hipStream_t, const TileArgs<float>&);

@@ -30,7 +30,8 @@ for name in ("fetch", "write"):
         if (k, r["Dispatch_Id"]) not in seen:
             seen.add((k, r["Dispatch_Id"])); n[k] += 1
     for k in acc:
-        if "k_rows" in k and "Li0EE" in k.replace(" ", "") or ("k_rows" in k and ", 0>" in k):
+        # the projection pass: the tile kernel (bsr_tile.hip) or, where it does not apply, k_rows<..., PROJECT>
+        if "k_tile" in k or ("k_rows" in k and ", 0>" in k):
             res.setdefault(k, {})[name] = acc[k] / n[k]; res[k]["launches_" + name] = n[k]
 summary = {}
 for k, v in res.items():
