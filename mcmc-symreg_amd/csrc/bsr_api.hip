@@ -597,9 +597,12 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       mx = std::max(mx, sp);
       pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
       ++ns;
-      // measured per-visit costs (tools/stamps.py), in units of ~150 cycles: plain op 1, column read 4, exp/inv 3, sin/cos 8
-      cost += (r.opcode == BSR_OP_TERMINAL) ? 4 : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 8
-              : (r.opcode == BSR_OP_EXP || r.opcode == BSR_OP_INV) ? 3 : 1;
+      // per-visit vector instructions of the row passes (tools/pmc_tile.sh, ISA listings), in units of ~8: column read
+      // incl. its operand copies 2, plain op 1, ln 2, cubic 5, inv 9, exp 16, sin/cos 25; the base 8 is the per-block
+      // share of the projection sums and the lane reduction
+      cost += (r.opcode == BSR_OP_TERMINAL) ? 2 : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 25
+              : (r.opcode == BSR_OP_EXP) ? 16 : (r.opcode == BSR_OP_INV) ? 9 : (r.opcode == BSR_OP_CUBIC) ? 5
+              : (r.opcode == BSR_OP_LN) ? 2 : 1;
     }
     (*loc)[i].n_stream = ns;
     (*loc)[i].cost = cost;

@@ -173,8 +173,10 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  const int b0 = slice * g.bps;
-  const int b1 = min(g.n_blocks, b0 + g.bps);
+  // even split of the blocks over the slices: the first n_blocks % n_slices slices hold one block more (bps)
+  const int base = g.n_blocks / g.n_slices, rem = g.n_blocks - base * g.n_slices;
+  const int b0 = slice * base + min(slice, rem);
+  const int b1 = b0 + base + (slice < rem ? 1 : 0);
   const int nb = max(0, b1 - b0);
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
@@ -260,8 +262,10 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  const int b0 = slice * g.bps;
-  const int b1 = min(g.n_blocks, b0 + g.bps);
+  // even split of the blocks over the slices: the first n_blocks % n_slices slices hold one block more (bps)
+  const int base = g.n_blocks / g.n_slices, rem = g.n_blocks - base * g.n_slices;
+  const int b0 = slice * base + min(slice, rem);
+  const int b1 = b0 + base + (slice < rem ? 1 : 0);
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const int32_t CONSTANT_AS* sched = as_const(a.sched);

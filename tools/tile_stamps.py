@@ -84,6 +84,19 @@ def main():
     per_wg = np.array([comp[w][ok[w]].max() / max(1e-9, comp[w][ok[w]].mean()) for w in range(n) if ok[w].any()])
     print("compute imbalance inside a workgroup (slowest wave / mean wave): median %.2f  max %.2f" %
           (np.median(per_wg), per_wg.max()))
+    wgs = [w for w in range(n) if ok[w].any()]
+    wg_mean = np.array([comp[w][ok[w]].mean() for w in wgs]) / mhz
+    wg_max = np.array([comp[w][ok[w]].max() for w in wgs]) / mhz
+    stat("per workgroup: mean wave compute", wg_mean)
+    stat("per workgroup: slowest wave compute", wg_max)
+    for g in range(T):
+        sel = np.array([w // n_slices == g for w in wgs])
+        if sel.any():
+            print("  tape group %d: workgroup mean compute median %.2f us, slowest wave median %.2f us, max %.2f us" %
+                  (g, np.median(wg_mean[sel]), np.median(wg_max[sel]), wg_max[sel].max()))
+    slow = np.argsort(-wg_max)[:8]
+    print("  slowest workgroups (id, xcd=id%%8, slice, group): %s" %
+          ", ".join("(%d,%d,%d,%d: %.1f us)" % (wgs[i], wgs[i] % 8, wgs[i] % n_slices, wgs[i] // n_slices, wg_max[i]) for i in slow))
     wl["scorer"].close()
 
 
