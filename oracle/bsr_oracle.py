@@ -192,19 +192,23 @@ def allcal(node, indata, faithful=False):
         if op == LN:
             node.data = node.a * v + node.b                               # :181 two roundings
         elif op == 'exp':
-            if faithful:                                                   # :182-188
-                col = v[:, 0]
-                for i in range(len(col)):
-                    col[i] = np.exp(col[i]) if col[i] <= 200 else 1e+10
+            if faithful:                                                   # :182-188, same element access pattern
+                for i in np.arange(len(v[:, 0])):                          # (2-D indexing per element: it IS the cost)
+                    if v[i, 0] <= 200:
+                        v[i, 0] = np.exp(v[i, 0])
+                    else:
+                        v[i, 0] = 1e+10
                 node.data = v
             else:
                 with np.errstate(all="ignore"):
                     node.data = np.where(v <= 200, np.exp(np.where(v <= 200, v, 0.0)), 1e+10)
         elif op == 'inv':
             if faithful:                                                   # :189-195
-                col = v[:, 0]
-                for i in range(len(col)):
-                    col[i] = 0 if col[i] == 0 else 1 / col[i]
+                for i in np.arange(len(v[:, 0])):
+                    if v[i, 0] == 0:
+                        v[i, 0] = 0
+                    else:
+                        v[i, 0] = 1 / v[i, 0]
                 node.data = v
             else:
                 with np.errstate(all="ignore"):

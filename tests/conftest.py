@@ -17,6 +17,39 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- exemptions from the 1e-6 log-likelihood bound are counted, reported and pinned -------------------------------
+# A parity test may exempt a proposal whose value is chaotic at the ulp level (the ORACLE's own log-likelihood moves
+# by more than the tolerance when X is perturbed by one ulp): the device's sin/cos/exp/x^3 are accurate to < 1 ulp
+# but are not, and cannot be, bit-equal to the numpy build the goldens were generated with (its exp and power are
+# AVX-512 SIMD routines that differ from the correctly rounded value in 4.8 % / 2.8 % of arguments; tools/libm_census.py).
+# Every exemption goes through note_exempt(): the count per test is printed at the end of the session, written to
+# gpurun_out/exemptions.json and must not exceed the pinned value in tests/golden/exemption_caps.json (observed + 1).
+_EXEMPT = {}
+
+
+def note_exempt(key, n_exempt, n_total):
+    _EXEMPT[key] = (int(n_exempt), int(n_total))
+    cap_file = os.path.join(GOLDEN, "exemption_caps.json")
+    caps = json.load(open(cap_file)) if os.path.exists(cap_file) else {}
+    if os.environ.get("BSR_EXEMPT_DISCOVER") != "1":
+        cap = caps.get(key, 0)
+        assert n_exempt <= cap, "%s: %d exemptions from the 1e-6 bound, pinned cap %d (of %d)" % (key, n_exempt, cap, n_total)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _EXEMPT:
+        return
+    lines = ["", "exemptions from the 1e-6 log-likelihood bound (ulp-chaotic trees), per test:"]
+    for k in sorted(_EXEMPT):
+        lines.append("  %-90s %4d of %d" % (k, _EXEMPT[k][0], _EXEMPT[k][1]))
+    lines.append("  total %d" % sum(v[0] for v in _EXEMPT.values()))
+    sys.stderr.write("\n".join(lines) + "\n")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "exemptions.json"), "w") as f:
+            json.dump({k: {"exempt": v[0], "of": v[1]} for k, v in sorted(_EXEMPT.items())}, f, indent=1)
+
+
 def unf(v):
     """Decode the fixture float encoding (None stays None; 'nan'/'inf'/'-inf' strings)."""
     if isinstance(v, str):

@@ -134,3 +134,75 @@ def test_fp32_vs_fp64_loglik_tolerance(N, d):
     rel = np.abs(r32["loglik"][ok] - r64["loglik"][ok]) / np.abs(r64["loglik"][ok])
     assert np.all(rel <= 5e-5), rel          # fp32 tolerance of the log-posterior on well-conditioned trees
     assert np.all(np.abs(r32["sse"][ok] - r64["sse"][ok]) <= 5e-5 * r64["sse"][ok])
+
+
+def _deep_tape_tree(d):
+    """Depth-12 tree that needs the interpreter's spill path: a comb of 6 levels carrying a balanced subtree of 5 levels over affine leaves
+    (Strahler number 6 > the 4 values the register stack holds); +, * and small affine maps keep the values O(1)."""
+    def balanced(level, j):
+        if level == 0:
+            return un('ln', leaf(j % d), 0.3, 0.1 * ((j % 5) - 2))
+        op = '+' if level % 2 else '*'
+        return bi(op, balanced(level - 1, 2 * j), balanced(level - 1, 2 * j + 1))
+    t = balanced(5, 1)
+    for lvl in range(6):
+        t = bi('+' if lvl % 2 else '*', un('ln', leaf((3 * lvl + 1) % d), 0.5, 0.2), t)
+    return t
+
+
+@pytest.mark.parametrize("N,d,K,deep", [(100_000, 10, 3, False), (100_000, 10, 8, False), (1_000_000, 50, 3, True)])
+def test_fullsize_real_mix_values_against_the_oracle(N, d, K, deep):
+    """BASELINE configs[1], [2], [4] at full size, VALUES not only properties: 64 proposals drawn by the real move mix
+    from a burnt-in chain are scored on the device and by the oracle's vectorised flavour (same values as the
+    reference-faithful one, tests/test_oracle_golden.py) -- rank exact, log-likelihood to 1e-6 relative."""
+    import pandas as pd
+    import bsr_oracle as O
+    from conftest import note_exempt, spec_from_node
+    from bsr.chain import Chain, DeviceScorer, run_chains
+    from bsr.node import getHeight
+    X, y = synth(N, d)
+    scorer = DeviceScorer(X, y, K, n_chains=1, max_batch=72)
+    np.random.seed(1000)
+    ch = Chain(0, scorer, N, d, K, val=10 ** 9)
+    run_chains([ch], scorer, batch_per_chain=32, max_props=200)
+    cands = ch.generate(64)
+    tapes = [c.tape for c in cands]
+    trees = [c.root for c in cands]
+    ks = [c.k for c in cands]
+    sig = [c.new_sigma for c in cands]
+    if deep:
+        t = _deep_tape_tree(d)
+        assert getHeight(t) == 12
+        tapes.append(flatten(t))
+        trees.append(t)
+        ks.append(0)
+        sig.append(0.9)
+    B = len(tapes)
+    res = scorer.ctx.score_batch(tapes, [0] * B, ks, sig)
+    Xdf = pd.DataFrame(X)
+
+    def ocol(node, Xd=Xdf):
+        with np.errstate(all="ignore"):
+            return O.allcal(O.tree_from_json(spec_from_node(node)), Xd, False)[:, 0]
+    cur = np.stack([ocol(r) for r in ch.roots], axis=1)
+    n_full = n_exempt = 0
+    for i in range(B):
+        col = ocol(trees[i])
+        want = O.score_proposal(cur, ks[i], col, y, sig[i])
+        tag = "proposal %d tree %d rank %r" % (i, ks[i], want["rank"])
+        assert int(res["rank"][i]) == want["rank"], (tag, res[i])
+        if want["rank"] != K:
+            continue
+        n_full += 1
+        assert abs(res["scale"][i] - want["scale"]) <= 1e-12 * want["scale"], tag
+        if not abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]):
+            vals = []
+            for eps in (2.0 ** -52, -2.0 ** -52, 2.0 ** -51):     # exempt only if the oracle's own value is ulp-chaotic
+                colp = ocol(trees[i], pd.DataFrame(X * (1.0 + eps)))
+                vals.append(O.score_proposal(cur, ks[i], colp, y, sig[i]).get("loglik", np.nan))
+            spread = max(abs(v - want["loglik"]) for v in vals)
+            assert spread > 1e-7 * abs(want["loglik"]), (tag, res[i], want, vals)
+            n_exempt += 1
+    assert n_full >= B // 2
+    note_exempt("full-size real mix N=%d d=%d K=%d" % (N, d, K), n_exempt, n_full)
+    scorer.close()
