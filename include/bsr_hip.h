@@ -39,7 +39,13 @@ extern "C" {
 enum {
   BSR_OP_INV = 0, BSR_OP_LN = 1, BSR_OP_NEG = 2, BSR_OP_SIN = 3, BSR_OP_COS = 4,
   BSR_OP_EXP = 5, BSR_OP_SQUARE = 6, BSR_OP_CUBIC = 7, BSR_OP_ADD = 8, BSR_OP_MUL = 9,
-  BSR_OP_TERMINAL = 10
+  BSR_OP_TERMINAL = 10,
+  /* 11, 12: reserved (fused entries of the device's opcode stream).
+   * Extensions beyond the reference's table (semantics defined by oracle/bsr_oracle.py: allcal):
+   *   sub  x - y                      (left - right, rows in tape order: left subtree first)
+   *   div  y == 0 ? 0 : x / y         (protected like the reference's inv, codes/funcs.py:189-195)
+   *   log  x == 0 ? 0 : log|x|        (natural logarithm; the reference's 'ln' is the affine map a*x+b) */
+  BSR_OP_SUB = 13, BSR_OP_DIV = 14, BSR_OP_LOG = 15
 };
 
 enum { BSR_DTYPE_F64 = 0, BSR_DTYPE_F32 = 1 };
@@ -215,6 +221,10 @@ const char* bsr_engine_last_error(const bsr_engine* e);
 /* reject = 0 (default): a NaN candidate aborts the run with BSR_E_LINALG, as the reference's matrix_rank call raises
  * (codes/funcs.py:1226); reject != 0: it is handled like a rank-gate rejection (documented divergence). */
 int bsr_engine_set_nan_policy(bsr_engine* e, int32_t reject);
+/* Operator table and prior weights (Ops / Op_weights / Op_type, hard-coded at codes/bsr_class.py:110-112): entry i has
+ * opcode opcodes[i] (arity follows from the opcode) and weight weights[i]; at most 16 entries.  Default: the reference's
+ * ten operators with weight 1/10.  Call before bsr_engine_init_chain. */
+int bsr_engine_set_ops(bsr_engine* e, int32_t n_ops, const int32_t* opcodes, const double* weights);
 int bsr_engine_seed(bsr_engine* e, int32_t chain, uint32_t seed);   /* == np.random.seed(seed) for that chain */
 int bsr_engine_set_rng(bsr_engine* e, int32_t chain, const uint32_t* key624, int32_t pos, int32_t has_gauss,
                        double gauss);                                /* == np.random.set_state(...) */

@@ -78,6 +78,7 @@ def lib():
         "bsr_engine_destroy": (C.c_int, [vp]),
         "bsr_engine_last_error": (C.c_char_p, [vp]),
         "bsr_engine_set_nan_policy": (C.c_int, [vp, i32]),
+        "bsr_engine_set_ops": (C.c_int, [vp, i32, vp, vp]),
         "bsr_engine_seed": (C.c_int, [vp, i32, C.c_uint32]),
         "bsr_engine_set_rng": (C.c_int, [vp, i32, vp, i32, i32, dbl]),
         "bsr_engine_get_rng": (C.c_int, [vp, i32, vp, pi, pi, pd]),
@@ -101,7 +102,7 @@ EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_des
            "bsr_score_wait", "bsr_fit_beta",
            "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_comm_unique_id",
            "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy", "bsr_engine_create", "bsr_engine_destroy",
-           "bsr_engine_last_error", "bsr_engine_set_nan_policy", "bsr_engine_seed", "bsr_engine_set_rng", "bsr_engine_get_rng",
+           "bsr_engine_last_error", "bsr_engine_set_nan_policy", "bsr_engine_set_ops", "bsr_engine_seed", "bsr_engine_set_rng", "bsr_engine_get_rng",
            "bsr_engine_init_chain", "bsr_engine_run", "bsr_engine_chain_result", "bsr_rng_selftest"]
 
 TRACE_DTYPE = np.dtype([("chain", "<i4"), ("count", "<i4"), ("action", "<i4"), ("change", "<i4"), ("rank", "<i4"),

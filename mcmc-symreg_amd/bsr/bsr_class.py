@@ -10,6 +10,9 @@ reference's meaning.  Extra keyword-only options (defaults preserve the referenc
                          reference; a list of ints: chain c is seeded with chain_seeds[c] and chains advance
                          together, several per launch (independent restarts are the reference's only parallelism,
                          codes/bsr_class.py:99)
+  ops, op_weights        operator table and prior weights (the reference hard-codes them, codes/bsr_class.py:110-112).
+                         Default: the reference's ten operators with weight 1/10 each.  Names from bsr.node.OP_CODE:
+                         the ten plus the extensions 'sub', 'div', 'log'.  Weights need not sum to one.
   devices                None: everything runs in this process on `device`.  A list of GPU indices: the chains are
                          sharded over one fresh process per listed GPU (chain c -> devices[c % len], seeded
                          chain_seeds[c], default 1000 + c), each rank drives its share with the native sampler and
@@ -35,7 +38,7 @@ except Exception:  # pragma: no cover
 class BSR(BaseEstimator, RegressorMixin):
     def __init__(self, treeNum=3, itrNum=5000, alpha1=0.4, alpha2=0.4, beta=-1, disp=False, val=100,
                  device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8, engine="native",
-                 devices=None):
+                 devices=None, ops=None, op_weights=None):
         self.treeNum = treeNum
         self.itrNum = itrNum
         self.alpha1 = alpha1
@@ -50,6 +53,8 @@ class BSR(BaseEstimator, RegressorMixin):
         self.chains_per_launch = chains_per_launch
         self.engine = engine
         self.devices = devices
+        self.ops = ops
+        self.op_weights = op_weights
 
     # ---- codes/bsr_class.py:37-51
     def model(self, last_ind=1):
@@ -116,8 +121,9 @@ class BSR(BaseEstimator, RegressorMixin):
             chains.append({"trees": trees, "beta": [enc(b) for b in np.asarray(self.betas_[c]).reshape(-1)],
                            "train_err": [enc(e) for e in self.train_err_[c]]})
         doc = {"format": "bsr-hip-model", "version": 1,
-               "operators": ["inv", "ln", "neg", "sin", "cos", "exp", "square", "cubic", "+", "*"],
-               "node_fields": ["opcode (index into operators, 10 = terminal)", "left", "right", "feature", "a", "b"],
+               "operators": {"0": "inv", "1": "ln", "2": "neg", "3": "sin", "4": "cos", "5": "exp", "6": "square",
+                             "7": "cubic", "8": "+", "9": "*", "10": "terminal", "13": "sub", "14": "div", "15": "log"},
+               "node_fields": ["opcode (key of operators)", "left", "right", "feature", "a", "b"],
                "params": {k: getattr(self, k) for k in ("treeNum", "itrNum", "alpha1", "alpha2", "beta", "val")},
                "chains": chains}
         with open(path, "w") as f:
@@ -159,7 +165,7 @@ class BSR(BaseEstimator, RegressorMixin):
         K = self.treeNum
         if self.devices is not None:
             return self._fit_sharded(X, y, K, y_is_series)
-        T = P.default_table()
+        T = self._table()
         seeds = self.chain_seeds
         n_slots = 1 if seeds is None else max(1, min(self.chains_per_launch, len(seeds), self.itrNum))
         scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, self.batch * n_slots), device=self.device,
@@ -203,6 +209,17 @@ class BSR(BaseEstimator, RegressorMixin):
             self.stats_["discarded"] += r["n_discarded"]
         return
 
+    def _table(self):
+        """OpTable of this estimator: Ops / Op_weights / Op_type of codes/bsr_class.py:110-112, or the user's."""
+        from .node import OPS, OP_ARITY
+        if self.ops is None and self.op_weights is None:
+            return P.default_table()
+        ops = list(self.ops) if self.ops is not None else list(OPS)
+        w = list(self.op_weights) if self.op_weights is not None else [1.0 / len(ops)] * len(ops)
+        if len(w) != len(ops):
+            raise ValueError("ops and op_weights differ in length")
+        return P.OpTable.get(ops, w, [OP_ARITY[o] for o in ops])
+
     def _fit_sharded(self, X, y, K, y_is_series):
         """One process per GPU of `devices`; this process touches no GPU (codes/bsr_class.py:99, 270-276 sharded)."""
         from .sharded import fit_sharded
@@ -210,7 +227,8 @@ class BSR(BaseEstimator, RegressorMixin):
         seeds = [int(v) for v in seeds[:self.itrNum]]
         recs = fit_sharded(X, y, K=K, seeds=seeds, devices=list(self.devices), batch=self.batch, val=self.val,
                            beta=self.beta, chains_per_launch=self.chains_per_launch, dtype=self.dtype,
-                           y_is_series=y_is_series)
+                           y_is_series=y_is_series, ops=None if self.ops is None and self.op_weights is None else self._table().ops,
+                           op_weights=None if self.ops is None and self.op_weights is None else self._table().weights)
         self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
         for r in recs:
             self.roots_.append(r["roots"])
@@ -225,6 +243,8 @@ class BSR(BaseEstimator, RegressorMixin):
     def _fit_native(self, scorer, N, d, K, seeds, n_slots, y_is_series):
         from .native import NativeEngine
         eng = NativeEngine(scorer.ctx, n_slots, d, beta=self.beta, val=self.val, y_is_series=y_is_series)
+        T = self._table()
+        eng.set_ops(T.ops, T.weights)
         results = []
         try:
             if seeds is None:

@@ -47,6 +47,15 @@ class NativeEngine:
         """False (default): NaN candidates raise LinAlgError like the reference; True: they are rejected."""
         self._check(self._L.bsr_engine_set_nan_policy(self._h, 1 if reject else 0))
 
+    def set_ops(self, ops, weights):
+        """Operator table and prior weights (names as in bsr.node.OP_CODE); default: the reference's ten, uniform."""
+        from .node import OP_CODE
+        codes = np.array([OP_CODE[o] for o in ops], dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if len(codes) != len(w):
+            raise ValueError("ops and op_weights differ in length")
+        self._check(self._L.bsr_engine_set_ops(self._h, len(codes), _lib.ptr(codes), _lib.ptr(w)))
+
     def seed(self, chain, seed):
         self._check(self._L.bsr_engine_seed(self._h, chain, int(seed) & 0xFFFFFFFF))
 

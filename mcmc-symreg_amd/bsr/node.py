@@ -10,6 +10,14 @@ import numpy as np
 OPS = ['inv', 'ln', 'neg', 'sin', 'cos', 'exp', 'square', 'cubic', '+', '*']   # codes/bsr_class.py:110
 OP_TYPE = [1, 1, 1, 1, 1, 1, 1, 1, 2, 2]                                        # codes/bsr_class.py:112
 OP_CODE = {name: i for i, name in enumerate(OPS)}
+# Extensions beyond the reference's table (opcodes of include/bsr_hip.h, semantics in the oracle):
+# sub x-y, div where(y==0, 0, x/y), log where(x==0, 0, log|x|).  Usable through BSR(ops=..., op_weights=...).
+EXT_OPS = ['sub', 'div', 'log']
+OP_CODE.update({'sub': 13, 'div': 14, 'log': 15})
+OP_ARITY = {name: OP_TYPE[i] for i, name in enumerate(OPS)}
+OP_ARITY.update({'sub': 2, 'div': 2, 'log': 1})
+OP_NAME = {code: name for name, code in OP_CODE.items()}
+COMMUTATIVE = ('+', '*')
 
 
 class Operator:
@@ -188,9 +196,15 @@ def Express(node):
             return "(" + inner + ")^2"
         if op == 'cubic':
             return "(" + inner + ")^3"
+        if op == 'log':
+            return "log(" + inner + ")"
         return "-(" + inner + ")"
     if node.operator == '+':
         return Express(node.left) + "+" + Express(node.right)
+    if node.operator == 'sub':
+        return "(" + Express(node.left) + ")-(" + Express(node.right) + ")"
+    if node.operator == 'div':
+        return "(" + Express(node.left) + ")/[" + Express(node.right) + "]"
     return "(" + Express(node.left) + ")*(" + Express(node.right) + ")"
 
 

@@ -19,7 +19,7 @@ from . import dist as D
 
 
 def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=-1, chains_per_launch=8,
-             dtype="f64", y_is_series=True, max_props=-1, scorer=None):
+             dtype="f64", y_is_series=True, max_props=-1, scorer=None, ops=None, op_weights=None):
     """Runs this rank's share of len(seeds) chains on `device` with the native sampler and gathers every rank's
     records.  Returns (raw records of ALL chains ordered by chain id: uint8 (n_chains, RECORD_BYTES), decode with
     bsr.dist.unpack_record; this rank's counters)."""
@@ -37,6 +37,8 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
     stats = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0, "chains": len(mine)}
     try:
         eng = NativeEngine(scorer.ctx, n_slots, X.shape[1], beta=beta, val=val, y_is_series=y_is_series)
+        if ops is not None:
+            eng.set_ops(ops, op_weights if op_weights is not None else [1.0 / len(ops)] * len(ops))
         try:
             todo = list(mine)
             while todo:
@@ -65,7 +67,8 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
 
 
 def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, val=100, beta=-1,
-                chains_per_launch=8, dtype="f64", y_is_series=True, timeout=None, env_extra=None):
+                chains_per_launch=8, dtype="f64", y_is_series=True, timeout=None, env_extra=None, ops=None,
+                op_weights=None):
     """Parent side.  Spawns one fresh process per entry of `devices` (this process needs no GPU and must not be
     asked to share its own context), waits, and returns the gathered chain records ordered by chain id."""
     from .launch import spawn
@@ -85,6 +88,9 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
         argv = ["-m", "bsr.sharded", "--data", work, "--out", out, "--K", str(K), "--batch", str(batch),
                 "--val", str(val), "--beta", repr(float(beta)), "--chains-per-launch", str(chains_per_launch),
                 "--dtype", dtype, "--y-is-series", "1" if y_is_series else "0"]
+        if ops is not None:
+            w = op_weights if op_weights is not None else [1.0 / len(ops)] * len(ops)
+            argv += ["--ops", ",".join(ops), "--op-weights", ",".join(repr(float(v)) for v in w)]
         codes, _ = spawn(len(devices), argv, env_extra=env, timeout=timeout, relay_rank0_stdout=False)
         if any(c != 0 for c in codes):
             raise RuntimeError("bsr.sharded: rank exit codes %r" % (codes,))
@@ -113,6 +119,8 @@ def main(argv=None):
     ap.add_argument("--chains-per-launch", type=int, default=8)
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--y-is-series", type=int, default=1)
+    ap.add_argument("--ops", default="", help="comma-separated operator names (default: the reference's ten)")
+    ap.add_argument("--op-weights", default="", help="comma-separated prior weights, one per operator")
     args = ap.parse_args(argv)
     from .launch import rank_env
     rank, world, local = rank_env()
@@ -123,7 +131,9 @@ def main(argv=None):
     seeds = [int(s) for s in np.load(os.path.join(args.data, "seeds.npy"))]
     allrecs, stats = run_rank(X, y, args.K, seeds, rank=rank, world=world, device=device, batch=args.batch,
                               val=args.val, beta=args.beta, chains_per_launch=args.chains_per_launch,
-                              dtype=args.dtype, y_is_series=bool(args.y_is_series))
+                              dtype=args.dtype, y_is_series=bool(args.y_is_series),
+                              ops=args.ops.split(",") if args.ops else None,
+                              op_weights=[float(v) for v in args.op_weights.split(",")] if args.op_weights else None)
     if rank == 0:
         tmp = args.out + ".tmp.npy"
         np.save(tmp, allrecs)

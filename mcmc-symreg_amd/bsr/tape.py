@@ -7,7 +7,7 @@ which keeps the interpreter's stack within its register slots; x+y and x*y are b
 """
 import numpy as np
 
-from .node import Node, OPS, OP_CODE, OP_TYPE
+from .node import Node, OPS, OP_CODE, OP_TYPE, OP_ARITY, OP_NAME, COMMUTATIVE
 
 NODE_DTYPE = np.dtype([("opcode", "<i4"), ("left", "<i4"), ("right", "<i4"), ("feature", "<i4"),
                        ("a", "<f8"), ("b", "<f8")], align=True)
@@ -40,7 +40,10 @@ def flatten(root):
                 need[id(n)] = need[id(n.left)]
             else:
                 a, b = need[id(n.left)], need[id(n.right)]
-                need[id(n)] = a + 1 if a == b else max(a, b)
+                if n.operator in COMMUTATIVE:
+                    need[id(n)] = a + 1 if a == b else max(a, b)
+                else:                                   # left is evaluated first and waits on the stack
+                    need[id(n)] = max(a, b + 1)
     # pass 2: emit
     rows = []
     index = {}
@@ -56,7 +59,7 @@ def flatten(root):
                 work.append((n.left, False))
             else:
                 first, second = (n.left, n.right)
-                if need[id(n.right)] > need[id(n.left)]:
+                if n.operator in COMMUTATIVE and need[id(n.right)] > need[id(n.left)]:
                     first, second = n.right, n.left
                 work.append((second, False))
                 work.append((first, False))
@@ -82,9 +85,9 @@ def unflatten(tape):
             n.type = 0
             n.feature = np.array([int(r["feature"])])
         else:
-            n.type = OP_TYPE[op]
-            n.operator = OPS[op]
-            n.op_ind = op
+            n.operator = OP_NAME[op]
+            n.type = OP_ARITY[n.operator]
+            n.op_ind = op if op < len(OPS) else None
             n.left = nodes[int(r["left"])]
             n.left.parent = n
             if n.type == 2:

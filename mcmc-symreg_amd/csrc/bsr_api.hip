@@ -395,6 +395,10 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+static inline bool is_binary_op(int op) {
+  return op == BSR_OP_ADD || op == BSR_OP_MUL || op == BSR_OP_SUB || op == BSR_OP_DIV;
+}
+
 static int check_tape(bsr_ctx* c, const bsr_node* t, int len, int* max_sp) {
   if (len <= 0) return fail(c, BSR_E_TAPE, "empty tape");
   if (len > BSR_MAX_TAPE) return fail(c, BSR_E_TOOBIG, "tape longer than BSR_MAX_TAPE");
@@ -404,9 +408,9 @@ static int check_tape(bsr_ctx* c, const bsr_node* t, int len, int* max_sp) {
     if (op == BSR_OP_TERMINAL) {
       if (t[i].feature < 0 || t[i].feature >= c->d) return fail(c, BSR_E_TAPE, "terminal feature out of range");
       ++sp;
-    } else if (op >= 0 && op < BSR_OP_ADD) {
+    } else if ((op >= 0 && op < BSR_OP_ADD) || op == BSR_OP_LOG) {
       if (sp < 1) return fail(c, BSR_E_TAPE, "unary operator on empty stack");
-    } else if (op == BSR_OP_ADD || op == BSR_OP_MUL) {
+    } else if (is_binary_op(op)) {
       if (sp < 2) return fail(c, BSR_E_TAPE, "binary operator needs two operands");
       --sp;
     } else {
@@ -507,7 +511,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         if (j > tape_off[i] && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
       } else if (rows[j].opcode == BSR_OP_LN) {
         ++nl;
-      } else if (rows[j].opcode >= BSR_OP_ADD) {
+      } else if (is_binary_op(rows[j].opcode)) {
         --fsp;
       }
       fmx = std::max(fmx, fsp);
@@ -591,7 +595,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         pl[2 * nl] = r.a;
         pl[2 * nl + 1] = r.b;
         ++nl;
-      } else if (r.opcode >= BSR_OP_ADD) {
+      } else if (is_binary_op(r.opcode)) {
         --sp;
       }
       mx = std::max(mx, sp);
@@ -601,7 +605,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       // incl. its operand copies 2, plain op 1, ln 2, cubic 5, inv 9, exp 16, sin/cos 25; the base 8 is the per-block
       // share of the projection sums and the lane reduction
       cost += (r.opcode == BSR_OP_TERMINAL) ? 2 : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 25
-              : (r.opcode == BSR_OP_EXP) ? 16 : (r.opcode == BSR_OP_INV) ? 9 : (r.opcode == BSR_OP_CUBIC) ? 5
+              : (r.opcode == BSR_OP_EXP || r.opcode == BSR_OP_LOG) ? 16
+              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 9 : (r.opcode == BSR_OP_CUBIC) ? 5
               : (r.opcode == BSR_OP_LN) ? 2 : 1;
     }
     (*loc)[i].n_stream = ns;

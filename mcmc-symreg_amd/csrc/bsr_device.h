@@ -316,7 +316,23 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
     }
     const int op = (int)(code & 15u);
     code >>= 4;
-    if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
+    if (op >= BSR_OP_SUB) {  // extensions beyond the reference's table (semantics: oracle/bsr_oracle.py allcal)
+      if (op == BSR_OP_LOG) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)log(fabs((double)acc[u]));
+      } else {
+        T lhs[U];
+        --sp;
+        st.pop(sp, lhs);
+        if (op == BSR_OP_SUB) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = lhs[u] - acc[u];
+        } else {  // BSR_OP_DIV: protected like inv
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : lhs[u] / acc[u];
+        }
+      }
+    } else if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
       if (op == BSR_OP_TERMINAL) {
         st.push(sp, acc);
         ++sp;

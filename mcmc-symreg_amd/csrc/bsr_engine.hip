@@ -179,8 +179,10 @@ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python max
 
 // ------------------------------------------------------------------------------------------------ trees
 enum { OP_INV = 0, OP_LN = 1, OP_TERMINAL = 10 };
-const int kOpType[10] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2};  // codes/bsr_class.py:112
-const double kOpW = 0.1;                                   // uniform weights, codes/bsr_class.py:111
+// Operator table (Ops / Op_weights / Op_type of codes/bsr_class.py:110-112).  A tree node keeps the operator's OPCODE
+// (bsr_hip.h) in `op` and the TABLE INDEX it was created with in `op_ind` -- never updated by ReassignOperator, as in
+// the reference, which matters as soon as the weights are not uniform.
+#define BSR_MAX_OPS 16
 
 struct TNode {
   int type = -1;     // -1 not grown, 0 terminal, 1 unary, 2 binary
@@ -288,23 +290,42 @@ void up_depth(Tree& t, int root) {
 struct Params {
   int n_feature;
   double beta;
-};
+  int n_ops = 0;
+  int op_code[BSR_MAX_OPS];    // opcode of table entry k
+  int op_type[BSR_MAX_OPS];    // arity of table entry k
+  double w[BSR_MAX_OPS], cdf[BSR_MAX_OPS], logw[BSR_MAX_OPS];
 
-int choose_op(LegacyRng& r) {  // np.random.choice(arange(10), p=uniform): cdf.searchsorted(u, 'right')
-  static double cdf[10];
-  static bool init = false;
-  if (!init) {
+  static int arity_of(int code) {
+    return (code == BSR_OP_ADD || code == BSR_OP_MUL || code == BSR_OP_SUB || code == BSR_OP_DIV) ? 2 : 1;
+  }
+  void set_table(int n, const int* codes, const double* weights) {
+    n_ops = n;
     double c = 0;
-    for (int i = 0; i < 10; ++i) {
-      c += kOpW;
+    for (int i = 0; i < n; ++i) {
+      op_code[i] = codes[i];
+      op_type[i] = arity_of(codes[i]);
+      w[i] = weights[i];
+      logw[i] = flog(weights[i]);
+      c += weights[i];                 // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
       cdf[i] = c;
     }
-    const double last = cdf[9];
-    for (int i = 0; i < 10; ++i) cdf[i] /= last;
-    init = true;
+    const double last = cdf[n - 1];
+    for (int i = 0; i < n; ++i) cdf[i] /= last;
   }
+  void set_default_table() {           // codes/bsr_class.py:110-112: the ten operators, uniform weights
+    int codes[10];
+    double weights[10];
+    for (int i = 0; i < 10; ++i) {
+      codes[i] = i;
+      weights[i] = 1.0 / 10;
+    }
+    set_table(10, codes, weights);
+  }
+};
+
+int choose_op(const Params& P, LegacyRng& r) {  // np.random.choice(arange(n), p=w): cdf.searchsorted(u, 'right')
   const double u = r.uniform();
-  return (int)(std::upper_bound(cdf, cdf + 10, u) - cdf);
+  return (int)(std::upper_bound(P.cdf, P.cdf + P.n_ops, u) - P.cdf);
 }
 
 void grow(Tree& t, int i, const Params& P, double sigma_a, double sigma_b, LegacyRng& r) {  // codes/funcs.py:74-119
@@ -319,9 +340,9 @@ void grow(Tree& t, int i, const Params& P, double sigma_a, double sigma_b, Legac
     }
   }
   if (pick) {
-    const int k = choose_op(r);
-    t.n[i].op = k;
-    t.n[i].type = kOpType[k];
+    const int k = choose_op(P, r);
+    t.n[i].op = P.op_code[k];
+    t.n[i].type = P.op_type[k];
     t.n[i].op_ind = k;
   }
   if (t.n[i].type == 0) {
@@ -351,7 +372,7 @@ void fstruc(const Tree& t, int i, const Params& P, double sigma_a, double sigma_
   // codes/funcs.py:349-398; uses each node's STORED depth and op_ind
   const TNode& nd = t.n[i];
   double ls = 0, lp = 0;
-  const double logw = std::log(kOpW);
+  const double logw = (nd.type != 0 && nd.op_ind >= 0) ? P.logw[nd.op_ind] : 0.0;
   if (nd.type == 0) {
     ls += flog(1 - 1 / std::pow(1 + nd.depth, -P.beta));
     ls -= std::log((double)P.n_feature);
@@ -500,6 +521,7 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
   } else if (u <= p_stay + p_grow + p_prune + p_detr) {                                 // :582-673
     action = A_DETR;
     const int dn = detcd[r.randint(0, (int64_t)detcd.size())];
+    const int det_oi = t.n[dn].op_ind;  // the removed node's table index as assigned at its creation
     int cut = -1;
     Q = p_detr / (double)detcd.size();
     if (t.n[dn].parent < 0) {
@@ -545,17 +567,17 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
     const double nd = (double)ndet.size();
     const double new_pdetr = (1 - new_pstay) * (1.0 / 3) * nd / (nd + 3);
     const double new_ptr = (1 - new_pstay) / 3 - new_pdetr;
-    Qinv = new_ptr * kOpW / (double)nt_order.size();
+    Qinv = new_ptr * P.w[det_oi] / (double)nt_order.size();
     if (cut >= 0) Qinv = Qinv * fexp(fstruc0(t, cut, P, sigma_a, sigma_b));  // cut keeps its stale depths
   } else if (u <= p_stay + p_grow + p_prune + p_detr + p_trans) {                       // :679-786
     action = A_TRANS;
     const int ins = tree[r.randint(0, (int64_t)tree.size())];
-    const int k = choose_op(r);
+    const int k = choose_op(P, r);
     const int nn = t.add(t.n[ins].depth);
-    t.n[nn].op = k;
-    t.n[nn].type = kOpType[k];
+    t.n[nn].op = P.op_code[k];
+    t.n[nn].type = P.op_type[k];
     t.n[nn].op_ind = k;
-    if (t.n[nn].type == 1 && k == OP_LN) change = CH_EXPAND;
+    if (t.n[nn].type == 1 && t.n[nn].op == OP_LN) change = CH_EXPAND;
     const int par = t.n[ins].parent;
     if (par < 0) {
       Root = nn;
@@ -568,14 +590,14 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
     t.n[ins].parent = nn;
     if (t.n[nn].type == 1) {
       up_depth(t, Root);
-      Q = p_trans * kOpW / (double)tree.size();
+      Q = p_trans * P.w[k] / (double)tree.size();
     } else {
       const int nr = t.add(t.n[nn].depth + 1);
       t.n[nn].right = nr;
       t.n[nr].parent = nn;
       up_depth(t, Root);
       grow(t, nr, P, sigma_a, sigma_b, r);
-      Q = p_trans * kOpW * fexp(fstruc0(t, nr, P, sigma_a, sigma_b)) / (double)tree.size();
+      Q = p_trans * P.w[k] * fexp(fstruc0(t, nr, P, sigma_a, sigma_b)) / (double)tree.size();
     }
     std::vector<int> nt_order, ndet;
     preorder(t, Root, nt_order);
@@ -591,52 +613,52 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
   } else if (u <= p_stay + p_grow + p_prune + p_detr + p_trans + p_rop) {               // :791-903
     action = A_ROP;
     const int cn = nterm[r.randint(0, (int64_t)nterm.size())];
-    const int last_op = t.n[cn].op, last_type = t.n[cn].type;
-    const int k = choose_op(r);
-    const int new_type = kOpType[k];
+    const int last_op = t.n[cn].op, last_type = t.n[cn].type, last_oi = t.n[cn].op_ind;
+    const int k = choose_op(P, r);
+    const int new_type = P.op_type[k], new_op = P.op_code[k];
     if (last_type == 1 && new_type == 1) {  // unary -> unary (op_ind not updated)
-      t.n[cn].op = k;
+      t.n[cn].op = new_op;
       if (last_op == OP_LN) {
-        if (k != OP_LN) change = CH_SHRINK;
-      } else if (k == OP_LN) {
+        if (new_op != OP_LN) change = CH_SHRINK;
+      } else if (new_op == OP_LN) {
         change = CH_EXPAND;
       }
-      Q = kOpW;
-      Qinv = kOpW;
+      Q = P.w[k];
+      Qinv = P.w[last_oi];
     } else if (last_type == 1) {  // unary -> binary
-      t.n[cn].op = k;
+      t.n[cn].op = new_op;
       t.n[cn].type = 2;
       const int rr = t.add(t.n[cn].depth + 1);
       t.n[cn].right = rr;
       t.n[rr].parent = cn;
       grow(t, rr, P, sigma_a, sigma_b, r);
       const double fs = fstruc0(t, rr, P, sigma_a, sigma_b);
-      Q = p_rop * fexp(fs) * kOpW / (double)nterm.size();
+      Q = p_rop * fexp(fs) * P.w[k] / (double)nterm.size();
       int new_n;
       const int nt = count_terms(t, Root, &new_n);
       const int new_lt = count_ln(t, Root);
       const double new_p0 = (double)new_lt / (4 * (new_lt + 3));
-      Qinv = 0.125 * (1 - new_p0) * kOpW / (new_n - nt);
+      Qinv = 0.125 * (1 - new_p0) * P.w[last_oi] / (new_n - nt);
       if (new_lt > ltNum) change = CH_EXPAND;
       else if (new_lt < ltNum) change = CH_SHRINK;
     } else if (new_type == 1) {  // binary -> unary
       const int cut = t.n[cn].right;
       const int p_lt = count_ln(t, cut);
       if (p_lt > 1) change = CH_SHRINK;
-      else if (k == OP_LN && p_lt == 0) change = CH_EXPAND;
+      else if (new_op == OP_LN && p_lt == 0) change = CH_EXPAND;
       t.n[cn].right = -1;
-      t.n[cn].op = k;
+      t.n[cn].op = new_op;
       t.n[cn].type = new_type;
-      Q = p_rop * kOpW / (double)nterm.size();
+      Q = p_rop * P.w[k] / (double)nterm.size();
       const int new_n = count_nodes(t, Root);
       const int new_lt = count_ln(t, Root);
       const double new_p0 = (double)new_lt / (4 * (new_lt + 3));
       const double fs = fstruc0(t, cut, P, sigma_a, sigma_b);
-      Qinv = 0.125 * (1 - new_p0) * fexp(fs) * kOpW / new_n;  // newTerm empty at :893-894
+      Qinv = 0.125 * (1 - new_p0) * fexp(fs) * P.w[last_oi] / new_n;  // newTerm empty at :893-894
     } else {  // binary -> binary
-      t.n[cn].op = k;
-      Q = kOpW;
-      Qinv = kOpW;
+      t.n[cn].op = new_op;
+      Q = P.w[k];
+      Qinv = P.w[last_oi];
     }
   } else {                                                                              // :907-917
     action = A_RFEAT;
@@ -804,7 +826,8 @@ void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
         need[i] = need[nd.left];
       } else {
         const int a = need[nd.left], b = need[nd.right];
-        need[i] = (a == b) ? a + 1 : std::max(a, b);
+        const bool comm = nd.op == BSR_OP_ADD || nd.op == BSR_OP_MUL;
+        need[i] = comm ? ((a == b) ? a + 1 : std::max(a, b)) : std::max(a, b + 1);  // sub/div: left waits on the stack
       }
     }
   }
@@ -829,7 +852,8 @@ void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
         st.push_back({nd.left, 0});
       } else {
         int first = nd.left, second = nd.right;
-        if (need[nd.right] > need[nd.left]) std::swap(first, second);
+        const bool comm = nd.op == BSR_OP_ADD || nd.op == BSR_OP_MUL;
+        if (comm && need[nd.right] > need[nd.left]) std::swap(first, second);
         st.push_back({second, 0});
         st.push_back({first, 0});
       }
@@ -1146,6 +1170,7 @@ extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chain
   e->y_is_series = y_is_series;
   e->P.n_feature = n_feature;
   e->P.beta = beta;
+  e->P.set_default_table();
   e->chains.resize(n_chains);
   for (int c = 0; c < n_chains; ++c) {
     e->chains[c].index = c;
@@ -1161,6 +1186,24 @@ extern "C" int bsr_engine_destroy(bsr_engine* e) {
 }
 
 extern "C" const char* bsr_engine_last_error(const bsr_engine* e) { return e ? e->err.c_str() : ""; }
+
+// Ops / Op_weights of codes/bsr_class.py:110-112 as data: opcodes[i] is the opcode of table entry i (arity follows
+// from it), weights[i] its prior weight (np.random.choice normalises them).  Call before bsr_engine_init_chain.
+extern "C" int bsr_engine_set_ops(bsr_engine* e, int32_t n_ops, const int32_t* opcodes, const double* weights) {
+  if (!e || !opcodes || !weights || n_ops <= 0 || n_ops > BSR_MAX_OPS) return BSR_E_ARG;
+  int codes[BSR_MAX_OPS];
+  double total = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const int c = opcodes[i];
+    const bool known = (c >= 0 && c < BSR_OP_TERMINAL) || c == BSR_OP_SUB || c == BSR_OP_DIV || c == BSR_OP_LOG;
+    if (!known || !(weights[i] >= 0)) return efail(e, BSR_E_ARG, "bsr_engine_set_ops: unknown opcode or negative weight");
+    codes[i] = c;
+    total += weights[i];
+  }
+  if (!(total > 0)) return efail(e, BSR_E_ARG, "bsr_engine_set_ops: weights sum to zero");
+  e->P.set_table(n_ops, codes, weights);
+  return BSR_OK;
+}
 
 extern "C" int bsr_engine_set_nan_policy(bsr_engine* e, int32_t reject) {
   if (!e) return BSR_E_ARG;
@@ -1408,12 +1451,14 @@ extern "C" int bsr_rng_selftest(uint32_t seed, int32_t n, const int32_t* kind, c
   if (!kind || !out) return BSR_E_ARG;
   LegacyRng r;
   r.seed(seed);
+  Params P10;
+  P10.set_default_table();
   for (int i = 0; i < n; ++i) {
     switch (kind[i]) {
       case 0: out[i] = r.uniform(); break;
       case 1: out[i] = (double)r.randint(lo[i], hi[i]); break;
       case 2: out[i] = r.standard_normal(); break;
-      case 3: out[i] = (double)choose_op(r); break;
+      case 3: out[i] = (double)choose_op(P10, r); break;
       default: out[i] = invgamma_rvs(r, (int)lo[i]); break;
     }
   }

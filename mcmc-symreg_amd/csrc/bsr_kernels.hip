@@ -228,10 +228,11 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
     // chip waiting for a few late, lonely waves (measured with tools/stamps.py: waves of one launch end anywhere
     // between 6 and 28 us).  Here the heaviest tapes go first (desc[i].order) and the tail is one task long.
     //  * Ticket counters are per XCD (blockIdx & 7, the hardware's round-robin placement): an XCD works on its own
-    //    eighth of the row blocks, like the static mapping, and bumps its counters with L2-local atomics (no sc1: a
-    //    device-scope atomic is executed memory-side, ~35 ns each once thousands of waves hit one address).  Should a
-    //    counter ever be touched from two XCDs, each L2 counts through its own copy: tasks may be repeated (the same
-    //    values stored again), never skipped.
+    //    eighth of the row blocks, like the static mapping, and bumps its counters with agent-scope relaxed atomics.
+    //    hipcc (ROCm 7.2, gfx950) emits `global_atomic_add ... sc0` for them -- the same encoding as for workgroup
+    //    scope, executed in the XCD's L2; only system scope adds sc1 (memory-side, ~35 ns each once thousands of waves
+    //    hit one address).  Should a counter ever be touched from two XCDs, each L2 counts through its own copy: tasks
+    //    may be repeated (the same values stored again), never skipped.
     //  * Even in L2 one address takes an atomic only every ~8 ns, so an XCD's tasks are spread over BSR_QUEUE_SUB
     //    counters (row block j of the XCD belongs to counter j % BSR_QUEUE_SUB).  A workgroup drains its own counter,
     //    then reads all of them at once (one lane each, through the atomic unit so the values are fresh) and moves to
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
     //  * Counters live 128 B apart; the launcher hands out a fresh, zeroed set per launch and this launch clears the
     //    set that comes up again half a ring later.
     const int x = blockIdx.x & 7;
-    if (blockIdx.x == 0 && threadIdx.x < 8 * BSR_QUEUE_SUB) queue_clear[threadIdx.x * 32] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 8 * BSR_QUEUE_SUB)
+      __hip_atomic_store(&queue_clear[threadIdx.x * 32], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ int s_tk[2], s_next;
     const int nrb_x = (n_rb - x + 7) >> 3;
     int32_t* qx = queue + x * (BSR_QUEUE_SUB * 32);
@@ -258,13 +260,13 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       const int n_tasks = nj * nquad;
       if (n_tasks > 0) {
         int32_t* q = qx + cq * 32;
-        if (threadIdx.x == 0) s_tk[par] = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (threadIdx.x == 0) s_tk[par] = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         for (;;) {
           const int t = __builtin_amdgcn_readfirstlane(s_tk[par]);
           if (t >= n_tasks) break;
           int tn = 0;
-          if (threadIdx.x == 0) tn = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (threadIdx.x == 0) tn = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // row-block-major: neighbouring tickets are different tapes on one row block (tape-major order put every wave
           // of the chip on the same two or three X columns at once and doubled the sweep time)
           const int jj = t / nquad;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
       if (wave == 0) {
         int seen = 0x7fffffff;
         if (lane < BSR_QUEUE_SUB)
-          seen = __hip_atomic_fetch_add(qx + my_c * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          seen = __hip_atomic_fetch_add(qx + my_c * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t open = (uint32_t)__ballot(lane < BSR_QUEUE_SUB && seen < my_n);
         // rotate by a workgroup- and round-dependent amount and take the first open counter from there
         const int rot = (wgid * 5 + round * 7) & (BSR_QUEUE_SUB - 1);

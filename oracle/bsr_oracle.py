@@ -33,6 +33,11 @@ OPS = ('inv', 'ln', 'neg', 'sin', 'cos', 'exp', 'square', 'cubic', '+', '*')  # 
 OP_ARITY = (1, 1, 1, 1, 1, 1, 1, 1, 2, 2)                                      # codes/bsr_class.py:112
 OP_WEIGHTS = tuple([1.0 / len(OPS)] * len(OPS))                                # codes/bsr_class.py:111
 LN = 'ln'
+# Extensions beyond the reference's table.  The reference cannot evaluate them, so THIS file is where
+# their semantics are defined: protected like the reference's inv (codes/funcs.py:189-195), element-wise numpy.
+#   sub  x - y      div  where(y == 0, 0, x / y)      log  where(x == 0, 0, log|x|)   (natural logarithm)
+EXT_OPS = ('sub', 'div', 'log')
+EXT_ARITY = (2, 2, 1)
 
 
 class ONode:
@@ -122,9 +127,15 @@ def express(node):  # codes/funcs.py:314-342
             return "(" + inner + ")^2"
         if op == 'cubic':
             return "(" + inner + ")^3"
+        if op == 'log':
+            return "log(" + inner + ")"
         return "-(" + inner + ")"
     if node.operator == '+':
         return express(node.left) + "+" + express(node.right)
+    if node.operator == 'sub':
+        return "(" + express(node.left) + ")-(" + express(node.right) + ")"
+    if node.operator == 'div':
+        return "(" + express(node.left) + ")/[" + express(node.right) + "]"
     return "(" + express(node.left) + ")*(" + express(node.right) + ")"
 
 
@@ -223,6 +234,9 @@ def allcal(node, indata, faithful=False):
             node.data = np.square(v)                                       # :203
         elif op == 'cubic':
             node.data = np.power(v, 3)                                     # :205
+        elif op == 'log':                                                  # extension (EXT_OPS)
+            with np.errstate(all="ignore"):
+                node.data = np.where(v == 0, 0.0, np.log(np.abs(np.where(v == 0, 1.0, v))))
         else:
             raise ValueError("no matching unary operator %r" % (op,))
     elif t == 2:
@@ -232,6 +246,11 @@ def allcal(node, indata, faithful=False):
             node.data = lv + rv                                            # :210
         elif node.operator == '*':
             node.data = lv * rv                                            # :212
+        elif node.operator == 'sub':                                       # extensions (EXT_OPS)
+            node.data = lv - rv
+        elif node.operator == 'div':
+            with np.errstate(all="ignore"):
+                node.data = np.where(rv == 0, 0.0, lv / np.where(rv == 0, 1.0, rv))
         else:
             raise ValueError("no matching binary operator %r" % (node.operator,))
     else:
@@ -791,7 +810,8 @@ def newprop(Roots, count, sigma, y, indata, n_feature, Ops, Op_weights, Op_type,
 
 
 # ------------------------------------------------------------------ chain loop (BSR.fit body)
-def run_chain(X, y, K=3, beta=-1, val=100, faithful=False, max_props=None, on_proposal=None):
+def run_chain(X, y, K=3, beta=-1, val=100, faithful=False, max_props=None, on_proposal=None, ops=None, weights=None,
+              arity=None):
     """One pass of the `while len(trainERRS) < MM` body (codes/bsr_class.py:99-273).
 
     Returns dict(roots, beta, errs, n_props, init_roots)."""
@@ -799,7 +819,14 @@ def run_chain(X, y, K=3, beta=-1, val=100, faithful=False, max_props=None, on_pr
         X = pd.DataFrame(X)
     n_feature = X.shape[1]
     n_train = X.shape[0]
-    Ops, W, T = list(OPS), list(OP_WEIGHTS), list(OP_ARITY)
+    Ops, W, T = list(OPS), list(OP_WEIGHTS), list(OP_ARITY)                # codes/bsr_class.py:110-112 ...
+    if ops is not None:                                                     # ... or the caller's table
+        Ops = list(ops)
+        W = list(weights) if weights is not None else [1.0 / len(Ops)] * len(Ops)
+        known = dict(zip(OPS + EXT_OPS, OP_ARITY + EXT_ARITY))
+        T = list(arity) if arity is not None else [known[o] for o in Ops]
+    elif weights is not None:
+        W = list(weights)
     RootLists = [[] for _ in range(K)]
     Siga, Sigb = [], []
     sigma = invgamma.rvs(1)

@@ -44,6 +44,8 @@ def test_reference_traces_through_the_native_engine(name, batch):
     K = g["K"]
     ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=64)
     eng = NativeEngine(ctx, 1, X.shape[1], val=g["val"], y_is_series=not name.endswith("yarr"))
+    if "weights" in g:
+        eng.set_ops(g["ops"], g["weights"])
     eng.seed(0, g["seed"])
     eng.init_chain(0)
     tr = eng.run(batch_per_chain=batch, max_props=g["n_props"] if g["truncated"] else -1, trace_cap=g["n_props"] + 8)

@@ -270,3 +270,52 @@ def test_k1_rescored_candidates_keep_the_batch_order_for_commit():
     for tk in t[1:]:
         ctx.score_wait(tk, out)
     ctx.close()
+
+
+@pytest.mark.parametrize("N", [130, 4097])
+def test_work_queue_soak_against_the_static_grid(N, monkeypatch):
+    """The ticket-queue launch of k_rows (per-XCD counters, four batches in flight, counters re-armed by the kernel
+    itself) hammered with 10^4 short launches: every result bit-identical to the static-grid launch of the same
+    kernel (LDS-staged variant), i.e. no ticket is ever skipped, even with rounds this short."""
+    from bsr.tape import flatten, pack
+    d, K, B = 4, 3, 24
+    rs = np.random.RandomState(17)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
+    np.random.seed(9)
+    trees = []
+    while len(trees) < K + B:
+        root = O.ONode(0)
+        O.grow(root, d, list(O.OPS), list(O.OP_WEIGHTS), list(O.OP_ARITY), -1, 1.0, 1.0)
+        if O.count_nodes(root) < 40:
+            trees.append(node_from_spec(spec_from_node(root)))
+    tapes = [flatten(t) for t in trees[K:]]
+    ks = (np.arange(B) % K).astype(np.int32)
+    sig = rs.uniform(0.5, 2.0, size=B)
+    zeros = np.zeros(B, np.int32)
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _ctx(X, y, K=K, n_chains=1, max_batch=B)
+        for k in range(K):
+            c.set_current(0, k, flatten(trees[k]))
+        c.refresh(0)
+        return c
+    static = make({"BSR_TILE": "0", "BSR_NO_LDS": "0"})           # static grid, X staged in LDS
+    want = static.score_batch(tapes, zeros, ks, sig).copy()
+    static.close()
+    queue = make({"BSR_TILE": "0", "BSR_NO_LDS": "1"})            # ticket queue
+    rows, off = pack(tapes)
+    out = np.zeros(B, dtype=want.dtype)
+    tickets = []
+    n_launch = 10_000
+    for i in range(n_launch):
+        tickets.append(queue.score_submit(rows, off, zeros, ks, sig))
+        if len(tickets) == 4:
+            queue.score_wait(tickets.pop(0), out)
+            assert out.tobytes() == want.tobytes(), i
+    while tickets:
+        queue.score_wait(tickets.pop(0), out)
+        assert out.tobytes() == want.tobytes()
+    queue.close()

@@ -187,7 +187,7 @@ def _ulp_sensitive(rec, X, y, rtol):
 
 
 TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr",
-          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24"]
+          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24", "weights_a", "weights_b"]
 
 
 def replay_trace(name, make_scorer, batch, ll_rtol):
@@ -198,8 +198,13 @@ def replay_trace(name, make_scorer, batch, ll_rtol):
     rows = []
     scorer = make_scorer(X, y, K)
     np.random.seed(g["seed"])
+    table = None
+    if "weights" in g:                     # non-uniform operator weights (golden g8)
+        from bsr import proposal as P
+        from bsr.node import OP_ARITY
+        table = P.OpTable.get(g["ops"], g["weights"], [OP_ARITY[o] for o in g["ops"]])
     ch = Chain(0, scorer, len(y), X.shape[1], K, val=g["val"], y_is_series=not name.endswith("yarr"),
-               trace=rows.append)
+               trace=rows.append, table=table)
     for spec, node in zip(g["init_trees"], ch.init_roots):
         _tree_match(spec, node, name + " init")
     run_chains([ch], scorer, batch_per_chain=batch, max_props=g["n_props"] if g["truncated"] else None)

@@ -89,7 +89,8 @@ def test_g3_yloglike():
 
 
 TRACES = ["f1_s0", "f1_s7", "synth_d10_s1000", "synth_K8_s1001", "synth_K1_s5", "synth_K2_s11_yarr",
-          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24"]
+          "synth_K4_s21", "synth_K5_s22", "synth_K6_s23", "synth_K7_s24",
+          "weights_a", "weights_b"]     # non-uniform operator weights: the stale-op_ind quirk of funcs.py:812-900 shows
 
 
 @pytest.mark.parametrize("name", TRACES)
@@ -102,7 +103,7 @@ def test_g5_newprop_trace(name):
     rows = []
     np.random.seed(g["seed"])
     res = O.run_chain(X, y, K=g["K"], val=g["val"], max_props=g["n_props"] if g["truncated"] else None,
-                      on_proposal=rows.append)
+                      on_proposal=rows.append, ops=g.get("ops"), weights=g.get("weights"))
     assert len(rows) == g["n_props"]
     for spec, node in zip(g["init_trees"], res["init_roots"]):
         _tree_equal(spec, node)

@@ -15,6 +15,8 @@ Fixtures:
   g5_trace_*.json/npz per-proposal newProp traces of BSR.fit    (funcs.py:1184-1306)
   g6_fit_f1.json      BSR(3,50).fit end to end on f1, seed 0    (bsr_class.py:77-278)
   g7_rng.json         RNG primitives as consumed by the path    
+  g5_trace_weights_*.json/npz  (g8) newProp driven with NON-UNIFORM operator weights (funcs.py:1184 takes the table as arguments;
+                      only bsr_class.py:110-112 hard-codes it): pins the stale-op_ind quirk of funcs.py:812-900
 """
 import os
 import sys
@@ -470,8 +472,56 @@ def g7():
                          "invgamma_pdf": pdfs, "norm_pdf": npdf})
 
 
+def g8():
+    """Traces with NON-UNIFORM operator weights.  BSR.fit hard-codes uniform ones (codes/bsr_class.py:110-112) but
+    newProp takes the table as arguments, so the chain loop of codes/bsr_class.py:116-243 is written here around the
+    reference's own grow / newProp, under the same tracer as the g5 traces (same file format plus "weights")."""
+    import copy
+    from scipy.stats import invgamma
+    for tag, seed, K, weights, n in (("a", 31, 3, [3, 1, 2, 1, 1, 2, 1, 1, 4, 4], 400),
+                                     ("b", 32, 2, [1, 5, 1, 3, 3, 1, 1, 1, 2, 6], 300)):
+        w = [float(v) / sum(weights) for v in weights]
+        rs = np.random.RandomState(100 + seed)
+        X = rs.uniform(-3, 3, size=(120, 3))
+        y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(120)
+        Xd, ys = pd.DataFrame(X), pd.Series(y)
+        tr = Tracer(None)
+        tr.install()
+        try:
+            np.random.seed(seed)
+            sigma = invgamma.rvs(1)
+            roots, sa, sb = [], [], []
+            for _ in range(K):
+                root = RF.Node(0)
+                a = invgamma.rvs(1)
+                b = invgamma.rvs(1)
+                RF.grow(root, 3, OPS, w, OPT, -1, a, b)
+                roots.append(root)
+                sa.append(a)
+                sb.append(b)
+            init = [tree_json(r) for r in roots]
+            done = 0
+            while done < n:
+                for k in range(K):
+                    res, sigma, root, a, b = RC.newProp(roots, k, sigma, ys, Xd, 3, OPS, w, OPT, -1, sa[k], sb[k])
+                    sa[k], sb[k] = a, b
+                    if res:
+                        roots[k] = copy.deepcopy(root)
+                    done += 1
+                    if done >= n:
+                        break
+        finally:
+            tr.remove()
+        name = "weights_%s" % tag
+        meta = {"versions": VERSIONS, "name": name, "K": K, "seed": seed, "val": 10 ** 9, "N": 120, "d": 3,
+                "truncated": True, "n_props": len(tr.rows), "init_trees": init, "props": tr.rows,
+                "ops": OPS, "weights": w, "n_accept": int(sum(r["accepted"] for r in tr.rows))}
+        dump("g5_trace_%s.json" % name, meta)
+        np.savez_compressed(os.path.join(OUT, "g5_trace_%s.npz" % name), X=X, y=y)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g5b", "g6", "g7"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g5b", "g6", "g7", "g8"]
     for t in todo:
         globals()[t]()
