@@ -179,7 +179,8 @@ class BSR(BaseEstimator, RegressorMixin):
                 if self.disp:
                     print('starting training...')
                 for _ in range(self.itrNum):
-                    ch = Chain(0, scorer, N, d, K, beta=self.beta, val=self.val, table=T, y_is_series=y_is_series)
+                    ch = Chain(0, scorer, N, d, K, beta=self.beta, val=self.val, table=T, y_is_series=y_is_series,
+                               feature_range=(X.min(axis=0), X.max(axis=0)))
                     run_chains([ch], scorer, batch_per_chain=self.batch)
                     rng.set_state(ch.rng_state)      # the next chain continues the same stream
                     results.append(ch.result())
@@ -192,7 +193,7 @@ class BSR(BaseEstimator, RegressorMixin):
                     for slot, ci in enumerate(wave):
                         np.random.seed(seeds[ci])
                         chains.append(Chain(slot, scorer, N, d, K, beta=self.beta, val=self.val, table=T,
-                                            y_is_series=y_is_series))
+                                            y_is_series=y_is_series, feature_range=(X.min(axis=0), X.max(axis=0))))
                     run_chains(chains, scorer, batch_per_chain=self.batch)
                     for ch in chains:
                         results.append(ch.result())

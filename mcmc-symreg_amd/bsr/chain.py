@@ -8,7 +8,11 @@ drawing its accept-uniform"; results are then consumed in order and the first ev
 the batch:
   * accept              -> adopt the candidate, rewind the RNG to just after that proposal's uniform;
   * rank-gate rejection -> the reference returns BEFORE drawing the uniform (codes/funcs.py:1226-1228), so the RNG
-                           is rewound to just before it and the tail of the batch is regenerated.
+                           is rewound to just before it and the tail of the batch is regenerated -- unless the
+                           rejection was speculated: the gate's verdict is mostly a property of the chain state
+                           (dependent siblings, siblings 1e14 apart in scale), so a tree whose recent proposals were
+                           gate-rejected is speculated as rejected again, no uniform is drawn behind it, and the batch
+                           stays on the right stream.  A wrong guess costs the tail, never exactness.
 Every chain owns its RNG stream (numpy legacy MT19937 state) so that several chains can share one launch.
 """
 import math
@@ -74,14 +78,14 @@ class DeviceScorer(Scorer):
 
 class _Cand:
     __slots__ = ("k", "root", "tape", "change", "Q", "Qinv", "hratio", "detjacob", "new_sigma", "new_sa2", "new_sb2",
-                 "state_before_u", "u", "action", "s_new")
+                 "state_before_u", "u", "action", "s_new", "pred_def")
 
 
 class Chain:
     """One chain: K trees, sigma, per-tree (sigma_a, sigma_b), the sweep position and its private RNG stream."""
 
     def __init__(self, index, scorer, N, n_feature, K, beta=-1, val=100, table=None, y_is_series=True,
-                 rng_state=None, trace=None):
+                 rng_state=None, trace=None, feature_range=None):
         self.index = index
         self.scorer = scorer
         self.N = N
@@ -97,6 +101,9 @@ class Chain:
         self.n_accept = 0
         self.n_rank_rejects = 0
         self.n_discarded = 0
+        self.def_ema = [0.0] * K           # share of tree k's recent proposals that the rank gate rejected
+        self.feature_range = feature_range  # (lo[d], hi[d]) of X, or None: only the history guess is used
+        self.colmax = [0.0] * K
         if rng_state is not None:
             rng.set_state(rng_state)
         self._init_state()
@@ -129,6 +136,7 @@ class Chain:
     def _refresh(self):
         info = self.scorer.refresh(self.index)
         self.colflags = [int(f) for f in info["colflags"]]
+        self.colmax = [float(v) for v in info.get("maxabs", [0.0] * self.K)]
         if any(self.colflags):
             # every fitted value of the old state is NaN: Series.sum(skipna=True) gives 0.0, ndarray sum NaN
             self.sse_old = 0.0 if self.y_is_series else float("nan")
@@ -144,6 +152,24 @@ class Chain:
         if self.fs_old[k] is None:
             self.fs_old[k] = P.fstruc_t(self.roots[k], self.n_feature, self.T, self.beta, self.siga[k], self.sigb[k])
         return self.fs_old[k]
+
+    # -- rank-gate guess (csrc/bsr_engine.hip: predict_gate_reject has the same two rules) ------------------------
+    def _predict_reject(self, root, k):
+        if self.def_ema[k] > 0.9:
+            return True
+        if self.K < 2 or self.feature_range is None:
+            return False
+        if any(self.colflags[j] for j in range(self.K) if j != k):
+            return True
+        sib = max(self.colmax[j] for j in range(self.K) if j != k)
+        lo, hi = P.tree_range(root, self.feature_range[0], self.feature_range[1], float(self.N))
+        est = max(abs(lo), abs(hi))
+        if est != est:
+            return False
+        if math.isinf(est):
+            return True
+        tol = max(self.N, self.K) * 2.220446049250313e-16
+        return est > sib * (10.0 / tol) or est < sib * (tol / 10.0)
 
     # -- speculative generation ---------------------------------------------------------------------------------
     def generate(self, max_n):
@@ -164,7 +190,8 @@ class Chain:
             c.root, c.change, c.Q, c.Qinv, c.action = mv.root, mv.change, mv.Q, mv.Qinv, mv.action
             c.tape = flatten(c.root)
             c.state_before_u = rng.get_state()
-            c.u = rng.uniform()
+            c.pred_def = self._predict_reject(mv.root, k)
+            c.u = None if c.pred_def else rng.uniform()
             cands.append(c)
             total += 1
             count = (count + 1) % self.K
@@ -195,11 +222,21 @@ class Chain:
             self.count = (k + 1) % self.K
             if rank < self.K:                                          # codes/funcs.py:1226-1228: no uniform drawn
                 self.n_rank_rejects += 1
-                self.rng_state = c.state_before_u
+                self.def_ema[k] = 0.75 * self.def_ema[k] + 0.25
                 if rec is not None:
                     self.trace(rec)
+                if c.pred_def:                                         # speculated exactly that: the batch goes on
+                    continue
+                self.rng_state = c.state_before_u
                 broke = True
                 break
+            self.def_ema[k] *= 0.75
+            tail_invalid = False
+            if c.pred_def:                                             # passed the gate after all: draw its uniform now
+                rng.set_state(c.state_before_u)
+                c.u = rng.uniform()
+                self.rng_state = rng.get_state()
+                tail_invalid = True
             yllstar = float(res["loglik"])
             yll = self._yll(self.sigma)
             s_new = P.fstruc_t(c.root, self.n_feature, self.T, self.beta, c.new_sa2, c.new_sb2)
@@ -211,6 +248,9 @@ class Chain:
             if not accepted:
                 if rec is not None:
                     self.trace(rec)
+                if tail_invalid:                                       # what follows was drawn on a shifted stream
+                    broke = True
+                    break
                 continue
             # ---- accepted: codes/bsr_class.py:200-243
             self.n_accept += 1
@@ -224,6 +264,9 @@ class Chain:
             self.Beta, rmse = self.scorer.fit_beta(self.index)
             self.errs.append(rmse)
             self.total = 0
+            for j in range(self.K):
+                if j != k:
+                    self.def_ema[j] = 0.0                              # their sibling set has changed
             rng.set_state(c.state_before_u)
             rng.uniform()
             self.rng_state = rng.get_state()

@@ -7,6 +7,8 @@ draw order, so every branch below follows the reference's behaviour, quirks incl
 """
 import math
 
+import numpy as np
+
 from . import rng
 from .node import Node, clone, genList, getNum, numLT, upDepth
 
@@ -504,3 +506,70 @@ def accept_test(logR, u):
     """`np.log(test) >= alpha` means reject (codes/funcs.py:1298-1306); NaN logR accepts, as in the reference."""
     alpha = 0 if 0 < logR else logR   # Python's min(logR, 0)
     return not (rng.flog(u) >= alpha)
+
+
+# ------------------------------------------------------------------------------------------------ value ranges
+def tree_range(node, xlo, xhi, N):
+    """Interval bound (lo, hi) of a tree's values over the per-feature ranges of X: what max|z| can be.  Used by the
+    chain engines to guess the rank gate's verdict on a candidate whose scale is far from its siblings'
+    (bsr.chain.Chain._predict_reject; the C++ sampler has the same function)."""
+    inf = float("inf")
+    if node.type == 0:
+        f = int(np.asarray(node.feature).reshape(-1)[0])
+        return float(xlo[f]), float(xhi[f])
+    lo, hi = tree_range(node.left, xlo, xhi, N)
+
+    def inv(l, h):
+        if l <= 0 <= h:
+            m = 2 * N / max(h - l, 1e-300)
+            return -m, m
+        return min(1 / l, 1 / h), max(1 / l, 1 / h)
+
+    def mul(a, b):
+        c = [a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1]]
+        c = [0.0 if v != v else v for v in c]
+        return min(c), max(c)
+
+    def cube(v):
+        try:
+            return v ** 3
+        except OverflowError:
+            return math.copysign(inf, v)
+    op = node.operator
+    if node.type == 1:
+        if op == LN:
+            p, q = node.a * lo + node.b, node.a * hi + node.b
+            return min(p, q), max(p, q)
+        if op == 'neg':
+            return -hi, -lo
+        if op in ('sin', 'cos'):
+            return -1.0, 1.0
+        if op == 'exp':
+            def ex(v):
+                if v > 200:
+                    return 1e10
+                return math.exp(v)
+            return ex(lo), max(ex(hi), ex(min(hi, 200.0)))
+        if op == 'square':
+            try:
+                a, b = lo * lo, hi * hi
+            except OverflowError:
+                return 0.0, inf
+            return (0.0 if lo <= 0 <= hi else min(a, b)), max(a, b)
+        if op == 'cubic':
+            return cube(lo), cube(hi)
+        if op == 'inv':
+            return inv(lo, hi)
+        if op == 'log':
+            top = math.log(max(abs(lo), abs(hi), 1e-300))
+            bot = math.log(max((hi - lo) / (2 * N), 1e-300)) if lo <= 0 <= hi else math.log(min(abs(lo), abs(hi)))
+            return min(bot, top), top
+        return lo, hi
+    rl, rh = tree_range(node.right, xlo, xhi, N)
+    if op == '+':
+        return lo + rl, hi + rh
+    if op == 'sub':
+        return lo - rh, hi - rl
+    if op == 'div':
+        return mul((lo, hi), inv(rl, rh))
+    return mul((lo, hi), (rl, rh))

@@ -103,6 +103,7 @@ struct bsr_ctx {
   RefreshPlan* h_plan = nullptr;       // pinned
   double* d_rpart = nullptr;
   int fast_refresh = 1;
+  std::vector<double> x_lo, x_hi;  // per-feature range of X (host side; the native sampler's rank-gate predictor)
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
   BatchSlot slot[BSR_MAX_INFLIGHT];
@@ -386,6 +387,15 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     for (auto& e : s.ev) CK(hipEventCreate(&e));
   }
 #undef CK
+  c->x_lo.assign(d, INFINITY);
+  c->x_hi.assign(d, -INFINITY);
+  for (int64_t n = 0; n < N; ++n) {
+    const double* row = X + (size_t)n * d;
+    for (int f = 0; f < d; ++f) {
+      c->x_lo[f] = std::min(c->x_lo[f], row[f]);   // NaN entries leave the range alone
+      c->x_hi[f] = std::max(c->x_hi[f], row[f]);
+    }
+  }
   rc = (dtype == BSR_DTYPE_F64) ? upload_data<double>(c, X, y) : upload_data<float>(c, X, y);
   if (rc != BSR_OK) return bail(rc);
   // every buffer initialised above (null-stream and main-stream memsets) is complete before any slot stream runs
@@ -943,6 +953,10 @@ extern "C" int bsr_commit(bsr_ctx* c, int32_t chain, int32_t k, int32_t idx) {
   return bsr_internal_commit(c, c->last_waited, chain, k, idx);
 }
 
+void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi) {
+  *lo = c->x_lo.data();
+  *hi = c->x_hi.data();
+}
 void bsr_internal_lock(bsr_ctx* c) { c->mu.lock(); }
 void bsr_internal_unlock(bsr_ctx* c) { c->mu.unlock(); }
 

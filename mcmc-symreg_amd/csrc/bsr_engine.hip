@@ -895,6 +895,7 @@ struct Cand {
   int change;
   double Q, Qinv, hratio, detjacob, new_sigma, new_sa2, new_sb2, u;
   int action;
+  bool pred_def = false;  // speculated as a rank-gate rejection: no accept-uniform was drawn behind it
   LegacyRng before_u;
   std::vector<bsr_node> tape;
 };
@@ -913,6 +914,16 @@ struct ChainS {
   bool done = false, inited = false, last_stale = false;
   int64_t n_props = 0, n_accept = 0, n_rank_rej = 0, n_discard = 0;
   double run_ema = 1e9;  // typical number of proposals consumed per batch (speculation length that pays off)
+  // Rank-gate predictor.  The reference draws no accept-uniform behind a proposal its rank gate rejects
+  // (codes/funcs.py:1226-1228), so a speculative batch stays on the right random stream only if the gate's verdicts
+  // are guessed.  Two cheap guesses, both exact-by-construction (a wrong one costs the tail of the batch):
+  //  * magnitude: an interval bound of max|z| over the features' ranges against the siblings' max|.| -- a column
+  //    1/(N eps) times larger or smaller than its siblings is what most rejections are (exp(x^3)^3 next to O(1) columns);
+  //  * history: def_ema[k], the share of tree k's recent proposals that were rejected, for states whose siblings are
+  //    dependent (every candidate for k is then rejected until one of them changes).
+  std::vector<double> def_ema;
+  std::vector<double> colmax;      // max|.| of the chain's current columns (from the last refresh)
+  std::vector<uint32_t> colflags;
   std::vector<Cand> cands;
   LegacyRng end_state;
 };
@@ -923,6 +934,9 @@ struct bsr_engine {
   bsr_ctx* ctx = nullptr;
   int K = 0, n_chains = 0, val = 100, y_is_series = 1;
   int nan_reject = 0;  // 0: a NaN candidate aborts like the reference (LinAlgError); 1: treat it as a rank-gate rejection
+  int predict_gate = 1;  // speculate the rank gate's verdict (BSR_ENGINE_PREDICT=0: off)
+  const double* x_lo = nullptr;  // per-feature range of X, owned by the context
+  const double* x_hi = nullptr;
   int64_t N = 0;
   Params P;
   std::vector<ChainS> chains;
@@ -954,7 +968,13 @@ int refresh_chain(bsr_engine* e, ChainS& c) {
   bsr_chain_info info;
   ECHK(e, bsr_refresh(e->ctx, c.index, &info));
   bool any = false;
-  for (int k = 0; k < e->K; ++k) any |= info.colflags[k] != 0;
+  c.colmax.assign(e->K, 0.0);
+  c.colflags.assign(e->K, 0u);
+  for (int k = 0; k < e->K; ++k) {
+    any |= info.colflags[k] != 0;
+    c.colmax[k] = info.maxabs[k];
+    c.colflags[k] = info.colflags[k];
+  }
   // every fitted value of a non-finite old state is NaN: Series.sum(skipna=True) gives 0.0, ndarray sum NaN
   c.sse_old = any ? (e->y_is_series ? 0.0 : kNaN) : info.sse_old;
   std::fill(c.fs_old_ok.begin(), c.fs_old_ok.end(), 0);
@@ -986,6 +1006,7 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.fs_old_s.assign(K, 0.0);
   c.fs_old_p.assign(K, 0.0);
   c.fs_old_ok.assign(K, 0);
+  c.def_ema.assign(K, 0.0);
   int rc = refresh_chain(e, c);
   if (rc != BSR_OK) return rc;
   c.Beta.assign(K + 1, 0.0);
@@ -1000,6 +1021,89 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.inited = true;
   c.n_props = c.n_accept = c.n_rank_rej = c.n_discard = 0;
   return BSR_OK;
+}
+
+// Interval bound of a tree's values over the per-feature ranges of X (what max|z| can be; loose for non-monotone
+// compositions, which only makes the predictor miss).  1/x and log|x| across zero are bounded by the spacing of N
+// values spread over the interval.
+struct Iv {
+  double lo, hi;
+};
+Iv tree_range(const Tree& t, int i, const double* xlo, const double* xhi, double N) {
+  const TNode& nd = t.n[i];
+  if (nd.type == 0) return {xlo[nd.feature], xhi[nd.feature]};
+  const Iv a = tree_range(t, nd.left, xlo, xhi, N);
+  auto mag = [](const Iv& v) { return std::max(std::fabs(v.lo), std::fabs(v.hi)); };
+  auto mul = [](const Iv& p, const Iv& q) {
+    double c[4] = {p.lo * q.lo, p.lo * q.hi, p.hi * q.lo, p.hi * q.hi};
+    double lo = kInf, hi = -kInf;
+    for (double v : c) {
+      if (v != v) v = 0.0;  // 0 * inf
+      lo = std::min(lo, v);
+      hi = std::max(hi, v);
+    }
+    return Iv{lo, hi};
+  };
+  auto inv = [&](const Iv& v) {
+    if (v.lo <= 0 && 0 <= v.hi) {
+      const double m = 2 * N / std::max(v.hi - v.lo, 1e-300);
+      return Iv{-m, m};
+    }
+    return Iv{std::min(1 / v.lo, 1 / v.hi), std::max(1 / v.lo, 1 / v.hi)};
+  };
+  if (nd.type == 1) {
+    switch (nd.op) {
+      case BSR_OP_LN: {
+        const double p = nd.a * a.lo + nd.b, q = nd.a * a.hi + nd.b;
+        return {std::min(p, q), std::max(p, q)};
+      }
+      case BSR_OP_NEG: return {-a.hi, -a.lo};
+      case BSR_OP_SIN:
+      case BSR_OP_COS: return {-1.0, 1.0};
+      case BSR_OP_EXP: {
+        auto ex = [](double v) { return v > 200 ? 1e10 : std::exp(v); };
+        return {ex(a.lo), std::max(ex(a.hi), ex(std::min(a.hi, 200.0)))};
+      }
+      case BSR_OP_SQUARE: {
+        const double m = std::max(a.lo * a.lo, a.hi * a.hi);
+        return {(a.lo <= 0 && 0 <= a.hi) ? 0.0 : std::min(a.lo * a.lo, a.hi * a.hi), m};
+      }
+      case BSR_OP_CUBIC: return {a.lo * a.lo * a.lo, a.hi * a.hi * a.hi};
+      case BSR_OP_INV: return inv(a);
+      case BSR_OP_LOG: {
+        const double top = std::log(std::max(mag(a), 1e-300));
+        const double bot = (a.lo <= 0 && 0 <= a.hi) ? std::log(std::max((a.hi - a.lo) / (2 * N), 1e-300))
+                                                    : std::log(std::min(std::fabs(a.lo), std::fabs(a.hi)));
+        return {std::min(bot, top), top};
+      }
+      default: return a;
+    }
+  }
+  const Iv b = tree_range(t, nd.right, xlo, xhi, N);
+  switch (nd.op) {
+    case BSR_OP_ADD: return {a.lo + b.lo, a.hi + b.hi};
+    case BSR_OP_SUB: return {a.lo - b.hi, a.hi - b.lo};
+    case BSR_OP_DIV: return mul(a, inv(b));
+    default: return mul(a, b);
+  }
+}
+
+bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k) {
+  if (!e->predict_gate) return false;
+  if (c.def_ema[k] > 0.9) return true;   // a state in which (nearly) every candidate for k is rejected
+  if (e->K < 2 || !e->x_lo) return false;
+  double sib = 0.0;
+  for (int j = 0; j < e->K; ++j) {
+    if (j == k) continue;
+    if (c.colflags[j]) return true;       // an inf/NaN sibling: rank 0 (or LinAlgError) whatever the candidate is
+    sib = std::max(sib, c.colmax[j]);
+  }
+  const Iv r = tree_range(t, t.root, e->x_lo, e->x_hi, (double)e->N);
+  const double est = std::max(std::fabs(r.lo), std::fabs(r.hi));
+  if (!(est == est)) return false;
+  if (!std::isfinite(est)) return true;  // overflows: inf in the column, rank 0
+  const double tol = (double)std::max<int64_t>(e->N, e->K) * 2.220446049250313e-16;  // numpy's relative rank tolerance
+  return est > sib * (10.0 / tol) || est < sib * (tol / 10.0);
 }
 
 void generate(bsr_engine* e, ChainS& c, int max_n) {
@@ -1022,7 +1126,8 @@ void generate(bsr_engine* e, ChainS& c, int max_n) {
     cd.action = mv.action;
     flatten(cd.tree, cd.tree.root, cd.tape);
     cd.before_u = c.rng;
-    cd.u = c.rng.uniform();
+    cd.pred_def = predict_gate_reject(e, c, cd.tree, k);
+    cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
     ++total;
     count = (count + 1) % e->K;
   }
@@ -1084,9 +1189,18 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.count = (k + 1) % K;
     if (sc.rank < K) {  // codes/funcs.py:1226-1228: no uniform drawn
       ++c.n_rank_rej;
+      c.def_ema[k] = 0.75 * c.def_ema[k] + 0.25;
+      if (cd.pred_def) continue;  // speculated exactly that: the candidates behind it are on the right stream
       c.rng = cd.before_u;
       broke = true;
       break;
+    }
+    c.def_ema[k] *= 0.75;
+    bool tail_invalid = false;
+    if (cd.pred_def) {  // the gate passed a proposal speculated as rejected: its uniform is drawn now, from the state
+      c.rng = cd.before_u;  // saved in front of it; whatever follows in the batch was generated on a shifted stream
+      cd.u = c.rng.uniform();
+      tail_invalid = true;
     }
     const double yllstar = sc.loglik;
     const double yll = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
@@ -1106,7 +1220,13 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       tr->u = cd.u;
       tr->accepted = accepted;
     }
-    if (!accepted) continue;
+    if (!accepted) {
+      if (tail_invalid) {  // rejected on the uniform just drawn: the chain goes on from the state behind it
+        broke = true;
+        break;
+      }
+      continue;
+    }
     // ---- accepted: codes/bsr_class.py:200-243
     ++c.n_accept;
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
@@ -1131,6 +1251,8 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     }
     c.errs.push_back(rmse);
     c.total = 0;
+    for (int j = 0; j < K; ++j)
+      if (j != k) c.def_ema[j] = 0.0;  // their sibling set has changed
     c.rng = cd.before_u;
     c.rng.uniform();
     if (tr) tr->rmse = rmse;
@@ -1171,6 +1293,8 @@ extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chain
   e->P.n_feature = n_feature;
   e->P.beta = beta;
   e->P.set_default_table();
+  if (getenv("BSR_ENGINE_PREDICT")) e->predict_gate = atoi(getenv("BSR_ENGINE_PREDICT")) != 0;
+  bsr_internal_feature_range(ctx, &e->x_lo, &e->x_hi);
   e->chains.resize(n_chains);
   for (int c = 0; c < n_chains; ++c) {
     e->chains[c].index = c;

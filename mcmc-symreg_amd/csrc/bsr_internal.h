@@ -159,6 +159,7 @@ __attribute__((visibility("hidden"))) int bsr_internal_submit(bsr_ctx* c, int sl
                         const int32_t* which_k, const double* sigma, int32_t B);
 __attribute__((visibility("hidden"))) int bsr_internal_wait(bsr_ctx* c, int slot, bsr_score* out);
 __attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int slot, int32_t chain, int32_t k, int32_t idx);
+__attribute__((visibility("hidden"))) void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi);
 __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
 __attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
 
