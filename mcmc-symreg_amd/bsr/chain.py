@@ -143,6 +143,7 @@ class Chain:
         else:
             self.sse_old = float(info["sse_old"])
         self.fs_old = [None] * self.K
+        self._ckeys = [None] * self.K
 
     def _yll(self, sigma):
         # codes/funcs.py:1172-1173 on the cached old-state SSE
@@ -153,11 +154,22 @@ class Chain:
             self.fs_old[k] = P.fstruc_t(self.roots[k], self.n_feature, self.T, self.beta, self.siga[k], self.sigb[k])
         return self.fs_old[k]
 
-    # -- rank-gate guess (csrc/bsr_engine.hip: predict_gate_reject has the same two rules) ------------------------
+    def _ckey(self, j):
+        if self._ckeys[j] is None:
+            self._ckeys[j] = P.canon_key(self.roots[j])
+        return self._ckeys[j]
+
+    # -- rank-gate guess (csrc/bsr_engine.hip: predict_gate_reject has the same rules) ---------------------------
     def _predict_reject(self, root, k):
         if self.def_ema[k] > 0.9:
             return True
-        if self.K < 2 or self.feature_range is None:
+        if self.K < 2:
+            return False
+        key = P.canon_key(root)
+        sibs = [self._ckey(j) for j in range(self.K) if j != k]
+        if key in sibs or len(set(sibs)) < len(sibs):                # repeats a sibling / siblings repeat each other
+            return True
+        if self.feature_range is None:
             return False
         if any(self.colflags[j] for j in range(self.K) if j != k):
             return True

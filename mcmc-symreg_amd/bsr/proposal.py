@@ -573,3 +573,21 @@ def tree_range(node, xlo, xhi, N):
     if op == 'div':
         return mul((lo, hi), inv(rl, rh))
     return mul((lo, hi), (rl, rh))
+
+
+def canon_key(node, top=True):
+    """Structural key of the column a tree computes: equal keys = equal columns up to sign (children of + and * order-free,
+    a negation at the root dropped).  The chain engines guess the rank gate with it: a candidate that repeats a sibling,
+    siblings that repeat each other."""
+    if top:
+        while node.type == 1 and node.operator == 'neg':
+            node = node.left
+    if node.type == 0:
+        return ("x", int(np.asarray(node.feature).reshape(-1)[0]))
+    if node.type == 1:
+        par = (float(node.a), float(node.b)) if node.operator == LN else ()
+        return (node.operator, par, canon_key(node.left, False))
+    l, r = canon_key(node.left, False), canon_key(node.right, False)
+    if node.operator in ('+', '*'):
+        l, r = sorted((l, r), key=repr)
+    return (node.operator, l, r)

@@ -889,6 +889,35 @@ uint64_t tree_hash(const Tree& t, int root) {  // FNV-1a over the pre-order (typ
   return h;
 }
 
+// Canonical key of the column a tree computes, as far as structure tells: equal keys = equal columns up to sign.
+// Children of + and * are combined order-free; a negation at the root is dropped (a column and its negative are
+// collinear).  Used to guess the rank gate: a candidate that repeats a sibling, or siblings that repeat each other.
+uint64_t canon_key_at(const Tree& t, int i) {
+  const TNode& nd = t.n[i];
+  auto mix = [](uint64_t h, uint64_t v) {
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    return h * 0xff51afd7ed558ccdull;
+  };
+  if (nd.type == 0) return mix(0x1234567ull, (uint64_t)nd.feature + 1000);
+  uint64_t h = mix(0x77ull, (uint64_t)nd.op + 1);
+  if (nd.op == OP_LN) {
+    uint64_t ba, bb;
+    memcpy(&ba, &nd.a, 8);
+    memcpy(&bb, &nd.b, 8);
+    h = mix(mix(h, ba), bb);
+  }
+  const uint64_t l = canon_key_at(t, nd.left);
+  if (nd.type == 1) return mix(h, l);
+  const uint64_t r = canon_key_at(t, nd.right);
+  if (nd.op == BSR_OP_ADD || nd.op == BSR_OP_MUL) return mix(h, (l < r ? mix(l, r) : mix(r, l)));
+  return mix(mix(h, l), r);
+}
+uint64_t canon_key(const Tree& t) {
+  int i = t.root;
+  while (t.n[i].type == 1 && t.n[i].op == BSR_OP_NEG) i = t.n[i].left;
+  return canon_key_at(t, i);
+}
+
 struct Cand {
   int k;
   Tree tree;
@@ -919,9 +948,12 @@ struct ChainS {
   // are guessed.  Two cheap guesses, both exact-by-construction (a wrong one costs the tail of the batch):
   //  * magnitude: an interval bound of max|z| over the features' ranges against the siblings' max|.| -- a column
   //    1/(N eps) times larger or smaller than its siblings is what most rejections are (exp(x^3)^3 next to O(1) columns);
-  //  * history: def_ema[k], the share of tree k's recent proposals that were rejected, for states whose siblings are
-  //    dependent (every candidate for k is then rejected until one of them changes).
+  //  * structure: a candidate that computes the same column as a sibling (up to sign), or siblings that repeat each
+  //    other (then every candidate for the remaining trees is rejected until one of the two changes): canon_key;
+  //  * history: def_ema[k], the share of tree k's recent proposals that were rejected, for dependent-sibling states
+  //    the structure does not show.
   std::vector<double> def_ema;
+  std::vector<uint64_t> ckey;      // canon_key of the chain's current trees
   std::vector<double> colmax;      // max|.| of the chain's current columns (from the last refresh)
   std::vector<uint32_t> colflags;
   std::vector<Cand> cands;
@@ -1007,6 +1039,8 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.fs_old_p.assign(K, 0.0);
   c.fs_old_ok.assign(K, 0);
   c.def_ema.assign(K, 0.0);
+  c.ckey.assign(K, 0);
+  for (int k = 0; k < K; ++k) c.ckey[k] = canon_key(c.roots[k]);
   int rc = refresh_chain(e, c);
   if (rc != BSR_OK) return rc;
   c.Beta.assign(K + 1, 0.0);
@@ -1091,7 +1125,15 @@ Iv tree_range(const Tree& t, int i, const double* xlo, const double* xhi, double
 bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k) {
   if (!e->predict_gate) return false;
   if (c.def_ema[k] > 0.9) return true;   // a state in which (nearly) every candidate for k is rejected
-  if (e->K < 2 || !e->x_lo) return false;
+  if (e->K < 2) return false;
+  const uint64_t key = canon_key(t);
+  for (int i = 0; i < e->K; ++i) {
+    if (i == k) continue;
+    if (c.ckey[i] == key) return true;                      // repeats a sibling
+    for (int j = i + 1; j < e->K; ++j)
+      if (j != k && c.ckey[i] == c.ckey[j]) return true;    // two siblings repeat each other
+  }
+  if (!e->x_lo) return false;
   double sib = 0.0;
   for (int j = 0; j < e->K; ++j) {
     if (j == k) continue;
@@ -1232,6 +1274,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
     c.last_stale = true;
     c.roots[k] = cd.tree;
+    c.ckey[k] = canon_key(cd.tree);
     c.tapes[k] = cd.tape;
     c.sigma = cd.new_sigma;
     c.siga[k] = cd.new_sa2;
