@@ -168,6 +168,39 @@ int bsr_score_submit(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off
                      const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket);
 int bsr_score_wait(bsr_ctx* ctx, int32_t ticket, bsr_score* out);
 
+/* ---- device-side Metropolis-Hastings step: codes/funcs.py:1226-1306 ----------------------
+ * The scalar tail of newProp -- log-ratio assembly, the accept test and the search for the first proposal of a
+ * speculative run that changes the chain -- evaluated on the device behind the scoring kernels, so that a batch
+ * answers with one event per chain.  The host supplies, per proposal, the terms it knows before scoring
+ * (terms[8*i + ...]):
+ *   0 yll          ylogLike of the chain's current state at its current sigma              (funcs.py:1235)
+ *   1 log_struc    structure-prior ratio, old - new, as funcs.py:1245 / :1289 assemble it
+ *   2 log_q        log max(1e-5, Qinv/Q)                                                     (funcs.py:1249)
+ *   3 log_h, 4 log_d   log max(1e-5, hratio), log max(1e-5, detjacob); used iff BSR_MH_JUMP   (funcs.py:1250-1251)
+ *   5 lig_new, 6 lig_old   log invgamma.pdf(new_sigma; 4), log invgamma.pdf(sigma; 4)        (funcs.py:1253-1254)
+ *   7 log_u        log of the accept uniform (funcs.py:1299); ignored with BSR_MH_NO_UNIFORM
+ * and the device forms logR in the reference's order of additions (bit-identical to the host's), accepts iff
+ * !(log_u >= min(logR, 0)) (funcs.py:1300-1304, NaN semantics included) and scans each chain's run.
+ * flags[i]: BSR_MH_JUMP = 'shrinkage'/'expansion' move; BSR_MH_NO_UNIFORM = the host speculated this proposal as a
+ * rank-gate rejection and drew no uniform behind it (codes/funcs.py:1226-1228).
+ * span_off[n_spans + 1]: proposals span_off[j] .. span_off[j+1]-1 are consecutive proposals of one chain.        */
+#define BSR_MH_JUMP 1
+#define BSR_MH_NO_UNIFORM 2
+enum { BSR_EV_NONE = 0,       /* every proposal of the run was rejected as speculated */
+       BSR_EV_ACCEPT = 1,     /* proposal `index` is accepted */
+       BSR_EV_GATE = 2,       /* proposal `index` is rejected by the rank gate but a uniform had been drawn behind it */
+       BSR_EV_GATE_PASSED = 3 /* proposal `index` passes the gate although it was speculated as rejected */ };
+typedef struct bsr_event {
+  int32_t index;            /* position inside the span; span length when kind == BSR_EV_NONE */
+  int32_t kind;
+  double logR;              /* of proposal `index` (NaN when no logR was formed) */
+} bsr_event;
+int bsr_score_submit_mh(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                        const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
+                        const int32_t* flags, const int32_t* span_off, int32_t n_spans, int32_t* ticket);
+/* out may be NULL (the per-proposal scores stay available through bsr_score_wait on the same ticket). */
+int bsr_score_wait_mh(bsr_ctx* ctx, int32_t ticket, bsr_score* out, bsr_event* events);
+
 /* ---- on-accept / initial OLS with intercept: codes/bsr_class.py:147-163, 211-233 */
 
 /* beta_out[K+1] = Beta/scale (intercept first), rmse_out = sqrt(mean((fitted-y)^2)). */

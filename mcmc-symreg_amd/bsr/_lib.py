@@ -65,6 +65,8 @@ def lib():
         "bsr_score_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp]),
         "bsr_score_submit": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, pi]),
         "bsr_score_wait": (C.c_int, [vp, i32, vp]),
+        "bsr_score_submit_mh": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, pi]),
+        "bsr_score_wait_mh": (C.c_int, [vp, i32, vp, vp]),
         "bsr_fit_beta": (C.c_int, [vp, i32, vp, pd]),
         "bsr_get_current": (C.c_int, [vp, i32, vp]),
         "bsr_yloglike_host": (C.c_int, [C.c_int, i64, i32, vp, vp, dbl, i32, pd, pd, pd, vp, pi]),
@@ -99,11 +101,15 @@ def lib():
 
 EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_destroy", "bsr_last_error",
            "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_score_submit",
-           "bsr_score_wait", "bsr_fit_beta",
+           "bsr_score_wait", "bsr_score_submit_mh", "bsr_score_wait_mh", "bsr_fit_beta",
            "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_comm_unique_id",
            "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy", "bsr_engine_create", "bsr_engine_destroy",
            "bsr_engine_last_error", "bsr_engine_set_nan_policy", "bsr_engine_set_ops", "bsr_engine_seed", "bsr_engine_set_rng", "bsr_engine_get_rng",
            "bsr_engine_init_chain", "bsr_engine_run", "bsr_engine_chain_result", "bsr_rng_selftest"]
+
+EVENT_DTYPE = np.dtype([("index", "<i4"), ("kind", "<i4"), ("logR", "<f8")], align=True)
+MH_JUMP, MH_NO_UNIFORM = 1, 2
+EV_NONE, EV_ACCEPT, EV_GATE, EV_GATE_PASSED = 0, 1, 2, 3
 
 TRACE_DTYPE = np.dtype([("chain", "<i4"), ("count", "<i4"), ("action", "<i4"), ("change", "<i4"), ("rank", "<i4"),
                         ("accepted", "<i4"), ("n_nodes", "<i4"), ("pad", "<i4"), ("Q", "<f8"), ("Qinv", "<f8"),

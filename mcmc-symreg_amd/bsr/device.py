@@ -113,6 +113,26 @@ class DeviceContext:
         _lib.check(self._L.bsr_score_wait(self._h, ticket, _lib.ptr(out)), self._h)
         return out
 
+    def score_submit_mh(self, rows, off, chains, ks, sig, terms8, flags, span_off):
+        """Scoring plus the device-side MH step (codes/funcs.py:1226-1306 on the device; include/bsr_hip.h):
+        terms8 (B, 8) float64, flags (B,) int32, span_off (n_spans + 1,) int32 -> ticket."""
+        terms8 = np.ascontiguousarray(terms8, dtype=np.float64)
+        flags = np.ascontiguousarray(flags, dtype=np.int32)
+        span_off = np.ascontiguousarray(span_off, dtype=np.int32)
+        t = C.c_int32(-1)
+        rc = self._L.bsr_score_submit_mh(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
+                                         _lib.ptr(sig), len(chains), _lib.ptr(terms8), _lib.ptr(flags),
+                                         _lib.ptr(span_off), len(span_off) - 1, C.byref(t))
+        _lib.check(rc, self._h)
+        self._mh_spans = len(span_off) - 1
+        return t.value
+
+    def score_wait_mh(self, ticket, out=None):
+        ev = np.zeros(self._mh_spans, dtype=_lib.EVENT_DTYPE)
+        rc = self._L.bsr_score_wait_mh(self._h, ticket, None if out is None else _lib.ptr(out), _lib.ptr(ev))
+        _lib.check(rc, self._h)
+        return ev
+
     def fit_beta(self, chain):
         beta = np.empty(self.K + 1, dtype=np.float64)
         rmse = C.c_double(0.0)

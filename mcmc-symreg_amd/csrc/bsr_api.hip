@@ -30,7 +30,12 @@ struct BatchSlot {
   uint8_t* h_in = nullptr;
   uint8_t* d_in = nullptr;
   size_t in_cap = 0;
-  size_t off_cols = 0, off_sched = 0, off_desc = 0, off_streams = 0;
+  size_t off_cols = 0, off_sched = 0, off_mh = 0, off_desc = 0, off_streams = 0;
+  // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
+  MhRes* d_mh = nullptr;
+  bsr_event* h_ev = nullptr;   // pinned, written by k_events
+  int n_spans = 0;             // spans of the batch in flight (0: plain scoring)
+  size_t mh_cap = 0;           // proposals the MH block has room for
   size_t code_words = 0, feat_words = 0, ln_words = 0;
   // tile pass (bsr_tile.hip): a second column stream with LDS slots instead of X columns sits behind the ln pairs
   bool tile = false;
@@ -68,6 +73,12 @@ struct BatchSlot {
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
   const void** h_cols() const { return reinterpret_cast<const void**>(h_in + off_cols); }
   int32_t* h_sched() const { return reinterpret_cast<int32_t*>(h_in + off_sched); }
+  double* h_terms() const { return reinterpret_cast<double*>(h_in + off_mh); }
+  int32_t* h_mhflags() const { return reinterpret_cast<int32_t*>(h_in + off_mh + mh_cap * 8 * sizeof(double)); }
+  int32_t* h_spans() const { return h_mhflags() + mh_cap; }
+  const double* d_terms() const { return reinterpret_cast<const double*>(d_in + off_mh); }
+  const int32_t* d_mhflags() const { return reinterpret_cast<const int32_t*>(d_in + off_mh + mh_cap * 8 * sizeof(double)); }
+  const int32_t* d_spans() const { return d_mhflags() + mh_cap; }
   const void* const* d_cols() const { return reinterpret_cast<const void* const*>(d_in + off_cols); }
   const int32_t* d_sched() const { return reinterpret_cast<const int32_t*>(d_in + off_sched); }
   PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
@@ -213,6 +224,8 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.d_coef) (void)hipFree(s.d_coef);
     if (s.d_flagged) (void)hipFree(s.d_flagged);
+    if (s.d_mh) (void)hipFree(s.d_mh);
+    if (s.h_ev) (void)hipHostFree(s.h_ev);
     if (s.queue) (void)hipFree(s.queue);
     if (s.part1) (void)hipFree(s.part1);
     if (s.part2) (void)hipFree(s.part2);
@@ -379,7 +392,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     s.off_cols = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
     s.off_sched = s.off_cols + ((size_t)(d + 1 + std::max(1, n_chains) * std::max(1, K)) * sizeof(void*) + 255) / 256 * 256;
-    s.off_desc = s.off_sched + (c->tile_sched_cap * sizeof(int32_t) + 255) / 256 * 256;
+    s.mh_cap = (size_t)max_batch;
+    s.off_mh = s.off_sched + (c->tile_sched_cap * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_desc = s.off_mh + (s.mh_cap * 8 * sizeof(double) + (2 * s.mh_cap + 2) * sizeof(int32_t) + 255) / 256 * 256;
+    CK(hipMalloc((void**)&s.d_mh, sizeof(MhRes) * (max_batch + 1)));
+    CK(hipHostMalloc((void**)&s.h_ev, sizeof(bsr_event) * (max_batch + 1)));
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
     s.chain_slot.assign(std::max(1, n_chains), -1);
     CK(hipHostMalloc((void**)&s.h_out, sizeof(bsr_score) * (max_batch + 1)));
@@ -823,12 +840,14 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   }
   if (s.timed) HIPCHK(c, hipEventRecord(s.ev[1], st));
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, P, n_part, s.part1, c->N, s.d_coef, s.h_out, rank_floor, s.d_flagged);
+  launch_solve(st, s.d_desc(), c->d_ck, P, n_part, s.part1, c->N, s.d_coef, s.h_out, rank_floor, s.d_flagged, s.d_mh);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[2], st));
   if (scoring) launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[3], st));
   if (scoring)
-    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor, s.d_flagged);
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor, s.d_flagged, s.d_mh);
+  if (scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
+    launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[4], st));
   HIPCHK(c, hipEventRecord(s.done, st));
   s.P = P;
@@ -1078,6 +1097,12 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
 // worker threads each own one).
 int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                         const int32_t* which_k, const double* sigma, int32_t B) {
+  return bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0);
+}
+
+int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                           const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
+                           const int32_t* mhflags, const int32_t* span_off, int32_t n_spans) {
   if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
   HIPCHK(c, hipSetDevice(c->device));
   const int K = c->K;
@@ -1115,6 +1140,20 @@ int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t*
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
   }
+  s.n_spans = 0;
+  if (n_spans > 0) {
+    if (!terms8 || !mhflags || !span_off || n_spans > B || span_off[0] != 0 || span_off[n_spans] != B)
+      return fail(c, BSR_E_ARG, "bsr_score_submit_mh: bad terms / flags / spans");
+    for (int j = 0; j < n_spans; ++j) {
+      if (span_off[j + 1] <= span_off[j]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: empty or unordered span");
+      for (int i = span_off[j]; i < span_off[j + 1]; ++i)
+        if (chain[i] != chain[span_off[j]]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: a span mixes chains");
+    }
+    memcpy(s.h_terms(), terms8, sizeof(double) * 8 * (size_t)B);
+    memcpy(s.h_mhflags(), mhflags, sizeof(int32_t) * (size_t)B);
+    memcpy(s.h_spans(), span_off, sizeof(int32_t) * ((size_t)n_spans + 1));
+    s.n_spans = n_spans;
+  }
   s.scored = true;
   ++s.gen;
   const long long th2 = host_now();
@@ -1149,6 +1188,38 @@ int bsr_internal_wait(bsr_ctx* c, int ticket, bsr_score* out) {
   s.waited_gen = s.gen;
   memcpy(out, s.h_out, sizeof(bsr_score) * s.P);
   return BSR_OK;
+}
+
+extern "C" int bsr_score_submit_mh(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                                   const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
+                                   const int32_t* flags, const int32_t* span_off, int32_t n_spans, int32_t* ticket) {
+  if (!c || !chain || !which_k || !sigma || !ticket || n_spans <= 0) return BSR_E_ARG;
+  if (c->K == 1) return fail(c, BSR_E_STATE, "bsr_score_submit_mh: treeNum = 1 rescoring needs the plain submit/wait pair");
+  const int si = c->next_slot;
+  int rc = bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, terms8, flags, span_off, n_spans);
+  if (rc != BSR_OK) return rc;
+  *ticket = si;
+  c->next_slot = (si + 1) % BSR_MAX_INFLIGHT;
+  return BSR_OK;
+}
+
+int bsr_internal_wait_mh(bsr_ctx* c, int ticket, bsr_score* out, bsr_event* events) {
+  HIPCHK(c, hipSetDevice(c->device));
+  BatchSlot& s = c->slot[ticket];
+  if (!s.scored || s.n_spans <= 0) return fail(c, BSR_E_STATE, "bsr_score_wait_mh: no MH batch under this ticket");
+  int rc = wait_slot(c, s);
+  if (rc != BSR_OK) return rc;
+  s.waited_gen = s.gen;
+  if (out) memcpy(out, s.h_out, sizeof(bsr_score) * s.P);
+  memcpy(events, s.h_ev, sizeof(bsr_event) * s.n_spans);
+  return BSR_OK;
+}
+
+extern "C" int bsr_score_wait_mh(bsr_ctx* c, int32_t ticket, bsr_score* out, bsr_event* events) {
+  if (!c || !events || ticket < 0 || ticket >= BSR_MAX_INFLIGHT) return BSR_E_ARG;
+  int rc = bsr_internal_wait_mh(c, ticket, out, events);
+  if (rc == BSR_OK) c->last_waited = ticket;
+  return rc;
 }
 
 extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {

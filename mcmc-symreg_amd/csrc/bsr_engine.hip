@@ -925,6 +925,9 @@ struct Cand {
   double Q, Qinv, hratio, detjacob, new_sigma, new_sa2, new_sb2, u;
   int action;
   bool pred_def = false;  // speculated as a rank-gate rejection: no accept-uniform was drawn behind it
+  double sn_s = 0, sn_p = 0;  // fStruc of the proposed tree (structure / ln-parameter parts)
+  double terms[8];            // what the device-side MH step needs (include/bsr_hip.h: bsr_score_submit_mh)
+  int mhflags = 0;
   LegacyRng before_u;
   std::vector<bsr_node> tape;
 };
@@ -943,6 +946,7 @@ struct ChainS {
   bool done = false, inited = false, last_stale = false;
   int64_t n_props = 0, n_accept = 0, n_rank_rej = 0, n_discard = 0;
   double run_ema = 1e9;  // typical number of proposals consumed per batch (speculation length that pays off)
+  int verify_expect_event = -1;  // BSR_ENGINE_VERIFY_MH: what the device said about the proposal being consumed
   // Rank-gate predictor.  The reference draws no accept-uniform behind a proposal its rank gate rejects
   // (codes/funcs.py:1226-1228), so a speculative batch stays on the right random stream only if the gate's verdicts
   // are guessed.  Two cheap guesses, both exact-by-construction (a wrong one costs the tail of the batch):
@@ -967,6 +971,10 @@ struct bsr_engine {
   int K = 0, n_chains = 0, val = 100, y_is_series = 1;
   int nan_reject = 0;  // 0: a NaN candidate aborts like the reference (LinAlgError); 1: treat it as a rank-gate rejection
   int predict_gate = 1;  // speculate the rank gate's verdict (BSR_ENGINE_PREDICT=0: off)
+  int device_mh = 0;     // BSR_ENGINE_DEVICE_MH=1: log-ratio, accept test and first-event scan on the device (k_events).
+                         // Off by default: measured 8 % slower end to end (one more launch per batch, 4 KB more
+                         // upload) than the 0.2 us per proposal the host spends on the same arithmetic.
+  int verify_mh = 0;     // BSR_ENGINE_VERIFY_MH=1: the host recomputes every decision and compares
   const double* x_lo = nullptr;  // per-feature range of X, owned by the context
   const double* x_hi = nullptr;
   int64_t N = 0;
@@ -1170,6 +1178,22 @@ void generate(bsr_engine* e, ChainS& c, int max_n) {
     cd.before_u = c.rng;
     cd.pred_def = predict_gate_reject(e, c, cd.tree, k);
     cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
+    {  // the scalar terms of codes/funcs.py:1230-1296 that do not depend on the score
+      fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &cd.sn_s, &cd.sn_p);
+      if (!c.fs_old_ok[k]) {
+        fstruc(c.roots[k], c.roots[k].root, e->P, c.siga[k], c.sigb[k], &c.fs_old_s[k], &c.fs_old_p[k]);
+        c.fs_old_ok[k] = 1;
+      }
+      cd.mhflags = (cd.change != CH_NONE ? BSR_MH_JUMP : 0) | (cd.pred_def ? BSR_MH_NO_UNIFORM : 0);
+      cd.terms[0] = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
+      cd.terms[1] = (cd.change != CH_NONE) ? (c.fs_old_s[k] + c.fs_old_p[k]) - (cd.sn_s + cd.sn_p) : (c.fs_old_s[k] - cd.sn_s);
+      cd.terms[2] = flog(pymax(1e-5, fdiv(cd.Qinv, cd.Q)));
+      cd.terms[3] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.hratio)) : 0.0;
+      cd.terms[4] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.detjacob)) : 0.0;
+      cd.terms[5] = flog(invgamma_pdf(cd.new_sigma, 4));
+      cd.terms[6] = flog(invgamma_pdf(c.sigma, 4));
+      cd.terms[7] = cd.pred_def ? kNaN : flog(cd.u);
+    }
     ++total;
     count = (count + 1) % e->K;
   }
@@ -1192,7 +1216,9 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
 
 // batch_slot < 0: the batch was scored through the public ticket API (one thread); otherwise by a worker thread that
 // owns that batch slot, and the accept path takes the context lock (commit, refresh and fit share the main stream)
-int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot) {
+// ev != nullptr: the device has already formed every log-ratio and found the first proposal of the run that is not
+// "rejected as speculated" (k_events); the proposals in front of it only need their bookkeeping.
+int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot, const bsr_event* ev) {
   const int K = e->K;
   int used = 0;
   bool broke = false;
@@ -1205,6 +1231,22 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     if (c.last_stale) {  // `Roots` is rebuilt before every newProp (codes/bsr_class.py:180-182)
       c.last_roots = c.roots;
       c.last_stale = false;
+    }
+    if (ev && !e->verify_mh && (int)i < ev->index && !(sc.rank < 0 && !e->nan_reject)) {
+      ++c.total;
+      c.count = (k + 1) % K;
+      if (sc.rank < K) {
+        ++c.n_rank_rej;
+        c.def_ema[k] = 0.75 * c.def_ema[k] + 0.25;
+      } else {
+        c.def_ema[k] *= 0.75;
+      }
+      continue;
+    }
+    if (ev && e->verify_mh) {  // every decision recomputed below must agree with the device's scan
+      const bool device_says_event = (int)i == ev->index;
+      if ((int)i > ev->index) return efail(e, BSR_E_STATE, "device MH scan stopped early");
+      c.verify_expect_event = device_says_event ? ev->kind : BSR_EV_NONE;
     }
     bsr_trace* tr = nullptr;
     if (e->trace && e->n_trace < e->trace_cap) {
@@ -1232,7 +1274,11 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     if (sc.rank < K) {  // codes/funcs.py:1226-1228: no uniform drawn
       ++c.n_rank_rej;
       c.def_ema[k] = 0.75 * c.def_ema[k] + 0.25;
-      if (cd.pred_def) continue;  // speculated exactly that: the candidates behind it are on the right stream
+      if (cd.pred_def) {  // speculated exactly that: the candidates behind it are on the right stream
+        if (e->verify_mh && ev && c.verify_expect_event != BSR_EV_NONE) return efail(e, BSR_E_STATE, "device MH scan: spurious event");
+        continue;
+      }
+      if (e->verify_mh && ev && c.verify_expect_event != BSR_EV_GATE) return efail(e, BSR_E_STATE, "device MH scan missed a gate rejection");
       c.rng = cd.before_u;
       broke = true;
       break;
@@ -1246,8 +1292,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     }
     const double yllstar = sc.loglik;
     const double yll = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
-    double sn_s, sn_p;
-    fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &sn_s, &sn_p);
+    const double sn_s = cd.sn_s, sn_p = cd.sn_p;  // fStruc of the proposed tree, computed when it was generated
     if (!c.fs_old_ok[k]) {
       fstruc(c.roots[k], c.roots[k].root, e->P, c.siga[k], c.sigb[k], &c.fs_old_s[k], &c.fs_old_p[k]);
       c.fs_old_ok[k] = 1;
@@ -1261,6 +1306,12 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       tr->logR = logR;
       tr->u = cd.u;
       tr->accepted = accepted;
+    }
+    if (e->verify_mh && ev) {
+      const int want = tail_invalid ? BSR_EV_GATE_PASSED : (accepted ? BSR_EV_ACCEPT : BSR_EV_NONE);
+      if (c.verify_expect_event != want) return efail(e, BSR_E_STATE, "device MH scan disagrees with the host's accept test");
+      if (want != BSR_EV_NONE && !(ev->logR == logR || (ev->logR != ev->logR && logR != logR)))
+        return efail(e, BSR_E_STATE, "device logR differs from the host's");
     }
     if (!accepted) {
       if (tail_invalid) {  // rejected on the uniform just drawn: the chain goes on from the state behind it
@@ -1338,6 +1389,8 @@ extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chain
   e->P.set_default_table();
   if (getenv("BSR_ENGINE_PREDICT")) e->predict_gate = atoi(getenv("BSR_ENGINE_PREDICT")) != 0;
   bsr_internal_feature_range(ctx, &e->x_lo, &e->x_hi);
+  if (getenv("BSR_ENGINE_DEVICE_MH")) e->device_mh = atoi(getenv("BSR_ENGINE_DEVICE_MH")) != 0;
+  if (getenv("BSR_ENGINE_VERIFY_MH")) e->verify_mh = atoi(getenv("BSR_ENGINE_VERIFY_MH")) != 0;
   e->chains.resize(n_chains);
   for (int c = 0; c < n_chains; ++c) {
     e->chains[c].index = c;
@@ -1425,7 +1478,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::vector<ChainS*> chains;
     std::vector<bsr_node> rows;
     std::vector<int32_t> off, chs, ks;
-    std::vector<double> sig;
+    std::vector<double> sig, terms;
+    std::vector<int32_t> mhflags, spans;
+    std::vector<bsr_event> events;
     std::vector<bsr_score> res;
     std::vector<std::pair<int, int>> span;
     int32_t ticket = -1;
@@ -1454,6 +1509,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
   for (int gi = 0; gi < n_groups; ++gi) groups[gi].slot = threaded ? gi : -1;
   const int per_group_cap = std::max(1, max_batch / n_groups);
+  const bool use_mh = e->device_mh && !trace && e->K > 1;
 
   auto submit = [&](Group& g) -> int {
     g.rows.clear();
@@ -1462,6 +1518,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     g.ks.clear();
     g.sig.clear();
     g.span.clear();
+    g.terms.clear();
+    g.mhflags.clear();
+    g.spans.assign(1, 0);
     int n_live = 0;
     for (ChainS* c : g.chains) n_live += is_live(*c) ? 1 : 0;
     if (n_live == 0) return BSR_OK;
@@ -1485,19 +1544,30 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         g.chs.push_back(c->index);
         g.ks.push_back(cd.k);
         g.sig.push_back(cd.new_sigma);
+        g.terms.insert(g.terms.end(), cd.terms, cd.terms + 8);
+        g.mhflags.push_back(cd.mhflags);
       }
+      if (!c->cands.empty()) g.spans.push_back((int32_t)g.chs.size());
       if (c->cands.empty()) c->done = true;
     }
     if (g.chs.empty()) return BSR_OK;
     g.res.resize(g.chs.size());
     const double ts0 = now_s();
     int r;
+    const int n_sp = (int)g.spans.size() - 1;
+    g.events.resize(std::max(1, n_sp));
     if (g.slot >= 0)
-      r = bsr_internal_submit(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
-                              (int)g.chs.size());
+      r = use_mh ? bsr_internal_submit_mh(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(),
+                                          g.sig.data(), (int)g.chs.size(), g.terms.data(), g.mhflags.data(),
+                                          g.spans.data(), n_sp)
+                 : bsr_internal_submit(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(),
+                                       g.sig.data(), (int)g.chs.size());
     else
-      r = bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
-                           (int)g.chs.size(), &g.ticket);
+      r = use_mh ? bsr_score_submit_mh(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
+                                       (int)g.chs.size(), g.terms.data(), g.mhflags.data(), g.spans.data(), n_sp,
+                                       &g.ticket)
+                 : bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
+                                    (int)g.chs.size(), &g.ticket);
     g.t_submit += now_s() - ts0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_submit: ") + bsr_last_error(e->ctx));
     g.inflight = true;
@@ -1507,14 +1577,22 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     if (!g.inflight) return BSR_OK;
     g.inflight = false;
     const double tw0 = now_s();
-    int r = (g.slot >= 0) ? bsr_internal_wait(e->ctx, g.slot, g.res.data())
-                          : bsr_score_wait(e->ctx, g.ticket, g.res.data());
+    int r;
+    if (use_mh)
+      r = (g.slot >= 0) ? bsr_internal_wait_mh(e->ctx, g.slot, g.res.data(), g.events.data())
+                        : bsr_score_wait_mh(e->ctx, g.ticket, g.res.data(), g.events.data());
+    else
+      r = (g.slot >= 0) ? bsr_internal_wait(e->ctx, g.slot, g.res.data())
+                        : bsr_score_wait(e->ctx, g.ticket, g.res.data());
     const double tw1 = now_s();
     g.t_wait += tw1 - tw0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_wait: ") + bsr_last_error(e->ctx));
+    int sp = 0;  // chains with proposals in this batch, in order: the spans of the MH scan
     for (size_t i = 0; i < g.chains.size(); ++i) {
       if (g.span[i].second == 0) continue;
-      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first, g.slot);
+      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first, g.slot,
+                  use_mh ? &g.events[sp] : nullptr);
+      ++sp;
       if (r != BSR_OK) return r;
     }
     g.t_consume += now_s() - tw1;

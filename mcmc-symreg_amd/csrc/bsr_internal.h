@@ -75,6 +75,13 @@ struct PropCoef {
   int32_t skip;           // 1: proposal already complete (or eval mode): the residual pass skips it
 };
 
+// device-side copy of what the MH scan needs from a proposal's score
+struct MhRes {
+  double loglik;
+  int32_t rank;
+  int32_t pad;
+};
+
 struct ChainFitOut {
   double sse, scale;
   double beta[BSR_MAX_K + 1];      // weights on the scaled columns (reference's Beta before "/ scale")
@@ -158,6 +165,10 @@ struct LaunchGeom {
 __attribute__((visibility("hidden"))) int bsr_internal_submit(bsr_ctx* c, int slot, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                         const int32_t* which_k, const double* sigma, int32_t B);
 __attribute__((visibility("hidden"))) int bsr_internal_wait(bsr_ctx* c, int slot, bsr_score* out);
+__attribute__((visibility("hidden"))) int bsr_internal_submit_mh(bsr_ctx* c, int slot, const bsr_node* rows, const int32_t* tape_off,
+                           const int32_t* chain, const int32_t* which_k, const double* sigma, int32_t B,
+                           const double* terms8, const int32_t* flags, const int32_t* span_off, int32_t n_spans);
+__attribute__((visibility("hidden"))) int bsr_internal_wait_mh(bsr_ctx* c, int slot, bsr_score* out, bsr_event* events);
 __attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int slot, int32_t chain, int32_t k, int32_t idx);
 __attribute__((visibility("hidden"))) void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi);
 __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
@@ -188,9 +199,11 @@ struct RowPassArgs {
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh);
+void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
+                   int n_spans, int K, bsr_event* events);
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
                           const double* col_maxabs, const uint32_t* col_flags, ChainB* cb);

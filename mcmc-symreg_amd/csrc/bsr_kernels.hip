@@ -338,6 +338,7 @@ struct SolveIn {
   int64_t N;
   uint32_t flags;
   double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
+  MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
 };
 
 // entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
@@ -359,6 +360,8 @@ __device__ __forceinline__ void store_score(const SolveIn& in, int K, bsr_score*
   out->smax = smax / in.s;
   out->rank = rank;
   out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+  in.mh->loglik = ll;
+  in.mh->rank = rank;
 }
 
 // K <= 4: the factor, its one-sided Jacobi SVD (W = S V ends with mutually orthogonal columns W[:,m] = sigma_m u_m)
@@ -613,7 +616,8 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
 __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
-                                                    double rank_floor, int32_t* __restrict__ flagged) {
+                                                    double rank_floor, int32_t* __restrict__ flagged,
+                                                    MhRes* __restrict__ mhv) {
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
@@ -646,6 +650,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
       out->flags = fl;
       out->rank = 0;
       out->loglik = out->sse = out->scale = out->smin = out->smax = 0.0;
+      mhv[p].loglik = 0.0;
+      mhv[p].rank = 0;
     }
     return;
   }
@@ -664,6 +670,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
       out->smin = out->smax = NAN;
       out->rank = (flags & BSR_F_NAN) ? -1 : 0;
       out->flags = flags | BSR_F_RANKDEF;
+      mhv[p].loglik = NAN;
+      mhv[p].rank = out->rank;
     }
     if (lane < BSR_MAX_K) out->beta[lane] = NAN;
     return;
@@ -679,6 +687,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
         out->flags = flags | BSR_F_SCALE_RETRY;
         out->rank = 0;
         out->loglik = out->sse = NAN;
+        mhv[p].loglik = NAN;
+        mhv[p].rank = 0;
       }
       return;
     }
@@ -731,6 +741,7 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   in.N = N;
   in.flags = flags;
   in.rank_floor = rank_floor;
+  in.mh = mhv + p;
   solve_any(in, lane, out);
 }
 
@@ -741,7 +752,7 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
                                                            const PropCoef* __restrict__ coef, int P, int n_rb,
                                                            const double* __restrict__ part2, int64_t N,
                                                            bsr_score* __restrict__ outv, double rank_floor,
-                                                           int32_t* __restrict__ flagged) {
+                                                           int32_t* __restrict__ flagged, MhRes* __restrict__ mhv) {
   // one workgroup of four waves walks the batch's list of flagged proposals, one proposal per wave at a time
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -781,7 +792,55 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
   in.N = N;
   in.flags = cf->flags;
   in.rank_floor = rank_floor;
+  in.mh = mhv + p;
   solve_any(in, lane, outv + p);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scalar tail of newProp on the device (codes/funcs.py:1226-1306): log-ratio, accept test and, per chain, the
+// first proposal of the speculative run that is not "rejected as speculated".  One lane per chain span; the terms
+// come from the host (include/bsr_hip.h), the additions are made in the reference's order, so logR -- and the
+// decision -- are bit-identical to the host's.
+__global__ __launch_bounds__(BSR_WAVE) void k_events(const MhRes* __restrict__ mh, const double* __restrict__ terms,
+                                                     const int32_t* __restrict__ flags,
+                                                     const int32_t* __restrict__ span_off, int n_spans, int K,
+                                                     bsr_event* __restrict__ events) {
+  for (int sp = blockIdx.x * BSR_WAVE + threadIdx.x; sp < n_spans; sp += gridDim.x * BSR_WAVE) {
+    const int lo = span_off[sp], hi = span_off[sp + 1];
+    bsr_event ev;
+    ev.index = hi - lo;
+    ev.kind = BSR_EV_NONE;
+    ev.logR = NAN;
+    for (int i = lo; i < hi; ++i) {
+      const bool no_u = (flags[i] & BSR_MH_NO_UNIFORM) != 0;
+      if (mh[i].rank < K) {                       // rank gate (NaN candidates, rank -1, come this way too)
+        if (no_u) continue;                       // speculated: the run goes on
+        ev.index = i - lo;
+        ev.kind = BSR_EV_GATE;
+        break;
+      }
+      const double* t = terms + 8 * (size_t)i;
+      const double log_y = mh[i].loglik - t[0];
+      double logR;
+      if (flags[i] & BSR_MH_JUMP) logR = log_y + t[1] + t[2] + t[3] + t[4];
+      else logR = log_y + t[1] + t[2];
+      logR = logR + t[5] - t[6];
+      if (no_u) {                                 // passed the gate against the speculation: the host draws the uniform
+        ev.index = i - lo;
+        ev.kind = BSR_EV_GATE_PASSED;
+        ev.logR = logR;
+        break;
+      }
+      const double alpha = (0 < logR) ? 0 : logR;  // Python's min(logR, 0)
+      if (!(t[7] >= alpha)) {
+        ev.index = i - lo;
+        ev.kind = BSR_EV_ACCEPT;
+        ev.logR = logR;
+        break;
+      }
+    }
+    events[sp] = ev;
   }
 }
 
@@ -1176,14 +1235,19 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 #undef BSR_CASE
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged) {
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh) {
   hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
-                     flagged);
+                     flagged, mh);
+}
+void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
+                   int n_spans, int K, bsr_event* events) {
+  hipLaunchKernelGGL(k_events, dim3((n_spans + BSR_WAVE - 1) / BSR_WAVE), dim3(BSR_WAVE), 0, st, mh, terms8, flags,
+                     span_off, n_spans, K, events);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged) {
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh) {
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
-                     rank_floor, flagged);
+                     rank_floor, flagged, mh);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,

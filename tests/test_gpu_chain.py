@@ -280,3 +280,101 @@ def test_rccl_gather_through_the_c_abi_single_rank():
     assert np.array_equal(got[0]["beta"].reshape(-1), [0.5, 1.5, -2.0])
     assert (got[0]["n_props"], got[0]["n_accept"], got[0]["n_errs"]) == (10, 2, 2)
     ctx.close()
+
+
+def test_device_side_mh_step_against_the_host(monkeypatch):
+    """log-ratio assembly, accept test and first-event scan on the device (k_events).
+    (1) through the C ABI with hand-made terms: the event of every span equals a numpy restatement of
+        codes/funcs.py:1226-1306 on the scores of the same batch, logR bit for bit;
+    (2) the native sampler with the device step on gives the chains it gives with the step off, and with
+        BSR_ENGINE_VERIFY_MH=1 the host recomputes every decision and logR and finds them identical."""
+    from bsr import _lib
+    from bsr.device import DeviceContext
+    from bsr.native import NativeEngine
+    from bsr.node import Express
+    from bsr.tape import flatten, pack
+    rs = np.random.RandomState(5)
+    N, d, K = 3000, 4, 3
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    ctx = DeviceContext(X, y, K=K, n_chains=2, max_batch=64)
+    np.random.seed(3)
+    trees = []
+    while len(trees) < 2 * K + 48:
+        root = O.ONode(0)
+        O.grow(root, d, list(O.OPS), list(O.OP_WEIGHTS), list(O.OP_ARITY), -1, 1.0, 1.0)
+        if O.count_nodes(root) < 40:
+            trees.append(node_from_spec(__import__("conftest").spec_from_node(root)))
+    for c in range(2):
+        for k in range(K):
+            ctx.set_current(c, k, flatten(trees[c * K + k]))
+        ctx.refresh(c)
+    tapes = [flatten(t) for t in trees[2 * K:]]
+    tapes[5] = flatten(trees[1])                       # repeats a sibling of chain 0: the rank gate rejects it
+    B = len(tapes)
+    chains = np.array([0] * 20 + [1] * 28, np.int32)
+    span_off = np.array([0, 20, 48], np.int32)
+    ks = (np.arange(B) % K).astype(np.int32)
+    ks[5] = 0
+    sig = rs.uniform(0.5, 2.0, size=B)
+    rows, off = pack(tapes)
+    plain = ctx.score_batch(tapes, chains, ks, sig).copy()
+    for trial in range(6):
+        terms = np.zeros((B, 8))
+        terms[:, 0] = np.where(np.isfinite(plain["loglik"]), plain["loglik"], 0.0) + rs.uniform(-3, 6, size=B)  # yll
+        terms[:, 1:7] = rs.uniform(-2, 2, size=(B, 6))
+        terms[:, 7] = np.log(rs.uniform(size=B))
+        flags = rs.randint(0, 2, size=B).astype(np.int32)            # JUMP or not
+        if trial % 2:
+            flags[rs.randint(0, B, size=6)] |= _lib.MH_NO_UNIFORM
+        if trial == 5:
+            terms[:, 0] += 50.0                                     # nothing is accepted: the gate decides
+        t = ctx.score_submit_mh(rows, off, chains, ks, sig, terms, flags, span_off)
+        out = np.zeros(B, dtype=plain.dtype)
+        ev = ctx.score_wait_mh(t, out)
+        assert out.tobytes() == plain.tobytes()
+        for sp in range(2):
+            want = (span_off[sp + 1] - span_off[sp], _lib.EV_NONE, np.nan)
+            for i in range(span_off[sp], span_off[sp + 1]):
+                no_u = bool(flags[i] & _lib.MH_NO_UNIFORM)
+                if out["rank"][i] < K:
+                    if no_u:
+                        continue
+                    want = (i - span_off[sp], _lib.EV_GATE, np.nan)
+                    break
+                tt = terms[i]
+                log_y = out["loglik"][i] - tt[0]
+                logR = (log_y + tt[1] + tt[2] + tt[3] + tt[4]) if flags[i] & _lib.MH_JUMP else (log_y + tt[1] + tt[2])
+                logR = logR + tt[5] - tt[6]
+                if no_u:
+                    want = (i - span_off[sp], _lib.EV_GATE_PASSED, logR)
+                    break
+                if not (tt[7] >= min(logR, 0)):
+                    want = (i - span_off[sp], _lib.EV_ACCEPT, logR)
+                    break
+            got = (int(ev["index"][sp]), int(ev["kind"][sp]), float(ev["logR"][sp]))
+            assert got[:2] == want[:2], (trial, sp, got, want)
+            assert got[2] == want[2] or (np.isnan(got[2]) and np.isnan(want[2])), (trial, sp, got, want)
+    ctx.close()
+    # (2) the sampler
+    runs = {}
+    for mode, env in (("host", {"BSR_ENGINE_DEVICE_MH": "0"}), ("device", {"BSR_ENGINE_DEVICE_MH": "1"}),
+                      ("verify", {"BSR_ENGINE_DEVICE_MH": "1", "BSR_ENGINE_VERIFY_MH": "1"})):
+        for k_, v_ in (("BSR_ENGINE_DEVICE_MH", None), ("BSR_ENGINE_VERIFY_MH", None)):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        ctx = DeviceContext(X, y, K=K, n_chains=6, max_batch=6 * 32)
+        eng = NativeEngine(ctx, 6, d, val=10 ** 9)
+        eng.set_nan_policy(True)
+        for c in range(6):
+            eng.seed(c, 700 + c)
+            eng.init_chain(c)
+        eng.run(batch_per_chain=32, max_props=3000)
+        res = [eng.result(c, current=True) for c in range(6)]
+        runs[mode] = [([Express(t) for t in r["roots"]], r["beta"].tobytes(), r["n_props"], r["n_accept"],
+                       r["n_rank_rejects"], eng.get_numpy_state(c)[1].tobytes()) for c, r in enumerate(res)]
+        eng.close()
+        ctx.close()
+    assert runs["host"] == runs["device"] == runs["verify"]
+    assert sum(r[3] for r in runs["host"]) > 0
