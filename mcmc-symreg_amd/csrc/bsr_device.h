@@ -4,7 +4,16 @@
 #pragma once
 
 #include "bsr_internal.h"
-#include "bsr_sincos.h"
+#define BSR_TABLE_QUALIFIER static __device__ const
+#include "bsr_tables.h"
+#include "bsr_fastmath.h"
+
+// The sin/cos/exp tables (9 KiB) live in LDS: every kernel that runs the interpreter copies them in once
+// (tables_to_lds + a workgroup barrier) before its first tape.
+static __shared__ double bsr_lds_tab[BSR_TAB_DOUBLES];
+__device__ __forceinline__ void tables_to_lds() {
+  for (int i = threadIdx.x; i < BSR_TAB_DOUBLES; i += blockDim.x) bsr_lds_tab[i] = bsr_tables_src[i];
+}
 
 #define CONSTANT_AS __attribute__((address_space(4)))
 
@@ -111,10 +120,11 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // ---------------------------------------------------------------------------------------------------------------
 // opcode semantics (codes/funcs.py:179-212)
 template <typename T> __device__ __forceinline__ T op_exp(T x);
-// exp is evaluated unconditionally on min(x,200) and the clamp applied by a select: a lane-divergent branch around
-// it would turn the interpreter loop into a structurized region (see sin_rows below).
+// exp is evaluated unconditionally and the clip applied by a select (NaN <= 200 is false: 1e10, as in the reference's
+// per-element loop): a lane-divergent branch around it would turn the interpreter loop into a structurized region
+// (see sin_rows below).  fp64: the table-driven bsr_exp (bsr_fastmath.h), which clamps its argument itself.
 template <> __device__ __forceinline__ double op_exp<double>(double x) {
-  const double e = exp(fmin(x, 200.0));
+  const double e = bsr_exp(x, bsr_lds_tab);
   return (x <= 200.0) ? e : 1e10;
 }
 template <> __device__ __forceinline__ float op_exp<float>(float x) {
@@ -131,20 +141,40 @@ template <>
 struct VecOf<double, 2> { using type = double2; };
 template <>
 struct VecOf<float, 2> { using type = float2; };
-// fp64: branch-free bsr_sincos (bsr_sincos.h) unless some lane of the wave holds a huge, infinite or NaN argument --
+// fp64: branch-free bsr_sincos (bsr_fastmath.h) unless some lane of the wave holds a huge, infinite or NaN argument --
 // a wave-uniform test -- in which case the whole wave takes the library routine.
 static __device__ __attribute__((noinline)) double2 sin_rows(double2 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;  // false for NaN
   if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(sin(v.x), sin(v.y));
-  return make_double2(bsr_sincos(v.x, 0), bsr_sincos(v.y, 0));
+  return make_double2(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab));
 }
 static __device__ __attribute__((noinline)) double2 cos_rows(double2 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;
   if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(cos(v.x), cos(v.y));
-  return make_double2(bsr_sincos(v.x, 1), bsr_sincos(v.y, 1));
+  return make_double2(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab));
+}
+static __device__ __attribute__((noinline)) double2 exp_rows(double2 v) {
+  return make_double2(op_exp<double>(v.x), op_exp<double>(v.y));
+}
+static __device__ __attribute__((noinline)) float2 exp_rows(float2 v) {
+  return make_float2(op_exp<float>(v.x), op_exp<float>(v.y));
 }
 static __device__ __attribute__((noinline)) float2 sin_rows(float2 v) { return make_float2(sinf(v.x), sinf(v.y)); }
 static __device__ __attribute__((noinline)) float2 cos_rows(float2 v) { return make_float2(cosf(v.x), cosf(v.y)); }
+// The table extensions (log, div) are out of line for a different reason: inlined, their temporaries push the
+// interpreter of the tile pass (128 VGPRs at 16 waves per CU) into scratch spills on every tape, used or not.
+static __device__ __attribute__((noinline)) double2 log_rows(double2 v) {
+  return make_double2(v.x == 0.0 ? 0.0 : log(fabs(v.x)), v.y == 0.0 ? 0.0 : log(fabs(v.y)));
+}
+static __device__ __attribute__((noinline)) float2 log_rows(float2 v) {
+  return make_float2(v.x == 0.0f ? 0.0f : (float)log(fabs((double)v.x)), v.y == 0.0f ? 0.0f : (float)log(fabs((double)v.y)));
+}
+static __device__ __attribute__((noinline)) double2 div_rows(double2 l, double2 r) {  // protected like inv
+  return make_double2(r.x == 0.0 ? 0.0 : l.x / r.x, r.y == 0.0 ? 0.0 : l.y / r.y);
+}
+static __device__ __attribute__((noinline)) float2 div_rows(float2 l, float2 r) {
+  return make_float2(r.x == 0.0f ? 0.0f : l.x / r.x, r.y == 0.0f ? 0.0f : l.y / r.y);
+}
 
 // np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
 // Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
@@ -319,7 +349,14 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
     if (op >= BSR_OP_SUB) {  // extensions beyond the reference's table (semantics: oracle/bsr_oracle.py allcal)
       if (op == BSR_OP_LOG) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)log(fabs((double)acc[u]));
+        for (int j = 0; j < U / 2; ++j) {
+          typename VecOf<T, 2>::type r, v;
+          v.x = acc[2 * j];
+          v.y = acc[2 * j + 1];
+          r = log_rows(v);
+          acc[2 * j] = r.x;
+          acc[2 * j + 1] = r.y;
+        }
       } else {
         T lhs[U];
         --sp;
@@ -327,9 +364,18 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
         if (op == BSR_OP_SUB) {
 #pragma unroll
           for (int u = 0; u < U; ++u) acc[u] = lhs[u] - acc[u];
-        } else {  // BSR_OP_DIV: protected like inv
+        } else {  // BSR_OP_DIV
 #pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : lhs[u] / acc[u];
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v, l;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            l.x = lhs[2 * j];
+            l.y = lhs[2 * j + 1];
+            r = div_rows(l, v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
         }
       }
     } else if (op >= BSR_OP_TERMINAL) {  // consumes the prefetched column
@@ -406,7 +452,14 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
           break;
         case BSR_OP_EXP:
 #pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = op_exp<T>(acc[u]);
+          for (int j = 0; j < U / 2; ++j) {
+            typename VecOf<T, 2>::type r, v;
+            v.x = acc[2 * j];
+            v.y = acc[2 * j + 1];
+            r = exp_rows(v);
+            acc[2 * j] = r.x;
+            acc[2 * j + 1] = r.y;
+          }
           break;
         case BSR_OP_SQUARE:
 #pragma unroll

@@ -82,6 +82,8 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   const int32_t CONSTANT_AS* flagged = as_const(queue);
   const int n_flag = (MODE == MODE_RESIDUAL) ? flagged[0] : 0;
   if (MODE == MODE_RESIDUAL && n_flag == 0) return;
+  tables_to_lds();
+  if (!LDS) __syncthreads();
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;

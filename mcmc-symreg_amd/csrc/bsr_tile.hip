@@ -188,6 +188,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;  // the first 16 list entries go to the waves in order
+  tables_to_lds();
   stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
   __syncthreads();
   TSTAMP(1);
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
 
+  tables_to_lds();  // visible after the first barrier below
   for (int pass = 0; pass < g.n_pass; ++pass) {
     const int32_t CONSTANT_AS* my = sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
     TapeAcc<KQ> A[QMAX];
@@ -371,7 +373,7 @@ void launch_kq(hipStream_t st, const TileArgs<T>& a) {
 
 }  // namespace
 
-size_t tile_lds_bytes_max() { return 160 * 1024; }
+size_t tile_lds_bytes_max() { return 160 * 1024 - BSR_TAB_DOUBLES * sizeof(double); }  // the math tables are static LDS
 
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a) {

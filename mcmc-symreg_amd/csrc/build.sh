@@ -13,10 +13,15 @@ srcs=(bsr_tile bsr_kernels bsr_api bsr_engine bsr_refresh)
 pids=()
 for s in "${srcs[@]}"; do
   [ -f "$here/$s.hip" ] || continue
-  "$ROCM/bin/hipcc" "${FLAGS[@]}" -c "$here/$s.hip" -o "$obj/$s.o" &
+  # the compiler's per-kernel resource report (registers, scratch) is kept next to the object: tests/test_build_resources.py
+  # fails when the tile row pass spills to scratch (it did once, silently, for 4.5 us per launch)
+  "$ROCM/bin/hipcc" "${FLAGS[@]}" -Rpass-analysis=kernel-resource-usage -c "$here/$s.hip" -o "$obj/$s.o" 2> "$obj/$s.resources.txt" &
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait "$p"; done
+rc=0
+for p in "${pids[@]}"; do wait "$p" || rc=1; done
+if [ $rc -ne 0 ]; then grep -h -B2 -A6 "error" "$obj"/*.resources.txt >&2 || true; exit 1; fi
+grep -h "warning:" "$obj"/*.resources.txt >&2 || true
 objs=()
 for s in "${srcs[@]}"; do [ -f "$obj/$s.o" ] && [ -f "$here/$s.hip" ] && objs+=("$obj/$s.o"); done
 "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" -o "$out"

@@ -1,0 +1,54 @@
+"""The compiler's per-kernel resource report of the in-tree build (csrc/build/*.resources.txt, written by build.sh):
+the row passes on the product's default path must not spill vector registers to scratch.  (Round 2: three more
+opcodes inlined into the interpreter pushed the tile pass to 6 spilled VGPRs -- 7 MB of scratch writes and 4.5 us per
+launch -- and nothing failed.)"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mcmc-symreg_amd", "csrc")
+
+
+def _report(name):
+    path = os.path.join(CSRC, "build", name + ".resources.txt")
+    if not os.path.exists(path):
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("no hipcc and no build report")
+        subprocess.run(["bash", os.path.join(CSRC, "build.sh")], check=True, capture_output=True)
+    out = {}
+    cur = None
+    for m in re.finditer(r"remark: +(Function Name|VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|Occupancy \[waves/SIMD\]): (\S+)",
+                         open(path).read()):
+        k, v = m.groups()
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        else:
+            cur[k] = int(v)
+    return out
+
+
+def test_tile_row_pass_has_no_scratch():
+    rep = _report("bsr_tile")
+    names = [n for n in rep if "k_tile1I" in n]
+    assert len(names) == 16, names            # double and float, K = 1..8
+    for n in names:
+        r = rep[n]
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (n, r)
+        assert r["VGPRs"] <= 128, (n, r)      # 16 waves per CU in one workgroup: 4 per SIMD
+
+
+def test_default_work_queue_row_pass_has_no_scratch():
+    """k_rows<T, K, U=2, ., .> is what scores data sets beyond LDS (config 5) and re-evaluates accepted trees."""
+    rep = _report("bsr_kernels")
+    seen = 0
+    for n, r in rep.items():
+        m = re.match(r"_Z6k_rowsI([df])Li(\d)ELi2ELb[01]ELi[012]E", n)
+        if not m or int(m.group(2)) > 7:
+            continue
+        seen += 1
+        assert r["ScratchSize [bytes/lane]"] == 0, (n, r)
+    assert seen >= 16
