@@ -141,6 +141,10 @@ template <>
 struct VecOf<double, 2> { using type = double2; };
 template <>
 struct VecOf<float, 2> { using type = float2; };
+template <>
+struct VecOf<double, 4> { using type = double4; };
+template <>
+struct VecOf<float, 4> { using type = float4; };
 // fp64: branch-free bsr_sincos (bsr_fastmath.h) unless some lane of the wave holds a huge, infinite or NaN argument --
 // a wave-uniform test -- in which case the whole wave takes the library routine.
 static __device__ __attribute__((noinline)) double2 sin_rows(double2 v) {
@@ -176,6 +180,65 @@ static __device__ __attribute__((noinline)) float2 div_rows(float2 l, float2 r) 
   return make_float2(r.x == 0.0f ? 0.0f : l.x / r.x, r.y == 0.0f ? 0.0f : l.y / r.y);
 }
 
+// Four values per call for the interpreter's two-block passes: arguments and results then occupy the same registers of
+// the call ABI, and nothing of the node being evaluated has to survive a call.
+static __device__ __attribute__((noinline)) double4 sin_rows(double4 v) {
+  const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT && fabs(v.z) < BSR_SINCOS_LIMIT &&
+                     fabs(v.w) < BSR_SINCOS_LIMIT;
+  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double4(sin(v.x), sin(v.y), sin(v.z), sin(v.w));
+  return make_double4(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab), bsr_sincos(v.z, 0, bsr_lds_tab),
+                      bsr_sincos(v.w, 0, bsr_lds_tab));
+}
+static __device__ __attribute__((noinline)) double4 cos_rows(double4 v) {
+  const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT && fabs(v.z) < BSR_SINCOS_LIMIT &&
+                     fabs(v.w) < BSR_SINCOS_LIMIT;
+  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double4(cos(v.x), cos(v.y), cos(v.z), cos(v.w));
+  return make_double4(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab), bsr_sincos(v.z, 1, bsr_lds_tab),
+                      bsr_sincos(v.w, 1, bsr_lds_tab));
+}
+static __device__ __attribute__((noinline)) double4 exp_rows(double4 v) {
+  return make_double4(op_exp<double>(v.x), op_exp<double>(v.y), op_exp<double>(v.z), op_exp<double>(v.w));
+}
+static __device__ __attribute__((noinline)) double4 log_rows(double4 v) {
+  return make_double4(v.x == 0.0 ? 0.0 : log(fabs(v.x)), v.y == 0.0 ? 0.0 : log(fabs(v.y)),
+                      v.z == 0.0 ? 0.0 : log(fabs(v.z)), v.w == 0.0 ? 0.0 : log(fabs(v.w)));
+}
+static __device__ __attribute__((noinline)) double4 div_rows(double4 l, double4 r) {
+  return make_double4(r.x == 0.0 ? 0.0 : l.x / r.x, r.y == 0.0 ? 0.0 : l.y / r.y, r.z == 0.0 ? 0.0 : l.z / r.z,
+                      r.w == 0.0 ? 0.0 : l.w / r.w);
+}
+static __device__ __attribute__((noinline)) float4 sin_rows(float4 v) { return make_float4(sinf(v.x), sinf(v.y), sinf(v.z), sinf(v.w)); }
+static __device__ __attribute__((noinline)) float4 cos_rows(float4 v) { return make_float4(cosf(v.x), cosf(v.y), cosf(v.z), cosf(v.w)); }
+static __device__ __attribute__((noinline)) float4 exp_rows(float4 v) {
+  return make_float4(op_exp<float>(v.x), op_exp<float>(v.y), op_exp<float>(v.z), op_exp<float>(v.w));
+}
+static __device__ __attribute__((noinline)) float4 log_rows(float4 v) {
+  return make_float4(v.x == 0.0f ? 0.0f : (float)log(fabs((double)v.x)), v.y == 0.0f ? 0.0f : (float)log(fabs((double)v.y)),
+                     v.z == 0.0f ? 0.0f : (float)log(fabs((double)v.z)), v.w == 0.0f ? 0.0f : (float)log(fabs((double)v.w)));
+}
+static __device__ __attribute__((noinline)) float4 div_rows(float4 l, float4 r) {
+  return make_float4(r.x == 0.0f ? 0.0f : l.x / r.x, r.y == 0.0f ? 0.0f : l.y / r.y, r.z == 0.0f ? 0.0f : l.z / r.z,
+                     r.w == 0.0f ? 0.0f : l.w / r.w);
+}
+
+// acc <- f(acc) through the out-of-line routine `f`, four values at a time where the pass holds a multiple of four
+#define BSR_CALL_ROWS(f)                                                           \
+  if constexpr (U % 4 == 0 && QUAD) {                                                      \
+    _Pragma("unroll") for (int j = 0; j < U / 4; ++j) {                            \
+      typename VecOf<T, 4>::type r, v;                                             \
+      v.x = acc[4 * j]; v.y = acc[4 * j + 1]; v.z = acc[4 * j + 2]; v.w = acc[4 * j + 3]; \
+      r = f(v);                                                                    \
+      acc[4 * j] = r.x; acc[4 * j + 1] = r.y; acc[4 * j + 2] = r.z; acc[4 * j + 3] = r.w; \
+    }                                                                              \
+  } else {                                                                         \
+    _Pragma("unroll") for (int j = 0; j < U / 2; ++j) {                            \
+      typename VecOf<T, 2>::type r, v;                                             \
+      v.x = acc[2 * j]; v.y = acc[2 * j + 1];                                      \
+      r = f(v);                                                                    \
+      acc[2 * j] = r.x; acc[2 * j + 1] = r.y;                                      \
+    }                                                                              \
+  }
+
 // np.power(x, 3) is libm pow (error < 1 ulp, in practice correctly rounded); x*x*x carries two roundings.
 // Compensated product: x^3 = (x2 + e) * x with x2 + e == x*x exactly, rounded once at the end.
 template <typename T> __device__ __forceinline__ T op_cube(T x);
@@ -185,7 +248,9 @@ template <> __device__ __forceinline__ double op_cube<double>(double x) {
   const double p = x2 * x;
   const double pe = fma(x2, x, -p);
   const double r = p + (pe + e * x);
-  return (isfinite(p) && isfinite(r)) ? r : p;  // keep inf/NaN and overflow behaviour of the plain product
+  // keep inf/NaN and overflow behaviour of the plain product: a non-finite p makes pe (and so r) NaN, and an r that
+  // overflowed next to the largest double falls back to the finite p -- one test covers both
+  return isfinite(r) ? r : p;
 }
 template <> __device__ __forceinline__ float op_cube<float>(float x) {
   const double xd = (double)x;
@@ -199,7 +264,6 @@ struct RegStack {
   T s[S][U];
   T* spill;  // per-wave: slot-major [slot][64*U]
   int lane;
-
   __device__ __forceinline__ void push(int sp, const T (&v)[U]) {
     if (sp < S) {
       switch (sp) {
@@ -207,10 +271,13 @@ struct RegStack {
   case i:                                                                \
     if constexpr (i < S) {                                               \
       _Pragma("unroll") for (int u = 0; u < U; ++u) s[i][u] = v[u];      \
+    } else {                                                             \
+      __builtin_unreachable();                                           \
     }                                                                    \
     break;
         X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #undef X
+        default: __builtin_unreachable();
       }
     } else {
       T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
@@ -225,10 +292,13 @@ struct RegStack {
   case i:                                                                \
     if constexpr (i < S) {                                               \
       _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = s[i][u];      \
+    } else {                                                             \
+      __builtin_unreachable();  /* otherwise: v undefined -> a zero the compiler materialises every pass */ \
     }                                                                    \
     break;
         X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #undef X
+        default: __builtin_unreachable();
       }
     } else {
       const T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
@@ -314,7 +384,8 @@ __device__ __forceinline__ TapeHead load_tape_head(const uint64_t* codes, const 
   return h;
 }
 
-template <typename T, int U, int S, typename Loader>
+// QUAD: the out-of-line routines take four values per call (a caller short of registers asks for pairs).
+template <typename T, int U, int S, typename Loader, bool QUAD = true>
 __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t* codes, const uint64_t* feats,
                                               const double* lnp, int n, const Loader& ldr, T (&acc)[U], T* spill,
                                               int lane) {
@@ -348,15 +419,7 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
     code >>= 4;
     if (op >= BSR_OP_SUB) {  // extensions beyond the reference's table (semantics: oracle/bsr_oracle.py allcal)
       if (op == BSR_OP_LOG) {
-#pragma unroll
-        for (int j = 0; j < U / 2; ++j) {
-          typename VecOf<T, 2>::type r, v;
-          v.x = acc[2 * j];
-          v.y = acc[2 * j + 1];
-          r = log_rows(v);
-          acc[2 * j] = r.x;
-          acc[2 * j + 1] = r.y;
-        }
+        BSR_CALL_ROWS(log_rows)
       } else {
         T lhs[U];
         --sp;
@@ -365,16 +428,27 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
 #pragma unroll
           for (int u = 0; u < U; ++u) acc[u] = lhs[u] - acc[u];
         } else {  // BSR_OP_DIV
+          if constexpr (U % 4 == 0 && QUAD) {
 #pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v, l;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            l.x = lhs[2 * j];
-            l.y = lhs[2 * j + 1];
-            r = div_rows(l, v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
+            for (int j = 0; j < U / 4; ++j) {
+              typename VecOf<T, 4>::type r, v, l;
+              v.x = acc[4 * j]; v.y = acc[4 * j + 1]; v.z = acc[4 * j + 2]; v.w = acc[4 * j + 3];
+              l.x = lhs[4 * j]; l.y = lhs[4 * j + 1]; l.z = lhs[4 * j + 2]; l.w = lhs[4 * j + 3];
+              r = div_rows(l, v);
+              acc[4 * j] = r.x; acc[4 * j + 1] = r.y; acc[4 * j + 2] = r.z; acc[4 * j + 3] = r.w;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < U / 2; ++j) {
+              typename VecOf<T, 2>::type r, v, l;
+              v.x = acc[2 * j];
+              v.y = acc[2 * j + 1];
+              l.x = lhs[2 * j];
+              l.y = lhs[2 * j + 1];
+              r = div_rows(l, v);
+              acc[2 * j] = r.x;
+              acc[2 * j + 1] = r.y;
+            }
           }
         }
       }
@@ -429,37 +503,13 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
           for (int u = 0; u < U; ++u) acc[u] = -acc[u];
           break;
         case BSR_OP_SIN:
-#pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            r = sin_rows(v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
-          }
+          BSR_CALL_ROWS(sin_rows)
           break;
         case BSR_OP_COS:
-#pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            r = cos_rows(v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
-          }
+          BSR_CALL_ROWS(cos_rows)
           break;
         case BSR_OP_EXP:
-#pragma unroll
-          for (int j = 0; j < U / 2; ++j) {
-            typename VecOf<T, 2>::type r, v;
-            v.x = acc[2 * j];
-            v.y = acc[2 * j + 1];
-            r = exp_rows(v);
-            acc[2 * j] = r.x;
-            acc[2 * j + 1] = r.y;
-          }
+          BSR_CALL_ROWS(exp_rows)
           break;
         case BSR_OP_SQUARE:
 #pragma unroll

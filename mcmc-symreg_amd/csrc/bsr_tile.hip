@@ -231,7 +231,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
       T z4[2 * U];
       LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
-      run_tape_head<T, 2 * U, S>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
+      // four values per out-of-line call, except where that costs the last registers (K = 6, 8 would spill two)
+      run_tape_head<T, 2 * U, S, LdsCols<T, 2 * U>, (sizeof(T) == 4 || (KQ != 6 && KQ != 8))>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
       const T za[U] = {z4[0], z4[1]}, zb[U] = {z4[2], z4[3]};
       add_block(za, off, b);
       add_block(zb, off + BSR_TILE_BLOCK, b + 1);
