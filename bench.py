@@ -69,6 +69,9 @@ def parse_args():
                     help="1: also run short legs of the other configs (c3, c5, c4's per-GPU share, native-engine chain "
                          "throughput) and report them under 'extra'; 0: headline only; -1: on for the default workload")
     ap.add_argument("--min-time", type=float, default=MIN_TIMED_S)
+    ap.add_argument("--rows", type=int, default=0,
+                    help="diagnostic only: override the workload's N (e.g. 2000 makes the GPU work negligible, so "
+                         "ms_per_step shows the host-side cost of a step); the line is then not a benchmark result")
     return ap.parse_args()
 
 
@@ -127,6 +130,8 @@ def build_workload(name, args, ranks, n_unique_min=64):
     from bsr.tape import pack
     W = WORKLOADS[name]
     N, d, K = W["N"], W["d"], W["K"]
+    if getattr(args, "rows", 0):
+        N = args.rows
     B = args.batch or W["batch"]
     C = args.chains or W["chains"]
     X, y = synth(N, d, seed=0)

@@ -10,7 +10,10 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "bsr_internal.h"
@@ -56,6 +59,8 @@ struct BatchSlot {
   int32_t* queue = nullptr;  // ring of work-queue counter sets for the projection pass (zeroed once; every launch
                              // takes the next set and clears the one half a ring ahead)
   uint32_t queue_seq = 0;
+  hipStream_t aux = nullptr;      // CU-partitioned contexts: stream of the kernels behind the row pass (own CUs)
+  hipEvent_t tile_done = nullptr; // orders `aux` behind the row pass
   hipEvent_t done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int P = 0;
@@ -65,6 +70,11 @@ struct BatchSlot {
   bool pending = false;
   uint32_t gen = 0;         // bumped by every submission on this slot
   uint32_t waited_gen = 0;  // generation whose results the last wait on this slot handed out
+  // submission thread (see Launcher): the generation whose solve / residual / finalise launches and `done` event have
+  // been issued, and the status of issuing them
+  std::atomic<uint32_t> tail_gen{0};
+  uint32_t tail_wanted = 0;
+  int tail_rc = 0;
   int timed = 0;        // profiling level the pending batch was enqueued with
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
@@ -94,6 +104,8 @@ struct bsr_ctx {
   int64_t N = 0, ld = 0;
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
   int n_cu = 256;
+  int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
+  int aux_cus = 0;
   int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the row pass is sized for (f64 kernels: 92 VGPRs -> 5)
   size_t esz = 8;
   bool has_y = false;
@@ -121,6 +133,7 @@ struct bsr_ctx {
   int next_slot = 0;
   int last_waited = -1;
   std::mutex mu;  // commit / refresh / fit share the main stream and one set of staging buffers (bsr_internal_lock)
+  struct Launcher* launcher = nullptr;  // second submission thread (BSR_SUBMIT_THREAD, default on)
   std::mutex err_mu;  // the error text may be written by worker threads
   double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
   // tuning
@@ -166,6 +179,9 @@ static inline long long host_now() {
                      : 0;
 }
 
+static void launcher_start(bsr_ctx* c);
+static void launcher_stop(bsr_ctx* c);
+
 static void set_err(bsr_ctx* c, const char* msg) {
   std::lock_guard<std::mutex> lk(c->err_mu);
   c->err = msg;
@@ -210,10 +226,13 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   }
   if (!c) return BSR_E_ARG;
   (void)hipSetDevice(c->device);
+  launcher_stop(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
-  for (BatchSlot& s : c->slot)
+  for (BatchSlot& s : c->slot) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.aux) (void)hipStreamSynchronize(s.aux);
+  }
   void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf, c->d_fit_icpt,
                  c->d_rin, c->d_plan, c->d_rpart, c->d_stamps};
   if (c->h_plan) (void)hipHostFree(c->h_plan);
@@ -231,6 +250,8 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.part2) (void)hipFree(s.part2);
     if (s.spill) (void)hipFree(s.spill);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.aux) (void)hipStreamDestroy(s.aux);
+    if (s.tile_done) (void)hipEventDestroy(s.tile_done);
     if (s.done) (void)hipEventDestroy(s.done);
     for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
   }
@@ -318,7 +339,15 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
+    // CU partition.  A tile workgroup needs a whole CU (its LDS and registers), so one wave of another batch's solve or
+    // residual kernel sitting on a CU holds up that CU's workgroup -- and the row pass ends when its last workgroup
+    // does.  The row pass therefore gets its own CUs (stream CU masks; mask bits are dealt round-robin over the XCDs)
+    // and the small kernels behind it the remaining few.  BSR_AUX_CUS=0 turns the partition off.
+    c->aux_cus = env_int("BSR_AUX_CUS", (c->tile_on && c->n_cu >= 64) ? 16 : 0);
+    if (c->aux_cus < 0 || c->aux_cus > c->n_cu / 2) c->aux_cus = 0;
     c->tile_multi = env_int("BSR_TILE_MULTI", 0);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    c->tile_cus = c->n_cu - c->aux_cus;
     c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
     const double data_mb = (double)N * (std::min(d, 32) + 1 + std::max(1, K)) * c->esz / 1e6;
     int T = 1;
@@ -326,20 +355,20 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     if (data_mb <= 24.0) T = std::min(4, want);
     else if (data_mb <= 96.0) T = std::min(2, want);
     T = std::max(1, std::min(8, T));
-    while (T > 1 && (c->n_cu % T) != 0) --T;
+    while (T > 1 && (c->tile_cus % T) != 0) --T;
     // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
     // fit LDS whole even then (staged once, no barrier per chunk).
     const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
-    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->n_cu / t); return (c->tile_blocks + sl - 1) / sl; };
+    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return (c->tile_blocks + sl - 1) / sl; };
     auto fits_whole = [&](int t) {
       return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
     };
     while (T > 1 && !fits_whole(T)) T >>= 1;
     T = env_int("BSR_TILE_T", T);
     T = std::max(1, std::min(8, T));
-    while (T > 1 && (c->n_cu % T) != 0) --T;
+    while (T > 1 && (c->tile_cus % T) != 0) --T;
     c->tile_T = T;
-    c->tile_slices = std::max(1, c->n_cu / T);
+    c->tile_slices = std::max(1, c->tile_cus / T);
     c->tile_bps = (c->tile_blocks + c->tile_slices - 1) / c->tile_slices;
     // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
     // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
@@ -349,7 +378,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       c->tile_sub = 2;
       c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
     }
-    c->tile_sched_cap = (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64;
+    c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
+    // a data set whose narrowest batch (one feature, y, one chain's basis) does not fit LDS never takes the tile pass:
+    // no partition then, the work-queue row pass keeps every CU
+    const bool ever_tiled = c->tile_on && (c->tile_multi ||
+        (size_t)(2 + std::max(1, K)) * c->tile_bps * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024);
+    if (ever_tiled || c->aux_cus == 0) break;
+    c->aux_cus = 0;
+  }
     if (env_int("BSR_TILE_STAMPS", 0)) {
       const size_t nb = (size_t)c->n_cu * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
       if (hipMalloc((void**)&c->d_stamps, nb) == hipSuccess) (void)hipMemset(c->d_stamps, 0, nb);
@@ -384,7 +420,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   CK(hipMalloc((void**)&c->d_rpart, refresh_part_doubles(N) * sizeof(double)));
   c->fast_refresh = env_int("BSR_FAST_REFRESH", 1);
   for (BatchSlot& s : c->slot) {
-    CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (c->aux_cus > 0 && env_int("BSR_CU_MASK", 0)) {
+      // mask bit i = i-th CU in the runtime's numbering, which deals consecutive bits to different XCDs: the low
+      // tile_cus bits leave every XCD the same share (tools/probes/cumask_probe.hip)
+      std::vector<uint32_t> lo((size_t)(c->n_cu + 31) / 32, 0u), hi(lo.size(), 0u);
+      for (int i = 0; i < c->n_cu; ++i) (i < c->tile_cus ? lo : hi)[i / 32] |= 1u << (i % 32);
+      CK(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)lo.size(), lo.data()));
+      CK(hipExtStreamCreateWithCUMask(&s.aux, (uint32_t)hi.size(), hi.data()));
+      CK(hipEventCreateWithFlags(&s.tile_done, hipEventDisableTiming));
+    } else {
+      CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
     CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * (max_batch + 2)));
     CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * (max_batch + 2)));
@@ -417,6 +463,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   if (rc != BSR_OK) return bail(rc);
   // every buffer initialised above (null-stream and main-stream memsets) is complete before any slot stream runs
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(c, BSR_E_HIP, "hipDeviceSynchronize after setup"));
+  if (env_int("BSR_SUBMIT_THREAD", 1)) launcher_start(c);
   *out = c;
   return BSR_OK;
 }
@@ -709,16 +756,158 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
 }
 
 static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const PropDesc* desc, int P,
-                            int spill_slots, int nq, int residual) {
+                            int spill_slots, int nq, int residual, hipStream_t st = nullptr) {
+  if (!st) st = s.stream;
   if (c->dtype == BSR_DTYPE_F64) {
     RowPassArgs<double> a;
     fill_row_args<double>(c, s, g, &a, desc, P, spill_slots, residual);
-    launch_rows<double>(s.stream, a, nq, residual);
+    launch_rows<double>(st, a, nq, residual);
   } else {
     RowPassArgs<float> a;
     fill_row_args<float>(c, s, g, &a, desc, P, spill_slots, residual);
-    launch_rows<float>(s.stream, a, nq, residual);
+    launch_rows<float>(st, a, nq, residual);
   }
+}
+
+// Everything a staged batch puts on the GPU: upload, row pass, the kernels behind it, the event the waiter blocks on.
+struct TailJob {
+  int slot, P, n_part, spill_slots, nq;
+  LaunchGeom g;
+  bool scoring, on_aux, tile;
+  double rank_floor;
+  size_t in_bytes;
+  TileGeom tg;
+};
+
+static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
+  hipStream_t st = j.on_aux ? s.aux : s.stream;
+  int rc = BSR_OK;
+  auto step = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == BSR_OK) {
+      set_err(c, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
+      rc = BSR_E_HIP;
+    }
+  };
+  {
+    // upload + row pass on the slot's stream
+    hipStream_t s0 = s.stream;
+    step(hipMemcpyAsync(s.d_in, s.h_in, j.in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
+    if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
+    if (j.tile) {
+      const uint64_t* codes = s.d_streams();
+      const uint64_t* feats = codes + s.code_words;
+      const double* lnp = reinterpret_cast<const double*>(feats + s.feat_words);
+      const uint64_t* feats_lds = reinterpret_cast<const uint64_t*>(lnp + s.ln_words);
+      if (c->dtype == BSR_DTYPE_F64) {
+        TileArgs<double> a;
+        a.g = j.tg; a.colsrc = (const double* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
+        a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
+        a.stamps = c->d_stamps;
+        launch_tile<double>(s0, a);
+      } else {
+        TileArgs<float> a;
+        a.g = j.tg; a.colsrc = (const float* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
+        a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
+        a.stamps = c->d_stamps;
+        launch_tile<float>(s0, a);
+      }
+    } else {
+      launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 0);
+    }
+    if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
+    if (j.on_aux) step(hipEventRecord(s.tile_done, s0), "hipEventRecord");
+  }
+  if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
+  // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
+  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.d_flagged, s.d_mh);
+  if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
+  if (j.scoring) {
+    launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st);
+  }
+  if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
+  if (j.scoring)
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.d_flagged, s.d_mh);
+  if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
+    launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
+  if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
+  step(hipEventRecord(s.done, st), "hipEventRecord");
+  s.tail_rc = rc;
+  s.tail_gen.store(s.tail_wanted, std::memory_order_release);
+  return rc;
+}
+
+// Second submission thread of a context.  It spins for a while after its last job (a sleeping thread would add its
+// wake-up time to every batch of a busy pipeline) and sleeps on the condition variable when the context goes quiet.
+struct Launcher {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<TailJob> q;
+  std::atomic<int> n_queued{0};
+  bool asleep = false, stop = false;
+};
+
+static void launcher_main(bsr_ctx* c) {
+  (void)hipSetDevice(c->device);
+  Launcher* L = c->launcher;
+  for (;;) {
+    TailJob job;
+    bool have = false;
+    const auto t_idle = std::chrono::steady_clock::now();
+    while (!have) {
+      if (L->n_queued.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> lk(L->mu);
+        if (!L->q.empty()) {
+          job = L->q.front();
+          L->q.pop_front();
+          L->n_queued.fetch_sub(1, std::memory_order_relaxed);
+          have = true;
+        }
+      } else if (std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(500)) {
+        std::unique_lock<std::mutex> lk(L->mu);
+        if (L->stop) return;
+        if (L->q.empty()) {
+          L->asleep = true;
+          L->cv.wait(lk, [&] { return L->stop || !L->q.empty(); });
+          L->asleep = false;
+          if (L->stop && L->q.empty()) return;
+        }
+      } else {
+        __builtin_ia32_pause();
+      }
+    }
+    (void)issue_batch(c, c->slot[job.slot], job);
+  }
+}
+
+static void launcher_push(bsr_ctx* c, const TailJob& job) {
+  Launcher* L = c->launcher;
+  bool wake;
+  {
+    std::lock_guard<std::mutex> lk(L->mu);
+    L->q.push_back(job);
+    L->n_queued.fetch_add(1, std::memory_order_release);
+    wake = L->asleep;
+  }
+  if (wake) L->cv.notify_one();
+}
+
+static void launcher_start(bsr_ctx* c) {
+  c->launcher = new Launcher;
+  c->launcher->th = std::thread(launcher_main, c);
+}
+
+static void launcher_stop(bsr_ctx* c) {
+  Launcher* L = c->launcher;
+  if (!L) return;
+  {
+    std::lock_guard<std::mutex> lk(L->mu);
+    L->stop = true;
+  }
+  L->cv.notify_one();
+  if (L->th.joinable()) L->th.join();
+  delete L;
+  c->launcher = nullptr;
 }
 
 // Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
@@ -809,47 +998,28 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
       s.wave_load[idx] += (double)hd[p].cost;
     }
   }
-  hipStream_t st = s.stream;
-  const size_t in_bytes = s.off_streams + (s.code_words + s.feat_words * (s.tile ? 2 : 1) + s.ln_words) * 8;
-  HIPCHK(c, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, st));
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
-  // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
-  const double rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
   s.timed = c->prof;  // the level in force when the batch was enqueued decides which events exist at wait time
-  if (s.timed) HIPCHK(c, hipEventRecord(s.ev[0], st));
-  if (tile) {
-    const uint64_t* codes = s.d_streams();
-    const uint64_t* feats = codes + s.code_words;
-    const double* lnp = reinterpret_cast<const double*>(feats + s.feat_words);
-    const uint64_t* feats_lds = reinterpret_cast<const uint64_t*>(lnp + s.ln_words);
-    if (c->dtype == BSR_DTYPE_F64) {
-      TileArgs<double> a;
-      a.g = tg; a.colsrc = (const double* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
-      a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = P; a.K = c->K;
-      a.stamps = c->d_stamps;
-      launch_tile<double>(st, a);
-    } else {
-      TileArgs<float> a;
-      a.g = tg; a.colsrc = (const float* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
-      a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = P; a.K = c->K;
-      a.stamps = c->d_stamps;
-      launch_tile<float>(st, a);
-    }
+  TailJob job;
+  job.slot = (int)(&s - c->slot);
+  job.P = P; job.n_part = n_part; job.g = g; job.spill_slots = spill_slots; job.nq = nq; job.scoring = scoring;
+  job.in_bytes = s.off_streams + (s.code_words + s.feat_words * (s.tile ? 2 : 1) + s.ln_words) * 8;
+  job.tile = tile;
+  job.tg = tg;
+  // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
+  job.rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
+  // CU-partitioned context: the kernels behind the row pass run on the slot's second stream (its own few CUs)
+  job.on_aux = scoring && s.aux != nullptr;
+  s.tail_rc = BSR_OK;
+  s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
+  // Seven HIP calls per batch cost the host more than staging the batch does.  A scoring batch is handed to the
+  // context's submission thread, which issues them while the caller returns to stage its next batch.
+  if (c->launcher && scoring) {
+    launcher_push(c, job);
   } else {
-    launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 0);
+    rc = issue_batch(c, s, job);
+    if (rc != BSR_OK) return rc;
   }
-  if (s.timed) HIPCHK(c, hipEventRecord(s.ev[1], st));
-  // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, P, n_part, s.part1, c->N, s.d_coef, s.h_out, rank_floor, s.d_flagged, s.d_mh);
-  if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[2], st));
-  if (scoring) launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1);
-  if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[3], st));
-  if (scoring)
-    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor, s.d_flagged, s.d_mh);
-  if (scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
-    launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
-  if (s.timed > 1) HIPCHK(c, hipEventRecord(s.ev[4], st));
-  HIPCHK(c, hipEventRecord(s.done, st));
   s.P = P;
   s.pending = true;
   return BSR_OK;
@@ -857,6 +1027,11 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
 
 static int wait_slot(bsr_ctx* c, BatchSlot& s) {
   if (!s.pending) return BSR_OK;
+  while (s.tail_gen.load(std::memory_order_acquire) != s.tail_wanted) __builtin_ia32_pause();  // submission thread
+  if (s.tail_rc != BSR_OK) {
+    s.pending = false;
+    return s.tail_rc;
+  }
   HIPCHK(c, hipEventSynchronize(s.done));
   HIPCHK(c, hipGetLastError());
   s.pending = false;
@@ -1369,12 +1544,12 @@ extern "C" int bsr_debug_tile_stamps(bsr_ctx* c, unsigned long long* out, int32_
   if (!c->d_stamps) return 0;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  const int n = std::min<int>(max_wgs, c->n_cu);
+  const int n = std::min<int>(max_wgs, c->tile_cus);
   if (hipMemcpy(out, c->d_stamps, (size_t)n * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long),
                 hipMemcpyDeviceToHost) != hipSuccess) return BSR_E_HIP;
   if (geom5) {
     geom5[0] = c->tile_T; geom5[1] = c->tile_slices; geom5[2] = c->tile_bps; geom5[3] = c->tile_blocks;
-    geom5[4] = c->n_cu * 100 + c->tile_sub;
+    geom5[4] = c->tile_cus * 100 + c->tile_sub;
   }
   return n;
 }
