@@ -65,6 +65,7 @@ struct BatchSlot {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int P = 0;
   int nF = 0;
+  int derived_used = 0;  // derived columns the batch being staged refers to
   bool use_lds = false;
   int rb_rows = 512;
   bool pending = false;
@@ -103,6 +104,9 @@ struct bsr_ctx {
   hipStream_t stream = nullptr;
   int64_t N = 0, ld = 0;
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
+  int n_cols = 0;          // columns of Xt: the d features, then (derived columns on) d per unary opcode of kDerivedOps
+  bool derived_ready = false;
+  bool tile_ever = false;  // some batch of this context can take the tile pass
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
   int aux_cus = 0;
@@ -179,8 +183,24 @@ static inline long long host_now() {
                      : 0;
 }
 
+// Derived columns.  Most transcendental nodes of a proposal sit directly on a terminal (`sin(x3)`, `exp(x0)`), and the
+// row passes are bound by the vector instructions those nodes cost -- for every tape and row again.  The context
+// therefore keeps op(x_f) for every feature f and every unary opcode without parameters as extra columns behind X
+// (computed once, by the same device routines the interpreter runs: the values are bit-identical to an inline
+// evaluation), and the stream encoder turns `terminal f, op` into one terminal of column d*(1+m)+f.  What the pass
+// pays instead is the read of one more column per distinct (op, feature) of the batch -- bandwidth, which it has.
+static const int kDerivedOps[] = {BSR_OP_INV, BSR_OP_NEG, BSR_OP_SIN, BSR_OP_COS, BSR_OP_EXP, BSR_OP_SQUARE, BSR_OP_CUBIC,
+                                  BSR_OP_LOG};
+static const int kNumDerivedOps = (int)(sizeof(kDerivedOps) / sizeof(kDerivedOps[0]));
+static inline int derived_index(int opcode) {
+  for (int m = 0; m < kNumDerivedOps; ++m)
+    if (kDerivedOps[m] == opcode) return m;
+  return -1;
+}
+
 static void launcher_start(bsr_ctx* c);
 static void launcher_stop(bsr_ctx* c);
+static int build_derived(bsr_ctx* c);
 
 static void set_err(bsr_ctx* c, const char* msg) {
   std::lock_guard<std::mutex> lk(c->err_mu);
@@ -313,7 +333,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
   c->wgs_per_cu = std::max(1, std::min(8, env_int("BSR_WGS_PER_CU", 5)));
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
-  for (BatchSlot& s : c->slot) s.slot_of.assign(d, -1);
+  // derived columns (see kDerivedOps): on unless asked off, the column ids would leave 16 bits, or X is so large that
+  // nine copies of it would take more than a third of the device's free memory
+  c->n_cols = d;
+  if (env_int("BSR_DERIVED", 1) && (int64_t)d * (1 + kNumDerivedOps) <= 65535) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(device);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        (double)(BSR_ROW_ALIGN + N) * c->esz * d * (1 + kNumDerivedOps) <= (double)free_b / 3.0)
+      c->n_cols = d * (1 + kNumDerivedOps);
+  }
+  for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
   int rc = BSR_OK;
   auto bail = [&](int code) {
     g_create_error = c->err;
@@ -339,12 +369,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
-    // CU partition.  A tile workgroup needs a whole CU (its LDS and registers), so one wave of another batch's solve or
-    // residual kernel sitting on a CU holds up that CU's workgroup -- and the row pass ends when its last workgroup
-    // does.  The row pass therefore gets its own CUs (stream CU masks; mask bits are dealt round-robin over the XCDs)
-    // and the small kernels behind it the remaining few.  BSR_AUX_CUS=0 turns the partition off.
-    c->aux_cus = env_int("BSR_AUX_CUS", (c->tile_on && c->n_cu >= 64) ? 16 : 0);
+    // Optional CU partition (BSR_AUX_CUS=n: the row pass is sized for n_cu - n CUs; with BSR_CU_MASK=1 the slot streams
+    // carry CU masks -- mask bits are dealt round-robin over the XCDs -- and the kernels behind the row pass run on a
+    // second stream confined to the other n).  The idea: a tile workgroup needs a whole CU, so a wave of another
+    // batch's solve or residual kernel sitting on a CU holds that CU's workgroup up.  Measured at C2: spare CUs change
+    // nothing (the pipeline is bound by the host's HIP calls, not by this), masked streams halve the throughput
+    // (more hardware queues than the runtime maps at once).  Off by default.
+    c->aux_cus = env_int("BSR_AUX_CUS", 0);
     if (c->aux_cus < 0 || c->aux_cus > c->n_cu / 2) c->aux_cus = 0;
+    // chunked variant (two LDS buffers filled by LDS-DMA) for slices that do not fit LDS whole: correct and tested, but
+    // at N = 1M it measures 206 us against the work-queue pass's 165 us (four tapes per wave leave no registers for
+    // two-block passes, so every 128 rows pay a full scalar decode of the tape), so it only runs when asked for
     c->tile_multi = env_int("BSR_TILE_MULTI", 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
     c->tile_cus = c->n_cu - c->aux_cus;
@@ -383,9 +418,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // no partition then, the work-queue row pass keeps every CU
     const bool ever_tiled = c->tile_on && (c->tile_multi ||
         (size_t)(2 + std::max(1, K)) * c->tile_bps * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024);
+    c->tile_ever = ever_tiled;
     if (ever_tiled || c->aux_cus == 0) break;
     c->aux_cus = 0;
   }
+    // derived columns pay where the batch's columns sit in LDS; the work-queue pass would read each of them from HBM
+    // for every tape again (N = 1M, d = 50: +60 % traffic for -31 % instructions, no time gained alone and slower
+    // with several batches in flight)
+    if (!c->tile_ever && c->n_cols > d && env_int("BSR_DERIVED", 1) < 2) {
+      c->n_cols = d;
+      for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
+    }
     if (env_int("BSR_TILE_STAMPS", 0)) {
       const size_t nb = (size_t)c->n_cu * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
       if (hipMalloc((void**)&c->d_stamps, nb) == hipSuccess) (void)hipMemset(c->d_stamps, 0, nb);
@@ -394,8 +437,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   }
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t colb = (size_t)c->ld * c->esz;
-  CK(hipMalloc(&c->Xt, colb * d));
-  CK(hipMemsetAsync(c->Xt, 0, colb * d, c->stream));
+  CK(hipMalloc(&c->Xt, colb * c->n_cols));
+  CK(hipMemsetAsync(c->Xt, 0, colb * c->n_cols, c->stream));
   CK(hipMalloc(&c->y, colb));
   CK(hipMemsetAsync(c->y, 0, colb, c->stream));
   if (K > 0 && n_chains > 0) {
@@ -436,8 +479,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * (max_batch + 2)));
     CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
-    s.off_cols = ((size_t)d * sizeof(int32_t) + 255) / 256 * 256;
-    s.off_sched = s.off_cols + ((size_t)(d + 1 + std::max(1, n_chains) * std::max(1, K)) * sizeof(void*) + 255) / 256 * 256;
+    s.off_cols = ((size_t)c->n_cols * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_sched = s.off_cols + ((size_t)(c->n_cols + 1 + std::max(1, n_chains) * std::max(1, K)) * sizeof(void*) + 255) / 256 * 256;
     s.mh_cap = (size_t)max_batch;
     s.off_mh = s.off_sched + (c->tile_sched_cap * sizeof(int32_t) + 255) / 256 * 256;
     s.off_desc = s.off_mh + (s.mh_cap * 8 * sizeof(double) + (2 * s.mh_cap + 2) * sizeof(int32_t) + 255) / 256 * 256;
@@ -463,6 +506,10 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   if (rc != BSR_OK) return bail(rc);
   // every buffer initialised above (null-stream and main-stream memsets) is complete before any slot stream runs
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(c, BSR_E_HIP, "hipDeviceSynchronize after setup"));
+  if (c->n_cols > d) {
+    rc = build_derived(c);
+    if (rc != BSR_OK) return bail(rc);
+  }
   if (env_int("BSR_SUBMIT_THREAD", 1)) launcher_start(c);
   *out = c;
   return BSR_OK;
@@ -571,6 +618,32 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   size_t cw = 0, fw = 0, lw = 0;
   int max_fused_sp = 0;
   std::fill(s.slot_of.begin(), s.slot_of.end(), -1);
+  // How many derived columns this batch may use.  A context that scores through the tile pass must keep the batch's
+  // columns inside LDS: the allowance is what the slice leaves after y, the chains' bases and every X column the tapes
+  // name (an upper bound of what stays in use).  Derived columns are admitted in tape order until it is spent; the
+  // values do not depend on which are (same routine either way), so neither do the results.
+  // (not with the LDS-staging variant of k_rows, BSR_NO_LDS=0: there the column count picks the row-block size, and the
+  // block size fixes the order of the sums)
+  const bool derive = c->derived_ready && c->n_cols > c->d && c->no_lds;
+  int allowance = derive ? c->n_cols : 0;
+  if (derive && c->tile_on && tile_chains > 0) {
+    int n_base = 0;
+    for (int j = 0; j < tape_off[n]; ++j)
+      if (rows[j].opcode == BSR_OP_TERMINAL && rows[j].feature >= 0 && rows[j].feature < c->d &&
+          s.slot_of[rows[j].feature] < 0) {
+        s.slot_of[rows[j].feature] = 0;
+        ++n_base;
+      }
+    std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
+    const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
+    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)c->tile_bps * BSR_TILE_BLOCK * c->esz);
+    if ((long)fit < fixed && c->tile_multi)   // chunked variant: one block per column in each of its buffers
+      fit = (tile_lds_bytes_max() - 1024) / ((size_t)((c->esz == 8) ? 2 : 1) * BSR_TILE_BLOCK * c->esz);
+    const long room = (long)fit - fixed;
+    // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
+    if (room >= 0) allowance = (int)std::min<long>(room, c->n_cols);
+  }
+  s.derived_used = 0;
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
@@ -580,9 +653,21 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
       if (rows[j].opcode == BSR_OP_TERMINAL) {
         ++nt;
-        s.slot_of[rows[j].feature] = 0;
+        int col = rows[j].feature;
+        if (derive && j + 1 < tape_off[i + 1]) {   // `terminal, unary op` -> the op's derived column
+          const int m = derived_index(rows[j + 1].opcode);
+          if (m >= 0) {
+            const int dc = c->d * (1 + m) + col;
+            if (s.slot_of[dc] >= 0 || s.derived_used < allowance) {
+              if (s.slot_of[dc] < 0) ++s.derived_used;
+              col = dc;
+              ++j;
+            }
+          }
+        }
+        s.slot_of[col] = 0;
         const int nxt = (j + 1 < tape_off[i + 1]) ? rows[j + 1].opcode : -1;
-        if (j > tape_off[i] && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
+        if (nt > 1 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
       } else if (rows[j].opcode == BSR_OP_LN) {
         ++nl;
       } else if (is_binary_op(rows[j].opcode)) {
@@ -604,7 +689,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   // columns of X referenced by this batch -> LDS slots (ascending feature order)
   s.nF = 0;
   int32_t* hfeat = s.h_feat();
-  for (int f = 0; f < c->d; ++f)
+  for (int f = 0; f < c->n_cols; ++f)
     if (s.slot_of[f] == 0) {
       s.slot_of[f] = s.nF;
       hfeat[s.nF++] = f;
@@ -627,10 +712,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   s.tile_chains = tile_chains;
   if (c->tile_on && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK) {
     const size_t ncols = (size_t)s.nF + 1 + (size_t)tile_chains * c->K;
-    // the whole slice in LDS at once (single-chunk variant); the chunked variant (no double buffering yet) is slower
-    // than k_rows on data sets beyond L2 and only runs when asked for (BSR_TILE_MULTI=1)
-    const size_t blocks = c->tile_multi ? 1 : (size_t)c->tile_bps;
-    if (ncols * blocks * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024) s.tile = true;
+    // the whole slice in LDS at once (single-chunk variant), or chunks of at least one block in two buffers
+    const size_t budget = tile_lds_bytes_max() - 1024;
+    const size_t nbuf = (c->esz == 8) ? 2 : 1;
+    if (ncols * (size_t)c->tile_bps * BSR_TILE_BLOCK * c->esz <= budget) s.tile = true;
+    else if (c->tile_multi && ncols * nbuf * BSR_TILE_BLOCK * c->esz <= budget) s.tile = true;
   }
   s.code_words = cw;
   s.feat_words = fw;
@@ -652,14 +738,22 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const bsr_node& r = rows[tape_off[i] + j];
       int code = r.opcode & 15;
       if (r.opcode == BSR_OP_TERMINAL) {
-        const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[r.feature] : r.feature);
+        int col = r.feature;
+        if (derive && j + 1 < L.n_nodes) {   // the column pass 1 admitted for `terminal, unary op` (slot assigned)
+          const int m = derived_index(rows[tape_off[i] + j + 1].opcode);
+          if (m >= 0 && s.slot_of[c->d * (1 + m) + col] >= 0) {
+            col = c->d * (1 + m) + col;
+            ++j;
+          }
+        }
+        const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[col] : col);
         pf[nt >> 2] |= id << (16 * (nt & 3));
-        if (s.tile) pf2[nt >> 2] |= (uint64_t)s.slot_of[r.feature] << (16 * (nt & 3));
+        if (s.tile) pf2[nt >> 2] |= (uint64_t)s.slot_of[col] << (16 * (nt & 3));
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
         // one stream entry: acc = acc op X[:,f], no push/pop
         const int nxt = (j + 1 < L.n_nodes) ? rows[tape_off[i] + j + 1].opcode : -1;
-        if (j > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
+        if (ns > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
           code = (nxt == BSR_OP_ADD) ? BSR_SOP_ADD_T : BSR_SOP_MUL_T;
           ++j;
         } else {
@@ -936,14 +1030,18 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     tg.ncols = s.nF + 1 + s.tile_chains * c->K;
     tg.y_slot = s.nF;
     const size_t per_block = (size_t)tg.ncols * BSR_TILE_BLOCK * c->esz;
-    tg.chunk_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)tg.bps, (tile_lds_bytes_max() - 1024) / per_block));
+    const size_t lds_budget = tile_lds_bytes_max() - 1024;
+    // the whole slice fits in LDS: staged once, waves pull tapes from the group's list (single-chunk variant);
+    // otherwise chunks of as many blocks as fit (fp64: in each of two buffers)
+    const bool single = per_block * tg.bps <= lds_budget && env_int("BSR_TILE_SINGLE", 1);
+    if (single) tg.chunk_blocks = tg.bps;
+    else tg.chunk_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)tg.bps, lds_budget / ((c->esz == 8) ? 2 : 1) / per_block));
     const int per_group = (P + tg.T - 1) / tg.T;
     const int q_need = (per_group + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;
     const int qb = (c->K <= 3) ? 4 : ((c->K <= 5) ? 3 : 2);
     tg.qmax = (q_need <= 1) ? 1 : qb;
     tg.n_pass = (q_need + tg.qmax - 1) / tg.qmax;
-    // the whole slice fits in LDS: staged once, waves pull tapes from the group's list (single-chunk variant)
-    tg.per_group = (tg.chunk_blocks >= tg.bps && env_int("BSR_TILE_SINGLE", 1)) ? per_group : 0;
+    tg.per_group = single ? per_group : 0;
     tg.n_sub = c->tile_sub;
     tg.sub_blocks = c->tile_sub_blocks;
     tg.n_part = tg.n_slices * tg.n_sub;
@@ -1114,6 +1212,44 @@ extern "C" int bsr_eval_tapes(bsr_ctx* c, const bsr_node* rows, const int32_t* t
 static int chain_ok(bsr_ctx* c, int chain, int k) {
   if (chain < 0 || chain >= c->n_chains) return fail(c, BSR_E_ARG, "chain index out of range");
   if (k < 0 || k >= c->K) return fail(c, BSR_E_ARG, "tree index out of range");
+  return BSR_OK;
+}
+
+// Fills the derived columns (kDerivedOps) behind X: d*kNumDerivedOps two-node tapes through the evaluation pass,
+// each writing its own column of Xt.  Runs once at context creation, before anything else uses the slots.
+static int build_derived(bsr_ctx* c) {
+  BatchSlot& s = c->slot[0];
+  const int total = c->d * kNumDerivedOps;
+  std::vector<bsr_node> rows((size_t)2 * c->max_batch);
+  std::vector<int32_t> off((size_t)c->max_batch + 1);
+  std::vector<TapeLoc> loc;
+  for (int t0 = 0; t0 < total; t0 += c->max_batch) {
+    const int n = std::min(c->max_batch, total - t0);
+    for (int i = 0; i < n; ++i) {
+      const int m = (t0 + i) / c->d, f = (t0 + i) % c->d;
+      bsr_node& a = rows[2 * i];
+      bsr_node& b = rows[2 * i + 1];
+      memset(&a, 0, sizeof a);
+      memset(&b, 0, sizeof b);
+      a.opcode = BSR_OP_TERMINAL; a.left = a.right = -1; a.feature = f;
+      b.opcode = kDerivedOps[m]; b.left = 2 * i; b.right = -1; b.feature = -1;
+      off[i] = 2 * i;
+    }
+    off[n] = 2 * n;
+    // node links are tape-relative
+    for (int i = 0; i < n; ++i) rows[2 * i + 1].left = 0;
+    int rc = stage_tapes(c, s, rows.data(), off.data(), n, &loc);
+    if (rc != BSR_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+      const int m = (t0 + i) / c->d, f = (t0 + i) % c->d;
+      fill_eval_desc(c, &s.h_desc()[i], loc[i], col_ptr(c, c->Xt, (int64_t)c->d * (1 + m) + f));
+    }
+    s.scored = false;
+    rc = enqueue(c, s, n, false);
+    if (rc == BSR_OK) rc = wait_slot(c, s);
+    if (rc != BSR_OK) return rc;
+  }
+  c->derived_ready = true;
   return BSR_OK;
 }
 

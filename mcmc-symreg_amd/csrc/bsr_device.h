@@ -145,17 +145,25 @@ template <>
 struct VecOf<double, 4> { using type = double4; };
 template <>
 struct VecOf<float, 4> { using type = float4; };
-// fp64: branch-free bsr_sincos (bsr_fastmath.h) unless some lane of the wave holds a huge, infinite or NaN argument --
-// a wave-uniform test -- in which case the whole wave takes the library routine.
+// fp64: branch-free bsr_sincos (bsr_fastmath.h).  When some lane of the wave holds a huge, infinite or NaN argument --
+// a wave-uniform test -- the wave also runs the library routine and THOSE lanes take its result: every value stays
+// a function of its own argument alone, whichever rows share its wave (the derived columns of bsr_api.hip and an
+// inline evaluation of the same node must agree to the bit).
+static __device__ __forceinline__ double sincos_big(double x, double fast, int which) {
+  const double lib = which ? cos(x) : sin(x);
+  return (fabs(x) < BSR_SINCOS_LIMIT) ? fast : lib;
+}
 static __device__ __attribute__((noinline)) double2 sin_rows(double2 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;  // false for NaN
-  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(sin(v.x), sin(v.y));
-  return make_double2(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab));
+  const double2 f = make_double2(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab));
+  if (__builtin_amdgcn_ballot_w64(!small) == 0) return f;
+  return make_double2(sincos_big(v.x, f.x, 0), sincos_big(v.y, f.y, 0));
 }
 static __device__ __attribute__((noinline)) double2 cos_rows(double2 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;
-  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double2(cos(v.x), cos(v.y));
-  return make_double2(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab));
+  const double2 f = make_double2(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab));
+  if (__builtin_amdgcn_ballot_w64(!small) == 0) return f;
+  return make_double2(sincos_big(v.x, f.x, 1), sincos_big(v.y, f.y, 1));
 }
 static __device__ __attribute__((noinline)) double2 exp_rows(double2 v) {
   return make_double2(op_exp<double>(v.x), op_exp<double>(v.y));
@@ -185,16 +193,18 @@ static __device__ __attribute__((noinline)) float2 div_rows(float2 l, float2 r) 
 static __device__ __attribute__((noinline)) double4 sin_rows(double4 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT && fabs(v.z) < BSR_SINCOS_LIMIT &&
                      fabs(v.w) < BSR_SINCOS_LIMIT;
-  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double4(sin(v.x), sin(v.y), sin(v.z), sin(v.w));
-  return make_double4(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab), bsr_sincos(v.z, 0, bsr_lds_tab),
-                      bsr_sincos(v.w, 0, bsr_lds_tab));
+  const double4 f = make_double4(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab),
+                                 bsr_sincos(v.z, 0, bsr_lds_tab), bsr_sincos(v.w, 0, bsr_lds_tab));
+  if (__builtin_amdgcn_ballot_w64(!small) == 0) return f;
+  return make_double4(sincos_big(v.x, f.x, 0), sincos_big(v.y, f.y, 0), sincos_big(v.z, f.z, 0), sincos_big(v.w, f.w, 0));
 }
 static __device__ __attribute__((noinline)) double4 cos_rows(double4 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT && fabs(v.z) < BSR_SINCOS_LIMIT &&
                      fabs(v.w) < BSR_SINCOS_LIMIT;
-  if (__builtin_amdgcn_ballot_w64(!small) != 0) return make_double4(cos(v.x), cos(v.y), cos(v.z), cos(v.w));
-  return make_double4(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab), bsr_sincos(v.z, 1, bsr_lds_tab),
-                      bsr_sincos(v.w, 1, bsr_lds_tab));
+  const double4 f = make_double4(bsr_sincos(v.x, 1, bsr_lds_tab), bsr_sincos(v.y, 1, bsr_lds_tab),
+                                 bsr_sincos(v.z, 1, bsr_lds_tab), bsr_sincos(v.w, 1, bsr_lds_tab));
+  if (__builtin_amdgcn_ballot_w64(!small) == 0) return f;
+  return make_double4(sincos_big(v.x, f.x, 1), sincos_big(v.y, f.y, 1), sincos_big(v.z, f.z, 1), sincos_big(v.w, f.w, 1));
 }
 static __device__ __attribute__((noinline)) double4 exp_rows(double4 v) {
   return make_double4(op_exp<double>(v.x), op_exp<double>(v.y), op_exp<double>(v.z), op_exp<double>(v.w));

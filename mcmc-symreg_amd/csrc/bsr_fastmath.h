@@ -45,6 +45,18 @@ static inline double bsr_vmax(double a, double b) { return __builtin_fmax(a, b);
 static inline double bsr_vmin(double a, double b) { return __builtin_fmin(a, b); }
 #endif
 
+// double -> int32 of an integral value.  On the device the instruction itself (saturating; NaN -> 0): the fast paths
+// also run on lanes whose huge or non-finite argument the caller replaces afterwards, where a C++ cast is undefined.
+#ifdef __HIPCC__
+__device__ __forceinline__ int bsr_cvt_i32(double k) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(k));
+  return r;
+}
+#else
+static inline int bsr_cvt_i32(double k) { return (k >= -2147483648.0 && k <= 2147483647.0) ? (int)k : 0; }
+#endif
+
 #define BSR_SINCOS_LIMIT 1647099.0   /* 2^20 * pi/2: beyond it the caller uses the library routine */
 
 // which = 0: sin(x), which = 1: cos(x); tab = the 1152-double table block (bsr_tables.h layout)
@@ -57,7 +69,7 @@ BSR_HD double bsr_sincos(double x, int which, const double* tab) {
   const double e = (rh - r) - ph;                            /* what the rounding of r dropped (exact also when rh and
                                                                 ph cancel: x next to a multiple of pi/128) */
   const double rl = __builtin_fma(-k, BSR_TRIG_P3, e - pl);
-  const int j = ((int)k + (which << 6)) & 255;
+  const int j = (bsr_cvt_i32(k) + (which << 6)) & 255;
   const double* t = tab + 4 * j;
   const double S = t[0], Sl = t[1], C = t[2], Cl = t[3];
   const double z = r * r;
@@ -81,7 +93,7 @@ BSR_HD double bsr_exp(double x, const double* tab) {
   const double k = __builtin_rint(xc * BSR_EXP_INV_STEP);
   double r = __builtin_fma(-k, BSR_EXP_L1, xc);
   r = __builtin_fma(-k, BSR_EXP_L2, r);
-  const int ki = (int)k;
+  const int ki = bsr_cvt_i32(k);
   const double* t = tab + BSR_TRIG_TAB_DOUBLES + 2 * (ki & 63);
   const double T = t[0], Tl = t[1];
   double q = __builtin_fma(r, 1.0 / 720.0, 1.0 / 120.0);

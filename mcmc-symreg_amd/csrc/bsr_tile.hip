@@ -97,6 +97,30 @@ __device__ __forceinline__ void stage_rows(T* sx, const T* const CONSTANT_AS* co
   }
 }
 
+// The same copy by LDS-DMA (fp64 columns): one instruction moves 64 lanes x 16 B of one column -- a 128-row block --
+// from per-lane global addresses to 1 KiB of LDS, without registers.  Issued and left in flight; the caller's next
+// workgroup barrier waits for it.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
+                                         int nb, int wave, int lane) {
+  static_assert(sizeof(T) == 8, "one 128-row block of a column per instruction");
+  const int n_units = ncols * nb;
+  int col = 0, blk = wave;
+  while (blk >= nb && col < ncols) { blk -= nb; ++col; }
+  for (int u = wave; u < n_units; u += BSR_TILE_WAVES) {
+    const T* src = colsrc[col] + (int64_t)(c0 + blk) * BSR_TILE_BLOCK + 2 * lane;
+    T* dst = buf + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
+    // Written as inline assembly on purpose: behind the builtin the compiler parks a vmcnt(0) in front of every later
+    // LDS read (it cannot tell the two buffers apart), which turns the double buffer back into a single one.  The
+    // caller waits for the copies itself (dma_wait) before the barrier that publishes them.
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+    blk += BSR_TILE_WAVES;
+    while (blk >= nb && col < ncols) { blk -= nb; ++col; }
+  }
+}
+
 // Lane reduction of one tape's sums and the store of its (tape, slice) partial record; every lane stores the same
 // totals (no lane-divergent branch).
 template <int KQ>
@@ -272,7 +296,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const int32_t CONSTANT_AS* sched = as_const(a.sched);
   const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
-  const T* sy = sx + (size_t)g.y_slot * chunk_rows;
   // diagnostics: shader-clock samples per wave (0 start, 1 first chunk staged, 2 first chunk computed, 3 all chunks
   // computed, 4 reductions stored; 7 and 6: the constant-rate 100 MHz clock at the start and at the end -- the shader
   // clock counters of different XCDs are not aligned, only differences inside one wave mean anything)
@@ -282,18 +305,40 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
 
   tables_to_lds();  // visible after the first barrier below
+  // Two LDS buffers of chunk_rows rows per column.  While the waves run their tapes over chunk c, the rows of chunk
+  // c+1 travel HBM -> LDS on their own (LDS-DMA: no registers, nothing for the waves to do); the barrier that ends the
+  // chunk also waits for them (its fence drains vmcnt).  f32 columns keep the register-staged single buffer.
+  constexpr bool DMA = sizeof(T) == 8;
+  const int buf_elems = DMA ? g.ncols * chunk_rows : 0;
   for (int pass = 0; pass < g.n_pass; ++pass) {
     const int32_t CONSTANT_AS* my = sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
     TapeAcc<KQ> A[QMAX];
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) A[q].clear();
 
-    for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks) {
-      const int nb = min(g.chunk_blocks, b1 - c0);
-      if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
-      stage_rows<T, 4>(sx, colsrc, g.ncols, chunk_rows, c0, nb, wave, lane);
+    if constexpr (DMA) {
+      if (pass != 0) __syncthreads();  // everyone is done with the last chunk of the pass before
+      dma_rows<T>(sx, colsrc, g.ncols, chunk_rows, b0, min(g.chunk_blocks, b1 - b0), wave, lane);
+      dma_wait();
       __syncthreads();
-      if (c0 == b0 && pass == 0) TSTAMP(1);
+      if (pass == 0) TSTAMP(1);
+    }
+    int ci = 0;
+    for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks, ++ci) {
+      const int nb = min(g.chunk_blocks, b1 - c0);
+      const T* cur = sx + (size_t)(ci & 1) * buf_elems;
+      if constexpr (DMA) {
+        const int n0 = c0 + g.chunk_blocks;
+        if (n0 < b1)
+          dma_rows<T>(sx + (size_t)((ci + 1) & 1) * buf_elems, colsrc, g.ncols, chunk_rows, n0, min(g.chunk_blocks, b1 - n0),
+                      wave, lane);
+      } else {
+        if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
+        stage_rows<T, 4>(sx, colsrc, g.ncols, chunk_rows, c0, nb, wave, lane);
+        __syncthreads();
+        if (c0 == b0 && pass == 0) TSTAMP(1);
+      }
+      const T* sy = cur + (size_t)g.y_slot * chunk_rows;
 #pragma unroll 1
       for (int q = 0; q < QMAX; ++q) {
         const int p = my[q];
@@ -303,13 +348,13 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
         const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
         const int n_nodes = dsc[p].n_nodes;
         const double s = dsc[p].s;
-        const T* sq = sx + (size_t)dsc[p].qslot * chunk_rows;
+        const T* sq = cur + (size_t)dsc[p].qslot * chunk_rows;
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
           const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk
           const int64_t row0 = (int64_t)(c0 + b) * BSR_TILE_BLOCK + 2 * lane;
           T z[U];
-          LdsCols<T, U> ldr{sx, chunk_rows, off};
+          LdsCols<T, U> ldr{cur, chunk_rows, off};
           run_tape<T, U, S>(pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
           const bool full = (int64_t)(c0 + b + 1) * BSR_TILE_BLOCK <= a.N;  // wave-uniform
 #define BSR_ACC_CASE(qq)                                                                              \
@@ -322,6 +367,10 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
           switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) BSR_ACC_CASE(2) BSR_ACC_CASE(3) }
 #undef BSR_ACC_CASE
         }
+      }
+      if constexpr (DMA) {  // chunk done by every wave, and the next one has landed
+        dma_wait();
+        __syncthreads();
       }
       if (c0 == b0 && pass == 0) TSTAMP(2);
     }
@@ -343,7 +392,8 @@ template <typename T, int KQ>
 void launch_kq(hipStream_t st, const TileArgs<T>& a) {
   const TileGeom& g = a.g;
   const dim3 grid((unsigned)(g.T * g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T);
+  // the chunked fp64 variant keeps two buffers (LDS-DMA double buffering)
+  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((g.per_group == 0 && sizeof(T) == 8) ? 2 : 1);
   if (g.per_group > 0) {
     static bool attr0 = false;
     if (!attr0) {

@@ -319,3 +319,52 @@ def test_work_queue_soak_against_the_static_grid(N, monkeypatch):
         queue.score_wait(tickets.pop(0), out)
         assert out.tobytes() == want.tobytes()
     queue.close()
+
+
+@pytest.mark.parametrize("N,d,K", [(100_000, 10, 3), (40_000, 6, 8), (300_000, 40, 3)])
+def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkeypatch):
+    """One batch through the tile pass's single-chunk variant, its chunked double-buffered variant (LDS-DMA), with and
+    without derived columns: the per-lane sums grow block by block in row order in every variant and a derived column
+    holds what the interpreter would compute inline, so the scores are bit-identical.  The work-queue row pass
+    (different partial blocks) agrees to rounding."""
+    import bsr_oracle as O
+    from conftest import node_from_spec, spec_from_node
+    from bsr.tape import flatten
+    B = 64
+    rs = np.random.RandomState(23)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
+    np.random.seed(31)
+    trees = []
+    while len(trees) < K + B:
+        root = O.ONode(0)
+        O.grow(root, d, list(O.OPS), list(O.OP_WEIGHTS), list(O.OP_ARITY), -1, 1.0, 1.0)
+        if O.count_nodes(root) < 30:
+            trees.append(node_from_spec(spec_from_node(root)))
+    tapes = [flatten(t) for t in trees[K:]]
+    ks = (np.arange(B) % K).astype(np.int32)
+    sig = rs.uniform(0.5, 2.0, size=B)
+    zeros = np.zeros(B, np.int32)
+
+    def run(env):
+        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _ctx(X, y, K=K, n_chains=1, max_batch=B)
+        for k in range(K):
+            c.set_current(0, k, flatten(trees[k]))
+        c.refresh(0)
+        out = c.score_batch(tapes, zeros, ks, sig).copy()
+        c.close()
+        return out
+    base = run({})
+    assert run({"BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_DERIVED": "0", "BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
+    rows = run({"BSR_TILE": "0"})
+    assert np.array_equal(rows["rank"], base["rank"])
+    ok = base["rank"] == K
+    assert np.allclose(rows["loglik"][ok], base["loglik"][ok], rtol=1e-9, atol=0)
+    assert run({"BSR_TILE": "0", "BSR_DERIVED": "0"}).tobytes() == rows.tobytes()
