@@ -2,6 +2,8 @@
 // Host-side orchestration only; all O(N) work is in bsr_kernels.hip.
 #include <rccl/rccl.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -106,7 +108,8 @@ struct bsr_ctx {
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
   int n_cols = 0;          // columns of Xt: the d features, then (derived columns on) d per unary opcode of kDerivedOps
   bool derived_ready = false;
-  bool tile_ever = false;  // some batch of this context can take the tile pass
+  bool tile_ever = false;
+  int tile_piped = 0;  // some batch of this context can take the tile pass
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
   int aux_cus = 0;
@@ -369,6 +372,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
+    c->tile_piped = env_int("BSR_TILE_PIPED", 0);
     // Optional CU partition (BSR_AUX_CUS=n: the row pass is sized for n_cu - n CUs; with BSR_CU_MASK=1 the slot streams
     // carry CU masks -- mask bits are dealt round-robin over the XCDs -- and the kernels behind the row pass run on a
     // second stream confined to the other n).  The idea: a tile workgroup needs a whole CU, so a wave of another
@@ -897,12 +901,14 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         a.g = j.tg; a.colsrc = (const double* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
         a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
         a.stamps = c->d_stamps;
+        for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const double*)s.h_cols()[i] : nullptr;
         launch_tile<double>(s0, a);
       } else {
         TileArgs<float> a;
         a.g = j.tg; a.colsrc = (const float* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
         a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
         a.stamps = c->d_stamps;
+        for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const float*)s.h_cols()[i] : nullptr;
         launch_tile<float>(s0, a);
       }
     } else {
@@ -939,6 +945,7 @@ struct Launcher {
   std::deque<TailJob> q;
   std::atomic<int> n_queued{0};
   bool asleep = false, stop = false;
+  int spin_us = 100;
 };
 
 static void launcher_main(bsr_ctx* c) {
@@ -957,7 +964,7 @@ static void launcher_main(bsr_ctx* c) {
           L->n_queued.fetch_sub(1, std::memory_order_relaxed);
           have = true;
         }
-      } else if (std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(500)) {
+      } else if (std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(L->spin_us)) {
         std::unique_lock<std::mutex> lk(L->mu);
         if (L->stop) return;
         if (L->q.empty()) {
@@ -987,7 +994,12 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
 }
 
 static void launcher_start(bsr_ctx* c) {
+  // needs a core of its own: with fewer than four usable CPUs the caller issues its launches itself
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) < 4 && env_int("BSR_SUBMIT_THREAD", 1) < 2) return;
   c->launcher = new Launcher;
+  c->launcher->spin_us = std::max(0, env_int("BSR_SUBMIT_SPIN_US", 100));
   c->launcher->th = std::thread(launcher_main, c);
 }
 
@@ -1042,6 +1054,10 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     tg.qmax = (q_need <= 1) ? 1 : qb;
     tg.n_pass = (q_need + tg.qmax - 1) / tg.qmax;
     tg.per_group = single ? per_group : 0;
+    // pipelined staging (the slice by LDS-DMA, first tapes start on the first pair of blocks): measured 1-2 us SLOWER
+    // at C2 -- every wave stalls ~3.4 us in the issue loop (the memory pipeline takes the 17 MB no faster however they
+    // are requested) before it runs anything -- so off unless asked for
+    tg.piped = c->tile_piped;
     tg.n_sub = c->tile_sub;
     tg.sub_blocks = c->tile_sub_blocks;
     tg.n_part = tg.n_slices * tg.n_sub;
@@ -1125,7 +1141,12 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
 
 static int wait_slot(bsr_ctx* c, BatchSlot& s) {
   if (!s.pending) return BSR_OK;
-  while (s.tail_gen.load(std::memory_order_acquire) != s.tail_wanted) __builtin_ia32_pause();  // submission thread
+  // the submission thread has issued this batch's launches (spin briefly, then give the core away: on a box with a
+  // CPU quota two spinning threads throttle each other)
+  for (int spins = 0; s.tail_gen.load(std::memory_order_acquire) != s.tail_wanted; ++spins) {
+    if (spins < 4000) __builtin_ia32_pause();
+    else std::this_thread::yield();
+  }
   if (s.tail_rc != BSR_OK) {
     s.pending = false;
     return s.tail_rc;

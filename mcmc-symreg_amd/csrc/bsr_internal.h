@@ -122,6 +122,7 @@ struct TileGeom {
   int bps;              // blocks per slice
   int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
   int chunk_blocks;     // blocks staged in LDS at a time
+  int piped;            // single-chunk variant: the slice arrives by LDS-DMA while the first tapes already run
   int n_pass;           // passes over the slice (tapes per wave beyond the accumulator sets)
   int qmax;             // accumulator sets of the launched variant (1 or up to BSR_TILE_QMAX)
   int ncols;            // LDS columns: referenced X columns, y, K basis columns per chain of the batch
@@ -146,7 +147,11 @@ struct TileArgs {
   int P;
   int K;
   unsigned long long* stamps; // diagnostics (BSR_TILE_STAMPS=1): [workgroup][wave][8] clock samples, else null
+  // the first BSR_TILE_ARG_COLS column pointers again, inside the kernel-argument block: the input block was written
+  // microseconds ago and is cold for every CU, the argument block is not
+  const T* cols[32];
 };
+#define BSR_TILE_ARG_COLS 32
 #define BSR_TILE_STAMP_WORDS 8
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);

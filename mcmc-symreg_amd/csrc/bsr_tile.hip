@@ -12,6 +12,8 @@
 //
 // What is summed in which order depends only on the context (rows per lane, slice boundaries), never on the batch:
 // a proposal's partial sums -- hence its score -- are bit-identical whatever else shares the launch.
+#include <cstddef>
+
 #include "bsr_device.h"
 
 namespace {
@@ -121,6 +123,51 @@ __device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* col
   }
 }
 
+// Single-chunk variant: the whole slice by LDS-DMA, issued pair of blocks by pair of blocks (the order the waves
+// consume them in), so the first tape of every wave starts on rows 0..255 while the rest of the slice is still on its
+// way.  Unit u of the issue order: pair u / (2*ncols), then column, then block of the pair; wave w issues units w,
+// w+16, ...  units_upto(e) counts the wave's units with index < e.
+__device__ __forceinline__ int units_upto(int e, int wave) { return e > wave ? (e - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES : 0; }
+template <typename T>
+__device__ __forceinline__ void dma_slice(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int b0,
+                                          int nb, int wave, int lane) {
+  static_assert(sizeof(T) == 8, "one 128-row block of a column per instruction");
+  const int full = (nb >> 1) * 2 * ncols, n_units = ncols * nb;
+  // the column pointers: one vector load (lane c holds column c's), then a readlane per copy -- a scalar load per
+  // copy would put a memory round trip in front of each of them
+  // (from the kernel-argument block when they all fit there: warm, unlike the freshly uploaded input block)
+  const T* const* cs = (ncols <= BSR_TILE_ARG_COLS)
+                           ? (const T* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs<T>, cols))
+                           : (const T* const*)colsrc;
+  const uint64_t mine = (lane < ncols) ? (uint64_t)cs[lane] : 0;
+  for (int u = wave; u < n_units; u += BSR_TILE_WAVES) {
+    int col, blk;
+    if (u < full) {
+      const int pp = u / (2 * ncols), r = u - pp * 2 * ncols;
+      col = r >> 1;
+      blk = 2 * pp + (r & 1);
+    } else {
+      col = u - full;
+      blk = nb - 1;
+    }
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), col) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)mine, col);
+    const T* src = (ncols <= BSR_WAVE ? (const T*)base : colsrc[col]) + (int64_t)(b0 + blk) * BSR_TILE_BLOCK + 2 * lane;
+    T* dst = buf + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+  }
+}
+// waits until at most `left` of the wave's copies are still in flight (copies complete in issue order)
+__device__ __forceinline__ void dma_wait_left(int left) {
+  switch (left) {
+#define X(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#undef X
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or more than the cases cover
+  }
+}
+
 // Lane reduction of one tape's sums and the store of its (tape, slice) partial record; every lane stores the same
 // totals (no lane-divergent branch).
 template <int KQ>
@@ -212,11 +259,47 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;  // the first 16 list entries go to the waves in order
-  tables_to_lds();
-  stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
-  __syncthreads();
+  // fp64, whole-slice units of work: the slice arrives by LDS-DMA while the waves already run their first tape; the
+  // wave's first pass over a pair of blocks waits for that pair (its own copies by vmcnt, everyone's by the barrier)
+  constexpr bool DMA = sizeof(T) == 8;
+  const bool piped = DMA && g.n_sub == 1 && g.piped;
+  int my_total = 0;
+  if constexpr (DMA) {
+    if (piped) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // s_next is in place before the first tape is pulled
+      TSTAMP(5);
+      // the math tables travel the same way, ahead of the slice (copies complete in issue order, so the wait for the
+      // first pair of blocks covers them)
+      if (wave < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024)) {
+        const char* src = (const char*)bsr_tables_src + wave * 1024 + lane * 16;
+        const uint32_t la = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + wave * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+      }
+      dma_slice<T>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
+      my_total = units_upto(g.ncols * nb, wave);
+    }
+  }
+  if (!piped) {
+    tables_to_lds();
+    stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
+    __syncthreads();
+  }
+  // arrival of blocks [.., b_end) of the slice: called by every wave of the workgroup, once per pass, in pass order
+  auto arrive = [&](int b_end) {
+    if constexpr (DMA) {
+      dma_wait_left(my_total - units_upto(g.ncols * min(nb, b_end), wave));
+      // a bare barrier: __syncthreads() would also wait for every copy still in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (b_end <= 2) TSTAMP(2);
+    }
+  };
+  bool first = piped;
   TSTAMP(1);
-  TSTAMP(2);
+  if (!piped) TSTAMP(2);
   // unit of work: (tape t of the group's list, sub-slice j); units are numbered tape-major, heaviest tape first
   const int n_items = g.per_group * g.n_sub;
   int idx = wave;
@@ -252,6 +335,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     int b = sb0;
 #pragma unroll 1
     for (; b + 1 < sb1; b += 2) {
+      if (first) arrive(b + 2);
       const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
       T z4[2 * U];
       LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
@@ -262,6 +346,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       add_block(zb, off + BSR_TILE_BLOCK, b + 1);
     }
     if (b < sb1) {
+      if (first) arrive(b + 1);
       const int off = b * BSR_TILE_BLOCK + 2 * lane;
       T z[U];
       LdsCols<T, U> ldr{sx, chunk_rows, off};
@@ -270,6 +355,12 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     }
     store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice * g.n_sub + j) * BSR_P1_WORDS, lane);
     idx = __builtin_amdgcn_readfirstlane(nxt);
+    first = false;
+  }
+  if (first) {  // a wave without a tape (fewer tapes than waves) still joins the workgroup's arrival barriers
+    int b = 0;
+    for (; b + 1 < nb; b += 2) arrive(b + 2);
+    if (b < nb) arrive(b + 1);
   }
   TSTAMP(3);
   TSTAMP(4);

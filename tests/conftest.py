@@ -3,6 +3,12 @@ import json
 import os
 import sys
 
+# The GPU boxes show 256 logical CPUs but grant a quota of about 16: a BLAS pool sized for what is visible gets
+# throttled to a crawl on the oracle's small matrices (whole-suite time 35 s -> 8 min on a busy box).  Must be set
+# before numpy loads its BLAS.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 import pytest
 

@@ -76,6 +76,9 @@ def main():
     stat("wave end (100 MHz clock)", rt1 - base)
     d = lambda a, b: (st[:, :, b] - st[:, :, a])[ok] / mhz
     stat("stage first chunk (0->1)", d(0, 1))
+    if (st[:, :, 5][ok] > 0).all():   # pipelined staging: stamp 5 = after the start-up barrier, 1 = copies issued,
+        stat("  start -> start-up barrier (0->5)", d(0, 5))      # 2 = first pair of blocks arrived
+        stat("  issue the copies (5->1)", d(5, 1))
     stat("compute first chunk (1->2)", d(1, 2))
     stat("all chunks incl. later staging (1->3)", d(1, 3))
     stat("reduce + store (3->4)", d(3, 4))
