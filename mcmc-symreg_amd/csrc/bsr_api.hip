@@ -52,7 +52,12 @@ struct BatchSlot {
   hipStream_t stream = nullptr;   // each slot has its own stream: the small solve/residual/finalise kernels of one
                                   // batch overlap the row pass of the other
   PropCoef* d_coef = nullptr;
-  int32_t* d_flagged = nullptr;  // [0] count, [1..] proposals k_solve hands to the residual pass; k_finalize empties it
+  int32_t* d_flagged = nullptr;  // two lists ([0] count, [1..] proposals k_solve hands to the residual pass), alternating by
+                                 // batch: each batch's k_solve empties the list the batch before it used
+  int flag_par = 0;
+  int32_t* flag_cur() const { return d_flagged + (size_t)flag_par * flag_stride; }
+  int32_t* flag_other() const { return d_flagged + (size_t)(flag_par ^ 1) * flag_stride; }
+  size_t flag_stride = 0;
   double* part1 = nullptr;
   double* part2 = nullptr;
   size_t part_cap = 0;   // in (proposal,row block) records
@@ -479,8 +484,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     }
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
-    CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * (max_batch + 2)));
-    CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * (max_batch + 2)));
+    s.flag_stride = (size_t)max_batch + 2;
+    CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * 2 * (max_batch + 2)));   // two lists, alternating by batch
+    CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * 2 * (max_batch + 2)));
     CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     s.off_cols = ((size_t)c->n_cols * sizeof(int32_t) + 255) / 256 * 256;
@@ -848,7 +854,7 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
     a->queue = s.queue + (size_t)(q % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
     a->queue_clear = s.queue + (size_t)((q + BSR_QUEUE_SETS / 2) % BSR_QUEUE_SETS) * BSR_QUEUE_SET_INTS;
   } else {
-    a->queue = s.d_flagged;
+    a->queue = s.flag_cur();
     a->queue_clear = nullptr;
   }
 }
@@ -919,14 +925,16 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   }
   if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.d_flagged, s.d_mh);
+  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+               s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   if (j.scoring) {
     launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st);
   }
   if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
   if (j.scoring)
-    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.d_flagged, s.d_mh);
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+                    c->K <= 4 ? 1 : 16);
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
@@ -1124,6 +1132,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   job.rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
   // CU-partitioned context: the kernels behind the row pass run on the slot's second stream (its own few CUs)
   job.on_aux = scoring && s.aux != nullptr;
+  s.flag_par ^= 1;   // this batch's list of flagged proposals; its k_solve empties the other one
   s.tail_rc = BSR_OK;
   s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
   // Seven HIP calls per batch cost the host more than staging the batch does.  A scoring batch is handed to the

@@ -204,9 +204,11 @@ struct RowPassArgs {
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh);
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
+                  int32_t* flagged_next);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh);
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
+                     int n_wg);
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
                    int n_spans, int K, bsr_event* events);
 template <typename T>

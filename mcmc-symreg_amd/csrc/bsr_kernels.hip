@@ -619,7 +619,10 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
                                                     double rank_floor, int32_t* __restrict__ flagged,
-                                                    MhRes* __restrict__ mhv) {
+                                                    MhRes* __restrict__ mhv, int32_t* __restrict__ flagged_next) {
+  // the slot's two lists of flagged proposals alternate between batches: this batch appends to `flagged`, the
+  // residual pass and k_finalize read it, and the other list -- consumed by the batch before -- is emptied here
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flagged_next) flagged_next[0] = 0;
   const int p = blockIdx.x;
   const int lane = threadIdx.x;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
@@ -755,16 +758,15 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
                                                            const double* __restrict__ part2, int64_t N,
                                                            bsr_score* __restrict__ outv, double rank_floor,
                                                            int32_t* __restrict__ flagged, MhRes* __restrict__ mhv) {
-  // one workgroup of four waves walks the batch's list of flagged proposals, one proposal per wave at a time
+  // the waves of all workgroups walk the batch's list of flagged proposals, one proposal per wave at a time (the
+  // list is emptied by the next batch's k_solve)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   __shared__ double sh_all[4][BSR_NQ_MAX];
   double* sh_c = sh_all[wave];
   const int n_flag = flagged[0];
-  __syncthreads();
-  if (threadIdx.x == 0) flagged[0] = 0;  // the list is consumed: empty for the slot's next batch
-  for (int fi = wave; fi < n_flag; fi += 4) {
+  for (int fi = blockIdx.x * 4 + wave; fi < n_flag; fi += gridDim.x * 4) {
   const int p = flagged[1 + fi];
   const PropCoef* cf = coef + p;
   double ww = 0.0, wy = 0.0;
@@ -1237,9 +1239,10 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 #undef BSR_CASE
 }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
-                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh) {
+                  int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
+                  int32_t* flagged_next) {
   hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
-                     flagged, mh);
+                     flagged, mh, flagged_next);
 }
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
                    int n_spans, int K, bsr_event* events) {
@@ -1247,8 +1250,10 @@ void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const 
                      span_off, n_spans, K, events);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
-                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
+                     const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
+                     int n_wg) {
+  // a few proposals per batch at K=3 (one workgroup of four waves), a dozen or more at K=8, each ~10 us of one wave
+  hipLaunchKernelGGL(k_finalize, dim3(n_wg), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
                      rank_floor, flagged, mh);
 }
 template <typename T>

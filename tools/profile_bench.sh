@@ -4,7 +4,10 @@
 tag=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-args="--steps 50 --warmup 5 --cpu-sample 0 $@"
+# --depth 1: one batch at a time.  With several batches in flight the kernels of different streams share the GPU and
+# the profiler's per-kernel duration includes the time a kernel waits for CUs (at N=1M two overlapping row passes each
+# read 2x their isolated time); the roofline figure is the kernel on its own, as bench.py's isolated events time it.
+args="--steps 50 --warmup 5 --cpu-sample 0 --depth 1 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $args > $out/bench_stats.json 2> $out/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $args > /dev/null 2> $out/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $args > /dev/null 2> $out/write.err
