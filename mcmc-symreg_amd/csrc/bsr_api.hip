@@ -1062,10 +1062,10 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     tg.qmax = (q_need <= 1) ? 1 : qb;
     tg.n_pass = (q_need + tg.qmax - 1) / tg.qmax;
     tg.per_group = single ? per_group : 0;
-    // pipelined staging (the slice by LDS-DMA, first tapes start on the first pair of blocks): measured 1-2 us SLOWER
-    // at C2 -- every wave stalls ~3.4 us in the issue loop (the memory pipeline takes the 17 MB no faster however they
-    // are requested) before it runs anything -- so off unless asked for
-    tg.piped = c->tile_piped;
+    // pipelined staging (four loader waves bring the slice in by LDS-DMA, the others start on the first pair of
+    // blocks): correct, but the copies arrive at a quarter of the rate sixteen issuing waves reach, so off
+    // unless asked for
+    tg.piped = (c->tile_piped && tg.bps <= 30) ? 1 : 0;   // the kernel keeps one arrival counter per pair of blocks (16)
     tg.n_sub = c->tile_sub;
     tg.sub_blocks = c->tile_sub_blocks;
     tg.n_part = tg.n_slices * tg.n_sub;

@@ -152,6 +152,7 @@ struct TileArgs {
   const T* cols[32];
 };
 #define BSR_TILE_ARG_COLS 32
+#define BSR_TILE_LOADERS 4      // waves per workgroup that stage the slice (piped staging)
 #define BSR_TILE_STAMP_WORDS 8
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);

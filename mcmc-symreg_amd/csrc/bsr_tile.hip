@@ -123,46 +123,11 @@ __device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* col
   }
 }
 
-// Single-chunk variant: the whole slice by LDS-DMA, issued pair of blocks by pair of blocks (the order the waves
-// consume them in), so the first tape of every wave starts on rows 0..255 while the rest of the slice is still on its
-// way.  Unit u of the issue order: pair u / (2*ncols), then column, then block of the pair; wave w issues units w,
-// w+16, ...  units_upto(e) counts the wave's units with index < e.
-__device__ __forceinline__ int units_upto(int e, int wave) { return e > wave ? (e - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES : 0; }
-template <typename T>
-__device__ __forceinline__ void dma_slice(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int b0,
-                                          int nb, int wave, int lane) {
-  static_assert(sizeof(T) == 8, "one 128-row block of a column per instruction");
-  const int full = (nb >> 1) * 2 * ncols, n_units = ncols * nb;
-  // the column pointers: one vector load (lane c holds column c's), then a readlane per copy -- a scalar load per
-  // copy would put a memory round trip in front of each of them
-  // (from the kernel-argument block when they all fit there: warm, unlike the freshly uploaded input block)
-  const T* const* cs = (ncols <= BSR_TILE_ARG_COLS)
-                           ? (const T* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs<T>, cols))
-                           : (const T* const*)colsrc;
-  const uint64_t mine = (lane < ncols) ? (uint64_t)cs[lane] : 0;
-  for (int u = wave; u < n_units; u += BSR_TILE_WAVES) {
-    int col, blk;
-    if (u < full) {
-      const int pp = u / (2 * ncols), r = u - pp * 2 * ncols;
-      col = r >> 1;
-      blk = 2 * pp + (r & 1);
-    } else {
-      col = u - full;
-      blk = nb - 1;
-    }
-    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), col) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)mine, col);
-    const T* src = (ncols <= BSR_WAVE ? (const T*)base : colsrc[col]) + (int64_t)(b0 + blk) * BSR_TILE_BLOCK + 2 * lane;
-    T* dst = buf + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
-    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
-  }
-}
 // waits until at most `left` of the wave's copies are still in flight (copies complete in issue order)
 __device__ __forceinline__ void dma_wait_left(int left) {
   switch (left) {
 #define X(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 #undef X
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or more than the cases cover
   }
@@ -258,27 +223,76 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
 #define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;  // the first 16 list entries go to the waves in order
-  // fp64, whole-slice units of work: the slice arrives by LDS-DMA while the waves already run their first tape; the
-  // wave's first pass over a pair of blocks waits for that pair (its own copies by vmcnt, everyone's by the barrier)
+  if (threadIdx.x == 0) s_next = (sizeof(T) == 8 && g.n_sub == 1 && g.piped) ? BSR_TILE_WAVES - BSR_TILE_LOADERS : BSR_TILE_WAVES;
+  // fp64, whole-slice units of work (piped): BSR_TILE_LOADERS waves bring the slice in by LDS-DMA, pair of blocks by
+  // pair of blocks, and publish each pair through an LDS counter; the other waves start their first tape as soon as
+  // the first pair has landed, and the loaders join the tape queue when they are done.
   constexpr bool DMA = sizeof(T) == 8;
+  constexpr int NL = BSR_TILE_LOADERS;
   const bool piped = DMA && g.n_sub == 1 && g.piped;
-  int my_total = 0;
+  __shared__ int s_pair[16];   // s_pair[pp]: loader waves whose copies of pair pp (blocks 2pp, 2pp+1) have landed
+  int ready = 0;               // pairs this wave has seen complete
   if constexpr (DMA) {
     if (piped) {
+      if (threadIdx.x < 16) s_pair[threadIdx.x] = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // s_next is in place before the first tape is pulled
+      __builtin_amdgcn_s_barrier();  // s_next and the counters are in place
+      asm volatile("" ::: "memory");
       TSTAMP(5);
-      // the math tables travel the same way, ahead of the slice (copies complete in issue order, so the wait for the
-      // first pair of blocks covers them)
-      if (wave < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024)) {
-        const char* src = (const char*)bsr_tables_src + wave * 1024 + lane * 16;
-        const uint32_t la = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + wave * 1024));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+      if (wave < NL) {
+        // a loader shares its SIMD with three computing waves: without priority its short instruction stream gets
+        // a quarter of the issue slots and the slice takes 11-14 us to arrive
+        __builtin_amdgcn_s_setprio(3);
+        // the math tables travel the same way, ahead of the slice (copies complete in issue order)
+        for (int t = wave; t < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024); t += NL) {
+          const char* src = (const char*)bsr_tables_src + t * 1024 + lane * 16;
+          const uint32_t la = __builtin_amdgcn_readfirstlane(
+              (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + t * 1024));
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+        }
+        const int npp = (nb + 1) >> 1;   // pairs, the odd last block counting as one
+        // column pointers: one vector load, then readlanes (kernel-argument block when they fit there)
+        const T* const* cs = (g.ncols <= BSR_TILE_ARG_COLS)
+                                 ? (const T* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs<T>, cols))
+                                 : (const T* const*)colsrc;
+        const uint64_t mine = (lane < g.ncols) ? (uint64_t)cs[lane] : 0;
+        auto issue_pair = [&](int pp) {   // this loader's share of pair pp's copies; returns how many
+          int cnt = 0;
+          const int nbp = min(2, nb - 2 * pp), n_u = g.ncols * nbp;   // units of the pair: column-major, then block
+          for (int u = wave; u < n_u; u += NL) {
+            const int col = (nbp == 2) ? (u >> 1) : u, blk = 2 * pp + ((nbp == 2) ? (u & 1) : 0);
+            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), col) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)mine, col);
+            const T* src = (g.ncols <= BSR_WAVE ? (const T*)base : colsrc[col]) + (int64_t)(b0 + blk) * BSR_TILE_BLOCK + 2 * lane;
+            T* dst = sx + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
+            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+            ++cnt;
+          }
+          return cnt;
+        };
+        auto publish = [&](int pp) {
+          if (lane == 0) __hip_atomic_fetch_add(&s_pair[pp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (npp > 0) {
+          // the first pair alone (and the tables): the sooner it lands, the sooner the other twelve waves compute
+          (void)issue_pair(0);
+          dma_wait_left(0);
+          publish(0);
+          // then everything else at once, published pair by pair as the copies (which complete in issue order) land
+          int left = 0;
+#pragma unroll 1
+          for (int pp = 1; pp < npp; ++pp) left += issue_pair(pp);
+#pragma unroll 1
+          for (int pp = 1; pp < npp; ++pp) {
+            const int n_u = g.ncols * min(2, nb - 2 * pp);
+            left -= n_u > wave ? (n_u - wave + NL - 1) / NL : 0;   // this loader's copies of pair pp
+            dma_wait_left(left);
+            publish(pp);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
       }
-      dma_slice<T>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
-      my_total = units_upto(g.ncols * nb, wave);
     }
   }
   if (!piped) {
@@ -286,23 +300,33 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
     __syncthreads();
   }
-  // arrival of blocks [.., b_end) of the slice: called by every wave of the workgroup, once per pass, in pass order
+  // blocks [.., b_end) of the slice are in LDS (piped staging: spin on the pair's counter)
   auto arrive = [&](int b_end) {
     if constexpr (DMA) {
-      dma_wait_left(my_total - units_upto(g.ncols * min(nb, b_end), wave));
-      // a bare barrier: __syncthreads() would also wait for every copy still in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      const int need = (b_end + 1) >> 1;
+      while (ready < need) {
+        while (__hip_atomic_load(&s_pair[ready], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NL)
+          __builtin_amdgcn_s_sleep(2);
+        ++ready;
+      }
       asm volatile("" ::: "memory");
       if (b_end <= 2) TSTAMP(2);
     }
   };
-  bool first = piped;
   TSTAMP(1);
   if (!piped) TSTAMP(2);
   // unit of work: (tape t of the group's list, sub-slice j); units are numbered tape-major, heaviest tape first
   const int n_items = g.per_group * g.n_sub;
+  // the first list entries go to the waves in order (piped: to the waves that do not load; the loaders pull theirs)
   int idx = wave;
+  if (piped) {
+    if (wave >= NL) idx = wave - NL;
+    else {
+      int first_idx = 0;
+      if (lane == 0) first_idx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      idx = __builtin_amdgcn_readfirstlane(first_idx);
+    }
+  }
   while (idx < n_items) {
     const int t = idx / g.n_sub, j = idx - t * g.n_sub;
     const int p = list[t];
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     int b = sb0;
 #pragma unroll 1
     for (; b + 1 < sb1; b += 2) {
-      if (first) arrive(b + 2);
+      if (piped) arrive(b + 2);
       const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
       T z4[2 * U];
       LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
@@ -346,7 +370,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       add_block(zb, off + BSR_TILE_BLOCK, b + 1);
     }
     if (b < sb1) {
-      if (first) arrive(b + 1);
+      if (piped) arrive(b + 1);
       const int off = b * BSR_TILE_BLOCK + 2 * lane;
       T z[U];
       LdsCols<T, U> ldr{sx, chunk_rows, off};
@@ -355,12 +379,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     }
     store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice * g.n_sub + j) * BSR_P1_WORDS, lane);
     idx = __builtin_amdgcn_readfirstlane(nxt);
-    first = false;
-  }
-  if (first) {  // a wave without a tape (fewer tapes than waves) still joins the workgroup's arrival barriers
-    int b = 0;
-    for (; b + 1 < nb; b += 2) arrive(b + 2);
-    if (b < nb) arrive(b + 1);
   }
   TSTAMP(3);
   TSTAMP(4);
