@@ -156,7 +156,7 @@ struct bsr_ctx {
   // tile pass geometry, fixed for the life of the context (a proposal's partial sums must not depend on the batch)
   int tile_on = 1;
   int tile_multi = 0;     // allow the chunked variant (slices larger than LDS)
-  int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1;
+  int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
   int tile_sub = 1, tile_sub_blocks = 1;   // sub-slices per slice (single-chunk contexts only) and their length
   size_t tile_sched_cap = 0;
   unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
@@ -403,7 +403,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
     // fit LDS whole even then (staged once, no barrier per chunk).
     const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
-    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return (c->tile_blocks + sl - 1) / sl; };
+    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
     auto fits_whole = [&](int t) {
       return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
     };
@@ -413,7 +413,10 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     while (T > 1 && (c->tile_cus % T) != 0) --T;
     c->tile_T = T;
     c->tile_slices = std::max(1, c->tile_cus / T);
-    c->tile_bps = (c->tile_blocks + c->tile_slices - 1) / c->tile_slices;
+    // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
+    // goes out as single (tape, block) units through a ticket counter (bsr_tile.hip: leftover_units)
+    c->tile_bps = c->tile_blocks / c->tile_slices;
+    c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
     // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
     // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
     c->tile_sub = 1;
@@ -426,7 +429,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // a data set whose narrowest batch (one feature, y, one chain's basis) does not fit LDS never takes the tile pass:
     // no partition then, the work-queue row pass keeps every CU
     const bool ever_tiled = c->tile_on && (c->tile_multi ||
-        (size_t)(2 + std::max(1, K)) * c->tile_bps * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024);
+        (size_t)(2 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024);
     c->tile_ever = ever_tiled;
     if (ever_tiled || c->aux_cus == 0) break;
     c->aux_cus = 0;
@@ -646,7 +649,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       }
     std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
     const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
-    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)c->tile_bps * BSR_TILE_BLOCK * c->esz);
+    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
     if ((long)fit < fixed && c->tile_multi)   // chunked variant: one block per column in each of its buffers
       fit = (tile_lds_bytes_max() - 1024) / ((size_t)((c->esz == 8) ? 2 : 1) * BSR_TILE_BLOCK * c->esz);
     const long room = (long)fit - fixed;
@@ -1031,7 +1034,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
   LaunchGeom g = geometry(c, s, P);
   const bool tile = scoring && s.tile;
-  const int n_part = tile ? c->tile_slices * c->tile_sub : g.n_rb;   // partial records per proposal that k_solve reduces
+  const int n_part = tile ? c->tile_slices * c->tile_sub + c->tile_left : g.n_rb;   // partial records per proposal that k_solve reduces
   {
     LaunchGeom gp = g;
     gp.n_rb = std::max(g.n_rb, n_part);
@@ -1054,7 +1057,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     // the whole slice fits in LDS: staged once, waves pull tapes from the group's list (single-chunk variant);
     // otherwise chunks of as many blocks as fit (fp64: in each of two buffers)
     const bool single = per_block * tg.bps <= lds_budget && env_int("BSR_TILE_SINGLE", 1);
-    if (single) tg.chunk_blocks = tg.bps;
+    if (single) tg.chunk_blocks = std::max(1, tg.bps);
     else tg.chunk_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)tg.bps, lds_budget / ((c->esz == 8) ? 2 : 1) / per_block));
     const int per_group = (P + tg.T - 1) / tg.T;
     const int q_need = (per_group + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;
@@ -1068,7 +1071,8 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     tg.piped = (c->tile_piped && tg.bps <= 30) ? 1 : 0;   // the kernel keeps one arrival counter per pair of blocks (16)
     tg.n_sub = c->tile_sub;
     tg.sub_blocks = c->tile_sub_blocks;
-    tg.n_part = tg.n_slices * tg.n_sub;
+    tg.n_left = c->tile_left;
+    tg.n_part = tg.n_slices * tg.n_sub + tg.n_left;
     if (tg.n_sub > 1 && tg.per_group == 0) return fail(c, BSR_E_STATE, "tile geometry: sub-slices need the single-chunk variant");
     // column table: referenced X columns, y, the basis columns of the batch's chains
     const void** hc = s.h_cols();

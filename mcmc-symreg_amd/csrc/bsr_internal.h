@@ -123,6 +123,7 @@ struct TileGeom {
   int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
   int chunk_blocks;     // blocks staged in LDS at a time
   int piped;            // single-chunk variant: the slice arrives by LDS-DMA while the first tapes already run
+  int n_left;           // blocks behind the last slice (n_blocks - n_slices * bps): (tape, block) units any wave takes
   int n_pass;           // passes over the slice (tapes per wave beyond the accumulator sets)
   int qmax;             // accumulator sets of the launched variant (1 or up to BSR_TILE_QMAX)
   int ncols;            // LDS columns: referenced X columns, y, K basis columns per chain of the batch

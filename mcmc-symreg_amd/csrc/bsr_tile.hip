@@ -194,6 +194,67 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
   }
 }
 
+// Column reads straight from global memory (L2) through the launch's column-pointer table, by LDS slot id: the loader of
+// the leftover units, whose rows are in no workgroup's LDS.
+template <typename T, int U>
+struct PtrCols {
+  const T* const CONSTANT_AS* colsrc;
+  int64_t r0;  // absolute row of the lane's pair
+  __device__ __forceinline__ void load(int slot, T (&v)[U]) const {
+    const T* col = colsrc[slot] + r0;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      v[2 * j] = col[j * 128];
+      v[2 * j + 1] = col[j * 128 + 1];
+    }
+  }
+};
+
+// The blocks behind the last slice (n_blocks is rarely a multiple of the slice count; at N = 100k: 14 of 782) as
+// (tape, block) units: tapes in cost order, every unit one single-block pass with its own partial record (index
+// n_slices * n_sub + block).  Unit u belongs to workgroup u mod n_wg (3 or 4 units each at C2 instead of a seventh
+// block for 28 workgroups); inside the workgroup the waves take them through the same LDS counter that hands out the
+// tapes, so they go to whoever runs dry first.  (A global ticket counter was tried first: 4 096 waves on one address
+// serialise at the memory side, 50 us.)  `li` is the wave's first leftover item, `counter` the LDS counter, `base`
+// its value at the first leftover item.
+template <typename T, int KQ>
+__device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileGeom& g, int lane, int li, int* counter,
+                                               int base) {
+  constexpr int U = BSR_TILE_U;
+  constexpr int S = BSR_REG_STACK;
+  using V2 = typename VecOf<T, 2>::type;
+  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
+  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
+  const int n_units = a.P * g.n_left, n_wg = (int)gridDim.x;
+  for (;;) {
+    const int tk = li * n_wg + (int)blockIdx.x;
+    if (tk >= n_units) break;
+    int nx = 0;
+    if (lane == 0) nx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int ti = tk / g.n_left, bi = tk - ti * g.n_left;
+    const int p = dsc[ti].order;   // the ti-th most expensive tape
+    const int blk = g.n_slices * g.bps + bi;
+    const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
+    const uint64_t* pc = a.codes + dsc[p].code_off;
+    const uint64_t* pf = a.feats + dsc[p].feat_off;
+    const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
+    const int qslot = dsc[p].qslot;
+    const V2 yv = *reinterpret_cast<const V2*>(colsrc[g.y_slot] + row0);
+    V2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(colsrc[qslot + i] + row0);
+    T z[U];
+    PtrCols<T, U> ldr{colsrc, row0};
+    run_tape<T, U, S>(pc, pf, pl, dsc[p].n_nodes, ldr, z, (T*)nullptr, lane);
+    TapeAcc<KQ> A;
+    A.clear();
+    if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, dsc[p].s, row0, a.N);
+    else accumulate_v<T, KQ, true>(A, z, yv, qv, dsc[p].s, row0, a.N);
+    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices * g.n_sub + bi) * BSR_P1_WORDS, lane);
+    li = __builtin_amdgcn_readfirstlane(nx) - base;
+  }
+}
+
 // Single-chunk variant: the workgroup's whole slice fits in LDS.  Staged once; then the waves pull tapes from the
 // group's list (heaviest first) through an LDS counter, and a wave runs its tape over all blocks of the slice with one
 // set of accumulators.  Which wave runs a tape does not matter to the sums (one wave, blocks in order).
@@ -209,11 +270,12 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  // even split of the blocks over the slices: the first n_blocks % n_slices slices hold one block more (bps)
-  const int base = g.n_blocks / g.n_slices, rem = g.n_blocks - base * g.n_slices;
-  const int b0 = slice * base + min(slice, rem);
-  const int b1 = b0 + base + (slice < rem ? 1 : 0);
-  const int nb = max(0, b1 - b0);
+  // every slice holds bps blocks; the n_left blocks behind the last slice are handed out one (tape, block) at a time
+  // to whichever wave runs dry first (leftover_units): no workgroup carries a block more than the others
+  const int b0 = slice * g.bps;
+  const int b1 = b0 + g.bps;
+  const int nb = g.bps;
+  (void)b1;
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const int32_t CONSTANT_AS* list = as_const(a.sched) + (size_t)tg * g.per_group;
@@ -330,7 +392,12 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   while (idx < n_items) {
     const int t = idx / g.n_sub, j = idx - t * g.n_sub;
     const int p = list[t];
-    if (p < 0) break;
+    if (p < 0) {   // padding behind the group's last tape: take the next item (the leftover units follow the list)
+      int nx = 0;
+      if (lane == 0) nx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      idx = __builtin_amdgcn_readfirstlane(nx);
+      continue;
+    }
     const int sb0 = min(nb, j * g.sub_blocks), sb1 = min(nb, sb0 + g.sub_blocks);
     // the next unit is requested now; its round trip hides under this one
     int nxt = 0;
@@ -381,6 +448,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     idx = __builtin_amdgcn_readfirstlane(nxt);
   }
   TSTAMP(3);
+  // the tape list is empty: idx - n_items is this wave's first item of the workgroup's leftover units
+  if (g.n_left > 0 && idx >= n_items) leftover_units<T, KQ>(a, g, lane, idx - n_items, &s_next, n_items);
   TSTAMP(4);
   if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
 #undef TSTAMP
@@ -397,10 +466,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  // even split of the blocks over the slices: the first n_blocks % n_slices slices hold one block more (bps)
-  const int base = g.n_blocks / g.n_slices, rem = g.n_blocks - base * g.n_slices;
-  const int b0 = slice * base + min(slice, rem);
-  const int b1 = b0 + base + (slice < rem ? 1 : 0);
+  const int b0 = slice * g.bps;   // slices of bps blocks; the blocks behind the last one: leftover_units
+  const int b1 = b0 + g.bps;
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const int32_t CONSTANT_AS* sched = as_const(a.sched);
@@ -413,6 +480,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
 
+  __shared__ int s_left;   // hands the workgroup's leftover units to its waves
+  if (threadIdx.x == 0) s_left = 0;
   tables_to_lds();  // visible after the first barrier below
   // Two LDS buffers of chunk_rows rows per column.  While the waves run their tapes over chunk c, the rows of chunk
   // c+1 travel HBM -> LDS on their own (LDS-DMA: no registers, nothing for the waves to do); the barrier that ends the
@@ -491,6 +560,11 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
       if (p < 0) continue;
       store_partial<KQ>(A[q], a.part + ((size_t)p * g.n_part + slice) * BSR_P1_WORDS, lane);
     }
+  }
+  if (g.n_left > 0) {
+    int li = 0;
+    if (lane == 0) li = __hip_atomic_fetch_add(&s_left, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    leftover_units<T, KQ>(a, g, lane, __builtin_amdgcn_readfirstlane(li), &s_left, 0);
   }
   TSTAMP(4);
   if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
