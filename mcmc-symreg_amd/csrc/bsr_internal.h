@@ -210,7 +210,7 @@ void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P,
                   int32_t* flagged_next);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
-                     int n_wg);
+                     int n_wg, uint32_t* done_flag, uint32_t done_gen, int32_t* arrive);
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
                    int n_spans, int K, bsr_event* events);
 template <typename T>

@@ -757,7 +757,9 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
                                                            const PropCoef* __restrict__ coef, int P, int n_rb,
                                                            const double* __restrict__ part2, int64_t N,
                                                            bsr_score* __restrict__ outv, double rank_floor,
-                                                           int32_t* __restrict__ flagged, MhRes* __restrict__ mhv) {
+                                                           int32_t* __restrict__ flagged, MhRes* __restrict__ mhv,
+                                                           uint32_t* __restrict__ done_flag, uint32_t done_gen,
+                                                           int32_t* __restrict__ arrive) {
   // the waves of all workgroups walk the batch's list of flagged proposals, one proposal per wave at a time (the
   // list is emptied by the next batch's k_solve)
   const int lane = threadIdx.x & 63;
@@ -798,6 +800,25 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
   in.rank_floor = rank_floor;
   in.mh = mhv + p;
   solve_any(in, lane, outv + p);
+  }
+  // Completion word for the host (pinned memory, polled instead of an event: two HIP calls fewer per batch).  This is
+  // the batch's last kernel; k_solve's results were complete when it started.  Every workgroup makes its own results
+  // visible system-wide and checks in; the last one to arrive writes the word and re-arms the counter.
+  if (done_flag) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bool last = true;
+      if (gridDim.x > 1) {
+        const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = old == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (last) {
+        __threadfence_system();
+        __hip_atomic_store(done_flag, done_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -1251,10 +1272,10 @@ void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const 
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
-                     int n_wg) {
+                     int n_wg, uint32_t* done_flag, uint32_t done_gen, int32_t* arrive) {
   // a few proposals per batch at K=3 (one workgroup of four waves), a dozen or more at K=8, each ~10 us of one wave
   hipLaunchKernelGGL(k_finalize, dim3(n_wg), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
-                     rank_floor, flagged, mh);
+                     rank_floor, flagged, mh, done_flag, done_gen, arrive);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,
