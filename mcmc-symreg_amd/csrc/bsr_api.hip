@@ -440,10 +440,12 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
     }
     c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
-    // a data set whose narrowest batch (one feature, y, one chain's basis) does not fit LDS never takes the tile pass:
-    // no partition then, the work-queue row pass keeps every CU
+    // a data set of which not even a narrow batch (eight features or all of them, y, one chain's basis) fits LDS will
+    // not take the tile pass in practice: no partition and no derived columns then, the work-queue row pass keeps
+    // every CU and reads X only
     const bool ever_tiled = c->tile_on && (c->tile_multi ||
-        (size_t)(2 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024);
+        (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <=
+            tile_lds_bytes_max() - 1024);
     c->tile_ever = ever_tiled;
     if (ever_tiled || c->aux_cus == 0) break;
     c->aux_cus = 0;
