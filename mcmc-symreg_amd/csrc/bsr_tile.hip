@@ -459,7 +459,6 @@ template <typename T, int KQ, int QMAX>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a) {
   constexpr int U = BSR_TILE_U;
   constexpr int S = BSR_REG_STACK;
-  constexpr int VEC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
   const TileGeom g = a.g;
