@@ -116,6 +116,7 @@ struct bsr_ctx {
   int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
   int n_cols = 0;          // columns of Xt: the d features, then (derived columns on) d per unary opcode of kDerivedOps
   bool derived_ready = false;
+  int derived_max = 8;         // BSR_DERIVED_MAX: cap on the derived columns one batch may use
   bool tile_ever = false;   // some batch of this context can take the tile pass
   int tile_piped = 0;
   int poll_done = 0;   // BSR_POLL_DONE: completion word in pinned memory instead of an event per scoring batch
@@ -387,6 +388,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
     c->tile_piped = env_int("BSR_TILE_PIPED", 0);
+    // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
+    // tape, and staging a column costs every workgroup what one use saves one wave (measured flat from 7 up)
+    c->derived_max = env_int("BSR_DERIVED_MAX", 8);
     // completion word in pinned memory, written by k_finalize and polled by the waiter, instead of an event per scoring
     // batch: one HIP call fewer on the submission thread (16.8 instead of 22.9 us per batch) and none in the wait.
     // At C2 the pipeline is bound by the GPU once the calls are off the caller's thread, so it buys nothing there;
@@ -673,6 +677,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     const long room = (long)fit - fixed;
     // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
     if (room >= 0) allowance = (int)std::min<long>(room, c->n_cols);
+    allowance = std::min(allowance, c->derived_max);
   }
   s.derived_used = 0;
   for (int i = 0; i < n; ++i) {
