@@ -615,7 +615,7 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
   }
 }
 
-__global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
+__global__ __launch_bounds__(4 * BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
                                                     double rank_floor, int32_t* __restrict__ flagged,
@@ -623,10 +623,15 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
   // the slot's two lists of flagged proposals alternate between batches: this batch appends to `flagged`, the
   // residual pass and k_finalize read it, and the other list -- consumed by the batch before -- is emptied here
   if (blockIdx.x == 0 && threadIdx.x == 0 && flagged_next) flagged_next[0] = 0;
-  const int p = blockIdx.x;
-  const int lane = threadIdx.x;
+  // one wave per proposal, four waves per workgroup: a quarter of the CUs touched (a tile workgroup of another batch
+  // cannot start on a CU that hosts even one of these waves)
+  const int wave_id = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + wave_id;
+  if (p >= P) return;
+  const int lane = threadIdx.x & 63;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
-  __shared__ double sh_c[BSR_NQ_MAX];
+  __shared__ double sh_all_c[4][BSR_NQ_MAX];
+  double* sh_c = sh_all_c[wave_id];
 
   double sum[BSR_NQ_MAX + 2];
 #pragma unroll
@@ -702,7 +707,8 @@ __global__ __launch_bounds__(BSR_WAVE) void k_solve(const PropDesc* __restrict__
 #pragma unroll
     for (int i = 0; i < BSR_NQ_MAX; ++i) sh_c[i] = sum[i];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (waves do not share sh_c)
   double cc = 0.0, cqy = 0.0;
 #pragma unroll
   for (int i = 0; i < BSR_NQ_MAX; ++i) {
@@ -1262,7 +1268,7 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                   int32_t* flagged_next) {
-  hipLaunchKernelGGL(k_solve, dim3(P), dim3(BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
+  hipLaunchKernelGGL(k_solve, dim3((P + 3) / 4), dim3(4 * BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
                      flagged, mh, flagged_next);
 }
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
