@@ -401,9 +401,11 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
           beta = fma(W[i][b], W[i][b], beta);
           gamma = fma(W[i][a], W[i][b], gamma);
         }
-        const double lim = sqrt(alpha) * sqrt(beta);
-        if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {
-          off = fmax(off, fabs(gamma) / lim);
+        // the rotation is skipped when |gamma| <= 1e-17 sqrt(alpha beta) and the sweep's measure is max |gamma| /
+        // sqrt(alpha beta): both compared in squares (two dependent square roots fewer per rotation)
+        const double ab = alpha * beta, g2 = gamma * gamma;
+        if (ab > 0.0 && g2 > 1e-34 * ab) {
+          off = fmax(off, g2 / ab);
           const double zeta = (beta - alpha) / (2.0 * gamma);
           const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
           const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
@@ -422,7 +424,7 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
         }
       }
     }
-    if (off <= 1e-15) break;
+    if (off <= 1e-30) break;
   }
   double h[M];
 #pragma unroll
@@ -487,6 +489,21 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
 // dependent steps instead of 28; the only cross-lane traffic is the partner's column (2K+1 shuffles per round), every
 // dot product is lane-local.  Both lanes of a pair evaluate the same expressions on the same operands, so they apply
 // bit-identical rotation coefficients.
+// v of lane (l ^ r), r in 1..7, inside groups of eight lanes -- with DPP moves (a couple of cycles) instead of
+// __shfl_xor, which lowers to ds_bpermute (an LDS round trip per 32 bits; the K >= 5 solver issues 17 of them per
+// rotation).  quad_perm covers r = 1, 2, 3; row_half_mirror is l -> 7 - l = l ^ 7; the rest are two steps.
+__device__ __forceinline__ double xor8(double v, int r) {
+  switch (r) {
+    case 1: return dpp_f64<0xB1, 0xF>(v);
+    case 2: return dpp_f64<0x4E, 0xF>(v);
+    case 3: return dpp_f64<0x1B, 0xF>(v);
+    case 4: return dpp_f64<0x1B, 0xF>(dpp_f64<0x141, 0xF>(v));
+    case 5: return dpp_f64<0x4E, 0xF>(dpp_f64<0x141, 0xF>(v));
+    case 6: return dpp_f64<0xB1, 0xF>(dpp_f64<0x141, 0xF>(v));
+    default: return dpp_f64<0x141, 0xF>(v);
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out) {
   constexpr int M = K + 1;
@@ -512,9 +529,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
       double Wp[M], Vp[K];
       double mine = 0.0, theirs = 0.0, gamma = 0.0;
 #pragma unroll
-      for (int i = 0; i < M; ++i) Wp[i] = __shfl_xor(W[i], r);
+      for (int i = 0; i < M; ++i) Wp[i] = xor8(W[i], r);
 #pragma unroll
-      for (int i = 0; i < K; ++i) Vp[i] = __shfl_xor(V[i], r);
+      for (int i = 0; i < K; ++i) Vp[i] = xor8(V[i], r);
 #pragma unroll
       for (int i = 0; i < M; ++i) {
         mine = fma(W[i], W[i], mine);
@@ -522,9 +539,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
         gamma = fma(W[i], Wp[i], gamma);
       }
       const double alpha = low ? mine : theirs, beta = low ? theirs : mine;
-      const double lim = sqrt(alpha) * sqrt(beta);
-      if (lim > 0.0 && fabs(gamma) > 1e-17 * lim) {
-        off = fmax(off, fabs(gamma) / lim);
+      const double ab = alpha * beta, g2 = gamma * gamma;   // squared criteria: see solve_regs
+      if (ab > 0.0 && g2 > 1e-34 * ab) {
+        off = fmax(off, g2 / ab);
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
@@ -535,10 +552,10 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
         for (int i = 0; i < K; ++i) V[i] = cs * V[i] + sp * Vp[i];
       }
     }
-    off = fmax(off, __shfl_xor(off, 1));
-    off = fmax(off, __shfl_xor(off, 2));
-    off = fmax(off, __shfl_xor(off, 4));
-    if (off <= 1e-15) break;  // wave-uniform: the lane groups are copies of each other
+    off = fmax(off, xor8(off, 1));
+    off = fmax(off, xor8(off, 2));
+    off = fmax(off, xor8(off, 4));
+    if (off <= 1e-30) break;  // wave-uniform: the lane groups are copies of each other
   }
   double h[M];
 #pragma unroll
@@ -560,9 +577,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     double t = gj * W[i];
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
+    t += xor8(t, 1);
+    t += xor8(t, 2);
+    t += xor8(t, 4);
     const double ri = h[i] - t;
     misfit = fma(ri, ri, misfit);
   }
@@ -585,9 +602,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     double b = V[i] * coef;
-    b += __shfl_xor(b, 1);
-    b += __shfl_xor(b, 2);
-    b += __shfl_xor(b, 4);
+    b += xor8(b, 1);
+    b += xor8(b, 2);
+    b += xor8(b, 4);
     bt[i] = b;
   }
   if (lane == 0) {
