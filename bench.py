@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=float, default=15.0,
                     help="seconds of CPU oracle work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--depth", type=int, default=4, help="batches in flight, 1..4 (1 = synchronous calls)")
+    ap.add_argument("--depth", type=int, default=8, help="batches in flight, 1..8 (1 = synchronous calls)")
     ap.add_argument("--extras", type=int, default=-1,
                     help="1: also run short legs of the other configs (c3, c5, c4's per-GPU share, native-engine chain "
                          "throughput) and report them under 'extra'; 0: headline only; -1: on for the default workload")
@@ -187,7 +187,7 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
     kern_us = np.zeros(5)
     n_timed = [0]
-    depth = max(1, min(4, depth))
+    depth = max(1, min(8, depth))
     TIMED_EVERY = 4
 
     def run_steps(n, first):
@@ -378,7 +378,7 @@ def main():
            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic"}
     out.update(summarize(wl, tr, ranks, args))
-    out["batches_in_flight"] = max(1, min(4, args.depth))
+    out["batches_in_flight"] = max(1, min(8, args.depth))
     attach_traffic(out, args.workload, wl["B"], wl["C"], args.dtype)
     n_g = gather_trees(wl, ranks)
     if n_g is not None:

@@ -163,7 +163,7 @@ int bsr_score_batch(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off,
  * host stages batch i+1 and the small per-proposal kernels of batch i overlap the row pass of batch i+1.  Chains of
  * a batch must not depend on accepts of a batch still in flight.  bsr_commit refers to the batch most recently
  * waited for and returns BSR_E_STATE once that batch's slot has been submitted to again. */
-#define BSR_MAX_INFLIGHT 4
+#define BSR_MAX_INFLIGHT 8
 int bsr_score_submit(bsr_ctx* ctx, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                      const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket);
 int bsr_score_wait(bsr_ctx* ctx, int32_t ticket, bsr_score* out);

@@ -6,6 +6,7 @@ import os
 import numpy as np
 
 MAX_K = 8
+MAX_INFLIGHT = 8          # include/bsr_hip.h: BSR_MAX_INFLIGHT (batch slots of a context)
 COMM_ID_BYTES = 128
 F_INF, F_NAN, F_RANKDEF, F_SCALE_RETRY = 1, 2, 4, 8
 DTYPE_F64, DTYPE_F32 = 0, 1

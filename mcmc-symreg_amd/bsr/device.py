@@ -87,7 +87,7 @@ class DeviceContext:
         return out
 
     def score_submit(self, rows, off, chains, ks, sig):
-        """Asynchronous scoring: enqueue a pre-packed batch, return its ticket (up to BSR_MAX_INFLIGHT = 4 batches may be in flight)."""
+        """Asynchronous scoring: enqueue a pre-packed batch, return its ticket (up to BSR_MAX_INFLIGHT = 8 batches may be in flight)."""
         t = C.c_int32(-1)
         rc = self._L.bsr_score_submit(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
                                       _lib.ptr(sig), len(chains), C.byref(t))

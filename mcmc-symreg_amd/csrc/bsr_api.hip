@@ -951,15 +951,16 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     if (j.on_aux) step(hipEventRecord(s.tile_done, s0), "hipEventRecord");
   }
   if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
+  static const int dbg_skip = env_int("BSR_DEBUG_SKIP_TAIL", 0);   // timing experiment: 1 = no residual/finalise, 2 = no solve either (results are wrong)
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+  if (dbg_skip < 2) launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
-  if (j.scoring) {
+  if (j.scoring && !dbg_skip) {
     launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st);
   }
   if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
-  if (j.scoring)
+  if (j.scoring && !dbg_skip)
     launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                     c->K <= 4 ? 1 : 16, s.use_flag ? s.h_flag : nullptr, s.flag_gen, s.d_flagged + 2 * s.flag_stride);
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span

@@ -357,8 +357,7 @@ struct WorkItem {
   int rb, pgi;
   bool valid;
 };
-__device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg) {
-  const int w = blockIdx.x;
+__device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg, int w) {
   const int xcd = w & 7, j = w >> 3;
   WorkItem it;
   it.pgi = j % n_pg;

@@ -1465,7 +1465,7 @@ extern "C" int bsr_engine_init_chain(bsr_engine* e, int32_t chain) {
 }
 
 // Advances every initialised, unfinished chain until it is done (or has consumed max_props proposals).
-// Chains are dealt into up to BSR_MAX_INFLIGHT groups; each group's batch (up to batch_per_chain speculative
+// Chains are dealt into up to four groups (BSR_ENGINE_GROUPS; each needs a batch slot of its own); each group's batch (up to batch_per_chain speculative
 // proposals per chain) is one asynchronous submission, so proposal generation and result handling of one group
 // overlap the GPU work of the others.  A chain belongs to one group only, hence never depends on a batch in flight.
 extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t max_props, bsr_trace* trace,
@@ -1498,7 +1498,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     return rc;
   }
   // tracing wants proposals in chain order: keep one group then
-  const int n_groups = trace ? 1 : std::max(1, std::min<int>(BSR_MAX_INFLIGHT, (int)live.size()));
+  // four groups: with more, the launches get small (8 chains in 8 groups = 32 proposals each) faster than the extra
+  // overlap pays
+  static const int max_groups = std::max(1, std::min<int>(BSR_MAX_INFLIGHT, getenv("BSR_ENGINE_GROUPS") ? atoi(getenv("BSR_ENGINE_GROUPS")) : 4));
+  const int n_groups = trace ? 1 : std::max(1, std::min<int>(max_groups, (int)live.size()));
   // One worker thread per group (each with its own batch slot and HIP stream): proposal generation, staging and the
   // 6-8 HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single
   // host thread leaves the GPU two thirds idle.  K == 1 keeps the single-threaded ticket path (its rescoring step

@@ -56,8 +56,17 @@ extern "C" int bsr_debug_stamps(unsigned long long* out, int n) {
 #define STAMP(i) do {} while (0)
 #endif
 
+// The residual pass (no LDS staging) runs FOUR of its 4-wave workgroups inside one 16-wave workgroup: a CU that hosts
+// any of its waves cannot take a tile workgroup of the next batch, so what the pass costs the pipeline is CUs touched
+// x time, and a quarter of the CUs do the same work in the same time (26 instead of 104 at N = 100k).
+template <bool LDS, int MODE>
+struct RowsShape {
+  static constexpr bool fat = (MODE == MODE_RESIDUAL) && !LDS;
+  static constexpr int waves = fat ? 4 * BSR_WG_WAVES : BSR_WG_WAVES;
+  static constexpr int min_waves = fat ? 1 : BSR_ROWS_MIN_WAVES;
+};
 template <typename T, int NQ, int U, bool LDS, int MODE>
-__global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_rows(
+__global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShape<LDS, MODE>::min_waves)) void k_rows(
     const T* __restrict__ Xt, const T* __restrict__ y, int64_t ld, int64_t N, const uint64_t* __restrict__ codes,
     const uint64_t* __restrict__ feats, const double* __restrict__ lnp, const PropDesc* __restrict__ desc,
     const PropCoef* __restrict__ coef, int P, int rb_rows, int pg, int n_rb, int n_pg,
@@ -68,12 +77,16 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   constexpr int VEC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [nF][rb_rows] then y[rb_rows]   (LDS variant only)
+  constexpr bool FAT = RowsShape<LDS, MODE>::fat;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave_raw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int vsub = FAT ? (wave_raw >> 2) : 0;      // which of the workgroup's four virtual 4-wave workgroups
+  const int wave = FAT ? (wave_raw & 3) : wave_raw;
+  const int vwg = FAT ? (int)blockIdx.x * 4 + vsub : (int)blockIdx.x;
   WorkItem wi = {0, 0, true};
   if constexpr (!DYN) {
-    wi = map_work(n_rb, n_pg);
-    if (!wi.valid) return;
+    wi = map_work(n_rb, n_pg, vwg);
+    if (!FAT && !wi.valid) return;
   }
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   const PropCoef CONSTANT_AS* cf = as_const(coef);
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   if (MODE == MODE_RESIDUAL && n_flag == 0) return;
   tables_to_lds();
   if (!LDS) __syncthreads();
+  if (FAT && !wi.valid) return;   // (behind the barrier: the other virtual workgroups of this one needed it)
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(BSR_WG_WAVES* BSR_WAVE, BSR_ROWS_MIN_WAVES) void k_
   }
   const T* sy = sx + (size_t)nF * rb_rows;
   const int sweeps = rb_rows / (BSR_WAVE * U);
-  const int gwave = blockIdx.x * BSR_WG_WAVES + wave;
+  const int gwave = vwg * BSR_WG_WAVES + wave;
   T* my_spill = spill ? spill + (size_t)gwave * spill_slots * (BSR_WAVE * 8) : nullptr;
   int stamp_i = 0;
   (void)stamp_i;
@@ -1249,7 +1263,11 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   const LaunchGeom& g = a.g;
   dim3 grid((unsigned)(((g.n_rb + 7) / 8) * 8 * g.n_pg)), block(BSR_WG_WAVES * BSR_WAVE);
   if (!a.feat_list && MODE == MODE_PROJECT) grid.x = (unsigned)g.dyn_wgs;  // work-queue launch
-  if (MODE == MODE_RESIDUAL) grid.x = (unsigned)(((g.n_rb + 7) / 8) * 8);   // one workgroup per row block, flagged list
+  if (MODE == MODE_RESIDUAL) grid.x = (unsigned)(((g.n_rb + 7) / 8) * 8);   // one (virtual) workgroup per row block, flagged list
+  if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape)
+    grid.x /= 4;
+    block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
+  }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
   if (a.feat_list) {
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);

@@ -259,7 +259,7 @@ def test_k1_rescored_candidates_keep_the_batch_order_for_commit():
     assert np.allclose(beta_i.reshape(-1), np.asarray(want_b).reshape(-1), rtol=1e-8) and abs(rmse - want_rmse) <= 1e-9 * want_rmse
     # a commit that refers to a batch whose slot has been submitted to again is refused
     t = [ctx.score_submit(*__import__("bsr.tape", fromlist=["pack"]).pack([flatten(cands[0])]), np.zeros(1, np.int32),
-                          np.zeros(1, np.int32), np.ones(1)) for _ in range(4)]
+                          np.zeros(1, np.int32), np.ones(1)) for _ in range(_lib.MAX_INFLIGHT)]
     out = np.zeros(1, dtype=_lib.SCORE_DTYPE)
     ctx.score_wait(t[0], out)
     t.append(ctx.score_submit(*__import__("bsr.tape", fromlist=["pack"]).pack([flatten(cands[1])]), np.zeros(1, np.int32),
