@@ -119,6 +119,7 @@ struct bsr_ctx {
   int derived_max = 8;         // BSR_DERIVED_MAX: cap on the derived columns one batch may use
   bool tile_ever = false;   // some batch of this context can take the tile pass
   int tile_piped = 0;
+  int fuse_finalize = 0;   // BSR_FUSE_FINALIZE: k_finalize's work behind the residual pass, in the same launch
   int poll_done = 0;   // BSR_POLL_DONE: completion word in pinned memory instead of an event per scoring batch
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
@@ -388,6 +389,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
     c->tile_piped = env_int("BSR_TILE_PIPED", 0);
+    // k_finalize's work behind the residual pass in the same launch (last workgroup to arrive): one launch fewer per
+    // batch, bit-identical -- and 3-4 us SLOWER per step at C2: the agent-scope release/acquire every residual
+    // workgroup needs around the arrival counter writes back and invalidates its XCD's L2 under the row passes of the
+    // other batches.  Opt-in.
+    c->fuse_finalize = env_int("BSR_FUSE_FINALIZE", 0);
     // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
     // tape, and staging a column costs every workgroup what one use saves one wave (measured flat from 7 up)
     c->derived_max = env_int("BSR_DERIVED_MAX", 8);
@@ -886,15 +892,20 @@ static void fill_row_args(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, RowPass
 }
 
 static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const PropDesc* desc, int P,
-                            int spill_slots, int nq, int residual, hipStream_t st = nullptr) {
+                            int spill_slots, int nq, int residual, hipStream_t st = nullptr,
+                            const FinArgs* fin = nullptr) {
   if (!st) st = s.stream;
+  FinArgs none;
+  memset(&none, 0, sizeof none);
   if (c->dtype == BSR_DTYPE_F64) {
     RowPassArgs<double> a;
     fill_row_args<double>(c, s, g, &a, desc, P, spill_slots, residual);
+    a.fin = fin ? *fin : none;
     launch_rows<double>(st, a, nq, residual);
   } else {
     RowPassArgs<float> a;
     fill_row_args<float>(c, s, g, &a, desc, P, spill_slots, residual);
+    a.fin = fin ? *fin : none;
     launch_rows<float>(st, a, nq, residual);
   }
 }
@@ -956,11 +967,22 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   if (dbg_skip < 2) launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
+  // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
+  // registers for the solver and reads X from global memory (16-wave workgroups): one launch fewer per batch
+  const bool fuse_fin = j.scoring && c->fuse_finalize && c->no_lds && residual_can_fuse_finalize(c->K);
   if (j.scoring && !dbg_skip) {
-    launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st);
+    FinArgs fin;
+    memset(&fin, 0, sizeof fin);
+    if (fuse_fin) {
+      fin.ck = c->d_ck; fin.out = s.h_out; fin.mh = s.d_mh; fin.rank_floor = j.rank_floor;
+      fin.arrive = s.d_flagged + 2 * s.flag_stride + 1;
+      fin.done_flag = s.use_flag ? s.h_flag : nullptr;
+      fin.done_gen = s.flag_gen;
+    }
+    launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st, fuse_fin ? &fin : nullptr);
   }
   if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
-  if (j.scoring && !dbg_skip)
+  if (j.scoring && !dbg_skip && !fuse_fin)
     launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                     c->K <= 4 ? 1 : 16, s.use_flag ? s.h_flag : nullptr, s.flag_gen, s.d_flagged + 2 * s.flag_stride);
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span

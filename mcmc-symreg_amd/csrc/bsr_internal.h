@@ -182,6 +182,17 @@ __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
 __attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
 
 // kernels (bsr_kernels.hip)
+// The finalise step fused behind the residual pass: its last workgroup to finish walks the flagged list (ck == null:
+// not fused, k_finalize is launched instead).
+struct FinArgs {
+  const ChainB* ck;
+  bsr_score* out;
+  MhRes* mh;
+  double rank_floor;
+  int32_t* arrive;       // workgroup arrival counter (zero between launches)
+  uint32_t* done_flag;   // pinned completion word, or null
+  uint32_t done_gen;
+};
 template <typename T>
 struct RowPassArgs {
   LaunchGeom g;
@@ -202,9 +213,12 @@ struct RowPassArgs {
   int rows_per_lane;          // 2, 4 or 8 (rb_rows must be a multiple of 64*rows_per_lane)
   int32_t* queue;             // work queue of the projection pass: 8 x BSR_QUEUE_SUB ticket counters, 128 B apart
   int32_t* queue_clear;       // the counter set this launch zeroes for a later one
+  FinArgs fin;                // residual pass only
 };
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
+// the finalise step can ride behind the residual pass for these K (register budget of its 16-wave workgroups)
+static inline bool residual_can_fuse_finalize(int K) { return K <= 3 || K == 5 || K == 6; }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                   int32_t* flagged_next);

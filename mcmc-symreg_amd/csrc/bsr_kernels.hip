@@ -56,6 +56,41 @@ extern "C" int bsr_debug_stamps(unsigned long long* out, int n) {
 #define STAMP(i) do {} while (0)
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-proposal small algebra.  One wave per proposal.
+//
+// The chain keeps ONE orthonormal basis of its K current columns, O_j d_j = sum_i Q_i R_ij (d_j: power-of-two column
+// prescales).  A proposal replaces tree k by the candidate z.  With s the candidate's prescale, c = Q^T (s z),
+// w = s z - Q c (orthogonal to Q, |w| = rho):
+//   s * new_outputs = [Q, w/rho] S,   S = [[R_{-k} (s/d), c], [0, rho]]      ((K+1) x K: R without column k)
+// (columns: siblings ascending, then the candidate).  [Q, w/rho] has orthonormal columns, so the singular values of S
+// are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with XX = new_outputs/scale = [Q, w/rho] (tau S),
+// tau = 1/(s*scale), h = [Q^T y, w.y/rho], S = U Sigma V^T (one-sided Jacobi on the K columns of length K+1):
+//   Beta = V (tau Sigma)/(tau^2 Sigma^2 + 1e-6) U^T h                  (ridge OLS, codes/funcs.py:1151-1155)
+//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + | h - U diag(d_m/(d_m + 1e-6)) U^T h |^2,  d_m = tau^2 sigma_m^2
+// (codes/funcs.py:1162): the first term is what lies outside the (K+1)-dimensional frame, the second the misfit
+// inside it -- the ridge shrinkage plus the one frame direction the new columns do not span (the old column k's own
+// contribution), measured as a residual vector, never as a difference of squares.  The only O(N) inputs are c,
+// |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2 would
+// cancel (candidate nearly inside the span of the current columns).
+struct SolveIn {
+  const ChainB* ck;
+  const double* c;   // LDS: projections of s*z on the basis (K values)
+  double rho2;       // |w|^2
+  double wy;         // w . y
+  double zz;         // |s z|^2
+  double tau, s, sigma, scale, maxabs;
+  int K, k;
+  int64_t N;
+  uint32_t flags;
+  double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
+  MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
+};
+template <int K>
+__device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out);
+template <int K>
+__device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out);
+
 // The residual pass (no LDS staging) runs FOUR of its 4-wave workgroups inside one 16-wave workgroup: a CU that hosts
 // any of its waves cannot take a tile workgroup of the next batch, so what the pass costs the pipeline is CUs touched
 // x time, and a quarter of the CUs do the same work in the same time (26 instead of 104 at N = 100k).
@@ -71,7 +106,7 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
     const uint64_t* __restrict__ feats, const double* __restrict__ lnp, const PropDesc* __restrict__ desc,
     const PropCoef* __restrict__ coef, int P, int rb_rows, int pg, int n_rb, int n_pg,
     const int32_t* __restrict__ feat_list, int nF, double* __restrict__ part, T* __restrict__ spill,
-    int spill_slots, int32_t* __restrict__ queue, int32_t* __restrict__ queue_clear) {
+    int spill_slots, int32_t* __restrict__ queue, int32_t* __restrict__ queue_clear, FinArgs fin) {
   constexpr bool DYN = !LDS && MODE == MODE_PROJECT;
   constexpr int S = (U >= 8) ? 2 : BSR_REG_STACK;
   constexpr int VEC = 16 / sizeof(T);
@@ -94,10 +129,15 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
   // proposal indices); one workgroup per row block walks that list -- nothing to stage or schedule when it is empty
   const int32_t CONSTANT_AS* flagged = as_const(queue);
   const int n_flag = (MODE == MODE_RESIDUAL) ? flagged[0] : 0;
-  if (MODE == MODE_RESIDUAL && n_flag == 0) return;
+  constexpr bool FAT0 = RowsShape<LDS, MODE>::fat;
+  // the finalise step can follow inside this kernel where its solver fits the residual pass's register budget (16 waves
+  // per workgroup: 128 VGPRs; K = 4, 7, 8 would spill)
+  constexpr bool CAN_FUSE = FAT0 && (NQ <= 3 || NQ == 5 || NQ == 6);
+  const bool fused = CAN_FUSE && fin.ck != nullptr;
+  if (MODE == MODE_RESIDUAL && n_flag == 0 && !(fused && fin.done_flag)) return;   // nothing to do, nobody to tell
   tables_to_lds();
   if (!LDS) __syncthreads();
-  if (FAT && !wi.valid) return;   // (behind the barrier: the other virtual workgroups of this one needed it)
+  const bool active = !(FAT && !wi.valid) && !(MODE == MODE_RESIDUAL && n_flag == 0);   // no early exit: the tail below has barriers
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;
@@ -311,7 +351,8 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
     }
   } else {
     if (MODE == MODE_RESIDUAL) {
-      for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], wi.rb, (int64_t)wi.rb * rb_rows);
+      if (active)
+        for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], wi.rb, (int64_t)wi.rb * rb_rows);
     } else {
       for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
         const int p = wi.pgi * pg + pi;
@@ -324,38 +365,65 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
   if (MODE == MODE_PROJECT && gwave < BSR_STAMP_WAVES && lane == 0)
     bsr_dbg_stamps[gwave * BSR_STAMP_SLOTS + 47] = wall_clock64();
 #endif
+  if constexpr (CAN_FUSE) {
+    if (!fused) return;
+    // Finalise, fused: every workgroup publishes its residual sums and checks in; the last one to arrive runs the
+    // flagged proposals' solves on its sixteen waves (one launch, one launch gap and one blocked CU fewer per batch).
+    __shared__ int s_last;
+    __shared__ double sh_fin[4 * BSR_WG_WAVES][BSR_NQ_MAX];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+      if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double* sh_c = sh_fin[wave_raw];
+    for (int fi = wave_raw; fi < n_flag; fi += 4 * BSR_WG_WAVES) {
+      const int p = flagged[1 + fi];
+      const PropCoef* cfp = coef + p;
+      double ww = 0.0, wy = 0.0;
+      for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
+        const double* q = part + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
+        ww += __builtin_nontemporal_load(q);        // written by other workgroups of this launch: not through a
+        wy += __builtin_nontemporal_load(q + 1);    // possibly stale line of this CU's caches
+      }
+      ww = wave_sum(ww);
+      wy = wave_sum(wy);
+      if (lane < BSR_NQ_MAX) sh_c[lane] = cfp->c[lane];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+      SolveIn in;
+      in.ck = fin.ck + dsc[p].ck;
+      in.c = sh_c;
+      in.rho2 = ww;
+      in.zz = cfp->zz;
+      in.wy = wy;
+      in.tau = cfp->tau;
+      in.s = cfp->s;
+      in.sigma = dsc[p].sigma;
+      in.scale = cfp->scale;
+      in.maxabs = cfp->maxabs;
+      in.K = dsc[p].K;
+      in.k = dsc[p].k;
+      in.N = N;
+      in.flags = cfp->flags;
+      in.rank_floor = fin.rank_floor;
+      in.mh = fin.mh + p;
+      if constexpr (NQ >= 1 && NQ <= 4) solve_regs<NQ>(in, lane, fin.out + p);
+      else if constexpr (NQ >= 5) solve_cols<NQ>(in, lane, fin.out + p);
+    }
+    if (fin.done_flag) {   // completion word for the polling host (see k_finalize)
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(fin.done_flag, fin.done_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Per-proposal small algebra.  One wave per proposal.
-//
-// The chain keeps ONE orthonormal basis of its K current columns, O_j d_j = sum_i Q_i R_ij (d_j: power-of-two column
-// prescales).  A proposal replaces tree k by the candidate z.  With s the candidate's prescale, c = Q^T (s z),
-// w = s z - Q c (orthogonal to Q, |w| = rho):
-//   s * new_outputs = [Q, w/rho] S,   S = [[R_{-k} (s/d), c], [0, rho]]      ((K+1) x K: R without column k)
-// (columns: siblings ascending, then the candidate).  [Q, w/rho] has orthonormal columns, so the singular values of S
-// are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with XX = new_outputs/scale = [Q, w/rho] (tau S),
-// tau = 1/(s*scale), h = [Q^T y, w.y/rho], S = U Sigma V^T (one-sided Jacobi on the K columns of length K+1):
-//   Beta = V (tau Sigma)/(tau^2 Sigma^2 + 1e-6) U^T h                  (ridge OLS, codes/funcs.py:1151-1155)
-//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + | h - U diag(d_m/(d_m + 1e-6)) U^T h |^2,  d_m = tau^2 sigma_m^2
-// (codes/funcs.py:1162): the first term is what lies outside the (K+1)-dimensional frame, the second the misfit
-// inside it -- the ridge shrinkage plus the one frame direction the new columns do not span (the old column k's own
-// contribution), measured as a residual vector, never as a difference of squares.  The only O(N) inputs are c,
-// |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2 would
-// cancel (candidate nearly inside the span of the current columns).
-struct SolveIn {
-  const ChainB* ck;
-  const double* c;   // LDS: projections of s*z on the basis (K values)
-  double rho2;       // |w|^2
-  double wy;         // w . y
-  double zz;         // |s z|^2
-  double tau, s, sigma, scale, maxabs;
-  int K, k;
-  int64_t N;
-  uint32_t flags;
-  double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
-  MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
-};
 
 // entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
 __device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
@@ -1273,11 +1341,11 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
     hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
-                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
+                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
   } else {
     hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
-                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear);
+                       (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
   }
 }
 template <typename T, int NQ, int MODE>

@@ -347,7 +347,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     zeros = np.zeros(B, np.int32)
 
     def run(env):
-        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD"):
+        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -364,6 +364,8 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_TILE_PIPED": "1"}).tobytes() == base.tobytes()      # slice staged by LDS-DMA under the first tapes
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
+    assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
+    assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0", "BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
     rows = run({"BSR_TILE": "0"})
