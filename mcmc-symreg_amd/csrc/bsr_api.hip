@@ -414,52 +414,52 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // at N = 1M it measures 206 us against the work-queue pass's 165 us (four tapes per wave leave no registers for
     // two-block passes, so every 128 rows pay a full scalar decode of the tape), so it only runs when asked for
     c->tile_multi = env_int("BSR_TILE_MULTI", 0);
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    c->tile_cus = c->n_cu - c->aux_cus;
-    c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
-    const double data_mb = (double)N * (std::min(d, 32) + 1 + std::max(1, K)) * c->esz / 1e6;
-    int T = 1;
-    const int want = (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // groups that give every wave one tape
-    if (data_mb <= 24.0) T = std::min(4, want);
-    else if (data_mb <= 96.0) T = std::min(2, want);
-    T = std::max(1, std::min(8, T));
-    while (T > 1 && (c->tile_cus % T) != 0) --T;
-    // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
-    // fit LDS whole even then (staged once, no barrier per chunk).
-    const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
-    auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
-    auto fits_whole = [&](int t) {
-      return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
-    };
-    while (T > 1 && !fits_whole(T)) T >>= 1;
-    T = env_int("BSR_TILE_T", T);
-    T = std::max(1, std::min(8, T));
-    while (T > 1 && (c->tile_cus % T) != 0) --T;
-    c->tile_T = T;
-    c->tile_slices = std::max(1, c->tile_cus / T);
-    // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
-    // goes out as single (tape, block) units through a ticket counter (bsr_tile.hip: leftover_units)
-    c->tile_bps = c->tile_blocks / c->tile_slices;
-    c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
-    // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
-    // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
-    c->tile_sub = 1;
-    c->tile_sub_blocks = c->tile_bps;
-    if (fits_whole(T) && c->tile_bps >= 4 && env_int("BSR_TILE_SUB", 1) > 1) {
-      c->tile_sub = 2;
-      c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      c->tile_cus = c->n_cu - c->aux_cus;
+      c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
+      const double data_mb = (double)N * (std::min(d, 32) + 1 + std::max(1, K)) * c->esz / 1e6;
+      int T = 1;
+      const int want = (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // groups that give every wave one tape
+      if (data_mb <= 24.0) T = std::min(4, want);
+      else if (data_mb <= 96.0) T = std::min(2, want);
+      T = std::max(1, std::min(8, T));
+      while (T > 1 && (c->tile_cus % T) != 0) --T;
+      // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
+      // fit LDS whole even then (staged once, no barrier per chunk).
+      const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
+      auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
+      auto fits_whole = [&](int t) {
+        return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
+      };
+      while (T > 1 && !fits_whole(T)) T >>= 1;
+      T = env_int("BSR_TILE_T", T);
+      T = std::max(1, std::min(8, T));
+      while (T > 1 && (c->tile_cus % T) != 0) --T;
+      c->tile_T = T;
+      c->tile_slices = std::max(1, c->tile_cus / T);
+      // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
+      // goes out as single (tape, block) units through a ticket counter (bsr_tile.hip: leftover_units)
+      c->tile_bps = c->tile_blocks / c->tile_slices;
+      c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
+      // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
+      // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
+      c->tile_sub = 1;
+      c->tile_sub_blocks = c->tile_bps;
+      if (fits_whole(T) && c->tile_bps >= 4 && env_int("BSR_TILE_SUB", 1) > 1) {
+        c->tile_sub = 2;
+        c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
+      }
+      c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
+      // a data set of which not even a narrow batch (eight features or all of them, y, one chain's basis) fits LDS will
+      // not take the tile pass in practice: no partition and no derived columns then, the work-queue row pass keeps
+      // every CU and reads X only
+      const bool ever_tiled = c->tile_on && (c->tile_multi ||
+          (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <=
+              tile_lds_bytes_max() - 1024);
+      c->tile_ever = ever_tiled;
+      if (ever_tiled || c->aux_cus == 0) break;
+      c->aux_cus = 0;
     }
-    c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
-    // a data set of which not even a narrow batch (eight features or all of them, y, one chain's basis) fits LDS will
-    // not take the tile pass in practice: no partition and no derived columns then, the work-queue row pass keeps
-    // every CU and reads X only
-    const bool ever_tiled = c->tile_on && (c->tile_multi ||
-        (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <=
-            tile_lds_bytes_max() - 1024);
-    c->tile_ever = ever_tiled;
-    if (ever_tiled || c->aux_cus == 0) break;
-    c->aux_cus = 0;
-  }
     // derived columns pay where the batch's columns sit in LDS; the work-queue pass would read each of them from HBM
     // for every tape again (N = 1M, d = 50: +60 % traffic for -31 % instructions, no time gained alone and slower
     // with several batches in flight)
