@@ -89,6 +89,8 @@ struct BatchSlot {
   int timed = 0;        // profiling level the pending batch was enqueued with
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
+  std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
+  std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // scratch of the cost sort
 
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
@@ -147,6 +149,9 @@ struct bsr_ctx {
   std::vector<double> x_lo, x_hi;  // per-feature range of X (host side; the native sampler's rank-gate predictor)
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
+  std::vector<uint64_t> cur_hash;              // [chain*K+k] canonical hash of the current tree (0: unknown)
+  std::vector<std::vector<bsr_node>> cur_tape;  // ... and its tape, to confirm a hash match
+  int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   BatchSlot slot[BSR_MAX_INFLIGHT];
   int next_slot = 0;
   int last_waited = -1;
@@ -389,6 +394,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
     c->tile_piped = env_int("BSR_TILE_PIPED", 0);
+    c->selfdup = env_int("BSR_SELFDUP", 1);
     // k_finalize's work behind the residual pass in the same launch (last workgroup to arrive): one launch fewer per
     // batch, bit-identical -- and 3-4 us SLOWER per step at C2: the agent-scope release/acquire every residual
     // workgroup needs around the arrival counter writes back and invalidates its XCD's L2 under the row passes of the
@@ -489,6 +495,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     c->h_ck.resize((size_t)n_chains);
     c->ready.assign(n_chains, 0);
     c->col_set.assign((size_t)n_chains * K, 0);
+    c->cur_hash.assign((size_t)n_chains * K, 0);
+    c->cur_tape.assign((size_t)n_chains * K, std::vector<bsr_node>());
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
   c->h_fit.resize(n_chains + 1);
@@ -557,6 +565,82 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Canonical form of the column a tape computes: children of + and * in a fixed order, negations at the root dropped
+// (the column then differs by sign only).  Two tapes with the same form compute bit-identical columns up to that sign.
+// Hash first (one pass over the postfix tape, a stack of hashes); the exact form, a string, only to confirm a match.
+static inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline bool is_commutative_op(int op) { return op == BSR_OP_ADD || op == BSR_OP_MUL; }
+static inline bool is_binary_op(int op);
+static uint64_t canon_hash(const bsr_node* t, int len) {
+  uint64_t h[BSR_MAX_STACK + 2], strip[BSR_MAX_STACK + 2];   // strip: the hash with leading negations removed
+  int sp = 0;
+  for (int i = 0; i < len; ++i) {
+    const int op = t[i].opcode;
+    if (op == BSR_OP_TERMINAL) {
+      if (sp > BSR_MAX_STACK) return 0;
+      h[sp] = strip[sp] = mix64(0x7465726Dull ^ ((uint64_t)(uint32_t)t[i].feature << 32));
+      ++sp;
+    } else if (is_binary_op(op)) {
+      if (sp < 2) return 0;
+      uint64_t l = h[sp - 2], r = h[sp - 1];
+      if (is_commutative_op(op) && l > r) std::swap(l, r);
+      --sp;
+      h[sp - 1] = strip[sp - 1] = mix64(mix64(l ^ ((uint64_t)op << 56)) + 3 * r);
+    } else {
+      if (sp < 1) return 0;
+      uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
+      if (op == BSR_OP_LN) {
+        uint64_t a, b;
+        memcpy(&a, &t[i].a, 8);
+        memcpy(&b, &t[i].b, 8);
+        x = mix64(x ^ mix64(a) ^ (mix64(b) << 1));
+      }
+      strip[sp - 1] = (op == BSR_OP_NEG) ? strip[sp - 1] : x;
+      h[sp - 1] = x;
+    }
+  }
+  return sp == 1 ? (strip[0] | 1ull) : 0;   // never 0: 0 means "no form"
+}
+static std::string canon_form(const bsr_node* t, int len) {
+  std::vector<std::string> st, strip;
+  char buf[64];
+  for (int i = 0; i < len; ++i) {
+    const int op = t[i].opcode;
+    if (op == BSR_OP_TERMINAL) {
+      snprintf(buf, sizeof buf, "x%d", t[i].feature);
+      st.push_back(buf);
+      strip.push_back(buf);
+    } else if (is_binary_op(op)) {
+      if (st.size() < 2) return std::string();
+      std::string r = st.back(); st.pop_back(); strip.pop_back();
+      std::string l = st.back(); st.pop_back(); strip.pop_back();
+      if (is_commutative_op(op) && r < l) std::swap(l, r);
+      snprintf(buf, sizeof buf, "(%d ", op);
+      st.push_back(buf + l + " " + r + ")");
+      strip.push_back(st.back());
+    } else {
+      if (st.empty()) return std::string();
+      if (op == BSR_OP_LN) {
+        uint64_t a, b;
+        memcpy(&a, &t[i].a, 8);
+        memcpy(&b, &t[i].b, 8);
+        snprintf(buf, sizeof buf, "[%d %016llx %016llx ", op, (unsigned long long)a, (unsigned long long)b);
+      } else {
+        snprintf(buf, sizeof buf, "[%d ", op);
+      }
+      const std::string x = buf + st.back() + "]";
+      if (op != BSR_OP_NEG) strip.back() = x;
+      st.back() = x;
+    }
+  }
+  return st.size() == 1 ? strip[0] : std::string();
+}
+
 static inline bool is_binary_op(int op) {
   return op == BSR_OP_ADD || op == BSR_OP_MUL || op == BSR_OP_SUB || op == BSR_OP_DIV;
 }
@@ -1391,6 +1475,8 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
   c->h_rin[chain].colflags[k] = s.h_out[0].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
+  c->cur_hash[(size_t)chain * c->K + k] = canon_hash(tape, len);
+  c->cur_tape[(size_t)chain * c->K + k].assign(tape, tape + len);
   return BSR_OK;
 }
 
@@ -1442,6 +1528,18 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
   c->h_rin[chain].colflags[k] = s.h_out[idx].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
+  {
+    const size_t ck = (size_t)chain * c->K + k;
+    if ((size_t)idx + 1 < s.off_copy.size()) {
+      const bsr_node* t = s.rows_copy.data() + s.off_copy[idx];
+      const int len = s.off_copy[idx + 1] - s.off_copy[idx];
+      c->cur_hash[ck] = canon_hash(t, len);
+      c->cur_tape[ck].assign(t, t + len);
+    } else {
+      c->cur_hash[ck] = 0;   // unknown: no shortcut for proposals on this tree
+      c->cur_tape[ck].clear();
+    }
+  }
   return BSR_OK;
 }
 
@@ -1567,7 +1665,20 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
     D->qslot = s.nF + 1 + s.chain_slot[chain[i]] * K;
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
+    // the candidate is the tree it would replace, again (same canonical form): tell k_solve its column is in the span
+    if (c->selfdup) {
+      const size_t ck = (size_t)chain[i] * K + which_k[i];
+      const bsr_node* t = rows + tape_off[i];
+      const int len = tape_off[i + 1] - tape_off[i];
+      const uint64_t h = c->cur_hash[ck];
+      if (h != 0 && h == canon_hash(t, len) &&
+          canon_form(t, len) == canon_form(c->cur_tape[ck].data(), (int)c->cur_tape[ck].size()))
+        D->self_dup = 1;
+    }
   }
+  // keep the batch's tapes: bsr_commit makes one of them a current tree (its canonical form is needed then)
+  s.rows_copy.assign(rows, rows + tape_off[B]);
+  s.off_copy.assign(tape_off, tape_off + B + 1);
   s.n_spans = 0;
   if (n_spans > 0) {
     if (!terms8 || !mhflags || !span_off || n_spans > B || span_off[0] != 0 || span_off[n_spans] != B)

@@ -343,11 +343,23 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
             trees.append(node_from_spec(spec_from_node(root)))
     tapes = [flatten(t) for t in trees[K:]]
     ks = (np.arange(B) % K).astype(np.int32)
+    # a few candidates that repeat the tree they would replace (as it is, and negated at the root): recognised on the
+    # host, scored without the residual pass (BSR_SELFDUP) -- to the bit what the residual pass makes of them
+    from bsr.node import Node
+    for j in range(min(K, 4)):
+        tapes[j] = flatten(trees[j])
+        ks[j] = j
+    neg = Node(0)
+    neg.type, neg.operator, neg.left = 1, 'neg', node_from_spec(spec_from_node(trees[0]))
+    neg.left.parent = neg
+    tapes[5] = flatten(neg)
+    ks[5] = 0
     sig = rs.uniform(0.5, 2.0, size=B)
     zeros = np.zeros(B, np.int32)
 
     def run(env):
-        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE"):
+        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
+                  "BSR_SELFDUP"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -364,6 +376,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_TILE_PIPED": "1"}).tobytes() == base.tobytes()      # slice staged by LDS-DMA under the first tapes
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
+    assert run({"BSR_SELFDUP": "0"}).tobytes() == base.tobytes()         # self-duplicates through the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
