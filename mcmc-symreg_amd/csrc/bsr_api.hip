@@ -1085,12 +1085,13 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
 // Second submission thread of a context.  It spins for a while after its last job (a sleeping thread would add its
 // wake-up time to every batch of a busy pipeline) and sleeps on the condition variable when the context goes quiet.
 struct Launcher {
-  std::thread th;
+  std::vector<std::thread> ths;   // one by default; BSR_SUBMIT_THREADS more share the queue (jobs of different slots)
   std::mutex mu;
   std::condition_variable cv;
   std::deque<TailJob> q;
   std::atomic<int> n_queued{0};
-  bool asleep = false, stop = false;
+  int asleep = 0;
+  bool stop = false;
   int spin_us = 100;
 };
 
@@ -1114,9 +1115,9 @@ static void launcher_main(bsr_ctx* c) {
         std::unique_lock<std::mutex> lk(L->mu);
         if (L->stop) return;
         if (L->q.empty()) {
-          L->asleep = true;
+          ++L->asleep;
           L->cv.wait(lk, [&] { return L->stop || !L->q.empty(); });
-          L->asleep = false;
+          --L->asleep;
           if (L->stop && L->q.empty()) return;
         }
       } else {
@@ -1134,19 +1135,49 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
     std::lock_guard<std::mutex> lk(L->mu);
     L->q.push_back(job);
     L->n_queued.fetch_add(1, std::memory_order_release);
-    wake = L->asleep;
+    wake = L->asleep > 0;
   }
   if (wake) L->cv.notify_one();
 }
 
-static void launcher_start(bsr_ctx* c) {
-  // needs a core of its own: with fewer than four usable CPUs the caller issues its launches itself
+// CPUs this process may use: the affinity mask, cut down to the cgroup's CPU quota (the GPU boxes show 256 CPUs and
+// grant 16), shared by the ranks of a multi-process run.
+static double cpu_budget() {
+  double n = 1e9;
   cpu_set_t set;
   CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) < 4 && env_int("BSR_SUBMIT_THREAD", 1) < 2) return;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = (double)CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+    char q[32];
+    double per = 0;
+    if (fscanf(f, "%31s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min(n, atof(q) / per);
+    fclose(f);
+  } else if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+    double quota = -1, per = 0;
+    if (fscanf(fq, "%lf", &quota) != 1) quota = -1;
+    fclose(fq);
+    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(fp, "%lf", &per) != 1) per = 0;
+      fclose(fp);
+    }
+    if (quota > 0 && per > 0) n = std::min(n, quota / per);
+  }
+  const int local_world = std::max(1, env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1)));
+  return n / local_world;
+}
+
+static void launcher_start(bsr_ctx* c) {
+  // Submission threads need cores of their own.  Two where the budget allows (HIP calls on different streams run in
+  // parallel: 26-33 -> 21.6 us per step on a box whose CPU needs 25-33 us for a batch's six calls), one on a tight
+  // budget, none below three CPUs (the caller then issues its launches itself).  BSR_SUBMIT_THREAD=0 / 2: never / always;
+  // BSR_SUBMIT_THREADS=n: that many.
+  const double cpus = cpu_budget();
+  const int mode = env_int("BSR_SUBMIT_THREAD", 1);
+  if (cpus < 3.0 && mode < 2) return;
   c->launcher = new Launcher;
   c->launcher->spin_us = std::max(0, env_int("BSR_SUBMIT_SPIN_US", 100));
-  c->launcher->th = std::thread(launcher_main, c);
+  const int n_th = std::max(1, std::min(4, env_int("BSR_SUBMIT_THREADS", cpus >= 6.0 ? 2 : 1)));
+  for (int i = 0; i < n_th; ++i) c->launcher->ths.emplace_back(launcher_main, c);
 }
 
 static void launcher_stop(bsr_ctx* c) {
@@ -1156,8 +1187,9 @@ static void launcher_stop(bsr_ctx* c) {
     std::lock_guard<std::mutex> lk(L->mu);
     L->stop = true;
   }
-  L->cv.notify_one();
-  if (L->th.joinable()) L->th.join();
+  L->cv.notify_all();
+  for (auto& th : L->ths)
+    if (th.joinable()) th.join();
   delete L;
   c->launcher = nullptr;
 }
