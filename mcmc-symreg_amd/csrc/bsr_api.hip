@@ -26,6 +26,7 @@ struct TapeLoc {
   int code_off, n_nodes, feat_off, ln_off, max_sp;
   int n_stream;  // opcode-stream entries after fusing `terminal, +|*` pairs
   int cost;      // rough relative cost of one sweep of the tape (orders the work queue: heaviest first)
+  uint64_t slots;  // tile pass: the LDS slots the tape's terminals read (bit = slot; ~0: some slot >= 64)
 };
 
 // Everything one batch in flight owns.  Two slots let the host stage batch i+1 while the GPU scores batch i.
@@ -89,6 +90,8 @@ struct BatchSlot {
   int timed = 0;        // profiling level the pending batch was enqueued with
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
+  uint64_t grp_mask[8] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};   // per tape group: slots to stage
+  std::vector<uint64_t> tape_slots;  // per tape of the staged batch: LDS slots it reads (tile pass)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // scratch of the cost sort
@@ -121,6 +124,7 @@ struct bsr_ctx {
   int derived_max = 8;         // BSR_DERIVED_MAX: cap on the derived columns one batch may use
   bool tile_ever = false;   // some batch of this context can take the tile pass
   int tile_piped = 0;
+  int stage_subset = 1;   // BSR_STAGE_SUBSET: a tape group stages only the columns its tapes read
   int fuse_finalize = 0;   // BSR_FUSE_FINALIZE: k_finalize's work behind the residual pass, in the same launch
   int poll_done = 0;   // BSR_POLL_DONE: completion word in pinned memory instead of an event per scoring batch
   int n_cu = 256;
@@ -394,6 +398,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
     c->tile_piped = env_int("BSR_TILE_PIPED", 0);
+    c->stage_subset = env_int("BSR_STAGE_SUBSET", 1);
     c->selfdup = env_int("BSR_SELFDUP", 1);
     // k_finalize's work behind the residual pass in the same launch (last workgroup to arrive): one launch fewer per
     // batch, bit-identical -- and 3-4 us SLOWER per step at C2: the agent-scope release/acquire every residual
@@ -860,6 +865,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     uint64_t* pf2 = hf2 + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
     int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 8;
+    uint64_t slots_mask = 0;
     for (int j = 0; j < L.n_nodes; ++j) {
       const bsr_node& r = rows[tape_off[i] + j];
       int code = r.opcode & 15;
@@ -874,7 +880,10 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         }
         const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[col] : col);
         pf[nt >> 2] |= id << (16 * (nt & 3));
-        if (s.tile) pf2[nt >> 2] |= (uint64_t)s.slot_of[col] << (16 * (nt & 3));
+        if (s.tile) {
+          pf2[nt >> 2] |= (uint64_t)s.slot_of[col] << (16 * (nt & 3));
+          slots_mask = (s.slot_of[col] < 64 && slots_mask != ~0ull) ? (slots_mask | (1ull << s.slot_of[col])) : ~0ull;
+        }
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
         // one stream entry: acc = acc op X[:,f], no push/pop
@@ -904,6 +913,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
               : (r.opcode == BSR_OP_LN) ? 2 : 1;
     }
     (*loc)[i].n_stream = ns;
+    (*loc)[i].slots = slots_mask;
     (*loc)[i].cost = cost;
     (*loc)[i].max_sp = mx;
     pl[2 * nl] = 1.0;
@@ -1030,6 +1040,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
         a.stamps = c->d_stamps;
         for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const double*)s.h_cols()[i] : nullptr;
+        for (int i = 0; i < 8; ++i) a.grp_mask[i] = (j.tg.per_group > 0) ? s.grp_mask[i] : ~0ull;
         launch_tile<double>(s0, a);
       } else {
         TileArgs<float> a;
@@ -1037,6 +1048,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
         a.stamps = c->d_stamps;
         for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const float*)s.h_cols()[i] : nullptr;
+        for (int i = 0; i < 8; ++i) a.grp_mask[i] = (j.tg.per_group > 0) ? s.grp_mask[i] : ~0ull;
         launch_tile<float>(s0, a);
       }
     } else {
@@ -1262,6 +1274,19 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     int32_t* sc = s.h_sched();
     for (size_t i = 0; i < n_sched; ++i) sc[i] = -1;
     for (int i = 0; i < P; ++i) sc[(size_t)(i % tg.T) * tg.per_group + i / tg.T] = s.order_tmp[i];
+    // what each group has to stage: the slots its tapes read, y, the bases of its tapes' chains
+    for (int gi = 0; gi < 8; ++gi) s.grp_mask[gi] = ~0ull;
+    if (tg.ncols <= 64 && (int)s.tape_slots.size() >= P && tg.T <= 8 && c->stage_subset) {
+      for (int gi = 0; gi < tg.T; ++gi) s.grp_mask[gi] = 1ull << tg.y_slot;
+      for (int i = 0; i < P; ++i) {
+        const int p = s.order_tmp[i], gi = i % tg.T;
+        uint64_t m = s.tape_slots[p];
+        for (int kq = 0; kq < c->K; ++kq) m |= 1ull << (hd[p].qslot + kq);
+        s.grp_mask[gi] = (m == ~0ull || s.grp_mask[gi] == ~0ull) ? ~0ull : (s.grp_mask[gi] | m);
+      }
+      for (int gi = 0; gi < tg.T; ++gi)
+        if (s.tape_slots.empty()) s.grp_mask[gi] = ~0ull;
+    }
   } else if (tile) {
     // Static schedule: tapes in cost order are dealt to the T groups round-robin; inside a group each goes to the
     // wave with the least work so far that still has a free slot (waves w, w+4, w+8, w+12 share a SIMD, but a light
@@ -1708,6 +1733,8 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
         D->self_dup = 1;
     }
   }
+  s.tape_slots.resize(B);
+  for (int i = 0; i < B; ++i) s.tape_slots[i] = loc[i].slots;
   // keep the batch's tapes: bsr_commit makes one of them a current tree (its canonical form is needed then)
   s.rows_copy.assign(rows, rows + tape_off[B]);
   s.off_copy.assign(tape_off, tape_off + B + 1);
@@ -1820,7 +1847,12 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
         D.s = std::ldexp(1.0, -e);
         s.h_desc()[j] = D;
       }
-      rc = enqueue(c, s, (int)redo.size(), true);
+      {   // the descriptors moved: the per-tape slot sets no longer line up with them (every group stages everything)
+        const std::vector<uint64_t> kept_slots = s.tape_slots;
+        s.tape_slots.clear();
+        rc = enqueue(c, s, (int)redo.size(), true);
+        s.tape_slots = kept_slots;
+      }
       if (rc == BSR_OK) rc = wait_slot(c, s);
       if (rc != BSR_OK) return rc;
       for (size_t j = 0; j < redo.size(); ++j) {

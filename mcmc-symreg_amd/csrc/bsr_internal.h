@@ -152,6 +152,9 @@ struct TileArgs {
   // the first BSR_TILE_ARG_COLS column pointers again, inside the kernel-argument block: the input block was written
   // microseconds ago and is cold for every CU, the argument block is not
   const T* cols[32];
+  // LDS slots each tape group needs (bit = slot; all ones: every column): a group does not stage what only the other
+  // groups' tapes read (derived columns mostly)
+  uint64_t grp_mask[8];
 };
 #define BSR_TILE_ARG_COLS 32
 #define BSR_TILE_LOADERS 4      // waves per workgroup that stage the slice (piped staging)

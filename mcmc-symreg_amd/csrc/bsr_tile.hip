@@ -65,14 +65,43 @@ __device__ __forceinline__ void accumulate(TapeAcc<KQ>& A, const T (&z)[BSR_TILE
 
 // Copies rows [c0*128, (c0+nb)*128) of every column of the launch into LDS.  Unit of work = 64 lanes x 16 B of one
 // column; wave w takes units w, w+16, ... and keeps DEPTH loads in flight before it writes them to LDS.
+// `mask`: the columns to stage (bit = LDS slot), ~0 = all of them.  A column's place in LDS does not depend on it.
 template <typename T, int DEPTH>
 __device__ __forceinline__ void stage_rows(T* sx, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
-                                           int nb, int wave, int lane) {
+                                           int nb, int wave, int lane, uint64_t mask = ~0ull) {
   constexpr int VEC = 16 / sizeof(T);
   using V4 = __attribute__((ext_vector_type(4))) float;
   constexpr int UPB = BSR_TILE_BLOCK / VEC / BSR_WAVE;      // units per column and block (f64: 1; f32: half a unit)
   const int upc = (UPB > 0) ? UPB * nb : (nb + 1) / 2;      // units per column
   const int nvec_col = nb * (BSR_TILE_BLOCK / VEC);         // 16-byte pieces per column
+  if (mask != ~0ull) {   // a subset: walk its set bits instead of 0..ncols-1
+    uint64_t m = mask;
+    int ub = wave;
+    while (ub >= upc && m != 0) { ub -= upc; m &= m - 1; }
+    while (m != 0) {
+      V4 r[DEPTH];
+      int de[DEPTH];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        de[j] = -1;
+        if (m != 0) {
+          const int col = __builtin_ctzll(m);
+          const int piece = ub * BSR_WAVE + lane;
+          if (piece < nvec_col) {
+            const int e = piece * VEC;
+            r[j] = *reinterpret_cast<const V4*>(colsrc[col] + (int64_t)c0 * BSR_TILE_BLOCK + e);
+            de[j] = col * chunk_rows + e;
+          }
+          ub += BSR_TILE_WAVES;
+          while (ub >= upc && m != 0) { ub -= upc; m &= m - 1; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j)
+        if (de[j] >= 0) *reinterpret_cast<V4*>(sx + de[j]) = r[j];
+    }
+    return;
+  }
   const int n_units = ncols * upc;
   int col = 0, ub = wave;                                   // unit = (col, ub): ub-th unit of column col
   while (ub >= upc && col < ncols) { ub -= upc; ++col; }
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   }
   if (!piped) {
     tables_to_lds();
-    stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane);
+    stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane, a.grp_mask[tg & 7]);
     __syncthreads();
   }
   // blocks [.., b_end) of the slice are in LDS (piped staging: spin on the pair's counter)

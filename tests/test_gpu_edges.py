@@ -359,7 +359,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 
     def run(env):
         for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
-                  "BSR_SELFDUP"):
+                  "BSR_SELFDUP", "BSR_STAGE_SUBSET"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -377,6 +377,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
     assert run({"BSR_SELFDUP": "0"}).tobytes() == base.tobytes()         # self-duplicates through the residual pass
+    assert run({"BSR_STAGE_SUBSET": "0"}).tobytes() == base.tobytes()    # every tape group stages every column
     assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
