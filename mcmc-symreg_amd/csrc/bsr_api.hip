@@ -91,6 +91,8 @@ struct BatchSlot {
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
   uint64_t grp_mask[8] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};   // per tape group: slots to stage
+  std::vector<std::pair<int, int>> derived_cand;   // scratch of the derived-column choice
+  std::vector<int> derived_benefit;
   std::vector<uint64_t> tape_slots;  // per tape of the staged batch: LDS slots it reads (tile pass)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
@@ -775,6 +777,36 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     allowance = std::min(allowance, c->derived_max);
   }
   s.derived_used = 0;
+  // Which derived columns: the ones that save the most.  One pass over the batch adds up, per (op, feature), the
+  // interpreter cost of the op on every `terminal f, op` it would replace; the `allowance` best are admitted (ties: the
+  // lower column), a single cheap use (neg, square) is not worth a column.  -2 marks an admitted column until the main
+  // pass below gives it its place.
+  if (derive && allowance > 0) {
+    std::vector<std::pair<int, int>>& cand = s.derived_cand;   // (benefit, column)
+    cand.clear();
+    std::vector<int>& ben = s.derived_benefit;
+    if ((int)ben.size() < c->n_cols) ben.assign(c->n_cols, 0);
+    for (int j = 0; j + 1 < tape_off[n]; ++j) {
+      if (rows[j].opcode != BSR_OP_TERMINAL || rows[j].feature < 0 || rows[j].feature >= c->d) continue;
+      const int op = rows[j + 1].opcode, m = derived_index(op);
+      if (m < 0) continue;
+      const int dc = c->d * (1 + m) + rows[j].feature;
+      const int w = (op == BSR_OP_SIN || op == BSR_OP_COS) ? 25 : (op == BSR_OP_EXP || op == BSR_OP_LOG) ? 16
+                    : (op == BSR_OP_INV) ? 9 : (op == BSR_OP_CUBIC) ? 5 : 1;
+      if (ben[dc] == 0) cand.push_back({0, dc});
+      ben[dc] += w;
+    }
+    // (a `terminal, op` pair that straddles two tapes cannot occur: a tape never ends in a terminal unless it is one)
+    for (auto& cd : cand) {
+      cd.first = ben[cd.second];
+      ben[cd.second] = 0;
+    }
+    std::sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+      return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    for (size_t q = 0; q < cand.size() && (int)q < allowance; ++q)
+      if (cand[q].first >= 5) s.slot_of[cand[q].second] = -2;
+  }
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
@@ -789,8 +821,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
           const int m = derived_index(rows[j + 1].opcode);
           if (m >= 0) {
             const int dc = c->d * (1 + m) + col;
-            if (s.slot_of[dc] >= 0 || s.derived_used < allowance) {
-              if (s.slot_of[dc] < 0) ++s.derived_used;
+            if (s.slot_of[dc] == -2 || s.slot_of[dc] == 0) {   // admitted above
+              if (s.slot_of[dc] == -2) ++s.derived_used;
               col = dc;
               ++j;
             }
