@@ -173,8 +173,8 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
   return;
 #endif
   // words 0..7: projections, 8: |s z|^2, 9: s z.y -- ten sums in groups of eight (wave_sum8), then max|z| and flags
-  constexpr int row_map[4] = {0, 2, 1, 3};
-  const int slot = row_map[lane >> 4];
+  const int slot = ((lane >> 3) & 2) | (lane >> 5);   // rows 0, 1, 2, 3 of the wave hold values 0, 2, 1, 3 (in arithmetic:
+                                                      // a table would be a memory load and a pointer kept in registers)
   double g0[8], lo0, hi0;
   if constexpr (KQ <= 6) {  // everything fits one group: c[0..KQ-1] at 0.., a0 at 6, a1 at 7
 #pragma unroll

@@ -22,6 +22,17 @@ rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 if [ $rc -ne 0 ]; then grep -h -B2 -A6 "error" "$obj"/*.resources.txt >&2 || true; exit 1; fi
 grep -h "warning:" "$obj"/*.resources.txt >&2 || true
+# scratch (private memory) instructions per function of the tile pass, counted in the disassembly: the resource report's
+# ScratchSize also counts stack slots the register allocator reserves and never touches
+objdump="$ROCM/lib/llvm/bin/llvm-objdump"
+if [ -x "$objdump" ]; then
+  tmp="$(mktemp -d)"
+  cp "$obj/bsr_tile.o" "$tmp/t.o"
+  (cd "$tmp" && "$objdump" --offloading t.o > /dev/null && "$objdump" -d t.o.*gfx950 |
+     awk '/^[0-9a-f]+ <.*>:$/ { name = $2; n[name] += 0 } /\<scratch_(load|store)/ { n[name]++ } END { for (k in n) print k, n[k] }') \
+    | sort > "$obj/bsr_tile.scratch_ops.txt" || true
+  rm -rf "$tmp"
+fi
 objs=()
 for s in "${srcs[@]}"; do [ -f "$obj/$s.o" ] && [ -f "$here/$s.hip" ] && objs+=("$obj/$s.o"); done
 "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" -o "$out"

@@ -37,8 +37,20 @@ def test_tile_row_pass_has_no_scratch():
     assert len(names) == 16, names            # double and float, K = 1..8
     for n in names:
         r = rep[n]
-        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (n, r)
+        # a stack slot the register allocator reserves without using it shows up as 32 bytes here; anything larger,
+        # or a spilled register, is real
+        assert r["ScratchSize [bytes/lane]"] <= 32 and r["VGPRs Spill"] == 0, (n, r)
         assert r["VGPRs"] <= 128, (n, r)      # 16 waves per CU in one workgroup: 4 per SIMD
+    # ... and the disassembly holds no scratch instruction in any of them (build.sh counts them per function)
+    ops = os.path.join(CSRC, "build", "bsr_tile.scratch_ops.txt")
+    if not os.path.exists(ops):
+        pytest.skip("no disassembly count (llvm-objdump missing at build time)")
+    counts = {}
+    for line in open(ops):
+        name, cnt = line.split()
+        counts[name.strip("<>:")] = int(cnt)
+    for n in names:
+        assert counts.get(n) == 0, (n, counts.get(n))
 
 
 def test_default_work_queue_row_pass_has_no_scratch():
