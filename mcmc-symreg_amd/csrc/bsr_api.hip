@@ -415,14 +415,19 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // At C2 the pipeline is bound by the GPU once the calls are off the caller's thread, so it buys nothing there;
     // opt-in
     c->poll_done = env_int("BSR_POLL_DONE", 0);
-    // Optional CU partition (BSR_AUX_CUS=n: the row pass is sized for n_cu - n CUs; with BSR_CU_MASK=1 the slot streams
-    // carry CU masks -- mask bits are dealt round-robin over the XCDs -- and the kernels behind the row pass run on a
-    // second stream confined to the other n).  The idea: a tile workgroup needs a whole CU, so a wave of another
-    // batch's solve or residual kernel sitting on a CU holds that CU's workgroup up.  Measured at C2: spare CUs change
-    // nothing (the pipeline is bound by the host's HIP calls, not by this), masked streams halve the throughput
-    // (more hardware queues than the runtime maps at once).  Off by default.
-    c->aux_cus = env_int("BSR_AUX_CUS", 0);
-    if (c->aux_cus < 0 || c->aux_cus > c->n_cu / 2) c->aux_cus = 0;
+    // Launch width of the tile pass: n_cu - BSR_AUX_CUS workgroups, by default three quarters of the CUs.  A tile
+    // workgroup needs a whole CU (LDS and registers), and a launch as wide as the machine ends when its last workgroup
+    // does: the CUs that finish early wait, the next batch's launch starts staging only then, and a CU that holds
+    // another batch's solve or residual waves holds a workgroup up.  With narrower launches the next batch's workgroups
+    // take the CUs as they come free -- staging of one batch runs under the arithmetic of another, and the small
+    // kernels find room.  Each workgroup then has a third more rows (8 blocks per slice instead of 6 at N = 100k), the
+    // kernel alone takes 25 instead of 21.5 us, and the pipelined step 18.9 instead of 21.1 us at K = 3 (29.0 instead
+    // of 32.8 at K = 8); half the CUs measures the same at K = 3 and worse at K = 8, a quarter loses.
+    // (tools/probes/aux_cus_sweep.sh)  With BSR_CU_MASK=1 the slot streams also carry CU masks and the
+    // kernels behind the row pass run on a second stream confined to the other CUs: masked streams halve the
+    // throughput (more hardware queues than the runtime maps at once), off.
+    c->aux_cus = env_int("BSR_AUX_CUS", c->n_cu / 4);
+    if (c->aux_cus < 0 || c->aux_cus > c->n_cu * 7 / 8) c->aux_cus = 0;
     // chunked variant (two LDS buffers filled by LDS-DMA) for slices that do not fit LDS whole: correct and tested, but
     // at N = 1M it measures 206 us against the work-queue pass's 165 us (four tapes per wave leave no registers for
     // two-block passes, so every 128 rows pay a full scalar decode of the tape), so it only runs when asked for
