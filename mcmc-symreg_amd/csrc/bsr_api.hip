@@ -127,11 +127,14 @@ struct bsr_ctx {
   bool tile_ever = false;   // some batch of this context can take the tile pass
   int tile_piped = 0;
   int stage_subset = 1;   // BSR_STAGE_SUBSET: a tape group stages only the columns its tapes read
+  int solo_tail = 0;       // BSR_SOLO_TAIL=n: n workgroups each take whole flagged proposals (residual + finalise), one launch
   int fuse_finalize = 0;   // BSR_FUSE_FINALIZE: k_finalize's work behind the residual pass, in the same launch
   int poll_done = 0;   // BSR_POLL_DONE: completion word in pinned memory instead of an event per scoring batch
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
   int aux_cus = 0;
+  int wait_stream = 0;
+  int bar_write = 0;       // the host writes a batch's input block straight into device memory (large-BAR devices)
   int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the row pass is sized for (f64 kernels: 92 VGPRs -> 5)
   size_t esz = 8;
   bool has_y = false;
@@ -392,6 +395,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+    // device memory mapped into the host's address space (large BAR): input blocks are written there directly
+    // (issue_batch; tools/probes/bar_write_probe.hip).  BSR_BAR_WRITE=0: hipMemcpyAsync as before.
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) large_bar = 0;
+    c->bar_write = (large_bar && env_int("BSR_BAR_WRITE", 1)) ? 1 : 0;
   }
   {
     // Tile pass: one workgroup per CU.  T tape groups share the CUs: n_cu / T row slices, each served by T
@@ -407,6 +415,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // workgroup needs around the arrival counter writes back and invalidates its XCD's L2 under the row passes of the
     // other batches.  Opt-in.
     c->fuse_finalize = env_int("BSR_FUSE_FINALIZE", 0);
+    c->solo_tail = env_int("BSR_SOLO_TAIL", 0);
     // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
     // tape, and staging a column costs every workgroup what one use saves one wave (measured flat from 7 up)
     c->derived_max = env_int("BSR_DERIVED_MAX", 8);
@@ -415,6 +424,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // At C2 the pipeline is bound by the GPU once the calls are off the caller's thread, so it buys nothing there;
     // opt-in
     c->poll_done = env_int("BSR_POLL_DONE", 0);
+    // the waiter synchronises with the slot's stream instead of an event recorded behind the batch (one HIP call fewer
+    // per batch on the submission threads, which is what bounds the pipelined step once the row passes overlap: the
+    // runtime takes ~3 us per call however many threads make them).  Measured: 34 us per step instead of 19 --
+    // hipStreamSynchronize holds up the other threads' launches while it waits.  Opt-in, for the record.
+    c->wait_stream = env_int("BSR_WAIT_STREAM", 0);
     // Launch width of the tile pass: n_cu - BSR_AUX_CUS workgroups, by default three quarters of the CUs.  A tile
     // workgroup needs a whole CU (LDS and registers), and a launch as wide as the machine ends when its last workgroup
     // does: the CUs that finish early wait, the next batch's launch starts staging only then, and a CU that holds
@@ -1064,7 +1078,16 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   {
     // upload + row pass on the slot's stream
     hipStream_t s0 = s.stream;
-    step(hipMemcpyAsync(s.d_in, s.h_in, j.in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
+    if (c->bar_write) {
+      // the input block goes into device memory by plain stores through the PCIe BAR (write-combined, ~1 us for
+      // 16 KB) instead of a copy command: one HIP call fewer per batch.  The slot's previous batch has been waited
+      // for, so nothing on the device reads the block now; the stores are globally ordered before the doorbell write
+      // of the launch below (fence, then posted writes in order), and every kernel start invalidates the caches
+      memcpy(s.d_in, s.h_in, j.in_bytes);
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+    } else {
+      step(hipMemcpyAsync(s.d_in, s.h_in, j.in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
+    }
     if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
     if (j.tile) {
       const uint64_t* codes = s.d_streams();
@@ -1102,7 +1125,12 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
   // registers for the solver and reads X from global memory (16-wave workgroups): one launch fewer per batch
-  const bool fuse_fin = j.scoring && c->fuse_finalize && c->no_lds && residual_can_fuse_finalize(c->K);
+  // ... or whole flagged proposals per workgroup (solo_tail): residual pass and finalise step of a proposal in one
+  // workgroup, nothing shared between workgroups.  A proposal's row blocks then run on sixteen waves instead of the
+  // whole grid: for data sets of up to 256 row blocks.
+  const bool solo = j.scoring && c->solo_tail > 0 && !s.use_flag && c->no_lds && residual_can_fuse_finalize(c->K) &&
+                    j.g.n_rb <= 256;
+  const bool fuse_fin = solo || (j.scoring && c->fuse_finalize && c->no_lds && residual_can_fuse_finalize(c->K));
   if (j.scoring && !dbg_skip) {
     FinArgs fin;
     memset(&fin, 0, sizeof fin);
@@ -1111,6 +1139,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       fin.arrive = s.d_flagged + 2 * s.flag_stride + 1;
       fin.done_flag = s.use_flag ? s.h_flag : nullptr;
       fin.done_gen = s.flag_gen;
+      fin.solo = solo ? c->solo_tail : 0;
     }
     launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st, fuse_fin ? &fin : nullptr);
   }
@@ -1121,7 +1150,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
-  if (!s.use_flag) step(hipEventRecord(s.done, st), "hipEventRecord");
+  if (!s.use_flag && !c->wait_stream) step(hipEventRecord(s.done, st), "hipEventRecord");
   s.tail_rc = rc;
   if (g_host_prof) {
     g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
@@ -1423,6 +1452,9 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+  } else if (c->wait_stream) {
+    HIPCHK(c, hipStreamSynchronize(s.aux ? s.aux : s.stream));   // the slot's stream holds this batch and nothing behind it
+    HIPCHK(c, hipGetLastError());
   } else {
     HIPCHK(c, hipEventSynchronize(s.done));
     HIPCHK(c, hipGetLastError());

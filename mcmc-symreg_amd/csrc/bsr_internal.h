@@ -196,6 +196,8 @@ struct FinArgs {
   int32_t* arrive;       // workgroup arrival counter (zero between launches)
   uint32_t* done_flag;   // pinned completion word, or null
   uint32_t done_gen;
+  int solo;              // > 0: that many workgroups, each taking whole flagged proposals (all row blocks, then the
+                         // finalise step): no workgroup waits for another, no device-scope fence
 };
 template <typename T>
 struct RowPassArgs {
@@ -222,7 +224,7 @@ struct RowPassArgs {
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 // the finalise step can ride behind the residual pass for these K (register budget of its 16-wave workgroups)
-static inline bool residual_can_fuse_finalize(int K) { return K <= 3 || K == 5 || K == 6; }
+static inline bool residual_can_fuse_finalize(int K) { return K <= 3; }
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                   int32_t* flagged_next);

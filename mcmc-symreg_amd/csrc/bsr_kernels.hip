@@ -131,13 +131,14 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
   const int n_flag = (MODE == MODE_RESIDUAL) ? flagged[0] : 0;
   constexpr bool FAT0 = RowsShape<LDS, MODE>::fat;
   // the finalise step can follow inside this kernel where its solver fits the residual pass's register budget (16 waves
-  // per workgroup: 128 VGPRs; K = 4, 7, 8 would spill)
-  constexpr bool CAN_FUSE = FAT0 && (NQ <= 3 || NQ == 5 || NQ == 6);
+  // per workgroup: 128 VGPRs; K >= 4 would spill)
+  constexpr bool CAN_FUSE = FAT0 && NQ <= 3;
   const bool fused = CAN_FUSE && fin.ck != nullptr;
   if (MODE == MODE_RESIDUAL && n_flag == 0 && !(fused && fin.done_flag)) return;   // nothing to do, nobody to tell
   tables_to_lds();
   if (!LDS) __syncthreads();
-  const bool active = !(FAT && !wi.valid) && !(MODE == MODE_RESIDUAL && n_flag == 0);   // no early exit: the tail below has barriers
+  const bool solo = fused && fin.solo > 0;   // whole proposals per workgroup (tail below), not row blocks
+  const bool active = !(FAT && !wi.valid) && !(MODE == MODE_RESIDUAL && n_flag == 0) && !solo;   // no early exit: the tail below has barriers
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;
@@ -367,28 +368,17 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
 #endif
   if constexpr (CAN_FUSE) {
     if (!fused) return;
-    // Finalise, fused: every workgroup publishes its residual sums and checks in; the last one to arrive runs the
-    // flagged proposals' solves on its sixteen waves (one launch, one launch gap and one blocked CU fewer per batch).
     __shared__ int s_last;
     __shared__ double sh_fin[4 * BSR_WG_WAVES][BSR_NQ_MAX];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-      if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
     double* sh_c = sh_fin[wave_raw];
-    for (int fi = wave_raw; fi < n_flag; fi += 4 * BSR_WG_WAVES) {
-      const int p = flagged[1 + fi];
+    // one flagged proposal: its residual sums over the row blocks (one wave, blocks lane-strided, as k_finalize), then
+    // the solve with the exact residual
+    auto finalize_one = [&](const int p) {
       const PropCoef* cfp = coef + p;
       double ww = 0.0, wy = 0.0;
       for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
         const double* q = part + ((size_t)p * n_rb + rb) * BSR_P2_WORDS;
-        ww += __builtin_nontemporal_load(q);        // written by other workgroups of this launch: not through a
+        ww += __builtin_nontemporal_load(q);        // written by other waves of this launch: not through a
         wy += __builtin_nontemporal_load(q + 1);    // possibly stale line of this CU's caches
       }
       ww = wave_sum(ww);
@@ -415,7 +405,35 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
       in.mh = fin.mh + p;
       if constexpr (NQ >= 1 && NQ <= 4) solve_regs<NQ>(in, lane, fin.out + p);
       else if constexpr (NQ >= 5) solve_cols<NQ>(in, lane, fin.out + p);
+    };
+    if (solo) {
+      // Whole proposals: workgroup b takes flagged proposals b, b + grid, ...; its sixteen waves run the proposal's
+      // row blocks (the same (proposal, row block) tasks and partial records as the block-per-workgroup form, so the
+      // sums are the same to the bit), meet at a workgroup barrier, and the first wave finalises.  Nothing crosses a
+      // workgroup: no arrival counter, no device-scope fence under the other batches' row passes.
+      for (int fi = (int)blockIdx.x; fi < n_flag; fi += (int)gridDim.x) {
+        const int p = flagged[1 + fi];
+        for (int rb = wave_raw; rb < n_rb; rb += 4 * BSR_WG_WAVES) run_task(p, rb, (int64_t)rb * rb_rows);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (wave_raw == 0) finalize_one(p);
+      }
+      return;
     }
+    // Finalise, fused: every workgroup publishes its residual sums and checks in; the last one to arrive runs the
+    // flagged proposals' solves on its sixteen waves (one launch, one launch gap and one blocked CU fewer per batch).
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+      if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int fi = wave_raw; fi < n_flag; fi += 4 * BSR_WG_WAVES) finalize_one(flagged[1 + fi]);
     if (fin.done_flag) {   // completion word for the polling host (see k_finalize)
       __threadfence_system();
       __syncthreads();
@@ -1340,6 +1358,7 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape)
     grid.x /= 4;
     block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
+    if (a.fin.ck && a.fin.solo > 0) grid.x = (unsigned)a.fin.solo;   // whole proposals per workgroup
   }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
   if (a.feat_list) {

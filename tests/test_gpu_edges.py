@@ -359,7 +359,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 
     def run(env):
         for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
-                  "BSR_SELFDUP", "BSR_STAGE_SUBSET"):
+                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -376,10 +376,20 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_TILE_PIPED": "1"}).tobytes() == base.tobytes()      # slice staged by LDS-DMA under the first tapes
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
+    assert run({"BSR_BAR_WRITE": "0"}).tobytes() == base.tobytes()       # input block by hipMemcpyAsync, not host stores
+    assert run({"BSR_WAIT_STREAM": "1"}).tobytes() == base.tobytes()     # the waiter synchronises with the stream, no event
+    # a launch as wide as the machine: other slices, other partial sums -- the same scores to rounding
+    wide = run({"BSR_AUX_CUS": "0"})
+    okw = base["rank"] == K
+    assert np.array_equal(wide["rank"], base["rank"])
+    assert np.allclose(wide["loglik"][okw], base["loglik"][okw], rtol=1e-9, atol=0)
     assert run({"BSR_SELFDUP": "0"}).tobytes() == base.tobytes()         # self-duplicates through the residual pass
     assert run({"BSR_STAGE_SUBSET": "0"}).tobytes() == base.tobytes()    # every tape group stages every column
     assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
+    assert run({"BSR_SOLO_TAIL": "16"}).tobytes() == base.tobytes()      # whole flagged proposals per workgroup (K <= 3)
+    assert run({"BSR_SOLO_TAIL": "0"}).tobytes() == base.tobytes()       # residual pass and k_finalize as two launches
+    assert run({"BSR_SOLO_TAIL": "3"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0", "BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
     rows = run({"BSR_TILE": "0"})
