@@ -97,6 +97,8 @@ struct BatchSlot {
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // scratch of the cost sort
+  bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
+                                 // descriptor restore): the next batch's input block then goes by a copy command
 
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
   const void** h_cols() const { return reinterpret_cast<const void**>(h_in + off_cols); }
@@ -1078,7 +1080,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   {
     // upload + row pass on the slot's stream
     hipStream_t s0 = s.stream;
-    if (c->bar_write) {
+    if (c->bar_write && !s.stream_dirty) {
       // the input block goes into device memory by plain stores through the PCIe BAR (write-combined, ~1 us for
       // 16 KB) instead of a copy command: one HIP call fewer per batch.  The slot's previous batch has been waited
       // for, so nothing on the device reads the block now; the stores are globally ordered before the doorbell write
@@ -1086,8 +1088,11 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       memcpy(s.d_in, s.h_in, j.in_bytes);
       std::atomic_thread_fence(std::memory_order_seq_cst);
     } else {
+      // (also when bsr_commit or a rescore left work on the slot's stream that nobody waited for -- it reads or writes
+      // the device block: the copy command is ordered behind it, host stores would not be)
       step(hipMemcpyAsync(s.d_in, s.h_in, j.in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
     }
+    s.stream_dirty = false;   // this batch's completion covers everything before it on the stream
     if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
     if (j.tile) {
       const uint64_t* codes = s.d_streams();
@@ -1650,6 +1655,7 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
   // the refresh that follows runs on the main stream: order it behind this column write
   HIPCHK(c, hipEventRecord(s.done, s.stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
+  s.stream_dirty = true;   // the re-run reads the slot's device input block and nobody waits for it here
   c->h_rin[chain].colmax[k] = s.h_out[idx].maxabs;
   c->h_rin[chain].colflags[k] = s.h_out[idx].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
@@ -1934,6 +1940,7 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
       memcpy(s.h_out, batch_scores.data(), sizeof(bsr_score) * B);
       memcpy(s.h_desc(), keep.data(), sizeof(PropDesc) * B);
       HIPCHK(c, hipMemcpyAsync(s.d_desc(), s.h_desc(), sizeof(PropDesc) * B, hipMemcpyHostToDevice, s.stream));
+      s.stream_dirty = true;   // a copy into the device input block is still on its way
       s.P = B;
       memcpy(c->last_us, timing, sizeof timing);
     }
