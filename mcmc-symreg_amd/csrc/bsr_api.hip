@@ -1225,7 +1225,9 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
 
 // CPUs this process may use: the affinity mask, cut down to the cgroup's CPU quota (the GPU boxes show 256 CPUs and
 // grant 16), shared by the ranks of a multi-process run.
-static double cpu_budget() {
+double bsr_internal_cpu_budget();
+static double cpu_budget() { return bsr_internal_cpu_budget(); }
+__attribute__((visibility("hidden"))) double bsr_internal_cpu_budget() {
   double n = 1e9;
   cpu_set_t set;
   CPU_ZERO(&set);

@@ -1498,9 +1498,13 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     return rc;
   }
   // tracing wants proposals in chain order: keep one group then
-  // four groups: with more, the launches get small (8 chains in 8 groups = 32 proposals each) faster than the extra
-  // overlap pays
-  static const int max_groups = std::max(1, std::min<int>(BSR_MAX_INFLIGHT, getenv("BSR_ENGINE_GROUPS") ? atoi(getenv("BSR_ENGINE_GROUPS")) : 4));
+  // A group's cycle is serial (generate, submit, wait for the batch's four dependent kernels, consume), so the groups
+  // in flight are what hides it.  Up to eight (one batch slot and one worker thread each) while K <= 4: 8 chains at
+  // K = 3 run at 1.55 M consumed proposals/s in eight groups against 1.14 M in four; at K = 8, where k_solve and
+  // k_finalize take 25 us per launch whatever its size, eight launches of 32 proposals lose 6 % against four of 64
+  // (tools/probes/engine_groups.sh).  Four also when the process has fewer than a dozen CPUs to itself.
+  const int dflt_groups = (e->K <= 4 && bsr_internal_cpu_budget() >= 12.0) ? 8 : 4;
+  const int max_groups = std::max(1, std::min<int>(BSR_MAX_INFLIGHT, getenv("BSR_ENGINE_GROUPS") ? atoi(getenv("BSR_ENGINE_GROUPS")) : dflt_groups));
   const int n_groups = trace ? 1 : std::max(1, std::min<int>(max_groups, (int)live.size()));
   // One worker thread per group (each with its own batch slot and HIP stream): proposal generation, staging and the
   // 6-8 HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single

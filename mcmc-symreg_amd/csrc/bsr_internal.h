@@ -184,6 +184,8 @@ __attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int sl
 __attribute__((visibility("hidden"))) void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi);
 __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
 __attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
+// CPUs this process may use (cgroup quota / local ranks): sizes the submission threads and the sampler's worker threads
+__attribute__((visibility("hidden"))) double bsr_internal_cpu_budget();
 
 // kernels (bsr_kernels.hip)
 // The finalise step fused behind the residual pass: its last workgroup to finish walks the flagged list (ck == null:
