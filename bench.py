@@ -293,6 +293,20 @@ def attach_traffic(out, name, B, C, dtype):
             rec = max(recs, key=lambda t: t[0])[1]
             out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
+    # the profiler's average duration of the same kernel from the committed kernel-stats run of this command
+    # (HIP events around one launch read 2-3 us more: the pair's own cost and the launch gap)
+    spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench_%s_B%d.csv" % (name, B))))
+    if C == WORKLOADS[name]["chains"] and dtype == "f64" and spaths:
+        import csv
+        best = None
+        for row in csv.DictReader(open(spaths[-1])):
+            kn = row.get("Name", "")
+            if "k_tile" in kn or ("k_rows" in kn and ", 0>" in kn):
+                if best is None or int(row["Calls"]) > int(best["Calls"]):
+                    best = row
+        if best:
+            out["roofline"]["kernel_us_rocprofv3"] = float(best["AverageNs"]) / 1e3
+            out["roofline"]["kernel_stats_source"] = os.path.relpath(spaths[-1], ROOT)
 
 
 def gather_trees(wl, ranks):
