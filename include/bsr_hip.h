@@ -120,7 +120,11 @@ int bsr_device_count(int* count);
  * (allcal / predict).  K and n_chains size the chain caches (current columns and their orthonormal basis);
  * max_batch bounds the proposals / tapes of one call and sizes the per-batch descriptor, partial-sum and result
  * blocks (O(max_batch * N / 1024) doubles).  Candidate columns are not stored by the scoring pass; the
- * max_batch * N column buffer of bsr_eval_tapes is allocated on its first use. */
+ * max_batch * N column buffer of bsr_eval_tapes is allocated on its first use.
+ * Side effect, once per process: the calling thread's CPU affinity is narrowed to one L3 domain of the host (the one
+ * it is on; one per LOCAL_RANK when several ranks share the node), and the threads the library and the HIP runtime
+ * start afterwards inherit it -- a batch crosses three threads, and across sockets that costs up to 20 % of the
+ * pipelined rate.  BSR_PIN=0 leaves the affinity alone, BSR_PIN_CPUS gives the CPU list. */
 int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor,
                    const double* y, int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype);
 int bsr_ctx_destroy(bsr_ctx* ctx);

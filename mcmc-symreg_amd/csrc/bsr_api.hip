@@ -333,10 +333,82 @@ static int upload_data(bsr_ctx* c, const double* X, const double* y) {
   return BSR_OK;
 }
 
+static std::atomic<bool> g_pinned{false};   // this process confined itself to an L3 domain of its own (pin_to_l3_domain)
+// "0-7,128-135" -> CPU set; false when nothing parses
+static bool parse_cpulist(const char* txt, cpu_set_t* set) {
+  CPU_ZERO(set);
+  int n = 0;
+  for (const char* p = txt; p && *p;) {
+    while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    if (*p < '0' || *p > '9') break;
+    char* end = nullptr;
+    long a = strtol(p, &end, 10), b = a;
+    if (end && *end == '-') b = strtol(end + 1, &end, 10);
+    for (long i = a; i <= b && i < CPU_SETSIZE; ++i) {
+      CPU_SET((int)i, set);
+      ++n;
+    }
+    p = end;
+  }
+  return n > 0;
+}
+static bool l3_domain_of(int cpu, cpu_set_t* set) {
+  char path[128], buf[1024];
+  snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+  fclose(f);
+  return ok && parse_cpulist(buf, set);
+}
+// The calling thread -- and with it every thread the context and the HIP runtime start from here on -- is confined to
+// the CPUs of one L3 domain (a CCX: 8 cores and their SMT siblings on the EPYC hosts of MI355X boxes).  A batch passes
+// through the caller, a submission thread and the runtime's own threads; left to roam two sockets and sixteen L3
+// domains, the pipelined step of the C2 bench measures anything from 17.9 to 21.6 us run by run, confined to one
+// domain 17.3 us every time (tools/probes/taskset_ab.sh).  One process: the domain the caller is on.  Several ranks
+// on the node (LOCAL_RANK / LOCAL_WORLD_SIZE): the domains of the allowed CPUs dealt evenly by local rank.
+// BSR_PIN=0: leave the affinity alone; BSR_PIN_CPUS="0-7,128-135": this list.  Once per process; never fails.
+static void pin_to_l3_domain() {
+  static std::atomic<bool> done{false};
+  if (done.exchange(true)) return;
+  if (!env_int("BSR_PIN", 1)) return;
+  cpu_set_t allowed, want;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+  CPU_ZERO(&want);
+  const char* list = getenv("BSR_PIN_CPUS");
+  if (list && *list) {
+    if (!parse_cpulist(list, &want)) return;
+  } else {
+    const int lr = env_int("LOCAL_RANK", -1), lw = env_int("LOCAL_WORLD_SIZE", 1);
+    if (lw > 1 && lr >= 0) {
+      std::vector<cpu_set_t> doms;
+      cpu_set_t seen;
+      CPU_ZERO(&seen);
+      for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+        if (!CPU_ISSET(cpu, &allowed) || CPU_ISSET(cpu, &seen)) continue;
+        cpu_set_t dset;
+        if (!l3_domain_of(cpu, &dset)) return;
+        CPU_OR(&seen, &seen, &dset);
+        doms.push_back(dset);
+      }
+      if (doms.empty()) return;
+      const size_t nd = doms.size();
+      want = doms[nd >= (size_t)lw ? ((size_t)lr * nd) / (size_t)lw : (size_t)lr % nd];
+    } else {
+      const int cpu = sched_getcpu();
+      if (cpu < 0 || !l3_domain_of(cpu, &want)) return;
+    }
+  }
+  CPU_AND(&want, &want, &allowed);
+  if (CPU_COUNT(&want) < 4) return;   // not worth it (and a submission thread needs a core of its own)
+  if (sched_setaffinity(0, sizeof want, &want) == 0) g_pinned.store(true);
+}
+
 extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X, const double* y,
                               int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype) {
   if (!out) return BSR_E_ARG;
   *out = nullptr;
+  pin_to_l3_domain();   // before the first HIP call of the process, if this is it
   if (!X || N <= 0 || d <= 0 || d > 65536) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
   if (K < 0 || K > BSR_MAX_K || n_chains < 0 || max_batch <= 0)
     return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad K/n_chains/max_batch");
@@ -1228,10 +1300,16 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
 double bsr_internal_cpu_budget();
 static double cpu_budget() { return bsr_internal_cpu_budget(); }
 __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget() {
-  double n = 1e9;
+  // what the ranks of the node share (the CPUs they may all run on, the cgroup's quota) is divided among them; a CPU
+  // set the rank has to itself (pin_to_l3_domain) is not
+  const int local_world = std::max(1, env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1)));
+  double n = 1e9, own = 1e9;
   cpu_set_t set;
   CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof set, &set) == 0) n = (double)CPU_COUNT(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) {
+    if (g_pinned.load()) own = (double)CPU_COUNT(&set);
+    else n = (double)CPU_COUNT(&set);
+  }
   if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
     char q[32];
     double per = 0;
@@ -1247,8 +1325,7 @@ __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget() {
     }
     if (quota > 0 && per > 0) n = std::min(n, quota / per);
   }
-  const int local_world = std::max(1, env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1)));
-  return n / local_world;
+  return std::min(own, n / local_world);
 }
 
 static void launcher_start(bsr_ctx* c) {
