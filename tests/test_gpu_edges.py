@@ -397,3 +397,49 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     ok = base["rank"] == K
     assert np.allclose(rows["loglik"][ok], base["loglik"][ok], rtol=1e-9, atol=0)
     assert run({"BSR_TILE": "0", "BSR_DERIVED": "0"}).tobytes() == rows.tobytes()
+
+
+def test_context_creation_confines_the_process_to_one_l3_domain():
+    """bsr_ctx_create narrows the calling thread's CPU affinity to one L3 domain of the host (DESIGN 7, "CPU placement");
+    BSR_PIN=0 leaves it alone, BSR_PIN_CPUS names the CPUs.  Fresh interpreters: the narrowing happens once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, os.path.join(%r, 'mcmc-symreg_amd'))\n"
+        "from bsr.device import DeviceContext\n"
+        "before = sorted(os.sched_getaffinity(0))\n"
+        "cpu = before[0]\n"
+        "X = np.random.RandomState(0).uniform(-1, 1, size=(300, 2))\n"
+        "c = DeviceContext(X, X[:, 0], K=2, n_chains=1, max_batch=4)\n"
+        "after = sorted(os.sched_getaffinity(0))\n"
+        "c.close()\n"
+        "print(json.dumps({'before': before, 'after': after}))\n" % root)
+
+    def run(extra):
+        env = dict(os.environ)
+        for k in ("BSR_PIN", "BSR_PIN_CPUS", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+            env.pop(k, None)
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    off = run({"BSR_PIN": "0"})
+    assert off["after"] == off["before"]
+    on = run({})
+    assert set(on["after"]) <= set(on["before"]) and len(on["after"]) >= min(4, len(on["before"]))
+    path = "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % on["before"][0]
+    if os.path.exists(path) and len(on["before"]) > 32:       # a big host: the domain is a strict subset
+        assert len(on["after"]) < len(on["before"])
+    if len(on["before"]) >= 8:
+        pick = on["before"][:4]
+        got = run({"BSR_PIN_CPUS": ",".join(str(c) for c in pick)})
+        assert got["after"] == pick
+    # two ranks on the node take different domains
+    if len(on["before"]) > 32:
+        r0 = run({"LOCAL_RANK": "0", "LOCAL_WORLD_SIZE": "2"})
+        r1 = run({"LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2"})
+        assert not (set(r0["after"]) & set(r1["after"]))
