@@ -36,6 +36,10 @@
 //                  (allcal / set_current).
 //   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
+#ifndef BSR_SOLVE_WAVES
+#define BSR_SOLVE_WAVES 4   // k_solve: proposals (waves) per workgroup (measured at C2 / K=8, us per step: 4: 17.3 / 27.2,
+                           // 8: 17.9 / 29.7, 16: 19.7 / 37.7 -- tools/probes/lib_ab.sh)
+#endif
 
 // In-kernel timing stamps (debug builds only: -DBSR_STAMPS): shader-clock samples of the first waves of the PROJECT
 // pass, read back with bsr_debug_stamps().  tools/stamps.py prints the per-phase cycle budget of a wave.
@@ -732,7 +736,7 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
   }
 }
 
-__global__ __launch_bounds__(4 * BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
+__global__ __launch_bounds__(BSR_SOLVE_WAVES * BSR_WAVE) void k_solve(const PropDesc* __restrict__ desc, const ChainB* __restrict__ cks,
                                                     int P, int n_rb, const double* __restrict__ part1, int64_t N,
                                                     PropCoef* __restrict__ coef, bsr_score* __restrict__ outv,
                                                     double rank_floor, int32_t* __restrict__ flagged,
@@ -741,13 +745,14 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_solve(const PropDesc* __restri
   // residual pass and k_finalize read it, and the other list -- consumed by the batch before -- is emptied here
   if (blockIdx.x == 0 && threadIdx.x == 0 && flagged_next) flagged_next[0] = 0;
   // one wave per proposal, four waves per workgroup: a quarter of the CUs touched (a tile workgroup of another batch
-  // cannot start on a CU that hosts even one of these waves)
+  // cannot start on a CU that hosts even one of these waves); eight or sixteen per workgroup measured slower -- the
+  // bigger workgroup itself waits longer for a CU with that many registers free
   const int wave_id = threadIdx.x >> 6;
-  const int p = blockIdx.x * 4 + wave_id;
+  const int p = blockIdx.x * BSR_SOLVE_WAVES + wave_id;
   if (p >= P) return;
   const int lane = threadIdx.x & 63;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
-  __shared__ double sh_all_c[4][BSR_NQ_MAX];
+  __shared__ double sh_all_c[BSR_SOLVE_WAVES][BSR_NQ_MAX];
   double* sh_c = sh_all_c[wave_id];
 
   double sum[BSR_NQ_MAX + 2];
@@ -1395,7 +1400,7 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                   int32_t* flagged_next) {
-  hipLaunchKernelGGL(k_solve, dim3((P + 3) / 4), dim3(4 * BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
+  hipLaunchKernelGGL(k_solve, dim3((P + BSR_SOLVE_WAVES - 1) / BSR_SOLVE_WAVES), dim3(BSR_SOLVE_WAVES * BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
                      flagged, mh, flagged_next);
 }
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
