@@ -810,7 +810,18 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
     s.part1 = s.part2 = nullptr;
     const size_t cap = recs + recs / 2;
     HIPCHK(c, hipMalloc((void**)&s.part1, cap * BSR_P1_WORDS * sizeof(double)));
-    HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double)));
+    // fuse_finalize == 2: the residual sums and the arrival counter live in uncached device memory, so the hand-over
+    // inside the fused launch needs no cache write-back or invalidate (8 B of counter behind the records)
+    if (c->fuse_finalize == 2) {
+      if (hipExtMallocWithFlags((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        c->fuse_finalize = 0;
+        HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64));
+      }
+      HIPCHK(c, hipMemset(s.part2, 0, cap * BSR_P2_WORDS * sizeof(double) + 64));
+    } else {
+      HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64));
+    }
     s.part_cap = cap;
   }
   if (spill_slots > 0) {
@@ -1195,9 +1206,12 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     if (j.on_aux) step(hipEventRecord(s.tile_done, s0), "hipEventRecord");
   }
   if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
-  static const int dbg_skip = env_int("BSR_DEBUG_SKIP_TAIL", 0);   // timing experiment: 1 = no residual/finalise, 2 = no solve either (results are wrong)
+  // timing experiments (results are wrong): 1 = no residual/finalise, 2 = no solve either, 3 = all three launched but
+  // the solve handles one proposal only (the launches and kernel boundaries without the work)
+  static const int dbg_raw = env_int("BSR_DEBUG_SKIP_TAIL", 0);
+  static const int dbg_skip = (dbg_raw == 3) ? 0 : dbg_raw;
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  if (dbg_skip < 2) launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+  if (dbg_skip < 2) launch_solve(st, s.d_desc(), c->d_ck, (dbg_raw == 3) ? 1 : j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
@@ -1214,6 +1228,11 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     if (fuse_fin) {
       fin.ck = c->d_ck; fin.out = s.h_out; fin.mh = s.d_mh; fin.rank_floor = j.rank_floor;
       fin.arrive = s.d_flagged + 2 * s.flag_stride + 1;
+      fin.uncached = 0;
+      if (c->fuse_finalize == 2 && !solo) {   // counter behind the uncached records
+        fin.arrive = reinterpret_cast<int32_t*>(s.part2 + s.part_cap * BSR_P2_WORDS);
+        fin.uncached = 1;
+      }
       fin.done_flag = s.use_flag ? s.h_flag : nullptr;
       fin.done_gen = s.flag_gen;
       fin.solo = solo ? c->solo_tail : 0;

@@ -198,6 +198,7 @@ struct FinArgs {
   int32_t* arrive;       // workgroup arrival counter (zero between launches)
   uint32_t* done_flag;   // pinned completion word, or null
   uint32_t done_gen;
+  int uncached;          // the partial records and `arrive` are in uncached memory: hand over without cache maintenance
   int solo;              // > 0: that many workgroups, each taking whole flagged proposals (all row blocks, then the
                          // finalise step): no workgroup waits for another, no device-scope fence
 };

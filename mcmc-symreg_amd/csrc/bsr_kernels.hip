@@ -427,16 +427,30 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
     }
     // Finalise, fused: every workgroup publishes its residual sums and checks in; the last one to arrive runs the
     // flagged proposals' solves on its sixteen waves (one launch, one launch gap and one blocked CU fewer per batch).
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-      if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fin.uncached) {
+      // records and counter in uncached memory: a store is globally visible once it is acknowledged, a load never
+      // sees a cache -- waiting for the wave's own stores is the whole release, and there is nothing to acquire
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+        if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!s_last) return;
+    } else {
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+        if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
     for (int fi = wave_raw; fi < n_flag; fi += 4 * BSR_WG_WAVES) finalize_one(flagged[1 + fi]);
     if (fin.done_flag) {   // completion word for the polling host (see k_finalize)
       __threadfence_system();

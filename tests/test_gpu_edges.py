@@ -387,6 +387,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_STAGE_SUBSET": "0"}).tobytes() == base.tobytes()    # every tape group stages every column
     assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
+    assert run({"BSR_FUSE_FINALIZE": "2"}).tobytes() == base.tobytes()   # ... handing over through uncached memory
     assert run({"BSR_SOLO_TAIL": "16"}).tobytes() == base.tobytes()      # whole flagged proposals per workgroup (K <= 3)
     assert run({"BSR_SOLO_TAIL": "0"}).tobytes() == base.tobytes()       # residual pass and k_finalize as two launches
     assert run({"BSR_SOLO_TAIL": "3"}).tobytes() == base.tobytes()
