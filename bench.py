@@ -64,7 +64,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=float, default=15.0,
                     help="seconds of CPU oracle work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--depth", type=int, default=8, help="batches in flight, 1..8 (1 = synchronous calls)")
+    ap.add_argument("--depth", type=int, default=6,
+                    help="batches in flight, 1..8 (1 = synchronous calls); 6 of the context's 8 slots measure best: "
+                         "beyond that a batch only waits longer for CUs (DESIGN 7)")
     ap.add_argument("--extras", type=int, default=-1,
                     help="1: also run short legs of the other configs (c3, c5, c4's per-GPU share, native-engine chain "
                          "throughput) and report them under 'extra'; 0: headline only; -1: on for the default workload")
