@@ -5,7 +5,7 @@ for rep in ${REPS:-1 2}; do
   for w in ${WORKLOADS:-c2}; do
     for s in "${sets[@]}"; do
       e="$s"; [ "$s" = "-" ] && e=""
-      r=$(env $e python bench.py --workload $w --steps 2000 --warmup 200 --cpu-sample 0 --extras 0 2>/dev/null | tail -1 |
+      r=$(env $e python bench.py --workload $w ${BENCH_ARGS:-} --steps 2000 --warmup 200 --cpu-sample 0 --extras 0 2>/dev/null | tail -1 |
           python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3f M/s %.2f us  solo %.1f' % (d['value']/1e6, d['ms_per_step']*1000, d['roofline']['kernel_us']))")
       echo "rep=$rep W=$w [$s] $r"
     done
