@@ -43,7 +43,7 @@ def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
     procs = []
     for r in range(nprocs):
         env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs), "MASTER_ADDR": "127.0.0.1",
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs), "LOCAL_WORLD_SIZE": str(nprocs), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "BSR_RDV_DIR": rdv, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         if env_extra:
             env.update(env_extra)

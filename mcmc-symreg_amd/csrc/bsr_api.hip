@@ -379,7 +379,7 @@ static void pin_to_l3_domain() {
   if (list && *list) {
     if (!parse_cpulist(list, &want)) return;
   } else {
-    const int lr = env_int("LOCAL_RANK", -1), lw = env_int("LOCAL_WORLD_SIZE", 1);
+    const int lr = env_int("LOCAL_RANK", -1), lw = env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1));
     if (lw > 1 && lr >= 0) {
       std::vector<cpu_set_t> doms;
       cpu_set_t seen;
