@@ -1169,6 +1169,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       // for, so nothing on the device reads the block now; the stores are globally ordered before the doorbell write
       // of the launch below (fence, then posted writes in order), and every kernel start invalidates the caches
       memcpy(s.d_in, s.h_in, j.in_bytes);
+      __builtin_ia32_sfence();   // drain the write-combining buffers before anything that rings the doorbell
       std::atomic_thread_fence(std::memory_order_seq_cst);
     } else {
       // (also when bsr_commit or a rescore left work on the slot's stream that nobody waited for -- it reads or writes
