@@ -97,6 +97,7 @@ struct BatchSlot {
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // scratch of the cost sort
+  int head_rc = 0;               // result of a split batch's first phase (issue_batch)
   bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
                                  // descriptor restore): the next batch's input block then goes by a copy command
 
@@ -135,6 +136,7 @@ struct bsr_ctx {
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
   int aux_cus = 0;
+  int split_issue = 0;     // BSR_SPLIT_ISSUE: a batch's row pass is issued at once, the launches behind it after the waiting row passes
   int wait_stream = 0;
   int bar_write = 0;       // the host writes a batch's input block straight into device memory (large-BAR devices)
   int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the row pass is sized for (f64 kernels: 92 VGPRs -> 5)
@@ -503,6 +505,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // runtime takes ~3 us per call however many threads make them).  Measured: 34 us per step instead of 19 --
     // hipStreamSynchronize holds up the other threads' launches while it waits.  Opt-in, for the record.
     c->wait_stream = env_int("BSR_WAIT_STREAM", 0);
+    c->split_issue = env_int("BSR_SPLIT_ISSUE", 0);
     // Launch width of the tile pass: n_cu - BSR_AUX_CUS workgroups, by default three quarters of the CUs.  A tile
     // workgroup needs a whole CU (LDS and registers), and a launch as wide as the machine ends when its last workgroup
     // does: the CUs that finish early wait, the next batch's launch starts staging only then, and a CU that holds
@@ -1148,19 +1151,21 @@ struct TailJob {
   double rank_floor;
   size_t in_bytes;
   TileGeom tg;
+  int phase = 0;   // 0: the whole batch; 1: upload and row pass, then the rest goes back into the queue as 2 (split_issue)
 };
+static void launcher_push(bsr_ctx* c, const TailJob& job);
 
 static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   const long long t_issue0 = host_now();
   hipStream_t st = j.on_aux ? s.aux : s.stream;
-  int rc = BSR_OK;
+  int rc = (j.phase == 2) ? s.head_rc : BSR_OK;
   auto step = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == BSR_OK) {
       set_err(c, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
       rc = BSR_E_HIP;
     }
   };
-  {
+  if (j.phase != 2) {
     // upload + row pass on the slot's stream
     hipStream_t s0 = s.stream;
     if (c->bar_write && !s.stream_dirty) {
@@ -1205,6 +1210,16 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     }
     if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
     if (j.on_aux) step(hipEventRecord(s.tile_done, s0), "hipEventRecord");
+  }
+  if (j.phase == 1) {
+    // The row pass is out; the launches behind it have its whole duration to get there.  They go to the back of the
+    // queue, behind the row passes of the batches that are waiting: what a batch waits for first is its row pass.
+    s.head_rc = rc;
+    if (g_host_prof) g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
+    TailJob rest = j;
+    rest.phase = 2;
+    launcher_push(c, rest);
+    return rc;
   }
   if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
   // timing experiments (results are wrong): 1 = no residual/finalise, 2 = no solve either, 3 = all three launched but
@@ -1263,7 +1278,8 @@ struct Launcher {
   std::vector<std::thread> ths;   // one by default; BSR_SUBMIT_THREADS more share the queue (jobs of different slots)
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<TailJob> q;
+  std::deque<TailJob> q;          // whole batches and row passes (phases 0, 1)
+  std::deque<TailJob> q_rest;     // the launches behind a row pass (phase 2): taken when no row pass is waiting
   std::atomic<int> n_queued{0};
   int asleep = 0;
   bool stop = false;
@@ -1280,20 +1296,21 @@ static void launcher_main(bsr_ctx* c) {
     while (!have) {
       if (L->n_queued.load(std::memory_order_acquire) > 0) {
         std::lock_guard<std::mutex> lk(L->mu);
-        if (!L->q.empty()) {
-          job = L->q.front();
-          L->q.pop_front();
+        std::deque<TailJob>& from = !L->q.empty() ? L->q : L->q_rest;
+        if (!from.empty()) {
+          job = from.front();
+          from.pop_front();
           L->n_queued.fetch_sub(1, std::memory_order_relaxed);
           have = true;
         }
       } else if (std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(L->spin_us)) {
         std::unique_lock<std::mutex> lk(L->mu);
         if (L->stop) return;
-        if (L->q.empty()) {
+        if (L->q.empty() && L->q_rest.empty()) {
           ++L->asleep;
-          L->cv.wait(lk, [&] { return L->stop || !L->q.empty(); });
+          L->cv.wait(lk, [&] { return L->stop || !L->q.empty() || !L->q_rest.empty(); });
           --L->asleep;
-          if (L->stop && L->q.empty()) return;
+          if (L->stop && L->q.empty() && L->q_rest.empty()) return;
         }
       } else {
         __builtin_ia32_pause();
@@ -1308,7 +1325,7 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
   bool wake;
   {
     std::lock_guard<std::mutex> lk(L->mu);
-    L->q.push_back(job);
+    (job.phase == 2 ? L->q_rest : L->q).push_back(job);
     L->n_queued.fetch_add(1, std::memory_order_release);
     wake = L->asleep > 0;
   }
@@ -1508,6 +1525,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   // Seven HIP calls per batch cost the host more than staging the batch does.  A scoring batch is handed to the
   // context's submission thread, which issues them while the caller returns to stage its next batch.
   if (c->launcher && scoring) {
+    job.phase = c->split_issue ? 1 : 0;
     launcher_push(c, job);
   } else {
     rc = issue_batch(c, s, job);

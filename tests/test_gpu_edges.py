@@ -359,7 +359,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 
     def run(env):
         for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
-                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE"):
+                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE", "BSR_SPLIT_ISSUE"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -377,6 +377,8 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
     assert run({"BSR_BAR_WRITE": "0"}).tobytes() == base.tobytes()       # input block by hipMemcpyAsync, not host stores
+    assert run({"BSR_SPLIT_ISSUE": "1"}).tobytes() == base.tobytes()     # row pass issued first, the rest re-queued
+    assert run({"BSR_SPLIT_ISSUE": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_WAIT_STREAM": "1"}).tobytes() == base.tobytes()     # the waiter synchronises with the stream, no event
     # a launch as wide as the machine: other slices, other partial sums -- the same scores to rounding
     wide = run({"BSR_AUX_CUS": "0"})
