@@ -27,6 +27,7 @@ struct TapeLoc {
   int n_stream;  // opcode-stream entries after fusing `terminal, +|*` pairs
   int cost;      // rough relative cost of one sweep of the tape (orders the work queue: heaviest first)
   uint64_t slots;  // tile pass: the LDS slots the tape's terminals read (bit = slot; ~0: some slot >= 64)
+  int acc_only;    // chain tape: one leading terminal, every other stream entry maps the accumulator to itself
 };
 
 // Everything one batch in flight owns.  Two slots let the host stage batch i+1 while the GPU scores batch i.
@@ -97,6 +98,8 @@ struct BatchSlot {
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // scratch of the cost sort
+  std::vector<bsr_node> rows_perm;   // the batch's tapes in the order the streams are written in (reorder_tape)
+  std::vector<int32_t> perm_kid, perm_stack;   // scratch of reorder_tape
   int head_rc = 0;               // result of a split batch's first phase (issue_batch)
   bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
                                  // descriptor restore): the next batch's input block then goes by a copy command
@@ -165,6 +168,8 @@ struct bsr_ctx {
   std::vector<uint64_t> cur_hash;              // [chain*K+k] canonical hash of the current tree (0: unknown)
   std::vector<std::vector<bsr_node>> cur_tape;  // ... and its tape, to confirm a hash match
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
+  int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
+  int chain_eval = 1;   // BSR_CHAIN_EVAL: chain tapes take the register-resident pass of the tile kernel
   BatchSlot slot[BSR_MAX_INFLIGHT];
   int next_slot = 0;
   int last_waited = -1;
@@ -486,6 +491,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     c->tile_piped = env_int("BSR_TILE_PIPED", 0);
     c->stage_subset = env_int("BSR_STAGE_SUBSET", 1);
     c->selfdup = env_int("BSR_SELFDUP", 1);
+    c->reorder = env_int("BSR_REORDER", 1);
+    c->chain_eval = env_int("BSR_CHAIN_EVAL", 1);
     // k_finalize's work behind the residual pass in the same launch (last workgroup to arrive): one launch fewer per
     // batch, bit-identical -- and 3-4 us SLOWER per step at C2: the agent-scope release/acquire every residual
     // workgroup needs around the arrival counter writes back and invalidates its XCD's L2 under the row passes of the
@@ -841,6 +848,79 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
   return BSR_OK;
 }
 
+// Operand order of the commutative operators in the streams.  A bare terminal (or a `terminal, unary op` pair that
+// became a derived column) as the SECOND operand of + or * fuses with the operator into one stream entry
+// (BSR_SOP_ADD_T / BSR_SOP_MUL_T) and needs no stack slot; as the first operand, with anything else second, it is
+// pushed and popped.  So where exactly the first operand is such a terminal the two subtrees trade places
+// (x3 + ln(x1) is written `x1 ln x3 +`): a + b == b + a and a * b == b * a bit for bit, the value of every row is
+// unchanged, and almost every tape of the real move mix becomes a chain (bsr_device.h: chain_eval).
+// `admitted(j)`: nodes j, j+1 are a `terminal, unary op` pair whose derived column this batch uses.
+// Writes the reordered tape to `out` (may alias nothing of `t`) and returns true, or returns false: order kept.
+template <typename Admitted>
+static bool reorder_tape(const bsr_node* t, int len, bsr_node* out, std::vector<int32_t>& kid, std::vector<int32_t>& stk,
+                         const Admitted& admitted) {
+  if (len < 4) return false;   // the shortest tape with something to swap: T, T, op, +
+  // pass 1: children of every node, "is one terminal entry" per subtree; is there anything to swap at all?
+  kid.resize((size_t)len * 2);
+  stk.clear();
+  bool any = false;
+  // kid[2j], kid[2j+1]: roots of the left / right subtree (-1: none); termlike(j): the subtree is one terminal entry
+  auto termlike = [&](int j) {
+    if (t[j].opcode == BSR_OP_TERMINAL) return true;
+    return j > 0 && t[j - 1].opcode == BSR_OP_TERMINAL && kid[2 * j] == j - 1 && kid[2 * j + 1] < 0 && admitted(j - 1);
+  };
+  for (int j = 0; j < len; ++j) {
+    const int op = t[j].opcode;
+    kid[2 * j] = kid[2 * j + 1] = -1;
+    if (op == BSR_OP_TERMINAL) {
+      stk.push_back(j);
+    } else if (op == BSR_OP_ADD || op == BSR_OP_MUL || op == BSR_OP_SUB || op == BSR_OP_DIV) {
+      if (stk.size() < 2) return false;
+      const int r = stk.back();
+      stk.pop_back();
+      const int l = stk.back();
+      kid[2 * j] = l;
+      kid[2 * j + 1] = r;
+      stk.back() = j;
+      if ((op == BSR_OP_ADD || op == BSR_OP_MUL) && termlike(l) && !termlike(r)) any = true;
+    } else {
+      if (stk.empty()) return false;
+      kid[2 * j] = stk.back();
+      stk.back() = j;
+    }
+  }
+  if (!any || stk.size() != 1) return false;
+  // pass 2: post-order walk from the root with the swapped child order (explicit stack; entry = node, or ~node once its
+  // children have been pushed)
+  int n_out = 0;
+  stk.clear();
+  stk.push_back(len - 1);
+  while (!stk.empty()) {
+    const int e = stk.back();
+    stk.pop_back();
+    if (e < 0) {
+      out[n_out++] = t[~e];
+      continue;
+    }
+    const int l = kid[2 * e], r = kid[2 * e + 1];
+    if (l < 0) {
+      out[n_out++] = t[e];
+      continue;
+    }
+    stk.push_back(~e);
+    if (r < 0) {
+      stk.push_back(l);
+    } else {
+      const int op = t[e].opcode;
+      const bool swap = (op == BSR_OP_ADD || op == BSR_OP_MUL) && termlike(l) && !termlike(r);
+      // popped first = evaluated first
+      if (swap) { stk.push_back(l); stk.push_back(r); }
+      else { stk.push_back(r); stk.push_back(l); }
+    }
+  }
+  return n_out == len;
+}
+
 // Validates the tapes, chooses LDS staging, and writes the compact streams the interpreter reads into the slot's
 // pinned input block:
 //   opcode stream  : 4 bits per entry, 16 per 64-bit word, one padding word per tape; an entry is a tape node, or a
@@ -914,18 +994,51 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     for (size_t q = 0; q < cand.size() && (int)q < allowance; ++q)
       if (cand[q].first >= 5) s.slot_of[cand[q].second] = -2;
   }
+  // the order the streams are written in: commutative operands swapped where that turns a push/pop into a fused entry
+  const bsr_node* src = rows;
+  if (c->reorder && tape_off[n] > 0) {
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+      const int len = tape_off[i + 1] - tape_off[i];
+      if (len < 4 || len > BSR_MAX_TAPE) continue;
+      const bsr_node* t = rows + tape_off[i];
+      auto admitted = [&](int j) {   // nodes j, j+1: `terminal, unary op` served by a derived column of this batch
+        if (!derive || j + 1 >= len) return false;
+        const int m = derived_index(t[j + 1].opcode), f = t[j].feature;
+        return m >= 0 && f >= 0 && f < c->d && s.slot_of[c->d * (1 + m) + f] == -2;
+      };
+      if (!any) {   // first tape that changes: from here on the passes below read the copy
+        if ((int)s.rows_perm.size() < tape_off[n]) s.rows_perm.resize((size_t)tape_off[n]);
+      }
+      if (reorder_tape(t, len, s.rows_perm.data() + tape_off[i], s.perm_kid, s.perm_stack, admitted)) {
+        if (!any) memcpy(s.rows_perm.data(), rows, (size_t)tape_off[i] * sizeof(bsr_node));
+        any = true;
+      } else if (any) {
+        memcpy(s.rows_perm.data() + tape_off[i], t, (size_t)len * sizeof(bsr_node));
+      }
+    }
+    if (any) {
+      // tapes skipped above (short or oversized: the latter fail validation below) still have to be in the copy
+      for (int i = 0; i < n; ++i) {
+        const int len = tape_off[i + 1] - tape_off[i];
+        if (len > 0 && (len < 4 || len > BSR_MAX_TAPE))
+          memcpy(s.rows_perm.data() + tape_off[i], rows + tape_off[i], (size_t)len * sizeof(bsr_node));
+      }
+      src = s.rows_perm.data();
+    }
+  }
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
-    int rc = check_tape(c, rows + tape_off[i], len, &L.max_sp);
+    int rc = check_tape(c, src + tape_off[i], len, &L.max_sp);
     if (rc != BSR_OK) return rc;
     int nt = 0, nl = 0, fsp = 0, fmx = 0;  // fsp: stack depth with `terminal, +|*` pairs fused (what the kernels run)
     for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
-      if (rows[j].opcode == BSR_OP_TERMINAL) {
+      if (src[j].opcode == BSR_OP_TERMINAL) {
         ++nt;
-        int col = rows[j].feature;
+        int col = src[j].feature;
         if (derive && j + 1 < tape_off[i + 1]) {   // `terminal, unary op` -> the op's derived column
-          const int m = derived_index(rows[j + 1].opcode);
+          const int m = derived_index(src[j + 1].opcode);
           if (m >= 0) {
             const int dc = c->d * (1 + m) + col;
             if (s.slot_of[dc] == -2 || s.slot_of[dc] == 0) {   // admitted above
@@ -936,11 +1049,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
           }
         }
         s.slot_of[col] = 0;
-        const int nxt = (j + 1 < tape_off[i + 1]) ? rows[j + 1].opcode : -1;
+        const int nxt = (j + 1 < tape_off[i + 1]) ? src[j + 1].opcode : -1;
         if (nt > 1 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
-      } else if (rows[j].opcode == BSR_OP_LN) {
+      } else if (src[j].opcode == BSR_OP_LN) {
         ++nl;
-      } else if (is_binary_op(rows[j].opcode)) {
+      } else if (is_binary_op(src[j].opcode)) {
         --fsp;
       }
       fmx = std::max(fmx, fsp);
@@ -1004,14 +1117,15 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     uint64_t* pf2 = hf2 + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
     int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 8;
+    int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
     uint64_t slots_mask = 0;
     for (int j = 0; j < L.n_nodes; ++j) {
-      const bsr_node& r = rows[tape_off[i] + j];
+      const bsr_node& r = src[tape_off[i] + j];
       int code = r.opcode & 15;
       if (r.opcode == BSR_OP_TERMINAL) {
         int col = r.feature;
         if (derive && j + 1 < L.n_nodes) {   // the column pass 1 admitted for `terminal, unary op` (slot assigned)
-          const int m = derived_index(rows[tape_off[i] + j + 1].opcode);
+          const int m = derived_index(src[tape_off[i] + j + 1].opcode);
           if (m >= 0 && s.slot_of[c->d * (1 + m) + col] >= 0) {
             col = c->d * (1 + m) + col;
             ++j;
@@ -1026,12 +1140,13 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
         // one stream entry: acc = acc op X[:,f], no push/pop
-        const int nxt = (j + 1 < L.n_nodes) ? rows[tape_off[i] + j + 1].opcode : -1;
+        const int nxt = (j + 1 < L.n_nodes) ? src[tape_off[i] + j + 1].opcode : -1;
         if (ns > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
           code = (nxt == BSR_OP_ADD) ? BSR_SOP_ADD_T : BSR_SOP_MUL_T;
           ++j;
         } else {
           ++sp;
+          ++n_push;
         }
       } else if (r.opcode == BSR_OP_LN) {
         pl[2 * nl] = r.a;
@@ -1039,6 +1154,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         ++nl;
       } else if (is_binary_op(r.opcode)) {
         --sp;
+        ++n_stack_ops;
       }
       mx = std::max(mx, sp);
       pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
@@ -1055,6 +1171,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     (*loc)[i].slots = slots_mask;
     (*loc)[i].cost = cost;
     (*loc)[i].max_sp = mx;
+    (*loc)[i].acc_only = (c->chain_eval && n_push == 1 && n_stack_ops == 0) ? 1 : 0;
     pl[2 * nl] = 1.0;
     pl[2 * nl + 1] = 0.0;
     if (!s.use_lds) {  // padding ids must name a valid column: repeat the first terminal's
@@ -1079,6 +1196,7 @@ static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
   D->ln_off = L.ln_off;
   D->spill_need = std::max(0, L.max_sp - 1 - 2);  // sized for the smallest register stack (2 slots at 8 rows/lane)
   D->cost = L.cost;
+  D->chain = L.acc_only;
 }
 
 static void fill_eval_desc(bsr_ctx* c, PropDesc* D, const TapeLoc& L, void* zout) {

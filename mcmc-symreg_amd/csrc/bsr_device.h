@@ -111,6 +111,52 @@ __device__ __forceinline__ void wave_sum8(double (&v)[8], double& lo, double& hi
   hi = row_sum16(v[4] + v[6]);  // rows: values 4, 6, 5, 7
 }
 
+// The in-row half of those reductions on the LDS crossbar instead of the VALU: ds_swizzle (bit mode: lane ^ x inside a
+// group of 32 lanes) moves the partner's value without touching memory, so a butterfly step costs the vector unit one
+// add instead of two DPP moves and an add.  The row pass is bound by vector issue and its LDS pipe has room.
+template <int XOR>
+__device__ __forceinline__ double swz_xor_f64(double v) {
+  constexpr int pat = 0x1f | (XOR << 10);   // and_mask 0x1f, or_mask 0, xor_mask XOR
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16_swz(double v) {  // all 16 lanes of a row end with the row's sum
+  v += swz_xor_f64<1>(v);
+  v += swz_xor_f64<2>(v);
+  v += swz_xor_f64<4>(v);
+  v += swz_xor_f64<8>(v);
+  return v;
+}
+// same combination order as wave_sum8 (swap32, swap16, then xor 1, 2, 4, 8 inside a row): bit-identical totals
+__device__ __forceinline__ void wave_sum8_swz(double (&v)[8], double& lo, double& hi) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    swap32(v[i], v[i + 1]);
+    v[i] += v[i + 1];
+  }
+  swap16(v[0], v[2]);
+  swap16(v[4], v[6]);
+  lo = row_sum16_swz(v[0] + v[2]);
+  hi = row_sum16_swz(v[4] + v[6]);
+}
+// maximum of non-negative values over the wave; lanes 32..63 end with it.  v_max_f64 itself (no canonicalising
+// self-maximum in front: the inputs are sums of |z| maxima, never signalling).
+__device__ __forceinline__ double vmax_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));   // the nops: a DPP read may follow
+  return r;
+}
+__device__ __forceinline__ double wave_max_swz_hi(double v) {
+  v = vmax_raw(v, swz_xor_f64<1>(v));
+  v = vmax_raw(v, swz_xor_f64<2>(v));
+  v = vmax_raw(v, swz_xor_f64<4>(v));
+  v = vmax_raw(v, swz_xor_f64<8>(v));
+  v = vmax_raw(v, swz_xor_f64<16>(v));
+  // lanes 0..31 hold the maximum of the lower half, lanes 32..63 of the upper: lane 31 -> rows 2, 3 (0 elsewhere)
+  return vmax_raw(v, dpp_f64<0x143, 0xC>(v));
+}
+
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
@@ -415,9 +461,6 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
   nt = 1;
   ldr.load((int)(fhead & 0xFFFFu), pre);  // data of the next terminal (padding repeats a valid column)
   code >>= 4;
-#ifdef BSR_ABLATE_TAPE     // timing experiment: the tape is its first terminal (results are wrong)
-  n = 1;
-#endif
   for (int i = 1; i < n; ++i) {
     if ((i & 15) == 0) {
       code = code_next;
@@ -529,6 +572,138 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
           for (int u = 0; u < U; ++u) acc[u] = op_cube<T>(acc[u]);
           break;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Chain tapes.  After the encoder's two fusions (`terminal f, unary op` -> derived column, `terminal, +|*` -> one entry;
+// commutative operands reordered so that a bare terminal comes second) almost every tape of the real move mix is a
+// CHAIN: its first entry is a terminal and every other entry maps the accumulator to the accumulator -- a unary
+// operator or `acc (+|*) column`.  A chain needs no value stack, so a wave can hold a whole pass of NB row blocks
+// (2 NB values per lane) in registers and run the tape over them entry by entry: the wave-uniform decode of an entry is
+// paid once per NB * 128 rows, every operator works in place (no operand copies), and the values of a row are the
+// same as the stack machine's (same operators, same order; a + b == b + a bit for bit).
+// Values 2j, 2j+1 of a pass = the lane's pair of rows of block j.  FULL: the pass holds NB blocks (the hot case: every
+// load has a compile-time offset); otherwise nb < NB of them, and the blocks behind copy block 0 -- computed along,
+// never accumulated.
+template <typename T, int NB, bool FULL>
+struct LdsPass {
+  const T* sx;
+  int rb_rows;
+  int off;  // element offset of the lane's pair in block 0 of the pass, inside the staged slice
+  int nb;   // blocks of this pass, 1..NB (wave-uniform)
+  __device__ __forceinline__ void load(int slot, T (&v)[2 * NB]) const {
+    using V2 = typename VecOf<T, 2>::type;
+    const T* col = sx + slot * rb_rows + off;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (FULL || j == 0 || j < nb) {
+        const V2 p = *reinterpret_cast<const V2*>(col + j * 128);
+        v[2 * j] = p.x;
+        v[2 * j + 1] = p.y;
+      } else {
+        v[2 * j] = v[0];
+        v[2 * j + 1] = v[1];
+      }
+    }
+  }
+};
+
+// acc <- f(acc) through the out-of-line routine `f`, four values per call; groups that hold no block of the pass are skipped
+#define BSR_CHAIN_CALL(f)                                                          \
+  _Pragma("unroll") for (int j = 0; j < U / 4; ++j) {                              \
+    if (FULL || j == 0 || 2 * j < nb) {                                            \
+      typename VecOf<T, 4>::type r, v;                                             \
+      v.x = acc[4 * j]; v.y = acc[4 * j + 1]; v.z = acc[4 * j + 2]; v.w = acc[4 * j + 3]; \
+      r = f(v);                                                                    \
+      acc[4 * j] = r.x; acc[4 * j + 1] = r.y; acc[4 * j + 2] = r.z; acc[4 * j + 3] = r.w; \
+    }                                                                              \
+  }
+
+template <typename T, int NB, bool FULL>
+__device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* codes, const uint64_t* feats,
+                                           const double* lnp, int n, const T* sx, int rb_rows, int off, int nb,
+                                           T (&acc)[2 * NB]) {
+  constexpr int U = 2 * NB;
+  static_assert(U % 4 == 0, "the out-of-line routines take four values");
+  const uint64_t CONSTANT_AS* cw = as_const(codes);
+  const uint64_t CONSTANT_AS* fw = as_const(feats);
+  const double CONSTANT_AS* lp = as_const(lnp);
+  const LdsPass<T, NB, FULL> ldr{sx, rb_rows, off, nb};
+  uint64_t code = hd.code0, code_next = hd.code1;
+  uint64_t fhead = hd.f0, fnext = hd.f1;
+  double la = hd.la, lb = hd.lb;
+  int ci = 1, fi = 1, li = 1, nt = 1;
+  ldr.load((int)(fhead & 0xFFFFu), acc);  // entry 0 is the chain's terminal
+  fhead >>= 16;
+  code >>= 4;
+  for (int i = 1; i < n; ++i) {
+    if ((i & 15) == 0) {
+      code = code_next;
+      ++ci;
+      code_next = cw[ci];
+    }
+    const int op = (int)(code & 15u);
+    code >>= 4;
+    switch (op) {
+      case BSR_SOP_ADD_T:
+      case BSR_SOP_MUL_T: {
+        T pre[U];
+        ldr.load((int)(fhead & 0xFFFFu), pre);
+        fhead >>= 16;
+        if (++nt == 4) {
+          fhead = fnext;
+          ++fi;
+          fnext = fw[fi];
+          nt = 0;
+        }
+        if (op == BSR_SOP_ADD_T) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
+        }
+      } break;
+      case BSR_OP_INV:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
+        break;
+      case BSR_OP_LN: {
+        const T a = (T)la, b = (T)lb;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
+        la = lp[2 * li];
+        lb = lp[2 * li + 1];
+        ++li;
+      } break;
+      case BSR_OP_NEG:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = -acc[u];
+        break;
+      case BSR_OP_SIN:
+        BSR_CHAIN_CALL(sin_rows)
+        break;
+      case BSR_OP_COS:
+        BSR_CHAIN_CALL(cos_rows)
+        break;
+      case BSR_OP_EXP:
+        BSR_CHAIN_CALL(exp_rows)
+        break;
+      case BSR_OP_LOG:
+        BSR_CHAIN_CALL(log_rows)
+        break;
+      case BSR_OP_SQUARE:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
+        break;
+      case BSR_OP_CUBIC:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = op_cube<T>(acc[u]);
+        break;
+      default:  // a chain holds no other entry (the host routes everything else to the stack machine)
+        break;
     }
   }
 }

@@ -56,6 +56,7 @@ struct PropDesc {
   int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
   int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
   int32_t qslot;        // tile pass: LDS slot of the chain's first basis column (K consecutive slots)
+  int32_t chain;        // the tape is a chain (bsr_device.h: chain_eval): first entry a terminal, every other one acc -> acc
   int32_t self_dup;     // the host found the candidate to be the chain's current tree k again (same canonical form, up to
                         // root negation): its column lies in the span exactly, w = 0 needs no residual pass
   const void* qbase;    // first basis column (nq columns, stride ld)

@@ -779,7 +779,9 @@ __global__ __launch_bounds__(BSR_SOLVE_WAVES * BSR_WAVE) void k_solve(const Prop
 #pragma unroll
     for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += q[i];
     amax = fmax(amax, q[10]);
-    fl |= (uint32_t)q[11];
+    // the census of a partial record: inf in a row <=> its max|z| is inf; NaN in a row <=> its |s z|^2 is NaN (the tile
+    // pass leaves word 11 zero and the census to these two tests; the work-queue pass also sets the bits itself)
+    fl |= (uint32_t)q[11] | ((q[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q[8]) ? BSR_F_NAN : 0u);
   }
 #pragma unroll
   for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = wave_sum(sum[i]);

@@ -13,6 +13,7 @@
 // What is summed in which order depends only on the context (rows per lane, slice boundaries), never on the batch:
 // a proposal's partial sums -- hence its score -- are bit-identical whatever else shares the launch.
 #include <cstddef>
+#include <type_traits>
 
 #include "bsr_device.h"
 
@@ -35,10 +36,6 @@ template <typename T, int KQ, bool MASK>
 __device__ __forceinline__ void accumulate_v(TapeAcc<KQ>& A, const T (&z)[BSR_TILE_U], const typename VecOf<T, 2>::type yv,
                                              const typename VecOf<T, 2>::type (&qv)[KQ > 0 ? KQ : 1], double s,
                                              int64_t row0, int64_t N) {
-#ifdef BSR_ABLATE_ACC      // timing experiment: one sum only (results are wrong)
-  A.a0 += (double)z[0] + (double)z[1];
-  return;
-#endif
 #pragma unroll
   for (int u = 0; u < BSR_TILE_U; ++u) {
     T zv = z[u];
@@ -162,17 +159,10 @@ __device__ __forceinline__ void dma_wait_left(int left) {
   }
 }
 
-// Lane reduction of one tape's sums and the store of its (tape, slice) partial record; every lane stores the same
-// totals (no lane-divergent branch).
+// Lane reduction of one tape's sums and the store of its (tape, slice) partial record.  Words 0..7: projections,
+// 8: |s z|^2, 9: s z.y, 10: max|z|, 11: 0 (the inf / NaN census is taken from words 10 and 8 by k_solve).
 template <int KQ>
 __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, int lane) {
-#ifdef BSR_ABLATE_REDUCE   // timing experiment: no lane reduction (results are wrong)
-#pragma unroll
-  for (int i = 0; i < BSR_NQ_MAX; ++i) o[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
-  o[8] = A.a0; o[9] = A.a1; o[10] = A.amax; o[11] = 0.0;
-  return;
-#endif
-  // words 0..7: projections, 8: |s z|^2, 9: s z.y -- ten sums in groups of eight (wave_sum8), then max|z| and flags
   const int slot = ((lane >> 3) & 2) | (lane >> 5);   // rows 0, 1, 2, 3 of the wave hold values 0, 2, 1, 3 (in arithmetic:
                                                       // a table would be a memory load and a pointer kept in registers)
   double g0[8], lo0, hi0;
@@ -181,11 +171,8 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
     for (int i = 0; i < 6; ++i) g0[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
     g0[6] = A.a0;
     g0[7] = A.a1;
-    wave_sum8(g0, lo0, hi0);
-    const double amax = wave_max(A.amax);
-    const double a0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hi0), 16),
-                                       __builtin_amdgcn_readlane(__double2loint(hi0), 16));  // value 6 lives in row 1 of hi
-    const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
+    wave_sum8_swz(g0, lo0, hi0);
+    const double amax = wave_max_swz_hi(A.amax);
     if ((lane & 15) == 0) {
       o[slot] = lo0;                                   // values 0..3
       const int hslot = 4 + slot;                      // values 4..7 -> words 4, 5 (projections) and 8, 9 (a0, a1)
@@ -194,8 +181,10 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
     if (lane == 0) {
       o[6] = 0.0;
       o[7] = 0.0;
+    }
+    if (lane == 63) {
       o[10] = amax;
-      o[11] = (double)fl;
+      o[11] = 0.0;
     }
   } else {
     double g1[8], lo1, hi1;
@@ -205,20 +194,17 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
     for (int i = 0; i < 8; ++i) g1[i] = 0.0;
     g1[0] = A.a0;
     g1[1] = A.a1;
-    wave_sum8(g0, lo0, hi0);
-    wave_sum8(g1, lo1, hi1);
-    const double amax = wave_max(A.amax);
-    const double a0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lo1), 0),
-                                       __builtin_amdgcn_readlane(__double2loint(lo1), 0));
-    const uint32_t fl = ((amax == INFINITY) ? BSR_F_INF : 0u) | (isnan(a0) ? BSR_F_NAN : 0u);
+    wave_sum8_swz(g0, lo0, hi0);
+    wave_sum8_swz(g1, lo1, hi1);
+    const double amax = wave_max_swz_hi(A.amax);
     if ((lane & 15) == 0) {
       o[slot] = lo0;
       o[4 + slot] = hi0;
       if (slot < 2) o[8 + slot] = lo1;                 // values 0 (a0, row 0) and 1 (a1, row 2 -> slot 1)
     }
-    if (lane == 0) {
+    if (lane == 63) {
       o[10] = amax;
-      o[11] = (double)fl;
+      o[11] = 0.0;
     }
   }
 }
@@ -287,10 +273,18 @@ __device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileG
 // Single-chunk variant: the workgroup's whole slice fits in LDS.  Staged once; then the waves pull tapes from the
 // group's list (heaviest first) through an LDS counter, and a wave runs its tape over all blocks of the slice with one
 // set of accumulators.  Which wave runs a tape does not matter to the sums (one wave, blocks in order).
+//
+// A chain tape (bsr_device.h: chain_eval) is run a pass of up to NBIG blocks at a time, the whole pass in registers:
+// one decode of the tape per pass, operators in place.  Any other tape goes through the stack machine two blocks at a
+// time.  Both produce the same values per row and add them up in the same order (per lane: blocks in order, the
+// lane's two rows of a block in order), so a proposal's sums do not depend on which route its tape takes.
 template <typename T, int KQ>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> a) {
   constexpr int U = BSR_TILE_U;
   constexpr int S = BSR_REG_STACK;
+  // blocks per pass of a chain tape: what the register file holds next to the accumulators (f64: K <= 4 eight blocks
+  // = 32 VGPRs of values, K >= 5 four)
+  constexpr int NBIG = (sizeof(T) == 4 || KQ <= 4) ? 8 : 4;
   using V2 = typename VecOf<T, 2>::type;
   extern __shared__ __align__(16) unsigned char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
@@ -302,122 +296,26 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   // every slice holds bps blocks; the n_left blocks behind the last slice are handed out one (tape, block) at a time
   // to whichever wave runs dry first (leftover_units): no workgroup carries a block more than the others
   const int b0 = slice * g.bps;
-  const int b1 = b0 + g.bps;
   const int nb = g.bps;
-  (void)b1;
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const int32_t CONSTANT_AS* list = as_const(a.sched) + (size_t)tg * g.per_group;
   const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
   const T* sy = sx + (size_t)g.y_slot * chunk_rows;
+  const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
   unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
 #define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0) s_next = (sizeof(T) == 8 && g.n_sub == 1 && g.piped) ? BSR_TILE_WAVES - BSR_TILE_LOADERS : BSR_TILE_WAVES;
-  // fp64, whole-slice units of work (piped): BSR_TILE_LOADERS waves bring the slice in by LDS-DMA, pair of blocks by
-  // pair of blocks, and publish each pair through an LDS counter; the other waves start their first tape as soon as
-  // the first pair has landed, and the loaders join the tape queue when they are done.
-  constexpr bool DMA = sizeof(T) == 8;
-  constexpr int NL = BSR_TILE_LOADERS;
-  const bool piped = DMA && g.n_sub == 1 && g.piped;
-  __shared__ int s_pair[16];   // s_pair[pp]: loader waves whose copies of pair pp (blocks 2pp, 2pp+1) have landed
-  int ready = 0;               // pairs this wave has seen complete
-  if constexpr (DMA) {
-    if (piped) {
-      if (threadIdx.x < 16) s_pair[threadIdx.x] = 0;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // s_next and the counters are in place
-      asm volatile("" ::: "memory");
-      TSTAMP(5);
-      if (wave < NL) {
-        // a loader shares its SIMD with three computing waves: without priority its short instruction stream gets
-        // a quarter of the issue slots and the slice takes 11-14 us to arrive
-        __builtin_amdgcn_s_setprio(3);
-        // the math tables travel the same way, ahead of the slice (copies complete in issue order)
-        for (int t = wave; t < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024); t += NL) {
-          const char* src = (const char*)bsr_tables_src + t * 1024 + lane * 16;
-          const uint32_t la = __builtin_amdgcn_readfirstlane(
-              (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + t * 1024));
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
-        }
-        const int npp = (nb + 1) >> 1;   // pairs, the odd last block counting as one
-        // column pointers: one vector load, then readlanes (kernel-argument block when they fit there)
-        const T* const* cs = (g.ncols <= BSR_TILE_ARG_COLS)
-                                 ? (const T* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs<T>, cols))
-                                 : (const T* const*)colsrc;
-        const uint64_t mine = (lane < g.ncols) ? (uint64_t)cs[lane] : 0;
-        auto issue_pair = [&](int pp) {   // this loader's share of pair pp's copies; returns how many
-          int cnt = 0;
-          const int nbp = min(2, nb - 2 * pp), n_u = g.ncols * nbp;   // units of the pair: column-major, then block
-          for (int u = wave; u < n_u; u += NL) {
-            const int col = (nbp == 2) ? (u >> 1) : u, blk = 2 * pp + ((nbp == 2) ? (u & 1) : 0);
-            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), col) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane((int)mine, col);
-            const T* src = (g.ncols <= BSR_WAVE ? (const T*)base : colsrc[col]) + (int64_t)(b0 + blk) * BSR_TILE_BLOCK + 2 * lane;
-            T* dst = sx + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
-            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
-            ++cnt;
-          }
-          return cnt;
-        };
-        auto publish = [&](int pp) {
-          if (lane == 0) __hip_atomic_fetch_add(&s_pair[pp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        if (npp > 0) {
-          // the first pair alone (and the tables): the sooner it lands, the sooner the other twelve waves compute
-          (void)issue_pair(0);
-          dma_wait_left(0);
-          publish(0);
-          // then everything else at once, published pair by pair as the copies (which complete in issue order) land
-          int left = 0;
-#pragma unroll 1
-          for (int pp = 1; pp < npp; ++pp) left += issue_pair(pp);
-#pragma unroll 1
-          for (int pp = 1; pp < npp; ++pp) {
-            const int n_u = g.ncols * min(2, nb - 2 * pp);
-            left -= n_u > wave ? (n_u - wave + NL - 1) / NL : 0;   // this loader's copies of pair pp
-            dma_wait_left(left);
-            publish(pp);
-          }
-        }
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  }
-  if (!piped) {
-    tables_to_lds();
-    stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane, a.grp_mask[tg & 7]);
-    __syncthreads();
-  }
-  // blocks [.., b_end) of the slice are in LDS (piped staging: spin on the pair's counter)
-  auto arrive = [&](int b_end) {
-    if constexpr (DMA) {
-      const int need = (b_end + 1) >> 1;
-      while (ready < need) {
-        while (__hip_atomic_load(&s_pair[ready], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NL)
-          __builtin_amdgcn_s_sleep(2);
-        ++ready;
-      }
-      asm volatile("" ::: "memory");
-      if (b_end <= 2) TSTAMP(2);
-    }
-  };
+  if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;
+  tables_to_lds();
+  stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane, a.grp_mask[tg & 7]);
+  __syncthreads();
   TSTAMP(1);
-  if (!piped) TSTAMP(2);
+  TSTAMP(2);
   // unit of work: (tape t of the group's list, sub-slice j); units are numbered tape-major, heaviest tape first
   const int n_items = g.per_group * g.n_sub;
-  // the first list entries go to the waves in order (piped: to the waves that do not load; the loaders pull theirs)
-  int idx = wave;
-  if (piped) {
-    if (wave >= NL) idx = wave - NL;
-    else {
-      int first_idx = 0;
-      if (lane == 0) first_idx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      idx = __builtin_amdgcn_readfirstlane(first_idx);
-    }
-  }
+  int idx = wave;   // the first list entries go to the waves in order
   while (idx < n_items) {
     const int t = idx / g.n_sub, j = idx - t * g.n_sub;
     const int p = list[t];
@@ -436,6 +334,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
     const int n_nodes = dsc[p].n_nodes;
     const double s = dsc[p].s;
+    const bool chain = dsc[p].chain != 0;
     const T* sq = sx + (size_t)dsc[p].qslot * chunk_rows;
     const TapeHead hd = load_tape_head(pc, pf, pl);
     TapeAcc<KQ> A;
@@ -447,31 +346,61 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       V2 qv[KQ > 0 ? KQ : 1];
 #pragma unroll
       for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * chunk_rows + off);
-      if ((int64_t)(b0 + b + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
+      if (b0 + b < n_full) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
       else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
     };
-    // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.  The
-    // per-lane sums still grow block by block in row order, so the result does not depend on the pairing.
     int b = sb0;
+    if (chain) {
+      // a pass of NB blocks: the tape once over 2 NB values per lane, then the blocks' sums in order
+      auto pass = [&](auto nb_tag, auto full_tag, int pn) {
+        constexpr int NB = decltype(nb_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (block j of the pass: 128 j rows on)
+        T z[2 * NB];
+        chain_eval<T, NB, FULL>(hd, pc, pf, pl, n_nodes, sx, chunk_rows, off, pn, z);
+        const T* yp = sy + off;
+        const T* qp = sq + off;
+        const bool whole = b0 + b + pn <= n_full;   // no block of the pass reaches beyond row N
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          if (FULL || jb < pn) {
+            const T zz[U] = {z[2 * jb], z[2 * jb + 1]};
+            const V2 yv = *reinterpret_cast<const V2*>(yp + jb * BSR_TILE_BLOCK);
+            V2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(qp + (size_t)i * chunk_rows + jb * BSR_TILE_BLOCK);
+            const int64_t row0 = (int64_t)(b0 + b + jb) * BSR_TILE_BLOCK + 2 * lane;
+            if (whole || b0 + b + jb < n_full) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
+            else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
+          }
+        }
+        b += pn;
+      };
+      using std::integral_constant;
+      while (NBIG > 4 && sb1 - b >= NBIG) pass(integral_constant<int, NBIG>{}, integral_constant<bool, true>{}, NBIG);
+      while (sb1 - b >= 4) pass(integral_constant<int, 4>{}, integral_constant<bool, true>{}, 4);
+      if (b < sb1) pass(integral_constant<int, 4>{}, integral_constant<bool, false>{}, sb1 - b);
+    } else {
+      // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.  The
+      // per-lane sums still grow block by block in row order, so the result does not depend on the pairing.
 #pragma unroll 1
-    for (; b + 1 < sb1; b += 2) {
-      if (piped) arrive(b + 2);
-      const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
-      T z4[2 * U];
-      LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
-      // four values per out-of-line call, except where that costs the last registers (K = 6, 8 would spill two)
-      run_tape_head<T, 2 * U, S, LdsCols<T, 2 * U>, (sizeof(T) == 4 || (KQ != 6 && KQ != 8))>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
-      const T za[U] = {z4[0], z4[1]}, zb[U] = {z4[2], z4[3]};
-      add_block(za, off, b);
-      add_block(zb, off + BSR_TILE_BLOCK, b + 1);
-    }
-    if (b < sb1) {
-      if (piped) arrive(b + 1);
-      const int off = b * BSR_TILE_BLOCK + 2 * lane;
-      T z[U];
-      LdsCols<T, U> ldr{sx, chunk_rows, off};
-      run_tape_head<T, U, S>(hd, pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
-      add_block(z, off, b);
+      for (; b + 1 < sb1; b += 2) {
+        const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
+        T z4[2 * U];
+        LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
+        // four values per out-of-line call, except where that costs the last registers (K = 6, 8 would spill two)
+        run_tape_head<T, 2 * U, S, LdsCols<T, 2 * U>, (sizeof(T) == 4 || (KQ != 6 && KQ != 8))>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
+        const T za[U] = {z4[0], z4[1]}, zb[U] = {z4[2], z4[3]};
+        add_block(za, off, b);
+        add_block(zb, off + BSR_TILE_BLOCK, b + 1);
+      }
+      if (b < sb1) {
+        const int off = b * BSR_TILE_BLOCK + 2 * lane;
+        T z[U];
+        LdsCols<T, U> ldr{sx, chunk_rows, off};
+        run_tape_head<T, U, S>(hd, pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
+        add_block(z, off, b);
+      }
     }
     store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice * g.n_sub + j) * BSR_P1_WORDS, lane);
     idx = __builtin_amdgcn_readfirstlane(nxt);

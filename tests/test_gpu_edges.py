@@ -359,7 +359,8 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 
     def run(env):
         for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
-                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE", "BSR_SPLIT_ISSUE"):
+                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE", "BSR_SPLIT_ISSUE",
+                  "BSR_CHAIN_EVAL", "BSR_REORDER"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
@@ -372,8 +373,12 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
         c.close()
         return out
     base = run({})
+    # chain tapes through the stack machine (two blocks per pass) instead of the register-resident pass; operands of
+    # + and * in tape order instead of fusing order: the same value for every row, the same sums
+    assert run({"BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_REORDER": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_REORDER": "0", "BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
-    assert run({"BSR_TILE_PIPED": "1"}).tobytes() == base.tobytes()      # slice staged by LDS-DMA under the first tapes
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
     assert run({"BSR_BAR_WRITE": "0"}).tobytes() == base.tobytes()       # input block by hipMemcpyAsync, not host stores
