@@ -186,7 +186,7 @@ struct bsr_ctx {
   int tile_on = 1;
   int tile_multi = 0;     // allow the chunked variant (slices larger than LDS)
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
-  int tile_sub = 1, tile_sub_blocks = 1;   // sub-slices per slice (single-chunk contexts only) and their length
+  int tile_sub = 1, tile_sub_blocks = 1;   // partial records per (tape, slice)
   size_t tile_sched_cap = 0;
   unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
   // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
@@ -215,6 +215,10 @@ static void set_err(bsr_ctx* c, const char* msg);
 static std::atomic<long long> g_ns_stage{0}, g_ns_desc{0}, g_ns_enq{0}, g_n_sub{0};  // worker threads submit too
 static std::atomic<long long> g_ns_issue{0}, g_n_issue{0}, g_ns_wait{0}, g_n_wait{0};   // HIP calls of a batch; waits
 static const bool g_host_prof = getenv("BSR_HOST_PROF") != nullptr;
+// BSR_STREAM_STATS=1: what the staged batches hold, by stream opcode and evaluator (printed by bsr_ctx_destroy; the
+// instruction audit of the row pass prices a launch with it: tools/isa_audit.py)
+static const bool g_stream_stats = getenv("BSR_STREAM_STATS") != nullptr;
+static std::atomic<long long> g_ss_entries[2][16], g_ss_tapes[2], g_ss_batches{0}, g_ss_derived{0}, g_ss_cols{0};
 static inline long long host_now() {
   return g_host_prof ? std::chrono::duration_cast<std::chrono::nanoseconds>(
                            std::chrono::steady_clock::now().time_since_epoch()).count()
@@ -284,6 +288,21 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
             g_ns_stage.load() / n * 1e-3, g_ns_desc.load() / n * 1e-3, g_ns_enq.load() / n * 1e-3, n,
             g_ns_issue.load() / std::max(1.0, (double)g_n_issue.load()) * 1e-3, (double)g_n_issue.load(),
             g_ns_wait.load() / std::max(1.0, (double)g_n_wait.load()) * 1e-3, (double)g_n_wait.load());
+  }
+  if (g_stream_stats && g_ss_batches.load() > 0) {
+    static const char* names[16] = {"inv", "ln", "neg", "sin", "cos", "exp", "square", "cubic", "add", "mul", "T", "add_T",
+                                    "mul_T", "sub", "div", "log"};
+    const double nb = (double)g_ss_batches.exchange(0);
+    fprintf(stderr, "bsr stream stats over %.0f batches: per batch %.2f chain tapes, %.2f stack tapes, %.2f derived columns, %.2f X columns\n",
+            nb, g_ss_tapes[0].load() / nb, g_ss_tapes[1].load() / nb, g_ss_derived.load() / nb, g_ss_cols.load() / nb);
+    for (int kind = 0; kind < 2; ++kind) {
+      fprintf(stderr, "  %s entries per batch:", kind ? "stack" : "chain");
+      for (int o = 0; o < 16; ++o) fprintf(stderr, " %s %.2f", names[o], g_ss_entries[kind][o].exchange(0) / nb);
+      fprintf(stderr, "\n");
+      g_ss_tapes[kind].store(0);
+    }
+    g_ss_derived.store(0);
+    g_ss_cols.store(0);
   }
   if (!c) return BSR_E_ARG;
   (void)hipSetDevice(c->device);
@@ -557,14 +576,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // goes out as single (tape, block) units through a ticket counter (bsr_tile.hip: leftover_units)
       c->tile_bps = c->tile_blocks / c->tile_slices;
       c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
-      // Sub-slices: finer units of work for the waves of a workgroup (a tape over half a slice instead of a whole one)
-      // so that the last wave to finish is at most half a tape behind.  Only where every launch is single-chunk.
-      c->tile_sub = 1;
+      c->tile_sub = 1;   // partial records per (tape, slice)
       c->tile_sub_blocks = c->tile_bps;
-      if (fits_whole(T) && c->tile_bps >= 4 && env_int("BSR_TILE_SUB", 1) > 1) {
-        c->tile_sub = 2;
-        c->tile_sub_blocks = ((c->tile_bps + 1) / 2 + 1) / 2 * 2;   // even: blocks are processed in pairs
-      }
       c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
       // a data set of which not even a narrow batch (eight features or all of them, y, one chain's basis) fits LDS will
       // not take the tile pass in practice: no partition and no derived columns then, the work-queue row pass keeps
@@ -1116,8 +1129,10 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     uint64_t* pf = hf + L.feat_off;
     uint64_t* pf2 = hf2 + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
-    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 8;
+    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 11;
     int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
+    uint8_t ss_codes[64];
+    int ss_n = 0;
     uint64_t slots_mask = 0;
     for (int j = 0; j < L.n_nodes; ++j) {
       const bsr_node& r = src[tape_off[i] + j];
@@ -1159,19 +1174,28 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       mx = std::max(mx, sp);
       pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
       ++ns;
-      // per-visit vector instructions of the row passes (tools/pmc_tile.sh, ISA listings), in units of ~8: column read
-      // incl. its operand copies 2, plain op 1, ln 2, cubic 5, inv 9, exp 16, sin/cos 25; the base 8 is the per-block
-      // share of the projection sums and the lane reduction
-      cost += (r.opcode == BSR_OP_TERMINAL) ? 2 : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 25
-              : (r.opcode == BSR_OP_EXP || r.opcode == BSR_OP_LOG) ? 16
-              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 9 : (r.opcode == BSR_OP_CUBIC) ? 5
-              : (r.opcode == BSR_OP_LN) ? 2 : 1;
+      if (g_stream_stats) ss_codes[ss_n < 64 ? ss_n++ : 63] = (uint8_t)code;
+      // vector instructions per 64 rows of the tile pass's chain evaluator (ISA listing + PMC totals, tools/isa_audit.py):
+      // a fused or leading terminal 0-1 (its reads are LDS work), plain operators 1, ln 2, cubic 9, inv 14, exp 27,
+      // sin / cos 35, log 40, a pushed terminal or a popping operator 3 (operand copies of the stack machine); the base
+      // 11 is the projection sums (7) and the block's share of the lane reduction and the per-tape set-up
+      cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 1
+              : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 3 : 0)
+              : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 35
+              : (r.opcode == BSR_OP_EXP) ? 27 : (r.opcode == BSR_OP_LOG) ? 40
+              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 14 : (r.opcode == BSR_OP_CUBIC) ? 9
+              : (r.opcode == BSR_OP_LN) ? 2 : is_binary_op(r.opcode) ? 3 : 1;
     }
     (*loc)[i].n_stream = ns;
     (*loc)[i].slots = slots_mask;
     (*loc)[i].cost = cost;
     (*loc)[i].max_sp = mx;
     (*loc)[i].acc_only = (c->chain_eval && n_push == 1 && n_stack_ops == 0) ? 1 : 0;
+    if (g_stream_stats) {
+      const int kind = (*loc)[i].acc_only ? 0 : 1;
+      g_ss_tapes[kind].fetch_add(1, std::memory_order_relaxed);
+      for (int q = 0; q < ss_n; ++q) g_ss_entries[kind][ss_codes[q]].fetch_add(1, std::memory_order_relaxed);
+    }
     pl[2 * nl] = 1.0;
     pl[2 * nl + 1] = 0.0;
     if (!s.use_lds) {  // padding ids must name a valid column: repeat the first terminal's
@@ -1184,6 +1208,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const int words = (nt + 1 + 3) / 4 + 1;
       for (int t = nt; t < words * 4; ++t) pf2[t >> 2] |= id0 << (16 * (t & 3));
     }
+  }
+  if (g_stream_stats) {
+    g_ss_batches.fetch_add(1, std::memory_order_relaxed);
+    g_ss_derived.fetch_add(s.derived_used, std::memory_order_relaxed);
+    g_ss_cols.fetch_add(s.nF, std::memory_order_relaxed);
   }
   return BSR_OK;
 }

@@ -682,8 +682,8 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = -acc[u];
         break;
-      case BSR_OP_SIN:
-        BSR_CHAIN_CALL(sin_rows)
+      case BSR_OP_SIN:   // out of line: inlined, the constants and temporaries of sixteen values spill (measured: 16 VGPRs,
+        BSR_CHAIN_CALL(sin_rows)   // 115 SGPRs), and a call costs ~3 register moves per value next to ~31 instructions
         break;
       case BSR_OP_COS:
         BSR_CHAIN_CALL(cos_rows)

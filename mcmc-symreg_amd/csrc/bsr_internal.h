@@ -131,8 +131,8 @@ struct TileGeom {
   int ncols;            // LDS columns: referenced X columns, y, K basis columns per chain of the batch
   int y_slot;           // LDS slot of y
   int per_group;        // single-chunk variant: tapes per group (length of a group's list in `sched`)
-  int n_sub;            // single-chunk variant: a slice is cut into n_sub sub-slices of sub_blocks blocks; the unit of
-  int sub_blocks;       // work a wave pulls is (tape, sub-slice) and there is one partial record per unit
+  int n_sub;            // partial records per (tape, slice): 1
+  int sub_blocks;       // = bps
   int n_part;           // partial records per proposal = n_slices * n_sub
 };
 template <typename T>

@@ -265,7 +265,7 @@ __device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileG
     A.clear();
     if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, dsc[p].s, row0, a.N);
     else accumulate_v<T, KQ, true>(A, z, yv, qv, dsc[p].s, row0, a.N);
-    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices * g.n_sub + bi) * BSR_P1_WORDS, lane);
+    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
     li = __builtin_amdgcn_readfirstlane(nx) - base;
   }
 }
@@ -313,19 +313,20 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   __syncthreads();
   TSTAMP(1);
   TSTAMP(2);
-  // unit of work: (tape t of the group's list, sub-slice j); units are numbered tape-major, heaviest tape first
-  const int n_items = g.per_group * g.n_sub;
+  // unit of work: a tape of the group's list over the whole slice, heaviest tape first.  (Finer units -- every tape, or
+  // only the heavy ones, in two halves -- were measured twice: the lane reduction and the decode each extra unit pays
+  // cost what the better balance gains.)
+  const int n_items = g.per_group;
   int idx = wave;   // the first list entries go to the waves in order
   while (idx < n_items) {
-    const int t = idx / g.n_sub, j = idx - t * g.n_sub;
-    const int p = list[t];
+    const int p = list[idx];
     if (p < 0) {   // padding behind the group's last tape: take the next item (the leftover units follow the list)
       int nx = 0;
       if (lane == 0) nx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       idx = __builtin_amdgcn_readfirstlane(nx);
       continue;
     }
-    const int sb0 = min(nb, j * g.sub_blocks), sb1 = min(nb, sb0 + g.sub_blocks);
+    const int sb0 = 0, sb1 = nb;
     // the next unit is requested now; its round trip hides under this one
     int nxt = 0;
     if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
         add_block(z, off, b);
       }
     }
-    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice * g.n_sub + j) * BSR_P1_WORDS, lane);
+    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + slice) * BSR_P1_WORDS, lane);
     idx = __builtin_amdgcn_readfirstlane(nxt);
   }
   TSTAMP(3);
