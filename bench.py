@@ -173,14 +173,14 @@ def generate_batches(wl, n_unique):
         feat_counts.append(len(feats))
         rec = (rows, off, np.array(chs, np.int32), np.array(ks, np.int32), np.array(sig, np.float64),
                np.zeros(len(tapes), dtype=_lib.SCORE_DTYPE), tapes)
-        packed.append(rec + (ctx.prepare(*rec[:5]),))     # input addresses resolved once: the batch is host-resident
+        packed.append(rec + (ctx.prepare(*rec[:5]), rec[5].ctypes.data))   # addresses resolved once: the batch is host-resident
     wl.update(packed=packed, feat_counts=feat_counts, n_nodes=n_nodes, n_trans=n_trans, P=len(packed[0][2]))
     return wl
 
 
 def timed_region(wl, ranks, steps, warmup, depth, min_time):
     """W warm-up steps, then R x `steps` timed steps between barriers (R chosen so the region lasts >= min_time),
-    several batches in flight; HIP events bracket the row pass of every 4th batch on the stream it runs on."""
+    several batches in flight; HIP events bracket the row pass of every 16th batch on the stream it runs on."""
     import numpy as np
     ctx, packed = wl["ctx"], wl["packed"]
     n_unique = len(packed)
@@ -190,7 +190,7 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
     kern_us = np.zeros(5)
     n_timed = [0]
     depth = max(1, min(8, depth))
-    TIMED_EVERY = 4
+    TIMED_EVERY = 16   # (a timed batch costs the caller three extra calls and the stream two event records)
 
     def run_steps(n, first):
         """n pipelined steps: the host stages batch i+1 while the GPU scores batch i (different chain groups in a real
@@ -206,13 +206,13 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
                 ctx.set_profiling(0)
             if len(tickets) >= depth:
                 t, rr, tm = tickets.pop(0)
-                ctx.score_wait(t, rr[5])
+                ctx.score_wait_ptr(t, rr[8])
                 if tm:
                     kern_us[:] += ctx.last_timing()
                     n_timed[0] += 1
         while tickets:
             t, rr, tm = tickets.pop(0)
-            ctx.score_wait(t, rr[5])
+            ctx.score_wait_ptr(t, rr[8])
             if tm:
                 kern_us[:] += ctx.last_timing()
                 n_timed[0] += 1

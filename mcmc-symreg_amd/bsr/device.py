@@ -27,6 +27,7 @@ class DeviceContext:
                               None if yv is None else _lib.ptr(yv), self.K, self.n_chains, self.max_batch, dt)
         _lib.check(rc, None)
         self._L = L
+        self._mh_pending = {}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -113,22 +114,38 @@ class DeviceContext:
         _lib.check(self._L.bsr_score_wait(self._h, ticket, _lib.ptr(out)), self._h)
         return out
 
+    def score_wait_ptr(self, ticket, out_ptr):
+        """score_wait into a result array whose address the caller resolved once (`out.ctypes.data`)."""
+        rc = self._L.bsr_score_wait(self._h, ticket, out_ptr)
+        if rc:
+            _lib.check(rc, self._h)
+
     def score_submit_mh(self, rows, off, chains, ks, sig, terms8, flags, span_off):
         """Scoring plus the device-side MH step (codes/funcs.py:1226-1306 on the device; include/bsr_hip.h):
         terms8 (B, 8) float64, flags (B,) int32, span_off (n_spans + 1,) int32 -> ticket."""
         terms8 = np.ascontiguousarray(terms8, dtype=np.float64)
         flags = np.ascontiguousarray(flags, dtype=np.int32)
         span_off = np.ascontiguousarray(span_off, dtype=np.int32)
+        B = len(chains)
+        if terms8.shape != (B, 8) or flags.shape != (B,) or span_off.ndim != 1 or len(span_off) < 2 or \
+                span_off[0] != 0 or span_off[-1] != B:
+            raise ValueError("score_submit_mh: terms8 must be (B, 8), flags (B,), span_off from 0 to B = %d" % B)
         t = C.c_int32(-1)
         rc = self._L.bsr_score_submit_mh(self._h, _lib.ptr(rows), _lib.ptr(off), _lib.ptr(chains), _lib.ptr(ks),
                                          _lib.ptr(sig), len(chains), _lib.ptr(terms8), _lib.ptr(flags),
                                          _lib.ptr(span_off), len(span_off) - 1, C.byref(t))
         _lib.check(rc, self._h)
-        self._mh_spans = len(span_off) - 1
+        # up to BSR_MAX_INFLIGHT MH batches may be in flight: what a ticket returns is sized by ITS submission
+        self._mh_pending[t.value] = (len(span_off) - 1, B)
         return t.value
 
     def score_wait_mh(self, ticket, out=None):
-        ev = np.zeros(self._mh_spans, dtype=_lib.EVENT_DTYPE)
+        if ticket not in self._mh_pending:
+            raise _lib.BsrError(-6, "score_wait_mh: no MH batch under ticket %r" % (ticket,))
+        n_spans, B = self._mh_pending.pop(ticket)
+        if out is not None and (out.dtype != _lib.SCORE_DTYPE or out.shape[0] < B or not out.flags["C_CONTIGUOUS"]):
+            raise ValueError("score_wait_mh: `out` must be a contiguous SCORE_DTYPE array of at least %d records" % B)
+        ev = np.zeros(n_spans, dtype=_lib.EVENT_DTYPE)
         rc = self._L.bsr_score_wait_mh(self._h, ticket, None if out is None else _lib.ptr(out), _lib.ptr(ev))
         _lib.check(rc, self._h)
         return ev

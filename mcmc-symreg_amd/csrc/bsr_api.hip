@@ -16,6 +16,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "bsr_internal.h"
@@ -26,7 +27,8 @@ struct TapeLoc {
   int code_off, n_nodes, feat_off, ln_off, max_sp;
   int n_stream;  // opcode-stream entries after fusing `terminal, +|*` pairs
   int cost;      // rough relative cost of one sweep of the tape (orders the work queue: heaviest first)
-  uint64_t slots;  // tile pass: the LDS slots the tape's terminals read (bit = slot; ~0: some slot >= 64)
+  int nt, nl;      // terminals in the column stream, (a, b) pairs in the ln stream
+  int grp;         // tile pass: the tape group that runs the tape (its LDS slot map numbers the tape's columns)
   int acc_only;    // chain tape: one leading terminal, every other stream entry maps the accumulator to itself
 };
 
@@ -38,6 +40,9 @@ struct BatchSlot {
   uint8_t* d_in = nullptr;
   size_t in_cap = 0;
   size_t off_cols = 0, off_sched = 0, off_mh = 0, off_desc = 0, off_streams = 0;
+  int cols_stride = 0;   // entries between the tape groups' column-pointer tables
+  size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
+  size_t recs_bytes = 0; // ... of which this batch uses so many bytes
   // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
   MhRes* d_mh = nullptr;
   bsr_event* h_ev = nullptr;   // pinned, written by k_events
@@ -50,6 +55,7 @@ struct BatchSlot {
   std::vector<int32_t> chain_slot;    // chain -> index among the batch's chains, -1 if absent
   std::vector<int32_t> batch_chains;  // the batch's chains in first-seen order
   std::vector<double> wave_load;      // scratch of the tile schedule
+  std::vector<int> wave_cnt;
   bsr_score* h_out = nullptr;
   hipStream_t stream = nullptr;   // each slot has its own stream: the small solve/residual/finalise kernels of one
                                   // batch overlap the row pass of the other
@@ -91,14 +97,21 @@ struct BatchSlot {
   int timed = 0;        // profiling level the pending batch was enqueued with
   bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
   std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
-  uint64_t grp_mask[8] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};   // per tape group: slots to stage
   std::vector<std::pair<int, int>> derived_cand;   // scratch of the derived-column choice
   std::vector<int> derived_benefit;
-  std::vector<uint64_t> tape_slots;  // per tape of the staged batch: LDS slots it reads (tile pass)
+  // tile pass: per tape group, the columns its tapes read (ascending) -> LDS slots 0.., then y, then the chains' bases
+  std::vector<int16_t> grp_slot;     // [group][column] LDS slot or -1
+  std::vector<int32_t> grp_cols;     // scratch: columns of one group
+  int grp_nF[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // X columns per group (= the group's y slot)
+  int tile_ncols = 0;                // most LDS columns of any group: sizes the LDS buffers
+  int tile_chunk = 0;                // blocks staged at a time: the whole slice, or what two buffers hold
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
-  std::vector<int> order_tmp;    // scratch of the cost sort
-  std::vector<bsr_node> rows_perm;   // the batch's tapes in the order the streams are written in (reorder_tape)
+  std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
+  std::vector<uint32_t> order_keys;
+  int order_n = -1;              // tapes order_tmp is valid for (-1: not)
+  std::vector<bsr_node> rows_perm;   // tapes rewritten in fusing order (reorder_tape), at their batch offsets
+  std::vector<const bsr_node*> tape_src;   // per tape: where the streams are written from (the caller's rows, or rows_perm)
   std::vector<int32_t> perm_kid, perm_stack;   // scratch of reorder_tape
   int head_rc = 0;               // result of a split batch's first phase (issue_batch)
   bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
@@ -106,7 +119,7 @@ struct BatchSlot {
 
   int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
   const void** h_cols() const { return reinterpret_cast<const void**>(h_in + off_cols); }
-  int32_t* h_sched() const { return reinterpret_cast<int32_t*>(h_in + off_sched); }
+  TapeRec* h_sched() const { return reinterpret_cast<TapeRec*>(h_in + off_recs); }
   double* h_terms() const { return reinterpret_cast<double*>(h_in + off_mh); }
   int32_t* h_mhflags() const { return reinterpret_cast<int32_t*>(h_in + off_mh + mh_cap * 8 * sizeof(double)); }
   int32_t* h_spans() const { return h_mhflags() + mh_cap; }
@@ -114,7 +127,7 @@ struct BatchSlot {
   const int32_t* d_mhflags() const { return reinterpret_cast<const int32_t*>(d_in + off_mh + mh_cap * 8 * sizeof(double)); }
   const int32_t* d_spans() const { return d_mhflags() + mh_cap; }
   const void* const* d_cols() const { return reinterpret_cast<const void* const*>(d_in + off_cols); }
-  const int32_t* d_sched() const { return reinterpret_cast<const int32_t*>(d_in + off_sched); }
+  const TapeRec* d_sched() const { return reinterpret_cast<const TapeRec*>(d_in + off_recs); }
   PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
   uint64_t* h_streams() const { return reinterpret_cast<uint64_t*>(h_in + off_streams); }
   const int32_t* d_feat() const { return reinterpret_cast<const int32_t*>(d_in); }
@@ -186,6 +199,8 @@ struct bsr_ctx {
   int tile_on = 1;
   int tile_multi = 0;     // allow the chunked variant (slices larger than LDS)
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
+  int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
+  bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
   int tile_sub = 1, tile_sub_blocks = 1;   // partial records per (tape, slice)
   size_t tile_sched_cap = 0;
   unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
@@ -549,50 +564,57 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // at N = 1M it measures 206 us against the work-queue pass's 165 us (four tapes per wave leave no registers for
     // two-block passes, so every 128 rows pay a full scalar decode of the tape), so it only runs when asked for
     c->tile_multi = env_int("BSR_TILE_MULTI", 0);
+    // Geometry of the row pass (bsr_tile.hip), fixed for the life of the context.  A wave holds tile_qmax(K) sets of
+    // sums, so one group of 16 waves takes 16 x qmax tapes per pass over its slice; `want` groups give every tape of the
+    // widest batch a set.  Slices that fit LDS whole are staged once (the largest T <= want for which they do even for
+    // the widest batch: every X column, y, every chain's basis); otherwise the slice streams through two LDS buffers
+    // chunk by chunk, every CU takes part (no spare CUs: the pass is then bound by HBM), and T = 2 groups by default so
+    // that a group's columns -- its tapes' features, y, the basis -- leave room for chunks of a few blocks.
+    c->tile_qmax = tile_qmax(std::max(1, K));
+    c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
+    const int want = std::max(1, std::min(8, (max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax)));
+    const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
+    const size_t budget = tile_lds_bytes_max() - 1024;
     for (int attempt = 0; attempt < 2; ++attempt) {
       c->tile_cus = c->n_cu - c->aux_cus;
-      c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
-      const double data_mb = (double)N * (std::min(d, 32) + 1 + std::max(1, K)) * c->esz / 1e6;
-      int T = 1;
-      const int want = (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // groups that give every wave one tape
-      if (data_mb <= 24.0) T = std::min(4, want);
-      else if (data_mb <= 96.0) T = std::min(2, want);
-      T = std::max(1, std::min(8, T));
-      while (T > 1 && (c->tile_cus % T) != 0) --T;
-      // the widest batch this context can see: every X column, y, the basis of every chain.  Prefer a T whose slices
-      // fit LDS whole even then (staged once, no barrier per chunk).
-      const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
       auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
-      auto fits_whole = [&](int t) {
-        return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= tile_lds_bytes_max() - 1024;
-      };
-      while (T > 1 && !fits_whole(T)) T >>= 1;
-      T = env_int("BSR_TILE_T", T);
-      T = std::max(1, std::min(8, T));
+      auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
+      // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):
+      // the largest T in {4, 2, 1} with a tape per wave at most -- fewer tapes per wave and longer slices (fewer lane
+      // reductions, record fetches and decodes per row), while every group stages the slice's columns again
+      int T = 0;
+      for (int t = 4; t >= 1 && T == 0; t >>= 1)
+        if (t <= (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES && c->tile_cus % t == 0 && fits_whole(t)) T = t;
+      if (T == 0 && fits_whole(1)) T = 1;
+      c->tile_whole = T > 0;
+      if (!c->tile_whole) {
+        if (c->aux_cus != 0) {   // chunked: all CUs
+          c->aux_cus = 0;
+          continue;
+        }
+        T = want;
+        while (T > 4) T = (T + 1) / 2;
+      }
+      T = std::max(1, std::min(8, env_int("BSR_TILE_T", T)));
       while (T > 1 && (c->tile_cus % T) != 0) --T;
+      if (c->tile_whole && !fits_whole(T)) c->tile_whole = false;
       c->tile_T = T;
       c->tile_slices = std::max(1, c->tile_cus / T);
       // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
-      // goes out as single (tape, block) units through a ticket counter (bsr_tile.hip: leftover_units)
+      // goes out as single (tape, block) units dealt to the waves of the launch (bsr_tile.hip: leftover_units)
       c->tile_bps = c->tile_blocks / c->tile_slices;
       c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
-      c->tile_sub = 1;   // partial records per (tape, slice)
-      c->tile_sub_blocks = c->tile_bps;
-      c->tile_sched_cap = std::max(c->tile_sched_cap, (size_t)max_batch + (size_t)T * BSR_TILE_WAVES * BSR_TILE_QMAX + 64);
-      // a data set of which not even a narrow batch (eight features or all of them, y, one chain's basis) fits LDS will
-      // not take the tile pass in practice: no partition and no derived columns then, the work-queue row pass keeps
-      // every CU and reads X only
-      const bool ever_tiled = c->tile_on && (c->tile_multi ||
-          (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz <=
-              tile_lds_bytes_max() - 1024);
-      c->tile_ever = ever_tiled;
-      if (ever_tiled || c->aux_cus == 0) break;
-      c->aux_cus = 0;
+      break;
     }
-    // derived columns pay where the batch's columns sit in LDS; the work-queue pass would read each of them from HBM
-    // for every tape again (N = 1M, d = 50: +60 % traffic for -31 % instructions, no time gained alone and slower
-    // with several batches in flight)
-    if (!c->tile_ever && c->n_cols > d && env_int("BSR_DERIVED", 1) < 2) {
+    c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
+                        (size_t)((max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax) + 1) + 64;
+    // a data set of which not even one block of a narrow group (eight features or all of them, y, one chain's basis)
+    // fits two LDS buffers never takes the tile pass: the work-queue row pass (bsr_kernels.hip: k_rows) serves it
+    c->tile_ever = c->tile_on && (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * 2 * BSR_TILE_BLOCK * c->esz <= budget;
+    // derived columns pay where the slice sits in LDS whole (a derived column is then one more column staged from L2);
+    // a chunked pass would stream each of them from HBM (N = 1M: 8 MB per column and group), the work-queue pass for
+    // every tape again
+    if (!(c->tile_ever && c->tile_whole) && c->n_cols > d && env_int("BSR_DERIVED", 1) < 2) {
       c->n_cols = d;
       for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
     }
@@ -650,9 +672,10 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     s.off_cols = ((size_t)c->n_cols * sizeof(int32_t) + 255) / 256 * 256;
-    s.off_sched = s.off_cols + ((size_t)(c->n_cols + 1 + std::max(1, n_chains) * std::max(1, K)) * sizeof(void*) + 255) / 256 * 256;
+    s.cols_stride = c->n_cols + 1 + std::max(1, n_chains) * std::max(1, K);   // column-pointer table: one per tape group
+    s.off_sched = s.off_cols + ((size_t)c->tile_T * s.cols_stride * sizeof(void*) + 255) / 256 * 256;
     s.mh_cap = (size_t)max_batch;
-    s.off_mh = s.off_sched + (c->tile_sched_cap * sizeof(int32_t) + 255) / 256 * 256;
+    s.off_mh = s.off_sched;   // (the tile schedule lives behind the batch's streams: only what a batch uses is uploaded)
     s.off_desc = s.off_mh + (s.mh_cap * 8 * sizeof(double) + (2 * s.mh_cap + 2) * sizeof(int32_t) + 255) / 256 * 256;
     CK(hipMalloc((void**)&s.d_mh, sizeof(MhRes) * (max_batch + 1)));
     CK(hipHostMalloc((void**)&s.h_ev, sizeof(bsr_event) * (max_batch + 1)));
@@ -934,6 +957,17 @@ static bool reorder_tape(const bsr_node* t, int len, bsr_node* out, std::vector<
   return n_out == len;
 }
 
+// Tapes by cost, heaviest first, equal costs in batch order: one key per tape, sorted in place (std::stable_sort
+// allocates a buffer on every call: two of them were a tenth of the caller's time per batch).
+template <typename CostOf>
+static void cost_order(std::vector<int>& order, std::vector<uint32_t>& keys, int n, const CostOf& cost_of) {
+  keys.resize((size_t)n);
+  for (int i = 0; i < n; ++i) keys[i] = ((uint32_t)(65535 - std::min(65535, std::max(0, cost_of(i)))) << 16) | (uint32_t)(i & 0xFFFF);
+  std::sort(keys.begin(), keys.end());
+  order.resize((size_t)n);
+  for (int i = 0; i < n; ++i) order[i] = (int)(keys[i] & 0xFFFFu);
+}
+
 // Validates the tapes, chooses LDS staging, and writes the compact streams the interpreter reads into the slot's
 // pinned input block:
 //   opcode stream  : 4 bits per entry, 16 per 64-bit word, one padding word per tape; an entry is a tape node, or a
@@ -947,6 +981,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   if (n > c->max_batch) return fail(c, BSR_E_TOOBIG, "batch larger than max_batch");
   if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
   loc->resize(n);
+  s.order_n = -1;
   size_t cw = 0, fw = 0, lw = 0;
   int max_fused_sp = 0;
   std::fill(s.slot_of.begin(), s.slot_of.end(), -1);
@@ -1007,69 +1042,70 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     for (size_t q = 0; q < cand.size() && (int)q < allowance; ++q)
       if (cand[q].first >= 5) s.slot_of[cand[q].second] = -2;
   }
-  // the order the streams are written in: commutative operands swapped where that turns a push/pop into a fused entry
-  const bsr_node* src = rows;
-  if (c->reorder && tape_off[n] > 0) {
-    bool any = false;
-    for (int i = 0; i < n; ++i) {
-      const int len = tape_off[i + 1] - tape_off[i];
-      if (len < 4 || len > BSR_MAX_TAPE) continue;
-      const bsr_node* t = rows + tape_off[i];
-      auto admitted = [&](int j) {   // nodes j, j+1: `terminal, unary op` served by a derived column of this batch
-        if (!derive || j + 1 >= len) return false;
-        const int m = derived_index(t[j + 1].opcode), f = t[j].feature;
-        return m >= 0 && f >= 0 && f < c->d && s.slot_of[c->d * (1 + m) + f] == -2;
-      };
-      if (!any) {   // first tape that changes: from here on the passes below read the copy
-        if ((int)s.rows_perm.size() < tape_off[n]) s.rows_perm.resize((size_t)tape_off[n]);
-      }
-      if (reorder_tape(t, len, s.rows_perm.data() + tape_off[i], s.perm_kid, s.perm_stack, admitted)) {
-        if (!any) memcpy(s.rows_perm.data(), rows, (size_t)tape_off[i] * sizeof(bsr_node));
-        any = true;
-      } else if (any) {
-        memcpy(s.rows_perm.data() + tape_off[i], t, (size_t)len * sizeof(bsr_node));
-      }
-    }
-    if (any) {
-      // tapes skipped above (short or oversized: the latter fail validation below) still have to be in the copy
-      for (int i = 0; i < n; ++i) {
-        const int len = tape_off[i + 1] - tape_off[i];
-        if (len > 0 && (len < 4 || len > BSR_MAX_TAPE))
-          memcpy(s.rows_perm.data() + tape_off[i], rows + tape_off[i], (size_t)len * sizeof(bsr_node));
-      }
-      src = s.rows_perm.data();
-    }
-  }
+  // Pass 1: validation, sizes, the columns in use.  A tape whose fused encoding still pushes more than one terminal
+  // (it is not a chain) is tried once more with its commutative operands in fusing order (reorder_tape): few tapes
+  // get there, so the reordering costs the batch next to nothing.
+  if ((int)s.tape_src.size() < n) s.tape_src.resize((size_t)n);
   for (int i = 0; i < n; ++i) {
     const int len = tape_off[i + 1] - tape_off[i];
     TapeLoc& L = (*loc)[i];
-    int rc = check_tape(c, src + tape_off[i], len, &L.max_sp);
+    const bsr_node* t = rows + tape_off[i];
+    int rc = check_tape(c, t, len, &L.max_sp);
     if (rc != BSR_OK) return rc;
-    int nt = 0, nl = 0, fsp = 0, fmx = 0;  // fsp: stack depth with `terminal, +|*` pairs fused (what the kernels run)
-    for (int j = tape_off[i]; j < tape_off[i + 1]; ++j) {
-      if (src[j].opcode == BSR_OP_TERMINAL) {
-        ++nt;
-        int col = src[j].feature;
-        if (derive && j + 1 < tape_off[i + 1]) {   // `terminal, unary op` -> the op's derived column
-          const int m = derived_index(src[j + 1].opcode);
-          if (m >= 0) {
-            const int dc = c->d * (1 + m) + col;
-            if (s.slot_of[dc] == -2 || s.slot_of[dc] == 0) {   // admitted above
-              if (s.slot_of[dc] == -2) ++s.derived_used;
-              col = dc;
-              ++j;
+    int nt = 0, nl = 0, fmx = 0, n_push = 0;
+    auto scan = [&](const bsr_node* tp) {
+      nt = nl = fmx = n_push = 0;
+      int fsp = 0;  // stack depth with `terminal, +|*` pairs fused (what the kernels run)
+      for (int j = 0; j < len; ++j) {
+        if (tp[j].opcode == BSR_OP_TERMINAL) {
+          ++nt;
+          int col = tp[j].feature;
+          if (derive && j + 1 < len) {   // `terminal, unary op` -> the op's derived column
+            const int m = derived_index(tp[j + 1].opcode);
+            if (m >= 0) {
+              const int dc = c->d * (1 + m) + col;
+              if (s.slot_of[dc] == -2 || s.slot_of[dc] == 0) {   // admitted above
+                if (s.slot_of[dc] == -2) ++s.derived_used;
+                col = dc;
+                ++j;
+              }
             }
           }
+          s.slot_of[col] = 0;
+          const int nxt = (j + 1 < len) ? tp[j + 1].opcode : -1;
+          if (nt > 1 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else { ++fsp; ++n_push; }
+        } else if (tp[j].opcode == BSR_OP_LN) {
+          ++nl;
+        } else if (is_binary_op(tp[j].opcode)) {
+          --fsp;
         }
-        s.slot_of[col] = 0;
-        const int nxt = (j + 1 < tape_off[i + 1]) ? src[j + 1].opcode : -1;
-        if (nt > 1 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else ++fsp;
-      } else if (src[j].opcode == BSR_OP_LN) {
-        ++nl;
-      } else if (is_binary_op(src[j].opcode)) {
-        --fsp;
+        fmx = std::max(fmx, fsp);
       }
-      fmx = std::max(fmx, fsp);
+    };
+    scan(t);
+    s.tape_src[i] = t;
+    if (c->reorder && n_push > 1 && len >= 4) {
+      auto admitted = [&](int j) {   // nodes j, j+1: `terminal, unary op` served by a derived column of this batch
+        if (!derive || j + 1 >= len) return false;
+        const int m = derived_index(t[j + 1].opcode), f = t[j].feature;
+        if (m < 0 || f < 0 || f >= c->d) return false;
+        const int sl = s.slot_of[c->d * (1 + m) + f];
+        return sl == -2 || sl == 0;
+      };
+      if ((int)s.rows_perm.size() < tape_off[n]) {
+        // (pointers into the copy handed out for earlier tapes must survive: size it once for the whole batch)
+        std::vector<bsr_node> grown((size_t)tape_off[n]);
+        for (int q = 0; q < i; ++q)
+          if (s.tape_src[q] != rows + tape_off[q]) {
+            memcpy(grown.data() + tape_off[q], s.tape_src[q], (size_t)(tape_off[q + 1] - tape_off[q]) * sizeof(bsr_node));
+            s.tape_src[q] = grown.data() + tape_off[q];
+          }
+        s.rows_perm.swap(grown);
+      }
+      if (reorder_tape(t, len, s.rows_perm.data() + tape_off[i], s.perm_kid, s.perm_stack, admitted)) {
+        s.tape_src[i] = s.rows_perm.data() + tape_off[i];
+        scan(s.tape_src[i]);
+      }
     }
     max_fused_sp = std::max(max_fused_sp, fmx);
     L.n_nodes = len;
@@ -1080,8 +1116,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     fw += (size_t)(nt + 1 + 3) / 4 + 1;
     lw += (size_t)nl + 1;
   }
-  int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw);
+  const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t)) / 8 + 32;
+  int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw + rec_words);
   if (rc != BSR_OK) return rc;
+  s.off_recs = (s.off_streams + (cw + 2 * fw + 2 * lw) * 8 + 127) / 128 * 128;
+  s.recs_bytes = 0;
   // columns of X referenced by this batch -> LDS slots (ascending feature order)
   s.nF = 0;
   int32_t* hfeat = s.h_feat();
@@ -1102,18 +1141,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       }
     }
   }
-  // tile pass: every column the batch touches (X columns, y, K basis columns per chain) must fit in LDS for at least
-  // one 128-row block, and no tape may need more value-stack slots than the register stack holds
   s.tile = false;
   s.tile_chains = tile_chains;
-  if (c->tile_on && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK) {
-    const size_t ncols = (size_t)s.nF + 1 + (size_t)tile_chains * c->K;
-    // the whole slice in LDS at once (single-chunk variant), or chunks of at least one block in two buffers
-    const size_t budget = tile_lds_bytes_max() - 1024;
-    const size_t nbuf = (c->esz == 8) ? 2 : 1;
-    if (ncols * (size_t)c->tile_bps * BSR_TILE_BLOCK * c->esz <= budget) s.tile = true;
-    else if (c->tile_multi && ncols * nbuf * BSR_TILE_BLOCK * c->esz <= budget) s.tile = true;
-  }
   s.code_words = cw;
   s.feat_words = fw;
   s.ln_words = 2 * lw;
@@ -1122,25 +1151,23 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   double* hl = reinterpret_cast<double*>(hf + fw);
   uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + 2 * lw);  // tile pass: the column stream in LDS slots
   memset(hc, 0, (cw + fw) * 8);
-  if (s.tile) memset(hf2, 0, fw * 8);
   for (int i = 0; i < n; ++i) {
     const TapeLoc L = (*loc)[i];
     uint64_t* pc = hc + L.code_off;
     uint64_t* pf = hf + L.feat_off;
-    uint64_t* pf2 = hf2 + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
+    const bsr_node* tsrc = s.tape_src[i];
     int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 11;
     int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
     uint8_t ss_codes[64];
     int ss_n = 0;
-    uint64_t slots_mask = 0;
     for (int j = 0; j < L.n_nodes; ++j) {
-      const bsr_node& r = src[tape_off[i] + j];
+      const bsr_node& r = tsrc[j];
       int code = r.opcode & 15;
       if (r.opcode == BSR_OP_TERMINAL) {
         int col = r.feature;
         if (derive && j + 1 < L.n_nodes) {   // the column pass 1 admitted for `terminal, unary op` (slot assigned)
-          const int m = derived_index(src[tape_off[i] + j + 1].opcode);
+          const int m = derived_index(tsrc[j + 1].opcode);
           if (m >= 0 && s.slot_of[c->d * (1 + m) + col] >= 0) {
             col = c->d * (1 + m) + col;
             ++j;
@@ -1148,14 +1175,10 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         }
         const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[col] : col);
         pf[nt >> 2] |= id << (16 * (nt & 3));
-        if (s.tile) {
-          pf2[nt >> 2] |= (uint64_t)s.slot_of[col] << (16 * (nt & 3));
-          slots_mask = (s.slot_of[col] < 64 && slots_mask != ~0ull) ? (slots_mask | (1ull << s.slot_of[col])) : ~0ull;
-        }
         ++nt;
         // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
         // one stream entry: acc = acc op X[:,f], no push/pop
-        const int nxt = (j + 1 < L.n_nodes) ? src[tape_off[i] + j + 1].opcode : -1;
+        const int nxt = (j + 1 < L.n_nodes) ? tsrc[j + 1].opcode : -1;
         if (ns > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
           code = (nxt == BSR_OP_ADD) ? BSR_SOP_ADD_T : BSR_SOP_MUL_T;
           ++j;
@@ -1187,7 +1210,9 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
               : (r.opcode == BSR_OP_LN) ? 2 : is_binary_op(r.opcode) ? 3 : 1;
     }
     (*loc)[i].n_stream = ns;
-    (*loc)[i].slots = slots_mask;
+    (*loc)[i].nt = nt;
+    (*loc)[i].nl = nl;
+    (*loc)[i].grp = 0;
     (*loc)[i].cost = cost;
     (*loc)[i].max_sp = mx;
     (*loc)[i].acc_only = (c->chain_eval && n_push == 1 && n_stack_ops == 0) ? 1 : 0;
@@ -1203,10 +1228,97 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const int words = (nt + 1 + 3) / 4 + 1;
       for (int t = nt; t < words * 4; ++t) pf[t >> 2] |= id0 << (16 * (t & 3));
     }
-    if (s.tile) {
-      const uint64_t id0 = pf2[0] & 0xFFFFu;
-      const int words = (nt + 1 + 3) / 4 + 1;
-      for (int t = nt; t < words * 4; ++t) pf2[t >> 2] |= id0 << (16 * (t & 3));
+  }
+  // ---- tile pass: tape groups, their LDS slot maps and column-pointer tables, the column stream in LDS slots.
+  // No tape may need more value-stack slots than the register stack holds.
+  if (c->tile_on && c->tile_ever && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK && !s.use_lds) {
+    const int T = c->tile_T, K = c->K;
+    const int cap = (n + T - 1) / T;   // tapes per group at most (keeps the groups' passes even)
+    // tapes by cost, heaviest first (stable: equal costs keep batch order)
+    cost_order(s.order_tmp, s.order_keys, n, [&](int i) { return (*loc)[i].cost; });
+    s.order_n = n;
+    if ((int)s.grp_slot.size() < T * c->n_cols) s.grp_slot.resize((size_t)T * c->n_cols);
+    std::fill(s.grp_slot.begin(), s.grp_slot.begin() + (size_t)T * c->n_cols, (int16_t)-1);
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tape_cols = [&](int i, auto&& fn) {   // the columns tape i reads, in stream order
+      const uint64_t* pf = hf + (*loc)[i].feat_off;
+      for (int t = 0; t < (*loc)[i].nt; ++t) fn((int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu));
+    };
+    for (int oi = 0; oi < n; ++oi) {
+      const int i = s.order_tmp[oi];
+      int g = 0;
+      if (T > 1 && c->tile_whole) {
+        g = oi % T;   // the slice sits in LDS whole: columns are cheap, balance the cost (LPT inside the group follows)
+      } else if (T > 1) {
+        // chunked: every column of a group costs LDS (shorter chunks) and HBM traffic (the group streams it over all
+        // rows): the group that needs the fewest new columns for this tape, then the lighter one
+        int best_new = 1 << 30;
+        for (int gi = 0; gi < T; ++gi) {
+          if (cnt[gi] >= cap) continue;
+          int n_new = 0;
+          tape_cols(i, [&](int col) { if (s.grp_slot[(size_t)gi * c->n_cols + col] < 0) ++n_new; });
+          if (n_new < best_new || (n_new == best_new && load[gi] < load[g])) { best_new = n_new; g = gi; }
+        }
+      }
+      (*loc)[i].grp = g;
+      ++cnt[g];
+      load[g] += (*loc)[i].cost;
+      tape_cols(i, [&](int col) {
+        int16_t& sl = s.grp_slot[(size_t)g * c->n_cols + col];
+        if (sl < 0) { sl = 0; ++ncol[g]; }
+      });
+    }
+    // slots in ascending column order per group; the group's table: X columns, y, every chain's basis
+    const void** hcols = s.h_cols();
+    int max_ncols = 0;
+    for (int g = 0; g < T; ++g) {
+      int nf = 0;
+      for (int col = 0; col < c->n_cols; ++col) {
+        int16_t& sl = s.grp_slot[(size_t)g * c->n_cols + col];
+        if (sl < 0) continue;
+        sl = (int16_t)nf;
+        hcols[(size_t)g * s.cols_stride + nf] = col_ptr(c, c->Xt, col);
+        ++nf;
+      }
+      s.grp_nF[g] = nf;
+      hcols[(size_t)g * s.cols_stride + nf] = c->y;
+      for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
+        for (int k = 0; k < K; ++k)
+          hcols[(size_t)g * s.cols_stride + nf + 1 + ci * K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * K + k);
+      max_ncols = std::max(max_ncols, nf + 1 + tile_chains * K);
+    }
+    // the whole slice in LDS at once, or chunks through two buffers (f32: one, staged through registers): as many
+    // blocks as fit, a whole number of chain passes where there is room for one
+    const size_t budget = tile_lds_bytes_max() - 1024;
+    const size_t per_block = (size_t)max_ncols * BSR_TILE_BLOCK * c->esz;
+    int chunk = 0;
+    static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hook: chunks of at most this many blocks
+    if (per_block * (size_t)c->tile_bps <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
+      chunk = c->tile_bps;
+    } else {
+      const size_t nbuf = (c->esz == 8) ? 2 : 1;
+      chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / (nbuf * per_block));
+      if (force_chunk > 0) chunk = std::min(chunk, force_chunk);
+      if (chunk >= BSR_TILE_NB) chunk = chunk / BSR_TILE_NB * BSR_TILE_NB;
+      else if (chunk >= 2) chunk = 2;
+    }
+    if (chunk >= 1 && max_ncols < 32768) {
+      s.tile = true;
+      s.tile_ncols = max_ncols;
+      s.tile_chunk = chunk;
+      memset(hf2, 0, fw * 8);
+      for (int i = 0; i < n; ++i) {
+        const TapeLoc& L = (*loc)[i];
+        const uint64_t* pf = hf + L.feat_off;
+        uint64_t* pf2 = hf2 + L.feat_off;
+        const int16_t* map = s.grp_slot.data() + (size_t)L.grp * c->n_cols;
+        const int words = (L.nt + 1 + 3) / 4 + 1;   // the padding ids repeat the first terminal's
+        for (int t = 0; t < words * 4; ++t) {
+          const int col = (int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu);
+          pf2[t >> 2] |= (uint64_t)(uint16_t)map[col] << (16 * (t & 3));
+        }
+      }
     }
   }
   if (g_stream_stats) {
@@ -1226,6 +1338,9 @@ static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
   D->spill_need = std::max(0, L.max_sp - 1 - 2);  // sized for the smallest register stack (2 slots at 8 rows/lane)
   D->cost = L.cost;
   D->chain = L.acc_only;
+  D->grp = L.grp;
+  D->n_term = L.nt;
+  D->n_ln = L.nl;
 }
 
 static void fill_eval_desc(bsr_ctx* c, PropDesc* D, const TapeLoc& L, void* zout) {
@@ -1335,21 +1450,27 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       const uint64_t* feats = codes + s.code_words;
       const double* lnp = reinterpret_cast<const double*>(feats + s.feat_words);
       const uint64_t* feats_lds = reinterpret_cast<const uint64_t*>(lnp + s.ln_words);
+      auto fill = [&](auto& a) {
+        using TT = typename std::remove_reference<decltype(a)>::type;
+        a.g = j.tg;
+        a.colsrc = (decltype(TT::colsrc))s.d_cols();
+        a.cols_stride = s.cols_stride;
+        a.N = c->N; a.codes = codes; a.feats = feats_lds; a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched();
+        a.part = s.part1; a.P = j.P; a.K = c->K; a.stamps = c->d_stamps;
+        for (int i = 0; i < 8; ++i) a.grp_nF[i] = s.grp_nF[i];
+        a.cols_in_args = (j.tg.T <= BSR_TILE_ARG_GROUPS && j.tg.ncols <= BSR_TILE_ARG_COLS) ? 1 : 0;
+        for (int gi = 0; gi < BSR_TILE_ARG_GROUPS; ++gi)
+          for (int i = 0; i < BSR_TILE_ARG_COLS; ++i)
+            a.cols[gi][i] = (a.cols_in_args && gi < j.tg.T && i < j.tg.ncols)
+                                ? (decltype(a.cols[0][0]))s.h_cols()[(size_t)gi * s.cols_stride + i] : nullptr;
+      };
       if (c->dtype == BSR_DTYPE_F64) {
         TileArgs<double> a;
-        a.g = j.tg; a.colsrc = (const double* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
-        a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
-        a.stamps = c->d_stamps;
-        for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const double*)s.h_cols()[i] : nullptr;
-        for (int i = 0; i < 8; ++i) a.grp_mask[i] = (j.tg.per_group > 0) ? s.grp_mask[i] : ~0ull;
+        fill(a);
         launch_tile<double>(s0, a);
       } else {
         TileArgs<float> a;
-        a.g = j.tg; a.colsrc = (const float* const*)s.d_cols(); a.N = c->N; a.codes = codes; a.feats = feats_lds;
-        a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched(); a.part = s.part1; a.P = j.P; a.K = c->K;
-        a.stamps = c->d_stamps;
-        for (int i = 0; i < BSR_TILE_ARG_COLS; ++i) a.cols[i] = (i < j.tg.ncols) ? (const float*)s.h_cols()[i] : nullptr;
-        for (int i = 0; i < 8; ++i) a.grp_mask[i] = (j.tg.per_group > 0) ? s.grp_mask[i] : ~0ull;
+        fill(a);
         launch_tile<float>(s0, a);
       }
     } else {
@@ -1547,7 +1668,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
   LaunchGeom g = geometry(c, s, P);
   const bool tile = scoring && s.tile;
-  const int n_part = tile ? c->tile_slices * c->tile_sub + c->tile_left : g.n_rb;   // partial records per proposal that k_solve reduces
+  const int n_part = tile ? c->tile_slices + c->tile_left : g.n_rb;   // partial records per proposal that k_solve reduces
   {
     LaunchGeom gp = g;
     gp.n_rb = std::max(g.n_rb, n_part);
@@ -1557,97 +1678,100 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   int rc = BSR_OK;
   TileGeom tg;
   memset(&tg, 0, sizeof tg);
+  // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
+  if (s.order_n != P || !scoring) cost_order(s.order_tmp, s.order_keys, P, [&](int i) { return hd[i].cost; });
+  s.order_n = -1;   // (a rescoring run reuses the slot with other descriptors)
+  for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
   if (tile) {
-    // geometry of this launch: the context's slices, as many blocks per chunk as the batch's columns leave room for
+    // geometry of this launch: the context's slices, the chunk the batch's columns leave room for, and the schedule:
+    // inside its group a tape goes -- heaviest first -- to the wave with the least work so far that still has a free
+    // set of sums (waves w, w+4, w+8, w+12 share a SIMD, but a light wave frees issue slots for its SIMD mates, so
+    // per-wave balance is what is worth having)
     tg.T = c->tile_T;
     tg.n_slices = c->tile_slices;
     tg.bps = c->tile_bps;
     tg.n_blocks = c->tile_blocks;
-    tg.ncols = s.nF + 1 + s.tile_chains * c->K;
-    tg.y_slot = s.nF;
-    const size_t per_block = (size_t)tg.ncols * BSR_TILE_BLOCK * c->esz;
-    const size_t lds_budget = tile_lds_bytes_max() - 1024;
-    // the whole slice fits in LDS: staged once, waves pull tapes from the group's list (single-chunk variant);
-    // otherwise chunks of as many blocks as fit (fp64: in each of two buffers)
-    const bool single = per_block * tg.bps <= lds_budget && env_int("BSR_TILE_SINGLE", 1);
-    if (single) tg.chunk_blocks = std::max(1, tg.bps);
-    else tg.chunk_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)tg.bps, lds_budget / ((c->esz == 8) ? 2 : 1) / per_block));
-    const int per_group = (P + tg.T - 1) / tg.T;
-    const int q_need = (per_group + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;
-    const int qb = (c->K <= 3) ? 4 : ((c->K <= 5) ? 3 : 2);
-    tg.qmax = (q_need <= 1) ? 1 : qb;
-    tg.n_pass = (q_need + tg.qmax - 1) / tg.qmax;
-    tg.per_group = single ? per_group : 0;
-    // pipelined staging (four loader waves bring the slice in by LDS-DMA, the others start on the first pair of
-    // blocks): correct, but the copies arrive at a quarter of the rate sixteen issuing waves reach, so off
-    // unless asked for
-    tg.piped = (c->tile_piped && tg.bps <= 30) ? 1 : 0;   // the kernel keeps one arrival counter per pair of blocks (16)
-    tg.n_sub = c->tile_sub;
-    tg.sub_blocks = c->tile_sub_blocks;
     tg.n_left = c->tile_left;
-    tg.n_part = tg.n_slices * tg.n_sub + tg.n_left;
-    if (tg.n_sub > 1 && tg.per_group == 0) return fail(c, BSR_E_STATE, "tile geometry: sub-slices need the single-chunk variant");
-    // column table: referenced X columns, y, the basis columns of the batch's chains
-    const void** hc = s.h_cols();
-    const int32_t* hfeat = s.h_feat();
-    for (int f = 0; f < s.nF; ++f) hc[f] = col_ptr(c, c->Xt, hfeat[f]);
-    hc[s.nF] = c->y;
-    for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
-      for (int k = 0; k < c->K; ++k)
-        hc[s.nF + 1 + ci * c->K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * c->K + k);
-  }
-  // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
-  s.order_tmp.resize(P);
-  for (int i = 0; i < P; ++i) s.order_tmp[i] = i;
-  std::stable_sort(s.order_tmp.begin(), s.order_tmp.end(), [&](int a, int b) { return hd[a].cost > hd[b].cost; });
-  for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
-  if (tile && tg.per_group > 0) {
-    // single-chunk variant: group g's list = tapes g, g+T, ... of the cost order, heaviest first
-    const size_t n_sched = (size_t)tg.T * tg.per_group;
-    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
-    int32_t* sc = s.h_sched();
-    for (size_t i = 0; i < n_sched; ++i) sc[i] = -1;
-    for (int i = 0; i < P; ++i) sc[(size_t)(i % tg.T) * tg.per_group + i / tg.T] = s.order_tmp[i];
-    // what each group has to stage: the slots its tapes read, y, the bases of its tapes' chains
-    for (int gi = 0; gi < 8; ++gi) s.grp_mask[gi] = ~0ull;
-    if (tg.ncols <= 64 && (int)s.tape_slots.size() >= P && tg.T <= 8 && c->stage_subset) {
-      for (int gi = 0; gi < tg.T; ++gi) s.grp_mask[gi] = 1ull << tg.y_slot;
-      for (int i = 0; i < P; ++i) {
-        const int p = s.order_tmp[i], gi = i % tg.T;
-        uint64_t m = s.tape_slots[p];
-        for (int kq = 0; kq < c->K; ++kq) m |= 1ull << (hd[p].qslot + kq);
-        s.grp_mask[gi] = (m == ~0ull || s.grp_mask[gi] == ~0ull) ? ~0ull : (s.grp_mask[gi] | m);
-      }
-      for (int gi = 0; gi < tg.T; ++gi)
-        if (s.tape_slots.empty()) s.grp_mask[gi] = ~0ull;
-    }
-  } else if (tile) {
-    // Static schedule: tapes in cost order are dealt to the T groups round-robin; inside a group each goes to the
-    // wave with the least work so far that still has a free slot (waves w, w+4, w+8, w+12 share a SIMD, but a light
-    // wave frees issue slots for its SIMD mates, so per-wave balance is what is worth having).
+    tg.n_part = n_part;
+    tg.ncols = s.tile_ncols;
+    tg.ncols_fixed = s.tile_chains * c->K;
+    tg.chunk_blocks = s.tile_chunk;
+    tg.qmax = c->tile_qmax;
+    int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];
+    int most = 0;
+    for (int gi = 0; gi < tg.T; ++gi) most = std::max(most, cnt_g[gi]);
+    const int per_pass = BSR_TILE_WAVES * tg.qmax;
+    tg.n_pass = std::max(1, (most + per_pass - 1) / per_pass);
     const int slots_per_wave = tg.n_pass * tg.qmax;
-    const size_t n_sched = (size_t)tg.T * tg.n_pass * BSR_TILE_WAVES * tg.qmax;
+    const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
     if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
-    int32_t* sc = s.h_sched();
-    for (size_t i = 0; i < n_sched; ++i) sc[i] = -1;
+    TapeRec* sc = s.h_sched();
+    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps ? most : 0;   // whole slice: the waves pull from the group's list
+    s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
+    for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
+    int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)
+    const uint64_t* hcodes = s.h_streams();
+    const uint64_t* hfeats = hcodes + s.code_words;
+    const double* hln = reinterpret_cast<const double*>(hfeats + s.feat_words);
+    const uint64_t* hfeats_lds = reinterpret_cast<const uint64_t*>(hln + s.ln_words);
     s.wave_load.assign((size_t)tg.T * BSR_TILE_WAVES, 0.0);
-    std::vector<int>& cnt = s.order_tmp;  // reuse below after copying the order
-    std::vector<int> order(s.order_tmp.begin(), s.order_tmp.begin() + P);
-    cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
+    s.wave_cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
     for (int i = 0; i < P; ++i) {
-      const int p = order[i];
-      const int grp = i % tg.T;
-      int best = -1;
-      for (int w = 0; w < BSR_TILE_WAVES; ++w) {
-        const int idx = grp * BSR_TILE_WAVES + w;
-        if (cnt[idx] >= slots_per_wave) continue;
-        if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
+      const int p = s.order_tmp[i];
+      const PropDesc& D = hd[p];
+      const int grp = D.grp;
+      if (grp < 0 || grp >= tg.T) return fail(c, BSR_E_STATE, "tile schedule: tape group out of range");
+      size_t ri;
+      if (tg.per_group > 0) {
+        // the waves pull their tapes: where in the group's share of the record array a record sits does not matter
+        ri = (size_t)grp * tg.n_pass * per_pass + (size_t)s.wave_cnt[grp * BSR_TILE_WAVES]++;
+      } else {
+        int best = -1;
+        for (int w = 0; w < BSR_TILE_WAVES; ++w) {
+          const int idx = grp * BSR_TILE_WAVES + w;
+          if (s.wave_cnt[idx] >= slots_per_wave) continue;
+          if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
+        }
+        if (best < 0) return fail(c, BSR_E_STATE, "tile schedule: no free set of sums");
+        const int idx = grp * BSR_TILE_WAVES + best;
+        const int slot = s.wave_cnt[idx]++;
+        const int pass = slot / tg.qmax, q = slot % tg.qmax;
+        ri = (((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q;
+        s.wave_load[idx] += (double)D.cost;
       }
-      const int idx = grp * BSR_TILE_WAVES + best;
-      const int slot = cnt[idx]++;
-      const int pass = slot / tg.qmax, q = slot % tg.qmax;
-      sc[(((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q] = p;
-      s.wave_load[idx] += (double)hd[p].cost;
+      left_idx[i] = (int32_t)ri;
+      // the tape's record: what the wave needs to start it, and the heads of its streams (a long tape reads on from them)
+      TapeRec& R = sc[ri];
+      R.p = p;
+      R.n_nodes = D.n_nodes;
+      R.chain = D.chain;
+      R.qslot = D.qslot;
+      R.s = D.s;
+      R.code0 = hcodes[D.code_off];
+      R.code1 = hcodes[D.code_off + 1];
+      R.f0 = hfeats_lds[D.feat_off];
+      R.f1 = hfeats_lds[D.feat_off + 1];
+      const double* pl = hln + 2 * (size_t)D.ln_off;
+      for (int t = 0; t < 3; ++t) {   // (the stream holds n_ln pairs and a padding pair)
+        R.ln[2 * t] = (t <= D.n_ln) ? pl[2 * t] : 1.0;
+        R.ln[2 * t + 1] = (t <= D.n_ln) ? pl[2 * t + 1] : 0.0;
+      }
+      R.code_off = D.code_off;
+      R.feat_off = D.feat_off;
+      R.ln_off = D.ln_off;
+      R.n_ln = D.n_ln;
+      R.n_term = D.n_term;
+      R.grp = grp;
+    }
+    if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
+      int32_t* glist = left_idx + P;
+      for (size_t i = 0; i < (size_t)tg.T * tg.per_group; ++i) glist[i] = -1;
+      int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < P; ++i) {
+        const int grp = hd[s.order_tmp[i]].grp;
+        glist[(size_t)grp * tg.per_group + fill[grp]++] = left_idx[i];
+      }
     }
   }
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
@@ -1655,7 +1779,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   TailJob job;
   job.slot = (int)(&s - c->slot);
   job.P = P; job.n_part = n_part; job.g = g; job.spill_slots = spill_slots; job.nq = nq; job.scoring = scoring;
-  job.in_bytes = s.off_streams + (s.code_words + s.feat_words * (s.tile ? 2 : 1) + s.ln_words) * 8;
+  job.in_bytes = tile ? s.off_recs + s.recs_bytes : s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
   job.tile = tile;
   job.tg = tg;
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
@@ -2058,7 +2182,7 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
     D->ck = chain[i];
     D->qbase = col_ptr(c, c->Q, (int64_t)chain[i] * K);
     D->zout = nullptr;
-    D->qslot = s.nF + 1 + s.chain_slot[chain[i]] * K;
+    D->qslot = s.grp_nF[loc[i].grp] + 1 + s.chain_slot[chain[i]] * K;   // slot of the chain's basis in the tape group's LDS map
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
     // the candidate is the tree it would replace, again (same canonical form): tell k_solve its column is in the span
@@ -2067,13 +2191,17 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
       const bsr_node* t = rows + tape_off[i];
       const int len = tape_off[i + 1] - tape_off[i];
       const uint64_t h = c->cur_hash[ck];
-      if (h != 0 && h == canon_hash(t, len) &&
+      // (the canonical form drops negations at the root and reorders operands: equal forms have equal node counts
+      // below the root's negations -- a cheap filter in front of the hash)
+      const std::vector<bsr_node>& cur = c->cur_tape[ck];
+      int lc = (int)cur.size(), lt = len;
+      while (lc > 0 && cur[lc - 1].opcode == BSR_OP_NEG) --lc;
+      while (lt > 0 && t[lt - 1].opcode == BSR_OP_NEG) --lt;
+      if (h != 0 && lc == lt && h == canon_hash(t, len) &&
           canon_form(t, len) == canon_form(c->cur_tape[ck].data(), (int)c->cur_tape[ck].size()))
         D->self_dup = 1;
     }
   }
-  s.tape_slots.resize(B);
-  for (int i = 0; i < B; ++i) s.tape_slots[i] = loc[i].slots;
   // keep the batch's tapes: bsr_commit makes one of them a current tree (its canonical form is needed then)
   s.rows_copy.assign(rows, rows + tape_off[B]);
   s.off_copy.assign(tape_off, tape_off + B + 1);
@@ -2186,12 +2314,7 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
         D.s = std::ldexp(1.0, -e);
         s.h_desc()[j] = D;
       }
-      {   // the descriptors moved: the per-tape slot sets no longer line up with them (every group stages everything)
-        const std::vector<uint64_t> kept_slots = s.tape_slots;
-        s.tape_slots.clear();
-        rc = enqueue(c, s, (int)redo.size(), true);
-        s.tape_slots = kept_slots;
-      }
+      rc = enqueue(c, s, (int)redo.size(), true);   // (a descriptor keeps its tape group: the group's LDS slot map numbers its columns)
       if (rc == BSR_OK) rc = wait_slot(c, s);
       if (rc != BSR_OK) return rc;
       for (size_t j = 0; j < redo.size(); ++j) {

@@ -423,7 +423,10 @@ __device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg, int w) {
 // row blocks loads them once (load_tape_head) instead of paying three scalar round trips per block.
 struct TapeHead {
   uint64_t code0, code1, f0, f1;
-  double la, lb;
+  double la, lb;            // the (a, b) pair of the tape's first ln node
+  const double* ln_near;    // three pairs (the first one again) in the tape's record, or null: the ln stream only
+  int n_ln, n_term;         // ln nodes / terminals of the tape, or -1: not known (the streams are then read ahead
+                            // unconditionally, as far as their padding allows)
 };
 __device__ __forceinline__ TapeHead load_tape_head(const uint64_t* codes, const uint64_t* feats, const double* lnp) {
   const uint64_t CONSTANT_AS* cw = as_const(codes);
@@ -436,8 +439,41 @@ __device__ __forceinline__ TapeHead load_tape_head(const uint64_t* codes, const 
   h.f1 = fw[1];
   h.la = lp[0];
   h.lb = lp[1];
+  h.ln_near = nullptr;
+  h.n_ln = -1;
+  h.n_term = -1;
   return h;
 }
+// The (a, b) pairs of a tape's ln nodes in stream order, fetched one ahead of their use.  The first three travel with
+// the tape's record (tile pass: the 128 bytes the wave has just read -- a hit in the scalar cache); later ones, and all
+// of them where there is no record, come from the ln stream: memory the host wrote microseconds ago, a miss in every
+// cache, and a wait that also holds up the LDS reads queued behind it.  A tape of the real mix (at most three ln
+// nodes, eight terminals, 32 entries) never goes there.
+struct LnFeed {
+  double a, b;
+  int used, n_ln;
+  const double CONSTANT_AS* lp;
+  const double CONSTANT_AS* near;
+  __device__ __forceinline__ void init(const TapeHead& hd, const double* lnp) {
+    a = hd.la;
+    b = hd.lb;
+    used = 0;
+    n_ln = hd.n_ln;
+    lp = as_const(lnp);
+    near = as_const(hd.ln_near);
+  }
+  __device__ __forceinline__ void next() {   // the pair in (a, b) has been used
+    ++used;
+    if (hd_near() && used < 3) {
+      a = near[2 * used];
+      b = near[2 * used + 1];
+    } else if (n_ln < 0 || used < n_ln) {
+      a = lp[2 * used];
+      b = lp[2 * used + 1];
+    }
+  }
+  __device__ __forceinline__ bool hd_near() const { return near != nullptr; }
+};
 
 // QUAD: the out-of-line routines take four values per call (a caller short of registers asks for pairs).
 template <typename T, int U, int S, typename Loader, bool QUAD = true>
@@ -452,8 +488,9 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
   st.lane = lane;
   uint64_t code = hd.code0, code_next = hd.code1;
   uint64_t fhead = hd.f0, fnext = hd.f1;
-  double la = hd.la, lb = hd.lb;
-  int ci = 1, fi = 1, li = 1, nt = 0;
+  LnFeed ln;
+  ln.init(hd, lnp);
+  int ci = 1, fi = 1, nt = 0;
   int sp = 0;  // values on the stack below the accumulator
   T pre[U];
   ldr.load((int)(fhead & 0xFFFFu), acc);  // node 0 is always a terminal
@@ -465,7 +502,7 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
     if ((i & 15) == 0) {
       code = code_next;
       ++ci;
-      code_next = cw[ci];
+      if (16 * ci < n) code_next = cw[ci];
     }
     const int op = (int)(code & 15u);
     code >>= 4;
@@ -521,7 +558,7 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
       if (++nt == 4) {
         fhead = fnext;
         ++fi;
-        fnext = fw[fi];
+        if (hd.n_term < 0 || 4 * fi <= hd.n_term) fnext = fw[fi];   // (one terminal is requested ahead of its use)
         nt = 0;
       }
       ldr.load((int)(fhead & 0xFFFFu), pre);
@@ -543,12 +580,10 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
           for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
           break;
         case BSR_OP_LN: {
-          const T a = (T)la, b = (T)lb;
+          const T a = (T)ln.a, b = (T)ln.b;
 #pragma unroll
           for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
-          la = lp[2 * li];
-          lb = lp[2 * li + 1];
-          ++li;
+          ln.next();
         } break;
         case BSR_OP_NEG:
 #pragma unroll
@@ -633,8 +668,9 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
   const LdsPass<T, NB, FULL> ldr{sx, rb_rows, off, nb};
   uint64_t code = hd.code0, code_next = hd.code1;
   uint64_t fhead = hd.f0, fnext = hd.f1;
-  double la = hd.la, lb = hd.lb;
-  int ci = 1, fi = 1, li = 1, nt = 1;
+  LnFeed ln;
+  ln.init(hd, lnp);
+  int ci = 1, fi = 1, nt = 1;
   ldr.load((int)(fhead & 0xFFFFu), acc);  // entry 0 is the chain's terminal
   fhead >>= 16;
   code >>= 4;
@@ -642,7 +678,7 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
     if ((i & 15) == 0) {
       code = code_next;
       ++ci;
-      code_next = cw[ci];
+      if (16 * ci < n) code_next = cw[ci];
     }
     const int op = (int)(code & 15u);
     code >>= 4;
@@ -655,7 +691,7 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
         if (++nt == 4) {
           fhead = fnext;
           ++fi;
-          fnext = fw[fi];
+          if (hd.n_term < 0 || 4 * fi < hd.n_term) fnext = fw[fi];
           nt = 0;
         }
         if (op == BSR_SOP_ADD_T) {
@@ -671,12 +707,10 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
         for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : (T)1 / acc[u];
         break;
       case BSR_OP_LN: {
-        const T a = (T)la, b = (T)lb;
+        const T a = (T)ln.a, b = (T)ln.b;
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = a * acc[u] + b;  // two roundings (contraction is off)
-        la = lp[2 * li];
-        lb = lp[2 * li + 1];
-        ++li;
+        ln.next();
       } break;
       case BSR_OP_NEG:
 #pragma unroll

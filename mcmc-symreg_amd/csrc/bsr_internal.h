@@ -56,6 +56,9 @@ struct PropDesc {
   int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
   int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
   int32_t qslot;        // tile pass: LDS slot of the chain's first basis column (K consecutive slots)
+  int32_t grp;          // tile pass: the tape group that runs the tape
+  int32_t n_term;       // terminals in the tape's column stream
+  int32_t n_ln;         // ln nodes ((a, b) pairs in its ln stream)
   int32_t chain;        // the tape is a chain (bsr_device.h: chain_eval): first entry a terminal, every other one acc -> acc
   int32_t self_dup;     // the host found the candidate to be the chain's current tree k again (same canonical form, up to
                         // root negation): its column lies in the span exactly, w = 0 needs no residual pass
@@ -117,52 +120,70 @@ struct RefreshPlan {  // per chain, device scratch handed from one refresh kerne
 #define BSR_TILE_WAVES 16                 // waves per workgroup (one workgroup per CU)
 #define BSR_TILE_U 2                      // rows per lane and block: a block is 64 * U = 128 rows
 #define BSR_TILE_BLOCK (BSR_WAVE * BSR_TILE_U)
-#define BSR_TILE_QMAX 4                   // tape slots per wave and pass (register accumulator sets)
+#define BSR_TILE_NB 4                     // blocks per pass of a chain tape (2 NB values per lane in registers)
+#define BSR_TILE_ARG_GROUPS 4
+#define BSR_TILE_ARG_COLS 32
+#define BSR_TILE_QMAX 2                   // tapes (sets of per-lane sums) per wave and pass: with four, the sums, a pass of
+                                          // values and its operand columns no longer fit 128 registers (K = 3: 17 spilled)
 struct TileGeom {
   int T;                // tape groups: workgroup w serves slice w % n_slices with the tapes of group w / n_slices
   int n_slices;         // row slices (partials per proposal)
   int bps;              // blocks per slice
   int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
-  int chunk_blocks;     // blocks staged in LDS at a time
-  int piped;            // single-chunk variant: the slice arrives by LDS-DMA while the first tapes already run
-  int n_left;           // blocks behind the last slice (n_blocks - n_slices * bps): (tape, block) units any wave takes
-  int n_pass;           // passes over the slice (tapes per wave beyond the accumulator sets)
-  int qmax;             // accumulator sets of the launched variant (1 or up to BSR_TILE_QMAX)
-  int ncols;            // LDS columns: referenced X columns, y, K basis columns per chain of the batch
-  int y_slot;           // LDS slot of y
-  int per_group;        // single-chunk variant: tapes per group (length of a group's list in `sched`)
-  int n_sub;            // partial records per (tape, slice): 1
-  int sub_blocks;       // = bps
-  int n_part;           // partial records per proposal = n_slices * n_sub
+  int chunk_blocks;     // blocks staged in LDS at a time: bps (the whole slice, staged once), or a multiple of BSR_TILE_NB
+                        // below it (two buffers, LDS-DMA)
+  int n_left;           // blocks behind the last slice (n_blocks - n_slices * bps): (tape, block) units dealt to the waves
+  int n_pass;           // passes over the slice (tapes per wave beyond the sets of sums)
+  int qmax;             // sets of sums per wave of the launched kernel (tile_qmax(K))
+  int ncols;            // most LDS columns of any tape group (X columns it reads, y, K basis columns per chain of the batch)
+  int ncols_fixed;      // ... of which the basis columns: chains of the batch x K
+  int n_part;           // partial records per proposal = n_slices + n_left
+  int per_group;        // > 0: whole-slice variant with tape pulling (k_tile1): entries of a group's list of record indices
+                        // (cost order, -1 padded), which sit behind the schedule's cost-order index
 };
+// Everything a wave needs to run one tape of the tile pass, in one 128-byte record the host writes into the schedule:
+// the wave fetches it with one scalar load instead of three dependent ones (schedule -> descriptor -> streams) from
+// memory that misses every cache -- the host wrote it microseconds ago.
+struct TapeRec {
+  int32_t p;            // tape (proposal) index, -1: no tape in this set of sums
+  int32_t n_nodes;      // stream entries
+  int32_t chain;        // chain tape (bsr_device.h: chain_eval)
+  int32_t qslot;        // LDS slot of the chain's first basis column in the group's map
+  double s;             // prescale of the candidate column
+  uint64_t code0, code1, f0, f1;   // first words of the opcode and column streams
+  double ln[6];         // first three (a, b) pairs of the ln stream
+  int32_t code_off, feat_off, ln_off;   // where the streams go on
+  int32_t n_ln, n_term;
+  int32_t grp;          // the tape's group
+};
+static_assert(sizeof(TapeRec) == 128, "one tape record per 128 bytes");
+
 template <typename T>
 struct TileArgs {
   TileGeom g;
-  const T* const* colsrc;     // [ncols] global column pointers (device memory)
+  const T* const* colsrc;     // [T][cols_stride] global column pointers (device memory): a tape group's X columns in LDS
+  int cols_stride;            // slot order, its y, the basis columns of the batch's chains
+  int cols_in_args;           // the groups' tables are also in `cols` below (at most 4 groups of at most 32 columns): the
+                              // table in memory was written microseconds ago and misses every cache, the argument block
+                              // is on its way to the workgroup anyway
+  int grp_nF[8];              // X columns per tape group (= the LDS slot of its y)
   int64_t N;
   const uint64_t* codes;
-  const uint64_t* feats;
+  const uint64_t* feats;      // column stream in the tape group's LDS slots
   const double* lnp;
   const PropDesc* desc;
-  const int32_t* sched;       // multi-chunk: [T][n_pass][BSR_TILE_WAVES][qmax] tape index or -1
-                              // single-chunk: [T][per_group] tape indices, heaviest first, -1 padded
-  double* part;               // [P][n_slices][BSR_P1_WORDS]
+  const TapeRec* sched;       // [T][n_pass][BSR_TILE_WAVES][qmax] the waves' tapes (host: cost-balanced)
+  double* part;               // [P][n_part][BSR_P1_WORDS]
   int P;
   int K;
   unsigned long long* stamps; // diagnostics (BSR_TILE_STAMPS=1): [workgroup][wave][8] clock samples, else null
-  // the first BSR_TILE_ARG_COLS column pointers again, inside the kernel-argument block: the input block was written
-  // microseconds ago and is cold for every CU, the argument block is not
-  const T* cols[32];
-  // LDS slots each tape group needs (bit = slot; all ones: every column): a group does not stage what only the other
-  // groups' tapes read (derived columns mostly)
-  uint64_t grp_mask[8];
+  const T* cols[BSR_TILE_ARG_GROUPS][BSR_TILE_ARG_COLS];
 };
-#define BSR_TILE_ARG_COLS 32
-#define BSR_TILE_LOADERS 4      // waves per workgroup that stage the slice (piped staging)
 #define BSR_TILE_STAMP_WORDS 8
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
 size_t tile_lds_bytes_max();
+int tile_qmax(int K);
 
 struct LaunchGeom {
   int rb_rows;      // rows per row block (multiple of 256)

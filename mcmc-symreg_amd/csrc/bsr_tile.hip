@@ -131,12 +131,19 @@ __device__ __forceinline__ void stage_rows(T* sx, const T* const CONSTANT_AS* co
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <typename T>
 __device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
-                                         int nb, int wave, int lane) {
+                                         int nb, int wave, int lane, uint64_t mask = ~0ull) {
   static_assert(sizeof(T) == 8, "one 128-row block of a column per instruction");
-  const int n_units = ncols * nb;
-  int col = 0, blk = wave;
-  while (blk >= nb && col < ncols) { blk -= nb; ++col; }
+  // unit = (column, block), column-major over the columns to stage (`mask`: bit = LDS slot, all ones = every column)
+  const int n_sel = (mask == ~0ull) ? ncols : __builtin_popcountll(mask);
+  const int n_units = n_sel * nb;
   for (int u = wave; u < n_units; u += BSR_TILE_WAVES) {
+    const int ci = u / nb, blk = u - ci * nb;
+    int col = ci;
+    if (mask != ~0ull) {
+      uint64_t m = mask;
+      for (int k = 0; k < ci; ++k) m &= m - 1;
+      col = __builtin_ctzll(m);
+    }
     const T* src = colsrc[col] + (int64_t)(c0 + blk) * BSR_TILE_BLOCK + 2 * lane;
     T* dst = buf + (size_t)col * chunk_rows + (size_t)blk * BSR_TILE_BLOCK;
     // Written as inline assembly on purpose: behind the builtin the compiler parks a vmcnt(0) in front of every later
@@ -144,18 +151,6 @@ __device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* col
     // caller waits for the copies itself (dma_wait) before the barrier that publishes them.
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
-    blk += BSR_TILE_WAVES;
-    while (blk >= nb && col < ncols) { blk -= nb; ++col; }
-  }
-}
-
-// waits until at most `left` of the wave's copies are still in flight (copies complete in issue order)
-__device__ __forceinline__ void dma_wait_left(int left) {
-  switch (left) {
-#define X(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
-#undef X
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or more than the cases cover
   }
 }
 
@@ -225,66 +220,332 @@ struct PtrCols {
   }
 };
 
+// Lane reduction of the sums of the QMAX tapes a wave ran, all at once, and the store of their (tape, slice) records.
+// The NV = KQ + 2 sums of every tape go through ONE swap network, densely packed: v_permlane32_swap + add halves the
+// lanes of two quantities at a time, v_permlane16_swap + add again, and the last four steps inside a 16-lane row run
+// on the LDS crossbar (ds_swizzle) -- for K = 3, four tapes: 20 sums in five registers' worth of in-row steps,
+// ~20 vector instructions per tape where one tape at a time took ~45.  max|z| likewise with maxima.  The totals land
+// in a per-wave LDS scratch, from where lane (q, word) writes word `word` of tape q's record.
+// Every sum is combined in the same order whatever else shares the network (halves, 16-lane rows, then lane ^ 1, 2, 4,
+// 8): a tape's totals do not depend on its companions.
+template <int KQ, int QMAX>
+__device__ __forceinline__ void reduce_store(const TapeAcc<KQ> (&A)[QMAX], const TapeRec* my, double* part,
+                                             int n_part, int rec, double* scratch, int lane) {
+  constexpr int NV = KQ + 2;
+  constexpr int NT = QMAX * NV;
+  constexpr int NTP = (NT + 3) / 4 * 4;
+  double v[NTP];
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q) {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) v[q * NV + i] = A[q].c[i];
+    v[q * NV + KQ] = A[q].a0;
+    v[q * NV + KQ + 1] = A[q].a1;
+  }
+#pragma unroll
+  for (int i = NT; i < NTP; ++i) v[i] = 0.0;
+  const int row = lane >> 4;
+  const int rmap = ((row & 1) << 1) | (row >> 1);   // rows 0, 1, 2, 3 of a register end with values 0, 2, 1, 3 of its four
+  const bool writer = (lane & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < NTP / 4; ++i) {
+    double w0, w1;
+    swap32(v[4 * i], v[4 * i + 1]);
+    w0 = v[4 * i] + v[4 * i + 1];
+    swap32(v[4 * i + 2], v[4 * i + 3]);
+    w1 = v[4 * i + 2] + v[4 * i + 3];
+    swap16(w0, w1);
+    const double x = row_sum16_swz(w0 + w1);
+    if (writer) scratch[4 * i + rmap] = x;
+  }
+  // max|z|: the same network with maxima (inputs are non-negative)
+  if constexpr (QMAX == 4) {
+    double m0 = A[0].amax, m1 = A[1].amax, m2 = A[2].amax, m3 = A[3].amax;
+    swap32(m0, m1);
+    m0 = vmax_raw(m0, m1);
+    swap32(m2, m3);
+    m2 = vmax_raw(m2, m3);
+    swap16(m0, m2);
+    double m = vmax_raw(m0, m2);
+    m = vmax_raw(m, swz_xor_f64<1>(m));
+    m = vmax_raw(m, swz_xor_f64<2>(m));
+    m = vmax_raw(m, swz_xor_f64<4>(m));
+    m = vmax_raw(m, swz_xor_f64<8>(m));
+    if (writer) scratch[NTP + rmap] = m;
+  } else {
+    static_assert(QMAX == 2, "two or four tapes per wave");
+    double m0 = A[0].amax, m1 = A[1].amax;
+    swap32(m0, m1);
+    double m = vmax_raw(m0, m1);     // lanes 0..31: tape 0, lanes 32..63: tape 1
+    m = vmax_raw(m, swz_xor_f64<1>(m));
+    m = vmax_raw(m, swz_xor_f64<2>(m));
+    m = vmax_raw(m, swz_xor_f64<4>(m));
+    m = vmax_raw(m, swz_xor_f64<8>(m));
+    m = vmax_raw(m, swz_xor_f64<16>(m));
+    if ((lane & 31) == 0) scratch[NTP + (lane >> 5)] = m;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (waves do not share scratch)
+  // lane (q, w): word w of tape q's record -- 0..7 projections, 8 |s z|^2, 9 s z.y, 10 max|z|, 11 zero
+  if (lane < QMAX * BSR_P1_WORDS) {
+    const int q = lane / BSR_P1_WORDS, w = lane - q * BSR_P1_WORDS;
+    const int p = my[q].p;
+    const int idx = (w < KQ) ? q * NV + w : (w == 8) ? q * NV + KQ : (w == 9) ? q * NV + KQ + 1 : NTP + q;
+    const bool has = (w < KQ) || (w >= 8 && w <= 10);
+    const double val = has ? scratch[idx] : 0.0;
+    if (p >= 0) part[((size_t)p * n_part + rec) * BSR_P1_WORDS + w] = val;
+  }
+  __builtin_amdgcn_wave_barrier();   // the scratch is reused by the wave's next pass
+}
+
+// a tape group's column-pointer table: from the kernel-argument block where it fits there
+template <typename T>
+__device__ __forceinline__ const T* const CONSTANT_AS* group_cols(const TileArgs<T>& a, int grp) {
+  return a.cols_in_args ? (const T* const CONSTANT_AS*)((const char CONSTANT_AS*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                        offsetof(TileArgs<T>, cols)) + (size_t)grp * BSR_TILE_ARG_COLS
+                        : (const T* const CONSTANT_AS*)a.colsrc + (size_t)grp * a.cols_stride;
+}
+
 // The blocks behind the last slice (n_blocks is rarely a multiple of the slice count; at N = 100k: 14 of 782) as
 // (tape, block) units: tapes in cost order, every unit one single-block pass with its own partial record (index
-// n_slices * n_sub + block).  Unit u belongs to workgroup u mod n_wg (3 or 4 units each at C2 instead of a seventh
-// block for 28 workgroups); inside the workgroup the waves take them through the same LDS counter that hands out the
-// tapes, so they go to whoever runs dry first.  (A global ticket counter was tried first: 4 096 waves on one address
-// serialise at the memory side, 50 us.)  `li` is the wave's first leftover item, `counter` the LDS counter, `base`
-// its value at the first leftover item.
+// n_slices + block), dealt to the waves of the launch in order: unit u goes to wave u mod (workgroups x 16) -- at C2
+// 896 units over 3 072 waves instead of a fifth block for some workgroups.  Their rows are in no workgroup's LDS:
+// columns are read through the launch's column-pointer table.
 template <typename T, int KQ>
-__device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileGeom& g, int lane, int li, int* counter,
-                                               int base) {
+__device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileGeom& g, int lane, int wave) {
   constexpr int U = BSR_TILE_U;
   constexpr int S = BSR_REG_STACK;
   using V2 = typename VecOf<T, 2>::type;
-  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
-  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
-  const int n_units = a.P * g.n_left, n_wg = (int)gridDim.x;
-  for (;;) {
-    const int tk = li * n_wg + (int)blockIdx.x;
-    if (tk >= n_units) break;
-    int nx = 0;
-    if (lane == 0) nx = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // the tapes in cost order: index of the tape's record in the schedule (the index list sits behind the records)
+  const int32_t CONSTANT_AS* left_idx = as_const(reinterpret_cast<const int32_t*>(a.sched + (size_t)g.T * g.n_pass * BSR_TILE_WAVES * g.qmax));
+  const int n_units = a.P * g.n_left, n_waves = (int)gridDim.x * BSR_TILE_WAVES;
+  for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units; tk += n_waves) {
     const int ti = tk / g.n_left, bi = tk - ti * g.n_left;
-    const int p = dsc[ti].order;   // the ti-th most expensive tape
+    const TapeRec CONSTANT_AS* rec = as_const(a.sched + left_idx[ti]);   // the ti-th most expensive tape
+    const int p = rec->p;
     const int blk = g.n_slices * g.bps + bi;
     const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
-    const uint64_t* pc = a.codes + dsc[p].code_off;
-    const uint64_t* pf = a.feats + dsc[p].feat_off;
-    const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
-    const int qslot = dsc[p].qslot;
-    const V2 yv = *reinterpret_cast<const V2*>(colsrc[g.y_slot] + row0);
+    const uint64_t* pc = a.codes + rec->code_off;
+    const uint64_t* pf = a.feats + rec->feat_off;
+    const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
+    const int qslot = rec->qslot, grp = rec->grp;
+    const T* const CONSTANT_AS* colsrc = group_cols<T>(a, grp);   // the tape's group
+    const V2 yv = *reinterpret_cast<const V2*>(colsrc[a.grp_nF[grp & 7]] + row0);
     V2 qv[KQ > 0 ? KQ : 1];
 #pragma unroll
     for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(colsrc[qslot + i] + row0);
+    TapeHead hd;
+    hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+    hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+    hd.ln_near = (const double*)rec->ln;
+    hd.n_ln = rec->n_ln;
+    hd.n_term = rec->n_term;
+    const double s = rec->s;
     T z[U];
     PtrCols<T, U> ldr{colsrc, row0};
-    run_tape<T, U, S>(pc, pf, pl, dsc[p].n_nodes, ldr, z, (T*)nullptr, lane);
+    run_tape_head<T, U, S, PtrCols<T, U>, false>(hd, pc, pf, pl, rec->n_nodes, ldr, z, (T*)nullptr, lane);
     TapeAcc<KQ> A;
     A.clear();
-    if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, dsc[p].s, row0, a.N);
-    else accumulate_v<T, KQ, true>(A, z, yv, qv, dsc[p].s, row0, a.N);
+    if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, s, row0, a.N);
+    else accumulate_v<T, KQ, true>(A, z, yv, qv, s, row0, a.N);
     store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
-    li = __builtin_amdgcn_readfirstlane(nx) - base;
   }
 }
 
-// Single-chunk variant: the workgroup's whole slice fits in LDS.  Staged once; then the waves pull tapes from the
-// group's list (heaviest first) through an LDS counter, and a wave runs its tape over all blocks of the slice with one
-// set of accumulators.  Which wave runs a tape does not matter to the sums (one wave, blocks in order).
+// The row pass.  Workgroup = (row slice, tape group); wave w of group g runs the up to QMAX tapes the host's schedule
+// gives it (cost-balanced, sched[g][pass][w][q]) over the slice, with one set of per-lane sums per tape, and reduces
+// them over the lanes together at the end (reduce_store).  The slice is staged in LDS whole where it fits (C2: 18
+// columns x 4 blocks), else chunk by chunk through two buffers filled by LDS-DMA, the next chunk travelling while the
+// waves run their tapes on this one (C5).
 //
-// A chain tape (bsr_device.h: chain_eval) is run a pass of up to NBIG blocks at a time, the whole pass in registers:
-// one decode of the tape per pass, operators in place.  Any other tape goes through the stack machine two blocks at a
-// time.  Both produce the same values per row and add them up in the same order (per lane: blocks in order, the
-// lane's two rows of a block in order), so a proposal's sums do not depend on which route its tape takes.
+// A chain tape (bsr_device.h: chain_eval) runs a pass of NB blocks at a time, the whole pass in registers: one decode
+// of the tape per pass, operators in place.  Any other tape goes through the stack machine two blocks at a time.
+// Both produce the same values per row and add them up in the same order (per lane: blocks in order, the lane's two
+// rows of a block in order), and what is summed in which order depends only on the context (slice boundaries), never
+// on the batch, the schedule or the chunking: a proposal's partial sums -- hence its score -- are bit-identical
+// whatever else shares the launch.
+template <typename T, int KQ>
+struct TileShape {
+  // blocks per pass of a chain tape: four (16 VGPRs of values, as many of operand columns) next to the sums of K <= 4
+  // basis columns, two beyond (K = 8: 22 VGPRs of sums per tape)
+  static constexpr int NB = (sizeof(T) == 4 || KQ <= 4) ? BSR_TILE_NB : BSR_TILE_NB / 2;
+  static constexpr int QMAX = BSR_TILE_QMAX;                   // tapes (sets of sums) per wave and pass
+};
+
+template <typename T, int KQ>
+__global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a) {
+  constexpr int U = BSR_TILE_U;
+  constexpr int S = BSR_REG_STACK;
+  constexpr int NB = TileShape<T, KQ>::NB;
+  constexpr int QMAX = TileShape<T, KQ>::QMAX;
+  using V2 = typename VecOf<T, 2>::type;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [buffers][ncols][chunk_rows]
+  __shared__ double s_red[BSR_TILE_WAVES][QMAX * (KQ + 2) + 8];
+  const TileGeom g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
+  const int b0 = slice * g.bps, b1 = b0 + g.bps;   // slices of bps blocks; the blocks behind the last one: leftover_units
+  const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
+  const bool multi = g.chunk_blocks < g.bps;   // the slice does not fit LDS whole: two buffers, LDS-DMA
+  const int buf_elems = multi ? g.ncols * chunk_rows : 0;
+  const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
+  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
+  const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
+  const int y_slot = a.grp_nF[tg & 7];
+  const int ncols = y_slot + 1 + (g.ncols_fixed);   // the group's LDS columns
+  // diagnostics: shader-clock samples per wave (0 start, 1 first chunk staged, 2 first chunk computed, 3 all chunks
+  // computed, 4 reductions stored; 7 and 6: the constant-rate 100 MHz clock at the start and at the end -- the shader
+  // clock counters of different XCDs are not aligned, only differences inside one wave mean anything)
+  unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
+#define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  TSTAMP(0);
+  if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+  tables_to_lds();  // visible after the first barrier below
+  for (int pass = 0; pass < g.n_pass; ++pass) {
+    const TapeRec* my = a.sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
+    TapeAcc<KQ> A[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) A[q].clear();
+    if (!multi) {
+      if (pass == 0) {
+        stage_rows<T, 8>(sx, colsrc, ncols, chunk_rows, b0, g.bps, wave, lane);
+        __syncthreads();
+        TSTAMP(1);
+      }
+    } else {
+      if constexpr (sizeof(T) == 8) {
+        if (pass != 0) __syncthreads();  // everyone is done with the last chunk of the pass before
+        dma_rows<T>(sx, colsrc, ncols, chunk_rows, b0, min(g.chunk_blocks, b1 - b0), wave, lane);
+        dma_wait();
+        __syncthreads();
+        if (pass == 0) TSTAMP(1);
+      }
+    }
+    int ci = 0;
+    for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks, ++ci) {
+      const int nbc = min(g.chunk_blocks, b1 - c0);
+      const T* cur = sx + (size_t)(ci & 1) * buf_elems;
+      if (multi) {
+        if constexpr (sizeof(T) == 8) {
+          const int n0 = c0 + g.chunk_blocks;
+          if (n0 < b1)
+            dma_rows<T>(sx + (size_t)((ci + 1) & 1) * buf_elems, colsrc, ncols, chunk_rows, n0, min(g.chunk_blocks, b1 - n0),
+                        wave, lane);
+        } else {
+          // f32 columns keep one register-staged buffer (LDS-DMA moves 16 bytes per lane: half a block of floats)
+          if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
+          stage_rows<T, 4>(sx, colsrc, ncols, chunk_rows, c0, nbc, wave, lane);
+          __syncthreads();
+          if (c0 == b0 && pass == 0) TSTAMP(1);
+        }
+      }
+      const T* sy = cur + (size_t)y_slot * chunk_rows;
+#pragma unroll 1
+      for (int q = 0; q < QMAX; ++q) {
+        const TapeRec CONSTANT_AS* rec = as_const(my + q);
+        if (rec->p < 0) continue;
+        const uint64_t* pc = a.codes + rec->code_off;
+        const uint64_t* pf = a.feats + rec->feat_off;
+        const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
+        const int n_nodes = rec->n_nodes;
+        const double s = rec->s;
+        const bool chain = rec->chain != 0;
+        const T* sq = cur + (size_t)rec->qslot * chunk_rows;
+        TapeHead hd;
+        hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+        hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+    hd.ln_near = (const double*)rec->ln;
+        hd.n_ln = rec->n_ln;
+        hd.n_term = rec->n_term;
+        // the sums of block `blk` (absolute), whose lane pair sits at `off` of the staged rows, into set q
+        auto add_block = [&](const T (&zz)[U], int off, int blk) {
+          const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
+          const V2 yv = *reinterpret_cast<const V2*>(sy + off);
+          V2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * chunk_rows + off);
+          const bool whole = blk < n_full;   // wave-uniform
+#define BSR_ACC_CASE(qq)                                                               \
+  case qq:                                                                             \
+    if constexpr (qq < QMAX) {                                                         \
+      if (whole) accumulate_v<T, KQ, false>(A[qq], zz, yv, qv, s, row0, a.N);          \
+      else accumulate_v<T, KQ, true>(A[qq], zz, yv, qv, s, row0, a.N);                 \
+    }                                                                                  \
+    break;
+          switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) }
+#undef BSR_ACC_CASE
+        };
+        int b = 0;
+        if (chain) {
+          // a pass of NB blocks: the tape once over 2 NB values per lane, then the blocks' sums in order
+          auto pass_nb = [&](auto full_tag, int pn) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk (block j of the pass: 128 j rows on)
+            T z[2 * NB];
+            chain_eval<T, NB, FULL>(hd, pc, pf, pl, n_nodes, cur, chunk_rows, off, pn, z);
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              if (FULL || jb < pn) {
+                const T zz[U] = {z[2 * jb], z[2 * jb + 1]};
+                add_block(zz, off + jb * BSR_TILE_BLOCK, c0 + b + jb);
+              }
+            }
+            b += pn;
+          };
+          while (nbc - b >= NB) pass_nb(std::integral_constant<bool, true>{}, NB);
+          if (b < nbc) pass_nb(std::integral_constant<bool, false>{}, nbc - b);
+        } else {
+          // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.
+#pragma unroll 1
+          for (; b + 1 < nbc; b += 2) {
+            const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk (second pair 128 rows on)
+            T z4[2 * U];
+            LdsCols<T, 2 * U> ldr{cur, chunk_rows, off};
+            run_tape_head<T, 2 * U, S, LdsCols<T, 2 * U>, false>(hd, pc, pf, pl, n_nodes, ldr, z4, (T*)nullptr, lane);
+            const T za[U] = {z4[0], z4[1]}, zb[U] = {z4[2], z4[3]};
+            add_block(za, off, c0 + b);
+            add_block(zb, off + BSR_TILE_BLOCK, c0 + b + 1);
+          }
+          if (b < nbc) {
+            const int off = b * BSR_TILE_BLOCK + 2 * lane;
+            T z[U];
+            LdsCols<T, U> ldr{cur, chunk_rows, off};
+            run_tape_head<T, U, S, LdsCols<T, U>, false>(hd, pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
+            add_block(z, off, c0 + b);
+          }
+        }
+      }
+      if (multi) {
+        if constexpr (sizeof(T) == 8) {  // chunk done by every wave, and the next one has landed
+          dma_wait();
+          __syncthreads();
+        }
+      }
+      if (c0 == b0 && pass == 0) TSTAMP(2);
+    }
+    if (pass == g.n_pass - 1) TSTAMP(3);
+    reduce_store<KQ, QMAX>(A, my, a.part, g.n_part, slice, s_red[wave], lane);
+  }
+  if (g.n_left > 0) leftover_units<T, KQ>(a, g, lane, wave);
+  TSTAMP(4);
+  if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#undef TSTAMP
+}
+
+// Whole-slice variant with tape pulling (contexts whose slices fit LDS whole: C2, C3, C4).  The slice is staged once;
+// then the waves PULL tapes from the group's list (heaviest first, a.glist) through an LDS counter, and a wave runs
+// its tape over all blocks of the slice with one set of sums: with two to four tapes per wave of very different cost
+// (a leaf: ~230 vector instructions per slice, a nest of three transcendentals: ~1 900) pulling balances what a
+// static schedule cannot, and a slice twice as long (T = 2 groups) halves the per-tape costs: decode, record fetch,
+// lane reduction.  Which wave runs a tape does not matter to the sums (one wave, blocks in order).  Chain tapes run a
+// pass of up to eight blocks at a time (K <= 4), the whole pass in registers.
 template <typename T, int KQ>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> a) {
   constexpr int U = BSR_TILE_U;
   constexpr int S = BSR_REG_STACK;
-  // blocks per pass of a chain tape: what the register file holds next to the accumulators (f64: K <= 4 eight blocks
-  // = 32 VGPRs of values, K >= 5 four)
-  constexpr int NBIG = (sizeof(T) == 4 || KQ <= 4) ? 8 : 4;
+  constexpr int NBIG = (sizeof(T) == 4 || KQ <= 4) ? 8 : 4;   // blocks per pass of a chain tape: what the registers hold
   using V2 = typename VecOf<T, 2>::type;
   extern __shared__ __align__(16) unsigned char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
@@ -293,51 +554,68 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  // every slice holds bps blocks; the n_left blocks behind the last slice are handed out one (tape, block) at a time
-  // to whichever wave runs dry first (leftover_units): no workgroup carries a block more than the others
   const int b0 = slice * g.bps;
   const int nb = g.bps;
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
-  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
-  const int32_t CONSTANT_AS* list = as_const(a.sched) + (size_t)tg * g.per_group;
-  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
-  const T* sy = sx + (size_t)g.y_slot * chunk_rows;
+  const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
+  const int y_slot = a.grp_nF[tg & 7];
+  const int ncols = y_slot + 1 + g.ncols_fixed;
+  const T* sy = sx + (size_t)y_slot * chunk_rows;
   const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
+  // the group's tapes in cost order: indices of their records
+  const int32_t CONSTANT_AS* list = as_const(reinterpret_cast<const int32_t*>(a.sched + (size_t)g.T * g.n_pass * BSR_TILE_WAVES * g.qmax) +
+                                             a.P + (size_t)tg * g.per_group);
   unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
 #define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;
-  tables_to_lds();
-  stage_rows<T, 8>(sx, colsrc, g.ncols, chunk_rows, b0, nb, wave, lane, a.grp_mask[tg & 7]);
+  // the slice's columns first, the math tables behind them: one round trip to memory for both (the tables in front,
+  // with their own wait before the LDS write, cost the staging a second one)
+  if constexpr (sizeof(T) == 8) {
+    dma_rows<T>(sx, colsrc, ncols, chunk_rows, b0, nb, wave, lane);
+    for (int t = wave; t < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024); t += BSR_TILE_WAVES) {
+      const char* src = (const char*)bsr_tables_src + t * 1024 + lane * 16;
+      const uint32_t la = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + t * 1024));
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+    }
+    dma_wait();
+  } else {
+    stage_rows<T, 8>(sx, colsrc, ncols, chunk_rows, b0, nb, wave, lane);
+    tables_to_lds();
+  }
   __syncthreads();
   TSTAMP(1);
   TSTAMP(2);
-  // unit of work: a tape of the group's list over the whole slice, heaviest tape first.  (Finer units -- every tape, or
-  // only the heavy ones, in two halves -- were measured twice: the lane reduction and the decode each extra unit pays
-  // cost what the better balance gains.)
   const int n_items = g.per_group;
   int idx = wave;   // the first list entries go to the waves in order
   while (idx < n_items) {
-    const int p = list[idx];
-    if (p < 0) {   // padding behind the group's last tape: take the next item (the leftover units follow the list)
+    const int ri = list[idx];
+    if (ri < 0) {   // padding behind the group's last tape
       int nx = 0;
       if (lane == 0) nx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       idx = __builtin_amdgcn_readfirstlane(nx);
       continue;
     }
-    const int sb0 = 0, sb1 = nb;
     // the next unit is requested now; its round trip hides under this one
     int nxt = 0;
     if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint64_t* pc = a.codes + dsc[p].code_off;
-    const uint64_t* pf = a.feats + dsc[p].feat_off;
-    const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
-    const int n_nodes = dsc[p].n_nodes;
-    const double s = dsc[p].s;
-    const bool chain = dsc[p].chain != 0;
-    const T* sq = sx + (size_t)dsc[p].qslot * chunk_rows;
-    const TapeHead hd = load_tape_head(pc, pf, pl);
+    const TapeRec CONSTANT_AS* rec = as_const(a.sched + ri);
+    const int p = rec->p;
+    const uint64_t* pc = a.codes + rec->code_off;
+    const uint64_t* pf = a.feats + rec->feat_off;
+    const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
+    const int n_nodes = rec->n_nodes;
+    const double s = rec->s;
+    const bool chain = rec->chain != 0;
+    const T* sq = sx + (size_t)rec->qslot * chunk_rows;
+    TapeHead hd;
+    hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+    hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+    hd.ln_near = (const double*)rec->ln;
+    hd.n_ln = rec->n_ln;
+    hd.n_term = rec->n_term;
     TapeAcc<KQ> A;
     A.clear();
     // one 128-row block: the lane's pair of rows, sums in row order
@@ -350,7 +628,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       if (b0 + b < n_full) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
       else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
     };
-    int b = sb0;
+    int b = 0;
     if (chain) {
       // a pass of NB blocks: the tape once over 2 NB values per lane, then the blocks' sums in order
       auto pass = [&](auto nb_tag, auto full_tag, int pn) {
@@ -378,14 +656,14 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
         b += pn;
       };
       using std::integral_constant;
-      while (NBIG > 4 && sb1 - b >= NBIG) pass(integral_constant<int, NBIG>{}, integral_constant<bool, true>{}, NBIG);
-      while (sb1 - b >= 4) pass(integral_constant<int, 4>{}, integral_constant<bool, true>{}, 4);
-      if (b < sb1) pass(integral_constant<int, 4>{}, integral_constant<bool, false>{}, sb1 - b);
+      while (NBIG > 4 && nb - b >= NBIG) pass(integral_constant<int, NBIG>{}, integral_constant<bool, true>{}, NBIG);
+      while (nb - b >= 4) pass(integral_constant<int, 4>{}, integral_constant<bool, true>{}, 4);
+      if (b < nb) pass(integral_constant<int, 4>{}, integral_constant<bool, false>{}, nb - b);
     } else {
       // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.  The
       // per-lane sums still grow block by block in row order, so the result does not depend on the pairing.
 #pragma unroll 1
-      for (; b + 1 < sb1; b += 2) {
+      for (; b + 1 < nb; b += 2) {
         const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the slice (second pair 128 rows on)
         T z4[2 * U];
         LdsCols<T, 2 * U> ldr{sx, chunk_rows, off};
@@ -395,7 +673,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
         add_block(za, off, b);
         add_block(zb, off + BSR_TILE_BLOCK, b + 1);
       }
-      if (b < sb1) {
+      if (b < nb) {
         const int off = b * BSR_TILE_BLOCK + 2 * lane;
         T z[U];
         LdsCols<T, U> ldr{sx, chunk_rows, off};
@@ -407,123 +685,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     idx = __builtin_amdgcn_readfirstlane(nxt);
   }
   TSTAMP(3);
-  // the tape list is empty: idx - n_items is this wave's first item of the workgroup's leftover units
-  if (g.n_left > 0 && idx >= n_items) leftover_units<T, KQ>(a, g, lane, idx - n_items, &s_next, n_items);
-  TSTAMP(4);
-  if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
-#undef TSTAMP
-}
-
-template <typename T, int KQ, int QMAX>
-__global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a) {
-  constexpr int U = BSR_TILE_U;
-  constexpr int S = BSR_REG_STACK;
-  extern __shared__ __align__(16) unsigned char smem[];
-  T* sx = reinterpret_cast<T*>(smem);  // [ncols][chunk_rows]
-  const TileGeom g = a.g;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  const int b0 = slice * g.bps;   // slices of bps blocks; the blocks behind the last one: leftover_units
-  const int b1 = b0 + g.bps;
-  const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
-  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
-  const int32_t CONSTANT_AS* sched = as_const(a.sched);
-  const T* const CONSTANT_AS* colsrc = (const T* const CONSTANT_AS*)a.colsrc;
-  // diagnostics: shader-clock samples per wave (0 start, 1 first chunk staged, 2 first chunk computed, 3 all chunks
-  // computed, 4 reductions stored; 7 and 6: the constant-rate 100 MHz clock at the start and at the end -- the shader
-  // clock counters of different XCDs are not aligned, only differences inside one wave mean anything)
-  unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
-#define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
-  TSTAMP(0);
-  if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
-
-  __shared__ int s_left;   // hands the workgroup's leftover units to its waves
-  if (threadIdx.x == 0) s_left = 0;
-  tables_to_lds();  // visible after the first barrier below
-  // Two LDS buffers of chunk_rows rows per column.  While the waves run their tapes over chunk c, the rows of chunk
-  // c+1 travel HBM -> LDS on their own (LDS-DMA: no registers, nothing for the waves to do); the barrier that ends the
-  // chunk also waits for them (its fence drains vmcnt).  f32 columns keep the register-staged single buffer.
-  constexpr bool DMA = sizeof(T) == 8;
-  const int buf_elems = DMA ? g.ncols * chunk_rows : 0;
-  for (int pass = 0; pass < g.n_pass; ++pass) {
-    const int32_t CONSTANT_AS* my = sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
-    TapeAcc<KQ> A[QMAX];
-#pragma unroll
-    for (int q = 0; q < QMAX; ++q) A[q].clear();
-
-    if constexpr (DMA) {
-      if (pass != 0) __syncthreads();  // everyone is done with the last chunk of the pass before
-      dma_rows<T>(sx, colsrc, g.ncols, chunk_rows, b0, min(g.chunk_blocks, b1 - b0), wave, lane);
-      dma_wait();
-      __syncthreads();
-      if (pass == 0) TSTAMP(1);
-    }
-    int ci = 0;
-    for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks, ++ci) {
-      const int nb = min(g.chunk_blocks, b1 - c0);
-      const T* cur = sx + (size_t)(ci & 1) * buf_elems;
-      if constexpr (DMA) {
-        const int n0 = c0 + g.chunk_blocks;
-        if (n0 < b1)
-          dma_rows<T>(sx + (size_t)((ci + 1) & 1) * buf_elems, colsrc, g.ncols, chunk_rows, n0, min(g.chunk_blocks, b1 - n0),
-                      wave, lane);
-      } else {
-        if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
-        stage_rows<T, 4>(sx, colsrc, g.ncols, chunk_rows, c0, nb, wave, lane);
-        __syncthreads();
-        if (c0 == b0 && pass == 0) TSTAMP(1);
-      }
-      const T* sy = cur + (size_t)g.y_slot * chunk_rows;
-#pragma unroll 1
-      for (int q = 0; q < QMAX; ++q) {
-        const int p = my[q];
-        if (p < 0) continue;
-        const uint64_t* pc = a.codes + dsc[p].code_off;
-        const uint64_t* pf = a.feats + dsc[p].feat_off;
-        const double* pl = a.lnp + 2 * (size_t)dsc[p].ln_off;
-        const int n_nodes = dsc[p].n_nodes;
-        const double s = dsc[p].s;
-        const T* sq = cur + (size_t)dsc[p].qslot * chunk_rows;
-#pragma unroll 1
-        for (int b = 0; b < nb; ++b) {
-          const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk
-          const int64_t row0 = (int64_t)(c0 + b) * BSR_TILE_BLOCK + 2 * lane;
-          T z[U];
-          LdsCols<T, U> ldr{cur, chunk_rows, off};
-          run_tape<T, U, S>(pc, pf, pl, n_nodes, ldr, z, (T*)nullptr, lane);
-          const bool full = (int64_t)(c0 + b + 1) * BSR_TILE_BLOCK <= a.N;  // wave-uniform
-#define BSR_ACC_CASE(qq)                                                                              \
-  case qq:                                                                                            \
-    if constexpr (qq < QMAX) {                                                                        \
-      if (full) accumulate<T, KQ, false>(A[qq], z, sy + off, sq + off, chunk_rows, s, row0, a.N);     \
-      else accumulate<T, KQ, true>(A[qq], z, sy + off, sq + off, chunk_rows, s, row0, a.N);           \
-    }                                                                                                 \
-    break;
-          switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) BSR_ACC_CASE(2) BSR_ACC_CASE(3) }
-#undef BSR_ACC_CASE
-        }
-      }
-      if constexpr (DMA) {  // chunk done by every wave, and the next one has landed
-        dma_wait();
-        __syncthreads();
-      }
-      if (c0 == b0 && pass == 0) TSTAMP(2);
-    }
-    if (pass == g.n_pass - 1) TSTAMP(3);
-    // one lane reduction per (tape, slice); every lane stores the same totals (no lane-divergent branch)
-#pragma unroll
-    for (int q = 0; q < QMAX; ++q) {
-      const int p = my[q];
-      if (p < 0) continue;
-      store_partial<KQ>(A[q], a.part + ((size_t)p * g.n_part + slice) * BSR_P1_WORDS, lane);
-    }
-  }
-  if (g.n_left > 0) {
-    int li = 0;
-    if (lane == 0) li = __hip_atomic_fetch_add(&s_left, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    leftover_units<T, KQ>(a, g, lane, __builtin_amdgcn_readfirstlane(li), &s_left, 0);
-  }
+  if (g.n_left > 0) leftover_units<T, KQ>(a, g, lane, wave);
   TSTAMP(4);
   if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
 #undef TSTAMP
@@ -533,39 +695,34 @@ template <typename T, int KQ>
 void launch_kq(hipStream_t st, const TileArgs<T>& a) {
   const TileGeom& g = a.g;
   const dim3 grid((unsigned)(g.T * g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  // the chunked fp64 variant keeps two buffers (LDS-DMA double buffering)
-  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((g.per_group == 0 && sizeof(T) == 8) ? 2 : 1);
+  // a slice that does not fit whole travels through two buffers (fp64: LDS-DMA double buffering)
+  const bool multi = g.chunk_blocks < g.bps;
+  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((multi && sizeof(T) == 8) ? 2 : 1);
   if (g.per_group > 0) {
-    static bool attr0 = false;
-    if (!attr0) {
-      (void)hipFuncSetAttribute((const void*)k_tile1<T, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(tile_lds_bytes_max() - 1024));
-      attr0 = true;
-    }
-    hipLaunchKernelGGL((k_tile1<T, KQ>), grid, block, lds, st, a);
-  } else if (g.qmax == 1) {
     static bool attr1 = false;
     if (!attr1) {
-      (void)hipFuncSetAttribute((const void*)k_tile<T, KQ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)k_tile1<T, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(tile_lds_bytes_max() - 1024));
       attr1 = true;
     }
-    hipLaunchKernelGGL((k_tile<T, KQ, 1>), grid, block, lds, st, a);
-  } else {
-    constexpr int QB = (KQ <= 3) ? 4 : ((KQ <= 5) ? 3 : 2);
-    static bool attrb = false;
-    if (!attrb) {
-      (void)hipFuncSetAttribute((const void*)k_tile<T, KQ, QB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(tile_lds_bytes_max() - 1024));
-      attrb = true;
-    }
-    hipLaunchKernelGGL((k_tile<T, KQ, QB>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_tile1<T, KQ>), grid, block, lds, st, a);
+    return;
   }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_tile<T, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(tile_lds_bytes_max() - 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_tile<T, KQ>), grid, block, lds, st, a);
 }
 
 }  // namespace
 
-size_t tile_lds_bytes_max() { return 160 * 1024 - BSR_TAB_DOUBLES * sizeof(double); }  // the math tables are static LDS
+int tile_qmax(int K) { (void)K; return BSR_TILE_QMAX; }
+
+// dynamic LDS a launch may ask for: the math tables and the reduction scratch are static LDS
+size_t tile_lds_bytes_max() { return 160 * 1024 - BSR_TAB_DOUBLES * sizeof(double) - 4096; }
 
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a) {

@@ -323,8 +323,8 @@ def test_work_queue_soak_against_the_static_grid(N, monkeypatch):
 
 @pytest.mark.parametrize("N,d,K", [(100_000, 10, 3), (40_000, 6, 8), (300_000, 40, 3)])
 def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkeypatch):
-    """One batch through the tile pass's single-chunk variant, its chunked double-buffered variant (LDS-DMA), with and
-    without derived columns: the per-lane sums grow block by block in row order in every variant and a derived column
+    """One batch through the tile pass with the slice staged whole and chunked through two LDS buffers (LDS-DMA), with and
+    without derived columns, chain tapes through either evaluator: the per-lane sums grow block by block in row order in every variant and a derived column
     holds what the interpreter would compute inline, so the scores are bit-identical.  The work-queue row pass
     (different partial blocks) agrees to rounding."""
     import bsr_oracle as O
@@ -358,11 +358,10 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     zeros = np.zeros(B, np.int32)
 
     def run(env):
-        for k in ("BSR_TILE", "BSR_TILE_SINGLE", "BSR_DERIVED", "BSR_TILE_PIPED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
-                  "BSR_SELFDUP", "BSR_STAGE_SUBSET", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE", "BSR_SPLIT_ISSUE",
+        for k in ("BSR_TILE", "BSR_TILE_CHUNK", "BSR_TILE_T", "BSR_DERIVED", "BSR_POLL_DONE", "BSR_SUBMIT_THREAD", "BSR_FUSE_FINALIZE",
+                  "BSR_SELFDUP", "BSR_WAIT_STREAM", "BSR_AUX_CUS", "BSR_SOLO_TAIL", "BSR_BAR_WRITE", "BSR_SPLIT_ISSUE",
                   "BSR_CHAIN_EVAL", "BSR_REORDER"):
             monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv("BSR_TILE_MULTI", "1")       # the chunked variant is opt-in (the third case needs it throughout)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = _ctx(X, y, K=K, n_chains=1, max_batch=B)
@@ -378,7 +377,10 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_REORDER": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_REORDER": "0", "BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()
-    assert run({"BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
+    # the slice through two LDS buffers, a chunk of two / four blocks at a time (LDS-DMA), instead of staged whole
+    assert run({"BSR_TILE_CHUNK": "2"}).tobytes() == base.tobytes()
+    assert run({"BSR_TILE_CHUNK": "4"}).tobytes() == base.tobytes()
+    assert run({"BSR_TILE_CHUNK": "1", "BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()
     assert run({"BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()       # completion word instead of an event
     assert run({"BSR_SUBMIT_THREAD": "0"}).tobytes() == base.tobytes()   # the caller issues the HIP calls itself
     assert run({"BSR_BAR_WRITE": "0"}).tobytes() == base.tobytes()       # input block by hipMemcpyAsync, not host stores
@@ -391,7 +393,10 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert np.array_equal(wide["rank"], base["rank"])
     assert np.allclose(wide["loglik"][okw], base["loglik"][okw], rtol=1e-9, atol=0)
     assert run({"BSR_SELFDUP": "0"}).tobytes() == base.tobytes()         # self-duplicates through the residual pass
-    assert run({"BSR_STAGE_SUBSET": "0"}).tobytes() == base.tobytes()    # every tape group stages every column
+    # two tape groups (slices twice as long): other partial sums -- the same scores to rounding
+    two = run({"BSR_TILE_T": "2"})
+    assert np.array_equal(two["rank"], base["rank"])
+    assert np.allclose(two["loglik"][okw], base["loglik"][okw], rtol=1e-9, atol=0)
     assert run({"BSR_FUSE_FINALIZE": "1"}).tobytes() == base.tobytes()   # k_finalize's work behind the residual pass
     assert run({"BSR_FUSE_FINALIZE": "1", "BSR_POLL_DONE": "1"}).tobytes() == base.tobytes()
     assert run({"BSR_FUSE_FINALIZE": "2"}).tobytes() == base.tobytes()   # ... handing over through uncached memory
@@ -399,7 +404,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_SOLO_TAIL": "0"}).tobytes() == base.tobytes()       # residual pass and k_finalize as two launches
     assert run({"BSR_SOLO_TAIL": "3"}).tobytes() == base.tobytes()
     assert run({"BSR_DERIVED": "0"}).tobytes() == base.tobytes()
-    assert run({"BSR_DERIVED": "0", "BSR_TILE_SINGLE": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_DERIVED": "0", "BSR_TILE_CHUNK": "2"}).tobytes() == base.tobytes()
     rows = run({"BSR_TILE": "0"})
     assert np.array_equal(rows["rank"], base["rank"])
     ok = base["rank"] == K
