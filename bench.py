@@ -247,8 +247,44 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
         kern_iso += ctx.last_timing()[0]
     ctx.set_profiling(0)
     kern_iso /= max(1, n_iso)
+    verified = verify_timed_results(wl, n_steps, warmup)
     return dict(elapsed=elapsed, n_steps=n_steps, repeats=repeats, kern_us_region=float(kern_us[0]),
-                kern_us=float(kern_iso))
+                kern_us=float(kern_iso), verified=verified)
+
+
+def verify_timed_results(wl, n_steps, first):
+    """The line proves its own work: every batch of the timed region wrote its scores into its own result array (the
+    last occurrence of each batch is what the arrays hold now); a few of them are scored again, one at a time with
+    nothing else in flight, and must come out byte for byte the same.  A pipelined region that skipped work, raced or
+    returned stale records fails here, and the bench exits non-zero."""
+    import numpy as np
+    ctx, packed = wl["ctx"], wl["packed"]
+    n_unique = len(packed)
+    timed = sorted({(first + i) % n_unique for i in range(max(0, n_steps - n_unique), n_steps)})
+    picks = timed[:: max(1, len(timed) // 4)][:4]
+    for bi in picks:
+        r = packed[bi]
+        got = r[5].copy()                       # what the pipelined region returned for this batch
+        if not np.isfinite(got["loglik"][got["rank"] == wl["K"]]).all() or (got["rank"] == 0).all():
+            raise SystemExit("bench.py: timed batch %d returned no scores" % bi)
+        again = np.zeros_like(got)
+        ctx.score_packed(r[0], r[1], r[2], r[3], r[4], again)
+        if again.tobytes() != got.tobytes():
+            bad = int(np.sum(again["loglik"].view(np.uint64) != got["loglik"].view(np.uint64)))
+            raise SystemExit("bench.py: batch %d of the timed region differs from its synchronous rescoring "
+                             "(%d of %d log-likelihoods)" % (bi, bad, len(got)))
+    return {"batches_rescored": len(picks), "byte_identical": True}
+
+
+def refuse_debug_knobs():
+    """Timing experiments and ablations change what a step does: a benchmark line is not produced under them.
+    Returns the BSR_* settings in force (they go into the line)."""
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("BSR_")}
+    bad = [k for k in knobs if k.startswith("BSR_DEBUG") or k.startswith("BSR_ABLATE")]
+    if bad:
+        sys.stderr.write("bench.py: refusing to benchmark under %s\n" % ", ".join(sorted(bad)))
+        raise SystemExit(2)
+    return knobs
 
 
 def summarize(wl, tr, ranks, args):
@@ -374,6 +410,7 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
 
 def main():
     args = parse_args()
+    knobs = refuse_debug_knobs()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_children(args)
     ranks = Ranks()
@@ -398,6 +435,8 @@ def main():
            "dtype": args.dtype, "data": "synthetic"}
     out.update(summarize(wl, tr, ranks, args))
     out["batches_in_flight"] = max(1, min(8, args.depth))
+    out["verified"] = tr["verified"]
+    out["env_knobs"] = {k: v for k, v in sorted(knobs.items()) if k not in ("BSR_SHARE_DEVICE",)}
     attach_traffic(out, args.workload, wl["B"], wl["C"], args.dtype)
     n_g = gather_trees(wl, ranks)
     if n_g is not None:
@@ -423,6 +462,7 @@ def main():
                 t2 = timed_region(w2, ranks, steps2, min(args.warmup, 10), args.depth, min(args.min_time, 0.5))
                 s2 = summarize(w2, t2, ranks, args)
                 s2["unit"] = "proposals/s"
+                s2["verified"] = t2["verified"]
                 s2["steps"] = steps2
                 attach_traffic(s2, name, w2["B"], w2["C"], args.dtype)
                 if ranks.world > 1:

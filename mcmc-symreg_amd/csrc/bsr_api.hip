@@ -104,7 +104,8 @@ struct BatchSlot {
   std::vector<int32_t> grp_cols;     // scratch: columns of one group
   int grp_nF[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // X columns per group (= the group's y slot)
   int tile_ncols = 0;                // most LDS columns of any group: sizes the LDS buffers
-  int tile_chunk = 0;                // blocks staged at a time: the whole slice, or what two buffers hold
+  int tile_chunk = 0;                // blocks staged at a time: the whole slice, or a chunk of the ring
+  int tile_ring = 1;                 // LDS buffers the chunks travel through (LDS-DMA)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
@@ -596,7 +597,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
         while (T > 4) T = (T + 1) / 2;
       }
       T = std::max(1, std::min(8, env_int("BSR_TILE_T", T)));
-      while (T > 1 && (c->tile_cus % T) != 0) --T;
+      while (c->tile_whole && T > 1 && (c->tile_cus % T) != 0) --T;   // (chunked: n_cu / T slices, a CU or two may idle)
       if (c->tile_whole && !fits_whole(T)) c->tile_whole = false;
       c->tile_T = T;
       c->tile_slices = std::max(1, c->tile_cus / T);
@@ -608,13 +609,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     }
     c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
                         (size_t)((max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax) + 1) + 64;
+    if (!c->tile_whole && !getenv("BSR_DERIVED_MAX")) c->derived_max = 16;   // chunked: the transcendentals saved are worth more columns
     // a data set of which not even one block of a narrow group (eight features or all of them, y, one chain's basis)
     // fits two LDS buffers never takes the tile pass: the work-queue row pass (bsr_kernels.hip: k_rows) serves it
     c->tile_ever = c->tile_on && (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * 2 * BSR_TILE_BLOCK * c->esz <= budget;
     // derived columns pay where the slice sits in LDS whole (a derived column is then one more column staged from L2);
     // a chunked pass would stream each of them from HBM (N = 1M: 8 MB per column and group), the work-queue pass for
     // every tape again
-    if (!(c->tile_ever && c->tile_whole) && c->n_cols > d && env_int("BSR_DERIVED", 1) < 2) {
+    if (!c->tile_ever && c->n_cols > d && env_int("BSR_DERIVED", 1) < 2) {
       c->n_cols = d;
       for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
     }
@@ -1004,9 +1006,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
     const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
     size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
-    if ((long)fit < fixed && c->tile_multi)   // chunked variant: one block per column in each of its buffers
-      fit = (tile_lds_bytes_max() - 1024) / ((size_t)((c->esz == 8) ? 2 : 1) * BSR_TILE_BLOCK * c->esz);
-    const long room = (long)fit - fixed;
+    long room = (long)fit - fixed;
+    if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
     // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
     if (room >= 0) allowance = (int)std::min<long>(room, c->n_cols);
     allowance = std::min(allowance, c->derived_max);
@@ -1026,8 +1027,8 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       const int op = rows[j + 1].opcode, m = derived_index(op);
       if (m < 0) continue;
       const int dc = c->d * (1 + m) + rows[j].feature;
-      const int w = (op == BSR_OP_SIN || op == BSR_OP_COS) ? 25 : (op == BSR_OP_EXP || op == BSR_OP_LOG) ? 16
-                    : (op == BSR_OP_INV) ? 9 : (op == BSR_OP_CUBIC) ? 5 : 1;
+      const int w = (op == BSR_OP_SIN || op == BSR_OP_COS) ? 77 : (op == BSR_OP_EXP) ? 59 : (op == BSR_OP_LOG) ? 90
+                    : (op == BSR_OP_INV) ? 35 : (op == BSR_OP_CUBIC) ? 23 : 3;   // the operator's cost (stage_tapes' cost model)
       if (ben[dc] == 0) cand.push_back({0, dc});
       ben[dc] += w;
     }
@@ -1039,8 +1040,11 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     std::sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
       return a.first != b.first ? a.first > b.first : a.second < b.second;
     });
+    // worth a column: one use of cubic or anything dearer where the slice is staged from L2; where it streams from HBM
+    // (8 bytes per row and group that uses it), an operator of 17 instructions or more per value
+    const int worth = c->tile_whole ? 15 : 35;
     for (size_t q = 0; q < cand.size() && (int)q < allowance; ++q)
-      if (cand[q].first >= 5) s.slot_of[cand[q].second] = -2;
+      if (cand[q].first >= worth) s.slot_of[cand[q].second] = -2;
   }
   // Pass 1: validation, sizes, the columns in use.  A tape whose fused encoding still pushes more than one terminal
   // (it is not a chain) is tried once more with its commutative operands in fusing order (reorder_tape): few tapes
@@ -1157,7 +1161,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     uint64_t* pf = hf + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
     const bsr_node* tsrc = s.tape_src[i];
-    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 11;
+    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 23;
     int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
     uint8_t ss_codes[64];
     int ss_n = 0;
@@ -1198,16 +1202,17 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
       ++ns;
       if (g_stream_stats) ss_codes[ss_n < 64 ? ss_n++ : 63] = (uint8_t)code;
-      // vector instructions per 64 rows of the tile pass's chain evaluator (ISA listing + PMC totals, tools/isa_audit.py):
-      // a fused or leading terminal 0-1 (its reads are LDS work), plain operators 1, ln 2, cubic 9, inv 14, exp 27,
-      // sin / cos 35, log 40, a pushed terminal or a popping operator 3 (operand copies of the stack machine); the base
-      // 11 is the projection sums (7) and the block's share of the lane reduction and the per-tape set-up
-      cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 1
-              : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 3 : 0)
-              : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 35
-              : (r.opcode == BSR_OP_EXP) ? 27 : (r.opcode == BSR_OP_LOG) ? 40
-              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 14 : (r.opcode == BSR_OP_CUBIC) ? 9
-              : (r.opcode == BSR_OP_LN) ? 2 : is_binary_op(r.opcode) ? 3 : 1;
+      // vector instructions per 64 rows of the tile pass's chain evaluator, in halves (ISA listing of k_tile1 / k_tile):
+      // a fused terminal 1.5 (its reads are LDS work), neg / square 1.5, ln 2.5, cubic 11.5, inv 17.5, exp 29.5,
+      // sin / cos 38.5 (31 of arithmetic, the huge-argument test, the call's register moves), log 45, a pushed terminal or
+      // a popping operator 3 (operand copies of the stack machine); each includes ~0.5 for its decode.  The base 11.5
+      // is the projection sums (7), the pass's set-up and the block's share of the lane reduction.
+      cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 3
+              : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 6 : 0)
+              : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 77
+              : (r.opcode == BSR_OP_EXP) ? 59 : (r.opcode == BSR_OP_LOG) ? 90
+              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 35 : (r.opcode == BSR_OP_CUBIC) ? 23
+              : (r.opcode == BSR_OP_LN) ? 5 : is_binary_op(r.opcode) ? 6 : 3;
     }
     (*loc)[i].n_stream = ns;
     (*loc)[i].nt = nt;
@@ -1241,6 +1246,9 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     std::fill(s.grp_slot.begin(), s.grp_slot.begin() + (size_t)T * c->n_cols, (int16_t)-1);
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long total_cost = 0;
+    for (int i = 0; i < n; ++i) total_cost += (*loc)[i].cost;
+    const long share = total_cost / T + total_cost / (8 * T) + 1;   // an even share of the batch's cost and an eighth
     auto tape_cols = [&](int i, auto&& fn) {   // the columns tape i reads, in stream order
       const uint64_t* pf = hf + (*loc)[i].feat_off;
       for (int t = 0; t < (*loc)[i].nt; ++t) fn((int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu));
@@ -1252,13 +1260,19 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         g = oi % T;   // the slice sits in LDS whole: columns are cheap, balance the cost (LPT inside the group follows)
       } else if (T > 1) {
         // chunked: every column of a group costs LDS (shorter chunks) and HBM traffic (the group streams it over all
-        // rows): the group that needs the fewest new columns for this tape, then the lighter one
+        // rows), and the launch ends with its heaviest group: among the groups this tape does not lift above an even
+        // share of the cost, the one that needs the fewest new columns for it; failing that, the lightest
         int best_new = 1 << 30;
+        g = -1;
         for (int gi = 0; gi < T; ++gi) {
-          if (cnt[gi] >= cap) continue;
+          if (cnt[gi] >= cap || load[gi] + (*loc)[i].cost > share) continue;
           int n_new = 0;
           tape_cols(i, [&](int col) { if (s.grp_slot[(size_t)gi * c->n_cols + col] < 0) ++n_new; });
           if (n_new < best_new || (n_new == best_new && load[gi] < load[g])) { best_new = n_new; g = gi; }
+        }
+        if (g < 0) {
+          for (int gi = 0; gi < T; ++gi)
+            if (cnt[gi] < cap && (g < 0 || load[gi] < load[g])) g = gi;
         }
       }
       (*loc)[i].grp = g;
@@ -1292,21 +1306,32 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
     // blocks as fit, a whole number of chain passes where there is room for one
     const size_t budget = tile_lds_bytes_max() - 1024;
     const size_t per_block = (size_t)max_ncols * BSR_TILE_BLOCK * c->esz;
-    int chunk = 0;
-    static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hook: chunks of at most this many blocks
+    int chunk = 0, ring = 1;
+    static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hooks: chunks of at most this many blocks,
+    static const int force_ring = env_int("BSR_TILE_RING", 0);     // a ring of this many buffers
     if (per_block * (size_t)c->tile_bps <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
       chunk = c->tile_bps;
-    } else {
-      const size_t nbuf = (c->esz == 8) ? 2 : 1;
-      chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / (nbuf * per_block));
-      if (force_chunk > 0) chunk = std::min(chunk, force_chunk);
+    } else if (c->esz == 4) {   // f32: one buffer, staged through registers
+      chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / per_block);
       if (chunk >= BSR_TILE_NB) chunk = chunk / BSR_TILE_NB * BSR_TILE_NB;
-      else if (chunk >= 2) chunk = 2;
+      if (force_chunk > 0) chunk = std::min(chunk, force_chunk);
+    } else {
+      // a ring of buffers, ring - 1 chunks in flight while the waves compute on one: what is in flight keeps HBM busy,
+      // so prefer the deepest ring that still leaves chunks of two blocks (a chain pass of four values per lane)
+      const int room = (int)(budget / per_block);   // blocks of all columns LDS holds
+      if (room >= 8) { ring = 4; chunk = room / 4 >= BSR_TILE_NB ? BSR_TILE_NB : 2; }
+      else if (room >= 6) { ring = 3; chunk = 2; }
+      else if (room >= 4) { ring = 2; chunk = 2; }
+      else if (room >= 2) { ring = 2; chunk = 1; }
+      if (force_ring >= 2 && force_ring <= 4 && room >= force_ring) { ring = force_ring; chunk = std::max(1, std::min(room / ring, BSR_TILE_NB)); }
+      if (force_chunk > 0 && chunk > 0) chunk = std::min(chunk, force_chunk);
+      chunk = std::min(chunk, c->tile_bps);
     }
     if (chunk >= 1 && max_ncols < 32768) {
       s.tile = true;
       s.tile_ncols = max_ncols;
       s.tile_chunk = chunk;
+      s.tile_ring = ring;
       memset(hf2, 0, fw * 8);
       for (int i = 0; i < n; ++i) {
         const TapeLoc& L = (*loc)[i];
@@ -1696,6 +1721,7 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
     tg.ncols = s.tile_ncols;
     tg.ncols_fixed = s.tile_chains * c->K;
     tg.chunk_blocks = s.tile_chunk;
+    tg.ring = s.tile_ring;
     tg.qmax = c->tile_qmax;
     int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];

@@ -130,8 +130,8 @@ struct TileGeom {
   int n_slices;         // row slices (partials per proposal)
   int bps;              // blocks per slice
   int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
-  int chunk_blocks;     // blocks staged in LDS at a time: bps (the whole slice, staged once), or a multiple of BSR_TILE_NB
-                        // below it (two buffers, LDS-DMA)
+  int chunk_blocks;     // blocks staged in LDS at a time: bps (the whole slice, staged once), or fewer: the slice then
+  int ring;             // streams through a ring of `ring` buffers (2..4) by LDS-DMA, ring - 1 chunks ahead
   int n_left;           // blocks behind the last slice (n_blocks - n_slices * bps): (tape, block) units dealt to the waves
   int n_pass;           // passes over the slice (tapes per wave beyond the sets of sums)
   int qmax;             // sets of sums per wave of the launched kernel (tile_qmax(K))

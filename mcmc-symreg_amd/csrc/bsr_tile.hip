@@ -130,13 +130,15 @@ __device__ __forceinline__ void stage_rows(T* sx, const T* const CONSTANT_AS* co
 // workgroup barrier waits for it.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <typename T>
-__device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
+__device__ __forceinline__ int dma_rows(T* buf, const T* const CONSTANT_AS* colsrc, int ncols, int chunk_rows, int c0,
                                          int nb, int wave, int lane, uint64_t mask = ~0ull) {
   static_assert(sizeof(T) == 8, "one 128-row block of a column per instruction");
   // unit = (column, block), column-major over the columns to stage (`mask`: bit = LDS slot, all ones = every column)
   const int n_sel = (mask == ~0ull) ? ncols : __builtin_popcountll(mask);
   const int n_units = n_sel * nb;
+  int issued = 0;
   for (int u = wave; u < n_units; u += BSR_TILE_WAVES) {
+    ++issued;
     const int ci = u / nb, blk = u - ci * nb;
     int col = ci;
     if (mask != ~0ull) {
@@ -151,6 +153,18 @@ __device__ __forceinline__ void dma_rows(T* buf, const T* const CONSTANT_AS* col
     // caller waits for the copies itself (dma_wait) before the barrier that publishes them.
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)dst);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+  }
+  return issued;
+}
+
+// waits until at most `left` of the wave's copies are still in flight (copies complete in issue order)
+__device__ __forceinline__ void dma_wait_left(int left) {
+  switch (left) {
+#define X(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+    X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
+#undef X
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or more than the cases cover
   }
 }
 
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const int b0 = slice * g.bps, b1 = b0 + g.bps;   // slices of bps blocks; the blocks behind the last one: leftover_units
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const bool multi = g.chunk_blocks < g.bps;   // the slice does not fit LDS whole: two buffers, LDS-DMA
-  const int buf_elems = multi ? g.ncols * chunk_rows : 0;
+  const int buf_elems = (multi && sizeof(T) == 8) ? g.ncols * chunk_rows : 0;   // one buffer of the ring (f32: one buffer at all)
   const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
   const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
@@ -403,36 +417,79 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   TSTAMP(0);
   if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
   tables_to_lds();  // visible after the first barrier below
+  unsigned long long busy = 0, t_busy = 0;   // diagnostics: cycles the wave spent running tapes (not waiting for copies or barriers)
   for (int pass = 0; pass < g.n_pass; ++pass) {
     const TapeRec* my = a.sched + (((size_t)tg * g.n_pass + pass) * BSR_TILE_WAVES + wave) * QMAX;
     TapeAcc<KQ> A[QMAX];
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) A[q].clear();
+    // f64 chunks travel through a ring of g.ring LDS buffers by LDS-DMA, ring - 1 chunks ahead of the one the waves
+    // run their tapes on: what is in flight per CU (ring - 1 chunks, ~100 KB at C5) is what keeps HBM busy -- with one
+    // chunk ahead the pass waited for memory three quarters of its time.  Copies complete in issue order, so "chunk ci
+    // has landed" is a count of the wave's later copies (vmcnt); the barrier behind it also says everyone is done
+    // with chunk ci - 1, whose buffer the next copies overwrite.
+    constexpr bool DMA = sizeof(T) == 8;
+    const int ring = (multi && DMA) ? g.ring : 1;
+    const int n_chunks = (g.bps + g.chunk_blocks - 1) / g.chunk_blocks;
+    int cnt[4] = {0, 0, 0, 0};   // copies this wave issued for chunk j, at j & 3
+    // A wave copies the same (column, block of the chunk) units of every chunk: unit u = wave + 16 k.  Lane k keeps
+    // unit k's source address (rows of chunk 0) and LDS offset, fetched ONCE from the column-pointer table -- a scalar
+    // load of the pointer in front of every copy put a memory round trip between the barrier and the copies of
+    // every chunk.
+    const int n_units = ncols * g.chunk_blocks;
+    const int n_mine = (multi && DMA && n_units > wave) ? min(BSR_WAVE, (n_units - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES) : 0;
+    unsigned long long my_src = 0;
+    int my_lds = 0, my_blk = 0;
+    if (multi && DMA) {
+      const int u = wave + BSR_TILE_WAVES * lane;
+      if (u < n_units) {
+        const int col = u / g.chunk_blocks;
+        my_blk = u - col * g.chunk_blocks;
+        my_src = (unsigned long long)(size_t)(colsrc[col] + (int64_t)(b0 + my_blk) * BSR_TILE_BLOCK);
+        my_lds = (int)(((size_t)col * chunk_rows + (size_t)my_blk * BSR_TILE_BLOCK) * sizeof(T));
+      }
+    }
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sx;
+    auto issue = [&](int j) {
+      if constexpr (DMA) {
+        const int nbj = min(g.chunk_blocks, g.bps - j * g.chunk_blocks);   // blocks of chunk j
+        const uint32_t buf = lds0 + (uint32_t)((size_t)(j % ring) * buf_elems * sizeof(T));
+        const unsigned long long adv = (unsigned long long)j * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T);
+        const uint32_t voff = (uint32_t)lane * 16u;
+        int n = 0;
+        for (int k = 0; k < n_mine; ++k) {
+          if (__builtin_amdgcn_readlane(my_blk, k) >= nbj) continue;
+          const unsigned long long src = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(my_src >> 32), k) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)my_src, k)) + adv;
+          const uint32_t la = buf + (uint32_t)__builtin_amdgcn_readlane(my_lds, k);
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(la) : "memory", "m0");
+          ++n;
+        }
+        cnt[j & 3] = n;
+      }
+    };
     if (!multi) {
       if (pass == 0) {
         stage_rows<T, 8>(sx, colsrc, ncols, chunk_rows, b0, g.bps, wave, lane);
         __syncthreads();
         TSTAMP(1);
       }
-    } else {
-      if constexpr (sizeof(T) == 8) {
-        if (pass != 0) __syncthreads();  // everyone is done with the last chunk of the pass before
-        dma_rows<T>(sx, colsrc, ncols, chunk_rows, b0, min(g.chunk_blocks, b1 - b0), wave, lane);
-        dma_wait();
-        __syncthreads();
-        if (pass == 0) TSTAMP(1);
-      }
+    } else if (DMA) {
+      if (pass != 0) __syncthreads();  // everyone is done with the last chunks of the pass before
+      for (int j = 0; j < min(ring - 1, n_chunks); ++j) issue(j);
     }
     int ci = 0;
     for (int c0 = b0; c0 < b1; c0 += g.chunk_blocks, ++ci) {
       const int nbc = min(g.chunk_blocks, b1 - c0);
-      const T* cur = sx + (size_t)(ci & 1) * buf_elems;
+      const T* cur = sx + (size_t)(ci % ring) * buf_elems;
       if (multi) {
-        if constexpr (sizeof(T) == 8) {
-          const int n0 = c0 + g.chunk_blocks;
-          if (n0 < b1)
-            dma_rows<T>(sx + (size_t)((ci + 1) & 1) * buf_elems, colsrc, ncols, chunk_rows, n0, min(g.chunk_blocks, b1 - n0),
-                        wave, lane);
+        if constexpr (DMA) {
+          int later = 0;
+          for (int j = ci + 1; j < min(ci + ring - 1, n_chunks); ++j) later += cnt[j & 3];
+          dma_wait_left(later);
+          __syncthreads();
+          if (ci + ring - 1 < n_chunks) issue(ci + ring - 1);
+          if (ci == 0 && pass == 0) TSTAMP(1);
         } else {
           // f32 columns keep one register-staged buffer (LDS-DMA moves 16 bytes per lane: half a block of floats)
           if (c0 != b0 || pass != 0) __syncthreads();  // everyone is done with the rows staged before
@@ -442,6 +499,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
         }
       }
       const T* sy = cur + (size_t)y_slot * chunk_rows;
+      if (stamp) t_busy = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
       for (int q = 0; q < QMAX; ++q) {
         const TapeRec CONSTANT_AS* rec = as_const(my + q);
@@ -479,14 +537,15 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
         };
         int b = 0;
         if (chain) {
-          // a pass of NB blocks: the tape once over 2 NB values per lane, then the blocks' sums in order
-          auto pass_nb = [&](auto full_tag, int pn) {
+          // a pass of PB blocks: the tape once over 2 PB values per lane, then the blocks' sums in order
+          auto pass_nb = [&](auto nb_tag, auto full_tag, int pn) {
+            constexpr int PB = decltype(nb_tag)::value;
             constexpr bool FULL = decltype(full_tag)::value;
             const int off = b * BSR_TILE_BLOCK + 2 * lane;  // the lane's pair inside the chunk (block j of the pass: 128 j rows on)
-            T z[2 * NB];
-            chain_eval<T, NB, FULL>(hd, pc, pf, pl, n_nodes, cur, chunk_rows, off, pn, z);
+            T z[2 * PB];
+            chain_eval<T, PB, FULL>(hd, pc, pf, pl, n_nodes, cur, chunk_rows, off, pn, z);
 #pragma unroll
-            for (int jb = 0; jb < NB; ++jb) {
+            for (int jb = 0; jb < PB; ++jb) {
               if (FULL || jb < pn) {
                 const T zz[U] = {z[2 * jb], z[2 * jb + 1]};
                 add_block(zz, off + jb * BSR_TILE_BLOCK, c0 + b + jb);
@@ -494,8 +553,11 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
             }
             b += pn;
           };
-          while (nbc - b >= NB) pass_nb(std::integral_constant<bool, true>{}, NB);
-          if (b < nbc) pass_nb(std::integral_constant<bool, false>{}, nbc - b);
+          using std::integral_constant;
+          while (nbc - b >= NB) pass_nb(integral_constant<int, NB>{}, integral_constant<bool, true>{}, NB);
+          // (chunks of two blocks -- wide groups at N = 1M -- and the tails of others: a pass of two, whole)
+          if (NB > 2 && nbc - b >= 2) pass_nb(integral_constant<int, 2>{}, integral_constant<bool, true>{}, 2);
+          if (b < nbc) pass_nb(integral_constant<int, 2>{}, integral_constant<bool, false>{}, nbc - b);
         } else {
           // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.
 #pragma unroll 1
@@ -517,15 +579,11 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
           }
         }
       }
-      if (multi) {
-        if constexpr (sizeof(T) == 8) {  // chunk done by every wave, and the next one has landed
-          dma_wait();
-          __syncthreads();
-        }
-      }
+      if (stamp) busy += __builtin_amdgcn_s_memtime() - t_busy;
       if (c0 == b0 && pass == 0) TSTAMP(2);
     }
     if (pass == g.n_pass - 1) TSTAMP(3);
+    if (stamp && lane == 0) stamp[5] = busy;
     reduce_store<KQ, QMAX>(A, my, a.part, g.n_part, slice, s_red[wave], lane);
   }
   if (g.n_left > 0) leftover_units<T, KQ>(a, g, lane, wave);
@@ -697,7 +755,7 @@ void launch_kq(hipStream_t st, const TileArgs<T>& a) {
   const dim3 grid((unsigned)(g.T * g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
   // a slice that does not fit whole travels through two buffers (fp64: LDS-DMA double buffering)
   const bool multi = g.chunk_blocks < g.bps;
-  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((multi && sizeof(T) == 8) ? 2 : 1);
+  const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((multi && sizeof(T) == 8) ? g.ring : 1);
   if (g.per_group > 0) {
     static bool attr1 = false;
     if (!attr1) {

@@ -76,12 +76,14 @@ def main():
     stat("wave end (100 MHz clock)", rt1 - base)
     d = lambda a, b: (st[:, :, b] - st[:, :, a])[ok] / mhz
     stat("stage first chunk (0->1)", d(0, 1))
-    if (st[:, :, 5][ok] > 0).all():   # pipelined staging: stamp 5 = after the start-up barrier, 1 = copies issued,
-        stat("  start -> start-up barrier (0->5)", d(0, 5))      # 2 = first pair of blocks arrived
-        stat("  issue the copies (5->1)", d(5, 1))
     stat("compute first chunk (1->2)", d(1, 2))
     stat("all chunks incl. later staging (1->3)", d(1, 3))
     stat("reduce + store (3->4)", d(3, 4))
+    if (st[:, :, 5][ok] > 0).any():   # chunked kernel: cycles a wave ran tapes, the rest of 1->3 it waited (copies, barriers)
+        busy = st[:, :, 5].astype(np.float64) / mhz
+        stat("running tapes (sum over chunks)", busy[ok])
+        per = np.array([busy[w][ok[w]].max() / max(1e-9, busy[w][ok[w]].mean()) for w in range(n) if ok[w].any()])
+        print("busy imbalance inside a workgroup (busiest wave / mean wave): median %.2f  max %.2f" % (np.median(per), per.max()))
     stat("wave lifetime (0->4)", d(0, 4))
     comp = (st[:, :, 3] - st[:, :, 1]).astype(np.float64)
     per_wg = np.array([comp[w][ok[w]].max() / max(1e-9, comp[w][ok[w]].mean()) for w in range(n) if ok[w].any()])
