@@ -28,6 +28,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mcmc-symreg_amd"))
+# this process is the benchmark and nothing else: confine it (caller included) to one L3 domain of the host.  The
+# library by itself only places its own threads (DESIGN 7 "CPU placement"); the setting is reported under env_knobs.
+os.environ.setdefault("BSR_PIN", "1")
 
 WORKLOADS = {
     "c2": dict(N=100_000, d=10, K=3, chains=1, batch=64,

@@ -2,6 +2,7 @@
 // Host-side orchestration only; all O(N) work is in bsr_kernels.hip.
 #include <rccl/rccl.h>
 
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -68,17 +69,13 @@ struct BatchSlot {
   size_t flag_stride = 0;
   double* part1 = nullptr;
   double* part2 = nullptr;
+  bool part2_uncached = false;   // part2 and the arrival counter behind it are uncached memory: the finalise step is fused
   size_t part_cap = 0;   // in (proposal,row block) records
   void* spill = nullptr;
   size_t spill_cap = 0;  // bytes
   int32_t* queue = nullptr;  // ring of work-queue counter sets for the projection pass (zeroed once; every launch
                              // takes the next set and clears the one half a ring ahead)
   uint32_t queue_seq = 0;
-  hipStream_t aux = nullptr;      // CU-partitioned contexts: stream of the kernels behind the row pass (own CUs)
-  hipEvent_t tile_done = nullptr; // orders `aux` behind the row pass
-  uint32_t* h_flag = nullptr;     // pinned completion word of scoring batches (written by the batch's last kernel)
-  uint32_t flag_gen = 0;          // value the pending batch will write
-  bool use_flag = false;          // the pending batch completes through h_flag, not through `done`
   hipEvent_t done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int P = 0;
@@ -109,12 +106,12 @@ struct BatchSlot {
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
+  std::vector<TapeLoc> loc_tmp;   // scratch of a submission
   std::vector<uint32_t> order_keys;
   int order_n = -1;              // tapes order_tmp is valid for (-1: not)
   std::vector<bsr_node> rows_perm;   // tapes rewritten in fusing order (reorder_tape), at their batch offsets
   std::vector<const bsr_node*> tape_src;   // per tape: where the streams are written from (the caller's rows, or rows_perm)
   std::vector<int32_t> perm_kid, perm_stack;   // scratch of reorder_tape
-  int head_rc = 0;               // result of a split batch's first phase (issue_batch)
   bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
                                  // descriptor restore): the next batch's input block then goes by a copy command
 
@@ -145,18 +142,11 @@ struct bsr_ctx {
   bool derived_ready = false;
   int derived_max = 8;         // BSR_DERIVED_MAX: cap on the derived columns one batch may use
   bool tile_ever = false;   // some batch of this context can take the tile pass
-  int tile_piped = 0;
-  int stage_subset = 1;   // BSR_STAGE_SUBSET: a tape group stages only the columns its tapes read
-  int solo_tail = 0;       // BSR_SOLO_TAIL=n: n workgroups each take whole flagged proposals (residual + finalise), one launch
-  int fuse_finalize = 0;   // BSR_FUSE_FINALIZE: k_finalize's work behind the residual pass, in the same launch
-  int poll_done = 0;   // BSR_POLL_DONE: completion word in pinned memory instead of an event per scoring batch
   int n_cu = 256;
   int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
   int aux_cus = 0;
-  int split_issue = 0;     // BSR_SPLIT_ISSUE: a batch's row pass is issued at once, the launches behind it after the waiting row passes
-  int wait_stream = 0;
   int bar_write = 0;       // the host writes a batch's input block straight into device memory (large-BAR devices)
-  int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the row pass is sized for (f64 kernels: 92 VGPRs -> 5)
+  int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the work-queue row pass is sized for (f64 kernels: 92 VGPRs -> 5)
   size_t esz = 8;
   bool has_y = false;
   void* Xt = nullptr;
@@ -198,11 +188,9 @@ struct bsr_ctx {
   int no_lds = 0;
   // tile pass geometry, fixed for the life of the context (a proposal's partial sums must not depend on the batch)
   int tile_on = 1;
-  int tile_multi = 0;     // allow the chunked variant (slices larger than LDS)
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
   bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
-  int tile_sub = 1, tile_sub_blocks = 1;   // partial records per (tape, slice)
   size_t tile_sched_cap = 0;
   unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
   // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
@@ -327,7 +315,6 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   for (BatchSlot& s : c->slot) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
-    if (s.aux) (void)hipStreamSynchronize(s.aux);
   }
   void* dev[] = {c->Xt, c->y, c->cur, c->Q, c->zbuf, c->d_ck, c->d_fit, c->d_stage, c->comm_buf, c->d_fit_icpt,
                  c->d_rin, c->d_plan, c->d_rpart, c->d_stamps};
@@ -346,9 +333,6 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.part2) (void)hipFree(s.part2);
     if (s.spill) (void)hipFree(s.spill);
     if (s.stream) (void)hipStreamDestroy(s.stream);
-    if (s.aux) (void)hipStreamDestroy(s.aux);
-    if (s.tile_done) (void)hipEventDestroy(s.tile_done);
-    if (s.h_flag) (void)hipHostFree(s.h_flag);
     if (s.done) (void)hipEventDestroy(s.done);
     for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
   }
@@ -375,7 +359,7 @@ static int upload_data(bsr_ctx* c, const double* X, const double* y) {
   return BSR_OK;
 }
 
-static std::atomic<bool> g_pinned{false};   // this process confined itself to an L3 domain of its own (pin_to_l3_domain)
+static std::atomic<bool> g_pinned{false};   // BSR_PIN=1: this process confined itself to the library's CPUs (choose_lib_cpus)
 // "0-7,128-135" -> CPU set; false when nothing parses
 static bool parse_cpulist(const char* txt, cpu_set_t* set) {
   CPU_ZERO(set);
@@ -403,17 +387,23 @@ static bool l3_domain_of(int cpu, cpu_set_t* set) {
   fclose(f);
   return ok && parse_cpulist(buf, set);
 }
-// The calling thread -- and with it every thread the context and the HIP runtime start from here on -- is confined to
-// the CPUs of one L3 domain (a CCX: 8 cores and their SMT siblings on the EPYC hosts of MI355X boxes).  A batch passes
-// through the caller, a submission thread and the runtime's own threads; left to roam two sockets and sixteen L3
-// domains, the pipelined step of the C2 bench measures anything from 17.9 to 21.6 us run by run, confined to one
-// domain 17.3 us every time (tools/probes/taskset_ab.sh).  One process: the domain the caller is on.  Several ranks
-// on the node (LOCAL_RANK / LOCAL_WORLD_SIZE): the domains of the allowed CPUs dealt evenly by local rank.
-// BSR_PIN=0: leave the affinity alone; BSR_PIN_CPUS="0-7,128-135": this list.  Once per process; never fails.
-static void pin_to_l3_domain() {
+// CPU placement.  A batch passes through the caller, a submission thread and (native sampler) a worker thread; left to
+// roam two sockets and sixteen L3 domains the pipelined step of the C2 bench measures anything from 17.9 to 21.6 us
+// run by run, with those threads inside ONE L3 domain (a CCX: 8 cores and their SMT siblings on the EPYC hosts of
+// MI355X boxes) 17.3 us every time (tools/probes/taskset_ab.sh).  The library therefore places ITS OWN threads
+// (submission threads, sampler workers: bsr_internal_place_thread, called by each of them) on the L3 domain the
+// context was created from -- with several ranks on the node (LOCAL_RANK / LOCAL_WORLD_SIZE) the domains of the
+// allowed CPUs are dealt evenly by local rank.  The CALLER's affinity is not touched: a drop-in library must not
+// narrow the CPU set of the host application's later threads.  A process that wants the whole effect for itself
+// (bench.py does) sets BSR_PIN=1: the calling thread is then confined too, once per process.  BSR_PIN=0: no placement
+// at all; BSR_PIN_CPUS="0-7,128-135": this list instead of an L3 domain.
+static cpu_set_t g_lib_cpus;
+static std::atomic<bool> g_lib_cpus_ok{false};
+static void choose_lib_cpus() {
   static std::atomic<bool> done{false};
   if (done.exchange(true)) return;
-  if (!env_int("BSR_PIN", 1)) return;
+  const int mode = env_int("BSR_PIN", -1);   // -1 (unset): the library's threads only; 0: nothing; 1: the caller as well
+  if (mode == 0) return;
   cpu_set_t allowed, want;
   if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
   CPU_ZERO(&want);
@@ -443,14 +433,21 @@ static void pin_to_l3_domain() {
   }
   CPU_AND(&want, &want, &allowed);
   if (CPU_COUNT(&want) < 4) return;   // not worth it (and a submission thread needs a core of its own)
-  if (sched_setaffinity(0, sizeof want, &want) == 0) g_pinned.store(true);
+  g_lib_cpus = want;
+  g_lib_cpus_ok.store(true, std::memory_order_release);
+  if (mode == 1 && sched_setaffinity(0, sizeof want, &want) == 0) g_pinned.store(true);
+}
+// called by every thread the library starts: confines that thread (and nothing else) to the library's CPUs
+__attribute__((visibility("hidden"))) void bsr_internal_place_thread() {
+  if (!g_lib_cpus_ok.load(std::memory_order_acquire)) return;
+  (void)pthread_setaffinity_np(pthread_self(), sizeof g_lib_cpus, &g_lib_cpus);
 }
 
 extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X, const double* y,
                               int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype) {
   if (!out) return BSR_E_ARG;
   *out = nullptr;
-  pin_to_l3_domain();   // before the first HIP call of the process, if this is it
+  choose_lib_cpus();   // (BSR_PIN=1: before the first HIP call of the process, if this is it)
   if (!X || N <= 0 || d <= 0 || d > 65536) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
   if (K < 0 || K > BSR_MAX_K || n_chains < 0 || max_batch <= 0)
     return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad K/n_chains/max_batch");
@@ -479,8 +476,6 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       (c->rb_rows % (64 * c->rows_per_lane)) != 0)
     c->rb_rows = rb_default;
   if (c->rb_rows % (64 * c->rows_per_lane) != 0) c->rows_per_lane = 2;  // a row block is a whole number of sweeps
-  c->target_wgs = env_int("BSR_TARGET_WGS", 2048);
-  c->wgs_per_cu = std::max(1, std::min(8, env_int("BSR_WGS_PER_CU", 5)));
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
   // derived columns (see kDerivedOps): on unless asked off, the column ids would leave 16 bits, or X is so large that
   // nine copies of it would take more than a third of the device's free memory
@@ -523,31 +518,12 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
-    c->tile_piped = env_int("BSR_TILE_PIPED", 0);
-    c->stage_subset = env_int("BSR_STAGE_SUBSET", 1);
     c->selfdup = env_int("BSR_SELFDUP", 1);
     c->reorder = env_int("BSR_REORDER", 1);
     c->chain_eval = env_int("BSR_CHAIN_EVAL", 1);
-    // k_finalize's work behind the residual pass in the same launch (last workgroup to arrive): one launch fewer per
-    // batch, bit-identical -- and 3-4 us SLOWER per step at C2: the agent-scope release/acquire every residual
-    // workgroup needs around the arrival counter writes back and invalidates its XCD's L2 under the row passes of the
-    // other batches.  Opt-in.
-    c->fuse_finalize = env_int("BSR_FUSE_FINALIZE", 0);
-    c->solo_tail = env_int("BSR_SOLO_TAIL", 0);
     // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
     // tape, and staging a column costs every workgroup what one use saves one wave (measured flat from 7 up)
     c->derived_max = env_int("BSR_DERIVED_MAX", 8);
-    // completion word in pinned memory, written by k_finalize and polled by the waiter, instead of an event per scoring
-    // batch: one HIP call fewer on the submission thread (16.8 instead of 22.9 us per batch) and none in the wait.
-    // At C2 the pipeline is bound by the GPU once the calls are off the caller's thread, so it buys nothing there;
-    // opt-in
-    c->poll_done = env_int("BSR_POLL_DONE", 0);
-    // the waiter synchronises with the slot's stream instead of an event recorded behind the batch (one HIP call fewer
-    // per batch on the submission threads, which is what bounds the pipelined step once the row passes overlap: the
-    // runtime takes ~3 us per call however many threads make them).  Measured: 34 us per step instead of 19 --
-    // hipStreamSynchronize holds up the other threads' launches while it waits.  Opt-in, for the record.
-    c->wait_stream = env_int("BSR_WAIT_STREAM", 0);
-    c->split_issue = env_int("BSR_SPLIT_ISSUE", 0);
     // Launch width of the tile pass: n_cu - BSR_AUX_CUS workgroups, by default three quarters of the CUs.  A tile
     // workgroup needs a whole CU (LDS and registers), and a launch as wide as the machine ends when its last workgroup
     // does: the CUs that finish early wait, the next batch's launch starts staging only then, and a CU that holds
@@ -556,15 +532,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // kernels find room.  Each workgroup then has a third more rows (8 blocks per slice instead of 6 at N = 100k), the
     // kernel alone takes 25 instead of 21.5 us, and the pipelined step 18.9 instead of 21.1 us at K = 3 (29.0 instead
     // of 32.8 at K = 8); half the CUs measures the same at K = 3 and worse at K = 8, a quarter loses.
-    // (tools/probes/aux_cus_sweep.sh)  With BSR_CU_MASK=1 the slot streams also carry CU masks and the
-    // kernels behind the row pass run on a second stream confined to the other CUs: masked streams halve the
-    // throughput (more hardware queues than the runtime maps at once), off.
+    // (tools/probes/aux_cus_sweep.sh)
     c->aux_cus = env_int("BSR_AUX_CUS", c->n_cu / 4);
     if (c->aux_cus < 0 || c->aux_cus > c->n_cu * 7 / 8) c->aux_cus = 0;
-    // chunked variant (two LDS buffers filled by LDS-DMA) for slices that do not fit LDS whole: correct and tested, but
-    // at N = 1M it measures 206 us against the work-queue pass's 165 us (four tapes per wave leave no registers for
-    // two-block passes, so every 128 rows pay a full scalar decode of the tape), so it only runs when asked for
-    c->tile_multi = env_int("BSR_TILE_MULTI", 0);
     // Geometry of the row pass (bsr_tile.hip), fixed for the life of the context.  A wave holds tile_qmax(K) sets of
     // sums, so one group of 16 waves takes 16 x qmax tapes per pass over its slice; `want` groups give every tape of the
     // widest batch a set.  Slices that fit LDS whole are staged once (the largest T <= want for which they do even for
@@ -656,17 +626,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   CK(hipMalloc((void**)&c->d_rpart, refresh_part_doubles(N) * sizeof(double)));
   c->fast_refresh = env_int("BSR_FAST_REFRESH", 1);
   for (BatchSlot& s : c->slot) {
-    if (c->aux_cus > 0 && env_int("BSR_CU_MASK", 0)) {
-      // mask bit i = i-th CU in the runtime's numbering, which deals consecutive bits to different XCDs: the low
-      // tile_cus bits leave every XCD the same share (tools/probes/cumask_probe.hip)
-      std::vector<uint32_t> lo((size_t)(c->n_cu + 31) / 32, 0u), hi(lo.size(), 0u);
-      for (int i = 0; i < c->n_cu; ++i) (i < c->tile_cus ? lo : hi)[i / 32] |= 1u << (i % 32);
-      CK(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)lo.size(), lo.data()));
-      CK(hipExtStreamCreateWithCUMask(&s.aux, (uint32_t)hi.size(), hi.data()));
-      CK(hipEventCreateWithFlags(&s.tile_done, hipEventDisableTiming));
-    } else {
-      CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    }
+    CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
     s.flag_stride = (size_t)max_batch + 2;
     CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * (2 * (max_batch + 2) + 16)));   // two lists, alternating by batch; then k_finalize's arrival counter
@@ -684,8 +644,6 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
     s.chain_slot.assign(std::max(1, n_chains), -1);
     CK(hipHostMalloc((void**)&s.h_out, sizeof(bsr_score) * (max_batch + 1)));
-    CK(hipHostMalloc((void**)&s.h_flag, 64));
-    *s.h_flag = 0;
     CK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     for (auto& e : s.ev) CK(hipEventCreate(&e));
   }
@@ -858,18 +816,20 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
     s.part1 = s.part2 = nullptr;
     const size_t cap = recs + recs / 2;
     HIPCHK(c, hipMalloc((void**)&s.part1, cap * BSR_P1_WORDS * sizeof(double)));
-    // fuse_finalize == 2: the residual sums and the arrival counter live in uncached device memory, so the hand-over
-    // inside the fused launch needs no cache write-back or invalidate (8 B of counter behind the records)
-    if (c->fuse_finalize == 2) {
-      if (hipExtMallocWithFlags((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64, hipDeviceMallocUncached) != hipSuccess) {
-        (void)hipGetLastError();
-        c->fuse_finalize = 0;
-        HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64));
-      }
-      HIPCHK(c, hipMemset(s.part2, 0, cap * BSR_P2_WORDS * sizeof(double) + 64));
+    // K <= 3: the finalise step rides behind the residual pass in the same launch (its last workgroup to arrive runs
+    // it).  The residual sums and the arrival counter then live in UNCACHED device memory: a store is visible once it
+    // is acknowledged and a load never sees a cache, so the hand-over needs no cache write-back or invalidate under
+    // the other batches' row passes (with agent-scope fences the fused launch measured 4 us per step slower than two
+    // launches; this way it is 0.3 us faster).  8 B of counter behind the records.
+    s.part2_uncached = false;
+    if (residual_can_fuse_finalize(c->K) && c->no_lds &&
+        hipExtMallocWithFlags((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64, hipDeviceMallocUncached) == hipSuccess) {
+      s.part2_uncached = true;
     } else {
+      (void)hipGetLastError();
       HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64));
     }
+    HIPCHK(c, hipMemset(s.part2, 0, cap * BSR_P2_WORDS * sizeof(double) + 64));
     s.part_cap = cap;
   }
   if (spill_slots > 0) {
@@ -997,13 +957,15 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
   int allowance = derive ? c->n_cols : 0;
   if (derive && c->tile_on && tile_chains > 0) {
     int n_base = 0;
-    for (int j = 0; j < tape_off[n]; ++j)
-      if (rows[j].opcode == BSR_OP_TERMINAL && rows[j].feature >= 0 && rows[j].feature < c->d &&
-          s.slot_of[rows[j].feature] < 0) {
-        s.slot_of[rows[j].feature] = 0;
-        ++n_base;
-      }
-    std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
+    if (c->tile_whole) {   // (chunked contexts: the allowance does not depend on the batch's base columns)
+      for (int j = 0; j < tape_off[n]; ++j)
+        if (rows[j].opcode == BSR_OP_TERMINAL && rows[j].feature >= 0 && rows[j].feature < c->d &&
+            s.slot_of[rows[j].feature] < 0) {
+          s.slot_of[rows[j].feature] = 0;
+          ++n_base;
+        }
+      std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
+    }
     const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
     size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
     long room = (long)fit - fixed;
@@ -1434,25 +1396,24 @@ static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const
 struct TailJob {
   int slot, P, n_part, spill_slots, nq;
   LaunchGeom g;
-  bool scoring, on_aux, tile;
+  bool scoring, tile;
   double rank_floor;
   size_t in_bytes;
   TileGeom tg;
-  int phase = 0;   // 0: the whole batch; 1: upload and row pass, then the rest goes back into the queue as 2 (split_issue)
 };
 static void launcher_push(bsr_ctx* c, const TailJob& job);
 
 static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   const long long t_issue0 = host_now();
-  hipStream_t st = j.on_aux ? s.aux : s.stream;
-  int rc = (j.phase == 2) ? s.head_rc : BSR_OK;
+  hipStream_t st = s.stream;
+  int rc = BSR_OK;
   auto step = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == BSR_OK) {
       set_err(c, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
       rc = BSR_E_HIP;
     }
   };
-  if (j.phase != 2) {
+  {
     // upload + row pass on the slot's stream
     hipStream_t s0 = s.stream;
     if (c->bar_write && !s.stream_dirty) {
@@ -1502,60 +1463,31 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 0);
     }
     if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
-    if (j.on_aux) step(hipEventRecord(s.tile_done, s0), "hipEventRecord");
   }
-  if (j.phase == 1) {
-    // The row pass is out; the launches behind it have its whole duration to get there.  They go to the back of the
-    // queue, behind the row passes of the batches that are waiting: what a batch waits for first is its row pass.
-    s.head_rc = rc;
-    if (g_host_prof) g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
-    TailJob rest = j;
-    rest.phase = 2;
-    launcher_push(c, rest);
-    return rc;
-  }
-  if (j.on_aux) step(hipStreamWaitEvent(st, s.tile_done, 0), "hipStreamWaitEvent");
-  // timing experiments (results are wrong): 1 = no residual/finalise, 2 = no solve either, 3 = all three launched but
-  // the solve handles one proposal only (the launches and kernel boundaries without the work)
-  static const int dbg_raw = env_int("BSR_DEBUG_SKIP_TAIL", 0);
-  static const int dbg_skip = (dbg_raw == 3) ? 0 : dbg_raw;
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  if (dbg_skip < 2) launch_solve(st, s.d_desc(), c->d_ck, (dbg_raw == 3) ? 1 : j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
-  // registers for the solver and reads X from global memory (16-wave workgroups): one launch fewer per batch
-  // ... or whole flagged proposals per workgroup (solo_tail): residual pass and finalise step of a proposal in one
-  // workgroup, nothing shared between workgroups.  A proposal's row blocks then run on sixteen waves instead of the
-  // whole grid: for data sets of up to 256 row blocks.
-  const bool solo = j.scoring && c->solo_tail > 0 && !s.use_flag && c->no_lds && residual_can_fuse_finalize(c->K) &&
-                    j.g.n_rb <= 256;
-  const bool fuse_fin = solo || (j.scoring && c->fuse_finalize && c->no_lds && residual_can_fuse_finalize(c->K));
-  if (j.scoring && !dbg_skip) {
+  // registers for the solver (K <= 3) and the hand-over memory is uncached (ensure_partials): one launch fewer
+  const bool fuse_fin = j.scoring && s.part2_uncached;
+  if (j.scoring) {
     FinArgs fin;
     memset(&fin, 0, sizeof fin);
     if (fuse_fin) {
       fin.ck = c->d_ck; fin.out = s.h_out; fin.mh = s.d_mh; fin.rank_floor = j.rank_floor;
-      fin.arrive = s.d_flagged + 2 * s.flag_stride + 1;
-      fin.uncached = 0;
-      if (c->fuse_finalize == 2 && !solo) {   // counter behind the uncached records
-        fin.arrive = reinterpret_cast<int32_t*>(s.part2 + s.part_cap * BSR_P2_WORDS);
-        fin.uncached = 1;
-      }
-      fin.done_flag = s.use_flag ? s.h_flag : nullptr;
-      fin.done_gen = s.flag_gen;
-      fin.solo = solo ? c->solo_tail : 0;
+      fin.arrive = reinterpret_cast<int32_t*>(s.part2 + s.part_cap * BSR_P2_WORDS);   // counter behind the uncached records
     }
     launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st, fuse_fin ? &fin : nullptr);
   }
   if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
-  if (j.scoring && !dbg_skip && !fuse_fin)
+  if (j.scoring && !fuse_fin)
     launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
-                    c->K <= 4 ? 1 : 16, s.use_flag ? s.h_flag : nullptr, s.flag_gen, s.d_flagged + 2 * s.flag_stride);
+                    c->K <= 4 ? 1 : 16);
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
-  if (!s.use_flag && !c->wait_stream) step(hipEventRecord(s.done, st), "hipEventRecord");
+  step(hipEventRecord(s.done, st), "hipEventRecord");
   s.tail_rc = rc;
   if (g_host_prof) {
     g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
@@ -1571,8 +1503,7 @@ struct Launcher {
   std::vector<std::thread> ths;   // one by default; BSR_SUBMIT_THREADS more share the queue (jobs of different slots)
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<TailJob> q;          // whole batches and row passes (phases 0, 1)
-  std::deque<TailJob> q_rest;     // the launches behind a row pass (phase 2): taken when no row pass is waiting
+  std::deque<TailJob> q;
   std::atomic<int> n_queued{0};
   int asleep = 0;
   bool stop = false;
@@ -1580,6 +1511,7 @@ struct Launcher {
 };
 
 static void launcher_main(bsr_ctx* c) {
+  bsr_internal_place_thread();
   (void)hipSetDevice(c->device);
   Launcher* L = c->launcher;
   for (;;) {
@@ -1589,7 +1521,7 @@ static void launcher_main(bsr_ctx* c) {
     while (!have) {
       if (L->n_queued.load(std::memory_order_acquire) > 0) {
         std::lock_guard<std::mutex> lk(L->mu);
-        std::deque<TailJob>& from = !L->q.empty() ? L->q : L->q_rest;
+        std::deque<TailJob>& from = L->q;
         if (!from.empty()) {
           job = from.front();
           from.pop_front();
@@ -1599,11 +1531,11 @@ static void launcher_main(bsr_ctx* c) {
       } else if (std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(L->spin_us)) {
         std::unique_lock<std::mutex> lk(L->mu);
         if (L->stop) return;
-        if (L->q.empty() && L->q_rest.empty()) {
+        if (L->q.empty()) {
           ++L->asleep;
-          L->cv.wait(lk, [&] { return L->stop || !L->q.empty() || !L->q_rest.empty(); });
+          L->cv.wait(lk, [&] { return L->stop || !L->q.empty(); });
           --L->asleep;
-          if (L->stop && L->q.empty() && L->q_rest.empty()) return;
+          if (L->stop && L->q.empty()) return;
         }
       } else {
         __builtin_ia32_pause();
@@ -1618,7 +1550,7 @@ static void launcher_push(bsr_ctx* c, const TailJob& job) {
   bool wake;
   {
     std::lock_guard<std::mutex> lk(L->mu);
-    (job.phase == 2 ? L->q_rest : L->q).push_back(job);
+    L->q.push_back(job);
     L->n_queued.fetch_add(1, std::memory_order_release);
     wake = L->asleep > 0;
   }
@@ -1631,7 +1563,7 @@ double bsr_internal_cpu_budget();
 static double cpu_budget() { return bsr_internal_cpu_budget(); }
 __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget() {
   // what the ranks of the node share (the CPUs they may all run on, the cgroup's quota) is divided among them; a CPU
-  // set the rank has to itself (pin_to_l3_domain) is not
+  // set the rank has to itself (BSR_PIN=1) is not
   const int local_world = std::max(1, env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1)));
   double n = 1e9, own = 1e9;
   cpu_set_t set;
@@ -1810,19 +1742,12 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
   job.tg = tg;
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
   job.rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
-  // CU-partitioned context: the kernels behind the row pass run on the slot's second stream (its own few CUs)
-  job.on_aux = scoring && s.aux != nullptr;
   s.flag_par ^= 1;   // this batch's list of flagged proposals; its k_solve empties the other one
-  // a scoring batch without events or the device-side MH step completes through the pinned word its last kernel
-  // (k_finalize) writes: no event to record, none to wait on
-  s.use_flag = scoring && !s.timed && s.n_spans == 0 && c->poll_done;
-  if (s.use_flag) s.flag_gen = s.flag_gen + 1 ? s.flag_gen + 1 : 1;
   s.tail_rc = BSR_OK;
   s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
   // Seven HIP calls per batch cost the host more than staging the batch does.  A scoring batch is handed to the
   // context's submission thread, which issues them while the caller returns to stage its next batch.
   if (c->launcher && scoring) {
-    job.phase = c->split_issue ? 1 : 0;
     launcher_push(c, job);
   } else {
     rc = issue_batch(c, s, job);
@@ -1854,30 +1779,8 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
     s.pending = false;
     return s.tail_rc;
   }
-  if (s.use_flag) {
-    // poll the completion word; now and then make sure the stream is still alive (a faulted kernel never writes it)
-    volatile uint32_t* f = s.h_flag;
-    auto t_chk = std::chrono::steady_clock::now();
-    for (long spins = 0; *f != s.flag_gen; ++spins) {
-      if (spins < 20000) { __builtin_ia32_pause(); continue; }
-      std::this_thread::yield();
-      if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t_chk > std::chrono::milliseconds(200)) {
-        t_chk = std::chrono::steady_clock::now();
-        hipError_t q = hipStreamQuery(s.aux ? s.aux : s.stream);
-        if (q != hipSuccess && q != hipErrorNotReady) {
-          s.pending = false;
-          return fail(c, BSR_E_HIP, (std::string("scoring batch: ") + hipGetErrorString(q)).c_str());
-        }
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  } else if (c->wait_stream) {
-    HIPCHK(c, hipStreamSynchronize(s.aux ? s.aux : s.stream));   // the slot's stream holds this batch and nothing behind it
-    HIPCHK(c, hipGetLastError());
-  } else {
-    HIPCHK(c, hipEventSynchronize(s.done));
-    HIPCHK(c, hipGetLastError());
-  }
+  HIPCHK(c, hipEventSynchronize(s.done));
+  HIPCHK(c, hipGetLastError());
   s.pending = false;
   if (s.timed) {
     float ms = 0;
@@ -2185,7 +2088,7 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
   }
   BatchSlot& s = c->slot[si];
   if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
-  std::vector<TapeLoc> loc;
+  std::vector<TapeLoc>& loc = s.loc_tmp;   // (kept with the slot: a fresh vector is an allocation per batch)
   const long long th0 = host_now();
   for (int32_t ch : s.batch_chains) s.chain_slot[ch] = -1;
   s.batch_chains.clear();
@@ -2466,7 +2369,7 @@ extern "C" int bsr_debug_tile_stamps(bsr_ctx* c, unsigned long long* out, int32_
                 hipMemcpyDeviceToHost) != hipSuccess) return BSR_E_HIP;
   if (geom5) {
     geom5[0] = c->tile_T; geom5[1] = c->tile_slices; geom5[2] = c->tile_bps; geom5[3] = c->tile_blocks;
-    geom5[4] = c->tile_cus * 100 + c->tile_sub;
+    geom5[4] = c->tile_cus * 100 + 1;
   }
   return n;
 }

@@ -1608,7 +1608,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
 
   if (threaded) {
     std::atomic<int> first_rc{BSR_OK};
-    auto worker = [&](Group& g) {
+    auto worker = [&](Group& g, bool own_thread) {
+      if (own_thread) bsr_internal_place_thread();   // (the caller's thread, which runs group 0, stays where it is)
       int r = BSR_OK;
       while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK) {
         r = submit(g);
@@ -1626,8 +1627,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       }
     };
     std::vector<std::thread> th;
-    for (int gi = 1; gi < n_groups; ++gi) th.emplace_back(worker, std::ref(groups[gi]));
-    worker(groups[0]);
+    for (int gi = 1; gi < n_groups; ++gi) th.emplace_back(worker, std::ref(groups[gi]), true);
+    worker(groups[0], false);
     for (auto& t : th) t.join();
     rc = first_rc.load();
   } else {

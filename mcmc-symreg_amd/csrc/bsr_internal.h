@@ -208,21 +208,18 @@ __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
 __attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
 // CPUs this process may use (cgroup quota / local ranks): sizes the submission threads and the sampler's worker threads
 __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget();
+// confines the calling thread (a thread the library started) to the library's CPUs: one L3 domain of the host
+__attribute__((visibility("hidden"))) void bsr_internal_place_thread();
 
 // kernels (bsr_kernels.hip)
-// The finalise step fused behind the residual pass: its last workgroup to finish walks the flagged list (ck == null:
-// not fused, k_finalize is launched instead).
+// The finalise step fused behind the residual pass (K <= 3): its last workgroup to finish walks the flagged list
+// (ck == null: not fused, k_finalize is launched instead).  The residual sums and `arrive` live in uncached memory.
 struct FinArgs {
   const ChainB* ck;
   bsr_score* out;
   MhRes* mh;
   double rank_floor;
   int32_t* arrive;       // workgroup arrival counter (zero between launches)
-  uint32_t* done_flag;   // pinned completion word, or null
-  uint32_t done_gen;
-  int uncached;          // the partial records and `arrive` are in uncached memory: hand over without cache maintenance
-  int solo;              // > 0: that many workgroups, each taking whole flagged proposals (all row blocks, then the
-                         // finalise step): no workgroup waits for another, no device-scope fence
 };
 template <typename T>
 struct RowPassArgs {
@@ -255,7 +252,7 @@ void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P,
                   int32_t* flagged_next);
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
-                     int n_wg, uint32_t* done_flag, uint32_t done_gen, int32_t* arrive);
+                     int n_wg);
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
                    int n_spans, int K, bsr_event* events);
 template <typename T>

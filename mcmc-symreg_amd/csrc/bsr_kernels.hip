@@ -138,11 +138,10 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
   // per workgroup: 128 VGPRs; K >= 4 would spill)
   constexpr bool CAN_FUSE = FAT0 && NQ <= 3;
   const bool fused = CAN_FUSE && fin.ck != nullptr;
-  if (MODE == MODE_RESIDUAL && n_flag == 0 && !(fused && fin.done_flag)) return;   // nothing to do, nobody to tell
+  if (MODE == MODE_RESIDUAL && n_flag == 0) return;   // nothing to do (the arrival counter stays zero)
   tables_to_lds();
   if (!LDS) __syncthreads();
-  const bool solo = fused && fin.solo > 0;   // whole proposals per workgroup (tail below), not row blocks
-  const bool active = !(FAT && !wi.valid) && !(MODE == MODE_RESIDUAL && n_flag == 0) && !solo;   // no early exit: the tail below has barriers
+  const bool active = !(FAT && !wi.valid);   // no early exit: the tail below has barriers
   if (LDS) {
     const int nvec = rb_rows / VEC;
     using V4 = __attribute__((ext_vector_type(4))) float;
@@ -410,53 +409,20 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
       if constexpr (NQ >= 1 && NQ <= 4) solve_regs<NQ>(in, lane, fin.out + p);
       else if constexpr (NQ >= 5) solve_cols<NQ>(in, lane, fin.out + p);
     };
-    if (solo) {
-      // Whole proposals: workgroup b takes flagged proposals b, b + grid, ...; its sixteen waves run the proposal's
-      // row blocks (the same (proposal, row block) tasks and partial records as the block-per-workgroup form, so the
-      // sums are the same to the bit), meet at a workgroup barrier, and the first wave finalises.  Nothing crosses a
-      // workgroup: no arrival counter, no device-scope fence under the other batches' row passes.
-      for (int fi = (int)blockIdx.x; fi < n_flag; fi += (int)gridDim.x) {
-        const int p = flagged[1 + fi];
-        for (int rb = wave_raw; rb < n_rb; rb += 4 * BSR_WG_WAVES) run_task(p, rb, (int64_t)rb * rb_rows);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (wave_raw == 0) finalize_one(p);
-      }
-      return;
-    }
     // Finalise, fused: every workgroup publishes its residual sums and checks in; the last one to arrive runs the
     // flagged proposals' solves on its sixteen waves (one launch, one launch gap and one blocked CU fewer per batch).
-    if (fin.uncached) {
-      // records and counter in uncached memory: a store is globally visible once it is acknowledged, a load never
-      // sees a cache -- waiting for the wave's own stores is the whole release, and there is nothing to acquire
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-        if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      if (!s_last) return;
-    } else {
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-        if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      if (!s_last) return;
-      __threadfence();
+    // records and counter are in uncached memory: a store is globally visible once it is acknowledged, a load never
+    // sees a cache -- waiting for the wave's own stores is the whole release, and there is nothing to acquire
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(fin.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+      if (s_last) __hip_atomic_store(fin.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (!s_last) return;
     for (int fi = wave_raw; fi < n_flag; fi += 4 * BSR_WG_WAVES) finalize_one(flagged[1 + fi]);
-    if (fin.done_flag) {   // completion word for the polling host (see k_finalize)
-      __threadfence_system();
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(fin.done_flag, fin.done_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
   }
 }
 
@@ -906,9 +872,7 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
                                                            const PropCoef* __restrict__ coef, int P, int n_rb,
                                                            const double* __restrict__ part2, int64_t N,
                                                            bsr_score* __restrict__ outv, double rank_floor,
-                                                           int32_t* __restrict__ flagged, MhRes* __restrict__ mhv,
-                                                           uint32_t* __restrict__ done_flag, uint32_t done_gen,
-                                                           int32_t* __restrict__ arrive) {
+                                                           int32_t* __restrict__ flagged, MhRes* __restrict__ mhv) {
   // the waves of all workgroups walk the batch's list of flagged proposals, one proposal per wave at a time (the
   // list is emptied by the next batch's k_solve)
   const int lane = threadIdx.x & 63;
@@ -949,25 +913,6 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
   in.rank_floor = rank_floor;
   in.mh = mhv + p;
   solve_any(in, lane, outv + p);
-  }
-  // Completion word for the host (pinned memory, polled instead of an event: two HIP calls fewer per batch).  This is
-  // the batch's last kernel; k_solve's results were complete when it started.  Every workgroup makes its own results
-  // visible system-wide and checks in; the last one to arrive writes the word and re-arms the counter.
-  if (done_flag) {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      bool last = true;
-      if (gridDim.x > 1) {
-        const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = old == (int)gridDim.x - 1;
-        if (last) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (last) {
-        __threadfence_system();
-        __hip_atomic_store(done_flag, done_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
   }
 }
 
@@ -1379,7 +1324,6 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape)
     grid.x /= 4;
     block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
-    if (a.fin.ck && a.fin.solo > 0) grid.x = (unsigned)a.fin.solo;   // whole proposals per workgroup
   }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
   if (a.feat_list) {
@@ -1426,10 +1370,10 @@ void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const 
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
-                     int n_wg, uint32_t* done_flag, uint32_t done_gen, int32_t* arrive) {
+                     int n_wg) {
   // a few proposals per batch at K=3 (one workgroup of four waves), a dozen or more at K=8, each ~10 us of one wave
   hipLaunchKernelGGL(k_finalize, dim3(n_wg), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
-                     rank_floor, flagged, mh, done_flag, done_gen, arrive);
+                     rank_floor, flagged, mh);
 }
 template <typename T>
 void launch_refresh_basis(hipStream_t st, const T* cur, T* Q, const T* y, int64_t ld, int64_t N, int K,

@@ -131,7 +131,7 @@ def test_g5_newprop_trace(name):
         assert _same(res["errs"], farr(g["train_err"]))
 
 
-@pytest.mark.parametrize("faithful", [False])
+@pytest.mark.parametrize("faithful", [False, True])
 def test_g6_fit_f1_first_chains(faithful):
     """First 6 chains of BSR(3,50).fit on f1, seed 0 (the full 50-chain run is the GPU-box bench baseline)."""
     g = load_golden("g6_fit_f1.json")
