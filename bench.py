@@ -363,9 +363,9 @@ def gather_trees(wl, ranks):
 
 
 def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
-    """End-to-end chain throughput of config 4's per-GPU share: the native sampler drives `chains` chains on this
-    rank's GPU (consumed MH proposals per second, host proposal generation and accept path included), then the
-    accepted trees of all ranks are gathered."""
+    """End-to-end chain throughput: the native sampler drives `chains` chains on this rank's GPU (consumed MH proposals
+    per second, host proposal generation and accept path included), then the accepted trees of all ranks are gathered.
+    chains=8, batch=32: config 4's per-GPU share; chains=1: config 2's single chain."""
     import numpy as np
     from bsr import dist as D
     from bsr.chain import DeviceScorer
@@ -409,6 +409,52 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
     finally:
         eng.close()
         scorer.close()
+
+
+def f32_leg(args, ranks):
+    """BASELINE configs[4]: the fp32 context (f32 storage and tree arithmetic, f64 accumulation) against the fp64 one at
+    N = 1M, d = 50: throughput and roofline of the f32 row pass (s = 4 bytes), and -- on the SAME chain state and the
+    SAME 64 real-mix proposals -- how far its log-likelihoods, rank decisions and accept decisions move."""
+    import numpy as np
+    from bsr.device import DeviceContext
+    from bsr.tape import flatten
+    short = argparse.Namespace(**vars(args))
+    short.batch, short.chains = 0, 0
+    short.dtype = "f32"
+    wl = build_workload("c5", short, ranks)
+    generate_batches(wl, 24)
+    steps = max(10, min(args.steps, 40))
+    tr = timed_region(wl, ranks, steps, 5, args.depth, min(args.min_time, 0.5))
+    res = summarize(wl, tr, ranks, short)
+    res["unit"], res["steps"], res["verified"] = "proposals/s", steps, tr["verified"]
+    # the comparison: this (f32-driven) chain's state and one of its batches through an f64 context as well
+    r = wl["packed"][0]
+    b32 = np.zeros_like(r[5])
+    wl["ctx"].score_packed(r[0], r[1], r[2], r[3], r[4], b32)
+    ch = wl["chains"][0]
+    ctx64 = DeviceContext(wl["X"], wl["y"], K=wl["K"], n_chains=1, max_batch=wl["B"], device=ranks.device(), dtype="f64")
+    for k in range(wl["K"]):
+        ctx64.set_current(0, k, flatten(ch.roots[k]))
+    ctx64.refresh(0)
+    a64 = np.zeros_like(r[5])
+    ctx64.score_packed(r[0], r[1], r[2], r[3], r[4], a64)
+    ctx64.close()
+    wl["scorer"].close()
+    K = wl["K"]
+    both = (a64["rank"] == K) & (b32["rank"] == K)
+    d_abs = np.abs(b32["loglik"][both] - a64["loglik"][both])
+    rel = d_abs / np.abs(a64["loglik"][both])
+    # the accept test compares log u with log R, in which only the likelihood term depends on the dtype
+    # (codes/funcs.py:1249-1254): a decision can flip only where |delta loglik| reaches the margin |log R - log u|, which
+    # is O(1) for almost every proposal -- count the proposals whose log-likelihood moves by more than 1e-2
+    res["vs_f64"] = {"proposals": int(len(a64)), "both_full_rank": int(both.sum()),
+                     "rel_dloglik_median": float(np.median(rel)) if rel.size else None,
+                     "rel_dloglik_max": float(np.max(rel)) if rel.size else None,
+                     "abs_dloglik_max": float(np.max(d_abs)) if rel.size else None,
+                     "rank_flips": int(np.sum(a64["rank"] != b32["rank"])),
+                     "rank_flips_towards_deficient": int(np.sum((a64["rank"] == K) & (b32["rank"] < K))),
+                     "accept_flip_candidates_abs_dloglik_over_1e-2": int(np.sum(d_abs > 1e-2))}
+    return res
 
 
 def main():
@@ -478,6 +524,17 @@ def main():
             ex["c4_native_engine"] = engine_leg(args, ranks)
         except Exception as exc:
             ex["c4_native_engine"] = {"error": repr(exc)}
+        try:
+            ex["c2_native_engine"] = engine_leg(args, ranks, chains=1, batch=64, seconds=2.0)
+            # what a single chain CONSUMES next to what the headline scores (speculative batches of a frozen state):
+            out["consumed_per_s"] = ex["c2_native_engine"]["value"]
+        except Exception as exc:
+            ex["c2_native_engine"] = {"error": repr(exc)}
+        if ranks.world == 1:
+            try:
+                ex["c5_f32"] = f32_leg(args, ranks)
+            except Exception as exc:
+                ex["c5_f32"] = {"error": repr(exc)}
         out["extra"] = ex
     if ranks.rank == 0:
         print(json.dumps(out))

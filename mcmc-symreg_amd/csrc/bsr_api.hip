@@ -174,7 +174,7 @@ struct bsr_ctx {
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
   int chain_eval = 1;   // BSR_CHAIN_EVAL: chain tapes take the register-resident pass of the tile kernel
-  BatchSlot slot[BSR_MAX_INFLIGHT];
+  BatchSlot slot[BSR_SLOTS];
   int next_slot = 0;
   int last_waited = -1;
   std::mutex mu;  // commit / refresh / fit share the main stream and one set of staging buffers (bsr_internal_lock)
@@ -1946,7 +1946,7 @@ void bsr_internal_unlock(bsr_ctx* c) { c->mu.unlock(); }
 int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t idx) {
   int rc = chain_ok(c, chain, k);
   if (rc != BSR_OK) return rc;
-  if (si < 0 || si >= BSR_MAX_INFLIGHT || !c->slot[si].scored)
+  if (si < 0 || si >= BSR_SLOTS || !c->slot[si].scored)
     return fail(c, BSR_E_STATE, "bsr_commit: no scored batch to commit from");
   BatchSlot& s = c->slot[si];
   if (s.pending || s.waited_gen != s.gen)

@@ -1156,9 +1156,11 @@ bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k) {
   return est > sib * (10.0 / tol) || est < sib * (tol / 10.0);
 }
 
-void generate(bsr_engine* e, ChainS& c, int max_n) {
+// `ahead`: candidates of this chain generated before and not consumed yet (a batch in flight: they are assumed to
+// end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
+void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
   c.cands.clear();
-  int total = c.total, count = c.count;
+  int total = c.total + ahead, count = (c.count + ahead) % e->K;
   while ((int)c.cands.size() < max_n) {
     if (count == 0 && total >= e->val) break;  // `while total < val` is only tested between sweeps
     c.cands.emplace_back();
@@ -1218,10 +1220,15 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
 // owns that batch slot, and the accept path takes the context lock (commit, refresh and fit share the main stream)
 // ev != nullptr: the device has already formed every log-ratio and found the first proposal of the run that is not
 // "rejected as speculated" (k_events); the proposals in front of it only need their bookkeeping.
-int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot, const bsr_event* ev) {
+// keep_rng: more candidates of this chain were generated behind these (a batch ahead): when every candidate here ends
+// as speculated the random stream already stands where it should; *broke_out tells the caller whether an event
+// (accept, gate verdict against the speculation, error) ended the run early -- what was generated behind is then void
+int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot, const bsr_event* ev,
+            bool keep_rng = false, bool* broke_out = nullptr) {
   const int K = e->K;
   int used = 0;
   bool broke = false;
+  if (broke_out) *broke_out = true;   // (early error returns count as events)
   for (size_t i = 0; i < c.cands.size(); ++i) {
     Cand& cd = c.cands[i];
     const bsr_score& sc = res[i];
@@ -1363,7 +1370,8 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     broke = true;
     break;
   }
-  if (!broke) c.rng = c.end_state;  // every candidate was consumed as a plain rejection
+  if (!broke && !keep_rng) c.rng = c.end_state;  // every candidate was consumed as a plain rejection
+  if (broke_out) *broke_out = broke;
   c.n_discard += (int64_t)c.cands.size() - used;
   if (broke) c.run_ema = (c.run_ema > 1e8) ? used : 0.7 * c.run_ema + 0.3 * used;
   else if (c.run_ema < 1e8) c.run_ema = 0.7 * c.run_ema + 0.3 * (2.0 * used);
@@ -1474,18 +1482,27 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   e->trace = trace;
   e->trace_cap = trace ? trace_cap : 0;
   e->n_trace = 0;
-  struct Group {
-    std::vector<ChainS*> chains;
+  // One batch in flight: its tapes, what was asked per proposal, the results, and per chain of the group the
+  // candidates it carries (a chain's candidate list travels with the batch: with a second batch generated ahead the
+  // chain object itself only holds what is being consumed).
+  struct Lane {
     std::vector<bsr_node> rows;
     std::vector<int32_t> off, chs, ks;
     std::vector<double> sig, terms;
     std::vector<int32_t> mhflags, spans;
     std::vector<bsr_event> events;
     std::vector<bsr_score> res;
-    std::vector<std::pair<int, int>> span;
+    std::vector<std::pair<int, int>> span;       // per chain of the group: first proposal, count
+    std::vector<std::vector<Cand>> cands;        // per chain: its candidates in this batch
+    std::vector<LegacyRng> end_state;            // per chain: the random stream behind its last candidate
+    std::vector<char> valid;                     // per chain: 0 once an event in the batch before made them void
     int32_t ticket = -1;
     int slot = -1;  // >= 0: this group's worker thread owns that batch slot
     bool inflight = false;
+  };
+  struct Group {
+    std::vector<ChainS*> chains;
+    Lane lane[2];
     double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
   };
   auto is_live = [&](const ChainS& c) { return c.inited && !c.done && (max_props < 0 || c.n_props < max_props); };
@@ -1498,108 +1515,145 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     return rc;
   }
   // tracing wants proposals in chain order: keep one group then
-  // A group's cycle is serial (generate, submit, wait for the batch's four dependent kernels, consume), so the groups
-  // in flight are what hides it.  Up to eight (one batch slot and one worker thread each) while K <= 4: 8 chains at
-  // K = 3 run at 1.55 M consumed proposals/s in eight groups against 1.14 M in four; at K = 8, where k_solve and
-  // k_finalize take 25 us per launch whatever its size, eight launches of 32 proposals lose 6 % against four of 64
+  // A group's cycle is serial (generate, submit, wait for the batch's dependent kernels, consume), so the batches in
+  // flight are what hides it.  Up to eight groups (a worker thread each) while K <= 4: 8 chains at K = 3 run at
+  // 1.55 M consumed proposals/s in eight groups against 1.14 M in four; at K = 8, where k_solve and k_finalize take
+  // 25 us per launch whatever its size, eight launches of 32 proposals lose 6 % against four of 64
   // (tools/probes/engine_groups.sh).  Four also when the process has fewer than a dozen CPUs to itself.
   const int dflt_groups = (e->K <= 4 && bsr_internal_cpu_budget() >= 12.0) ? 8 : 4;
   const int max_groups = std::max(1, std::min<int>(BSR_MAX_INFLIGHT, getenv("BSR_ENGINE_GROUPS") ? atoi(getenv("BSR_ENGINE_GROUPS")) : dflt_groups));
   const int n_groups = trace ? 1 : std::max(1, std::min<int>(max_groups, (int)live.size()));
-  // One worker thread per group (each with its own batch slot and HIP stream): proposal generation, staging and the
-  // 6-8 HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single
+  // One worker thread per group (each with its own batch slots and HIP streams): proposal generation, staging and the
+  // HIP calls of a submission cost the host ~1.3 us per proposal, more than the GPU needs to score it, so a single
   // host thread leaves the GPU two thirds idle.  K == 1 keeps the single-threaded ticket path (its rescoring step
   // drains every slot).
   const int want_threads = getenv("BSR_ENGINE_THREADS") ? atoi(getenv("BSR_ENGINE_THREADS")) : 1;
   const bool threaded = n_groups > 1 && e->K > 1 && want_threads != 0;
+  // A SECOND batch per group, generated while the first is on the GPU on the assumption that the first ends as
+  // speculated (four in five do): a worker used to wait 63 % of its time for its batch.  An event in the first batch
+  // (accept, gate verdict against the speculation) makes the chain's share of the second one void -- it is skipped
+  // when it arrives, and the chain generates afresh from the state behind the event: the sequence of consumed
+  // proposals is the reference's whatever is thrown away (codes/funcs.py:1300-1303, :1226-1228).
+  const bool lookahead = threaded && (getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) != 0 : true);
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
-  for (int gi = 0; gi < n_groups; ++gi) groups[gi].slot = threaded ? gi : -1;
+  for (int gi = 0; gi < n_groups; ++gi) {
+    groups[gi].lane[0].slot = threaded ? gi : -1;
+    groups[gi].lane[1].slot = threaded ? BSR_MAX_INFLIGHT + gi : -1;
+  }
   const int per_group_cap = std::max(1, max_batch / n_groups);
   const bool use_mh = e->device_mh && !trace && e->K > 1;
 
-  auto submit = [&](Group& g) -> int {
-    g.rows.clear();
-    g.off.assign(1, 0);
-    g.chs.clear();
-    g.ks.clear();
-    g.sig.clear();
-    g.span.clear();
-    g.terms.clear();
-    g.mhflags.clear();
-    g.spans.assign(1, 0);
+  // generates and submits the batch of lane `li`; ahead: behind the candidates the group's other lane has in flight
+  auto submit = [&](Group& g, int li, bool ahead) -> int {
+    Lane& L = g.lane[li];
+    const Lane& O = g.lane[li ^ 1];
+    L.rows.clear();
+    L.off.assign(1, 0);
+    L.chs.clear();
+    L.ks.clear();
+    L.sig.clear();
+    L.span.clear();
+    L.terms.clear();
+    L.mhflags.clear();
+    L.spans.assign(1, 0);
+    const size_t nc = g.chains.size();
+    L.cands.resize(nc);
+    L.end_state.resize(nc);
+    L.valid.assign(nc, 1);
     int n_live = 0;
     for (ChainS* c : g.chains) n_live += is_live(*c) ? 1 : 0;
     if (n_live == 0) return BSR_OK;
     const int per = std::max(1, std::min<int>(batch_per_chain, per_group_cap / n_live));
-    for (ChainS* c : g.chains) {
+    for (size_t ci = 0; ci < nc; ++ci) {
+      ChainS* c = g.chains[ci];
+      L.cands[ci].clear();
       if (!is_live(*c)) {
-        g.span.push_back({(int)g.chs.size(), 0});
+        L.span.push_back({(int)L.chs.size(), 0});
         continue;
       }
+      // what this chain has in flight ahead of the new candidates (the other lane's share, unless an event voided it)
+      const int n_ahead = (ahead && O.inflight && ci < O.valid.size() && O.valid[ci]) ? O.span[ci].second : 0;
       int room = per;
       // speculate only about as far as this chain's batches have recently been consumed
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
-      if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props);
+      if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props - n_ahead);
       const double tg0 = now_s();
-      generate(e, *c, room);
+      if (room > 0) generate(e, *c, room, n_ahead);
+      else c->cands.clear();
       g.t_gen += now_s() - tg0;
-      g.span.push_back({(int)g.chs.size(), (int)c->cands.size()});
+      L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
-        g.rows.insert(g.rows.end(), cd.tape.begin(), cd.tape.end());
-        g.off.push_back((int32_t)g.rows.size());
-        g.chs.push_back(c->index);
-        g.ks.push_back(cd.k);
-        g.sig.push_back(cd.new_sigma);
-        g.terms.insert(g.terms.end(), cd.terms, cd.terms + 8);
-        g.mhflags.push_back(cd.mhflags);
+        L.rows.insert(L.rows.end(), cd.tape.begin(), cd.tape.end());
+        L.off.push_back((int32_t)L.rows.size());
+        L.chs.push_back(c->index);
+        L.ks.push_back(cd.k);
+        L.sig.push_back(cd.new_sigma);
+        L.terms.insert(L.terms.end(), cd.terms, cd.terms + 8);
+        L.mhflags.push_back(cd.mhflags);
       }
-      if (!c->cands.empty()) g.spans.push_back((int32_t)g.chs.size());
-      if (c->cands.empty()) c->done = true;
+      if (!c->cands.empty()) L.spans.push_back((int32_t)L.chs.size());
+      if (c->cands.empty() && !ahead && room > 0) c->done = true;
+      L.end_state[ci] = c->end_state;
+      L.cands[ci].swap(c->cands);
     }
-    if (g.chs.empty()) return BSR_OK;
-    g.res.resize(g.chs.size());
+    if (L.chs.empty()) return BSR_OK;
+    L.res.resize(L.chs.size());
     const double ts0 = now_s();
     int r;
-    const int n_sp = (int)g.spans.size() - 1;
-    g.events.resize(std::max(1, n_sp));
-    if (g.slot >= 0)
-      r = use_mh ? bsr_internal_submit_mh(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(),
-                                          g.sig.data(), (int)g.chs.size(), g.terms.data(), g.mhflags.data(),
-                                          g.spans.data(), n_sp)
-                 : bsr_internal_submit(e->ctx, g.slot, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(),
-                                       g.sig.data(), (int)g.chs.size());
+    const int n_sp = (int)L.spans.size() - 1;
+    L.events.resize(std::max(1, n_sp));
+    if (L.slot >= 0)
+      r = use_mh ? bsr_internal_submit_mh(e->ctx, L.slot, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(),
+                                          L.sig.data(), (int)L.chs.size(), L.terms.data(), L.mhflags.data(),
+                                          L.spans.data(), n_sp)
+                 : bsr_internal_submit(e->ctx, L.slot, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(),
+                                       L.sig.data(), (int)L.chs.size());
     else
-      r = use_mh ? bsr_score_submit_mh(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
-                                       (int)g.chs.size(), g.terms.data(), g.mhflags.data(), g.spans.data(), n_sp,
-                                       &g.ticket)
-                 : bsr_score_submit(e->ctx, g.rows.data(), g.off.data(), g.chs.data(), g.ks.data(), g.sig.data(),
-                                    (int)g.chs.size(), &g.ticket);
+      r = use_mh ? bsr_score_submit_mh(e->ctx, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(), L.sig.data(),
+                                       (int)L.chs.size(), L.terms.data(), L.mhflags.data(), L.spans.data(), n_sp,
+                                       &L.ticket)
+                 : bsr_score_submit(e->ctx, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(), L.sig.data(),
+                                    (int)L.chs.size(), &L.ticket);
     g.t_submit += now_s() - ts0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_submit: ") + bsr_last_error(e->ctx));
-    g.inflight = true;
+    L.inflight = true;
     return BSR_OK;
   };
-  auto collect = [&](Group& g) -> int {
-    if (!g.inflight) return BSR_OK;
-    g.inflight = false;
+  // waits for lane `li`'s batch and consumes it chain by chain
+  auto collect = [&](Group& g, int li) -> int {
+    Lane& L = g.lane[li];
+    Lane& O = g.lane[li ^ 1];
+    if (!L.inflight) return BSR_OK;
+    L.inflight = false;
     const double tw0 = now_s();
     int r;
     if (use_mh)
-      r = (g.slot >= 0) ? bsr_internal_wait_mh(e->ctx, g.slot, g.res.data(), g.events.data())
-                        : bsr_score_wait_mh(e->ctx, g.ticket, g.res.data(), g.events.data());
+      r = (L.slot >= 0) ? bsr_internal_wait_mh(e->ctx, L.slot, L.res.data(), L.events.data())
+                        : bsr_score_wait_mh(e->ctx, L.ticket, L.res.data(), L.events.data());
     else
-      r = (g.slot >= 0) ? bsr_internal_wait(e->ctx, g.slot, g.res.data())
-                        : bsr_score_wait(e->ctx, g.ticket, g.res.data());
+      r = (L.slot >= 0) ? bsr_internal_wait(e->ctx, L.slot, L.res.data())
+                        : bsr_score_wait(e->ctx, L.ticket, L.res.data());
     const double tw1 = now_s();
     g.t_wait += tw1 - tw0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_wait: ") + bsr_last_error(e->ctx));
     int sp = 0;  // chains with proposals in this batch, in order: the spans of the MH scan
     for (size_t i = 0; i < g.chains.size(); ++i) {
-      if (g.span[i].second == 0) continue;
-      r = consume(e, *g.chains[i], g.res.data() + g.span[i].first, g.span[i].first, g.slot,
-                  use_mh ? &g.events[sp] : nullptr);
+      if (L.span[i].second == 0) continue;
+      ChainS& c = *g.chains[i];
+      const bsr_event* ev = use_mh ? &L.events[sp] : nullptr;
       ++sp;
+      if (!L.valid[i] || c.done) {   // generated behind a batch that did not end as speculated (or that ended the chain): thrown away unseen
+        c.n_discard += (int64_t)L.cands[i].size();
+        L.cands[i].clear();
+        continue;
+      }
+      c.cands.swap(L.cands[i]);
+      c.end_state = L.end_state[i];
+      const bool more_ahead = O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0;
+      bool broke = false;
+      r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke);
+      if (broke && O.inflight && i < O.valid.size()) O.valid[i] = 0;   // what was generated behind these is void
       if (r != BSR_OK) return r;
     }
     g.t_consume += now_s() - tw1;
@@ -1610,16 +1664,24 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::atomic<int> first_rc{BSR_OK};
     auto worker = [&](Group& g, bool own_thread) {
       if (own_thread) bsr_internal_place_thread();   // (the caller's thread, which runs group 0, stays where it is)
-      int r = BSR_OK;
-      while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK) {
-        r = submit(g);
-        if (r != BSR_OK || !g.inflight) break;
-        r = collect(g);
+      int cur = 0;
+      int r = submit(g, 0, false);
+      while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK && g.lane[cur].inflight) {
+        if (lookahead) {
+          r = submit(g, cur ^ 1, true);
+          if (r != BSR_OK) break;
+        }
+        r = collect(g, cur);
+        if (r != BSR_OK) break;
+        if (g.lane[cur ^ 1].inflight) cur ^= 1;
+        else r = submit(g, cur, false);
       }
-      if (r == BSR_OK && g.inflight) r = collect(g);
-      if (g.inflight) {  // left in flight by an error elsewhere: drain so the context stays usable
-        g.inflight = false;
-        (void)bsr_internal_wait(e->ctx, g.slot, g.res.data());
+      for (int li = 0; li < 2; ++li) {
+        Lane& L = g.lane[li];
+        if (!L.inflight) continue;   // left in flight by an error (here or elsewhere): drain so the context stays usable
+        L.inflight = false;
+        (void)bsr_internal_wait(e->ctx, L.slot, L.res.data());
+        for (size_t i = 0; i < g.chains.size() && i < L.cands.size(); ++i) g.chains[i]->n_discard += (int64_t)L.cands[i].size();
       }
       if (r != BSR_OK) {
         int expect = BSR_OK;
@@ -1633,26 +1695,26 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     rc = first_rc.load();
   } else {
     for (Group& g : groups) {
-      rc = submit(g);
+      rc = submit(g, 0, false);
       if (rc != BSR_OK) break;
     }
     while (rc == BSR_OK) {
       bool any = false;
       for (Group& g : groups) {
-        if (!g.inflight) continue;
+        if (!g.lane[0].inflight) continue;
         any = true;
-        rc = collect(g);
+        rc = collect(g, 0);
         if (rc != BSR_OK) break;
-        rc = submit(g);
+        rc = submit(g, 0, false);
         if (rc != BSR_OK) break;
       }
       if (!any) break;
     }
     if (rc != BSR_OK) {  // drain what is still in flight so the context stays usable
       for (Group& g : groups)
-        if (g.inflight) {
-          g.inflight = false;
-          (void)bsr_score_wait(e->ctx, g.ticket, g.res.data());
+        if (g.lane[0].inflight) {
+          g.lane[0].inflight = false;
+          (void)bsr_score_wait(e->ctx, g.lane[0].ticket, g.lane[0].res.data());
         }
     }
   }

@@ -7,6 +7,8 @@
 
 #include "../../include/bsr_hip.h"
 
+#define BSR_SLOTS (2 * BSR_MAX_INFLIGHT)   // batch slots of a context: the public tickets use the first BSR_MAX_INFLIGHT, the native
+                                          // sampler's worker threads a second one each for the batch they generate ahead
 #define BSR_NQ_MAX BSR_MAX_K        // basis columns per chain (one orthonormal column per current tree output)
 #define BSR_WAVE 64
 #define BSR_WG_WAVES 4              // waves per workgroup in the row-pass kernels
