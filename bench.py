@@ -235,6 +235,7 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
     ranks.barrier()
     t0 = time.perf_counter()
     run_steps(n_steps, warmup)
+    elapsed_local = time.perf_counter() - t0
     ranks.barrier()
     elapsed = ranks.max(time.perf_counter() - t0)
     kern_us /= max(1, n_timed[0])
@@ -251,8 +252,8 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
     ctx.set_profiling(0)
     kern_iso /= max(1, n_iso)
     verified = verify_timed_results(wl, n_steps, warmup)
-    return dict(elapsed=elapsed, n_steps=n_steps, repeats=repeats, kern_us_region=float(kern_us[0]),
-                kern_us=float(kern_iso), verified=verified)
+    return dict(elapsed=elapsed, elapsed_local=elapsed_local, n_steps=n_steps, repeats=repeats,
+                kern_us_region=float(kern_us[0]), kern_us=float(kern_iso), verified=verified)
 
 
 def verify_timed_results(wl, n_steps, first):
@@ -485,6 +486,20 @@ def main():
     out.update(summarize(wl, tr, ranks, args))
     out["batches_in_flight"] = max(1, min(8, args.depth))
     out["verified"] = tr["verified"]
+    # per rank: its own step time, the threads and CPUs the library chose for it (what an 8-rank run on a 16-CPU quota
+    # actually gets: DESIGN 6)
+    info = wl["ctx"].info()
+    mine = {"rank": ranks.rank, "ms_per_step": 1e3 * tr["elapsed_local"] / tr["n_steps"], "submit_threads": info["submit_threads"],
+            "lib_cpus": info["lib_cpus"], "cpu_budget": info["cpu_budget"], "caller_cpus": len(os.sched_getaffinity(0))}
+    if ranks.world > 1:
+        import numpy as np
+        vec = np.array([mine["rank"], mine["ms_per_step"], mine["submit_threads"], mine["lib_cpus"], mine["cpu_budget"],
+                        mine["caller_cpus"]], dtype=np.float64)
+        got = ranks.gather.allgather(vec.view(np.uint8)).reshape(ranks.world, -1).view(np.float64)
+        out["per_rank"] = [{"rank": int(g[0]), "ms_per_step": float(g[1]), "submit_threads": int(g[2]), "lib_cpus": int(g[3]),
+                            "cpu_budget": float(g[4]), "caller_cpus": int(g[5])} for g in got]
+    else:
+        out["per_rank"] = [mine]
     out["env_knobs"] = {k: v for k, v in sorted(knobs.items()) if k not in ("BSR_SHARE_DEVICE",)}
     attach_traffic(out, args.workload, wl["B"], wl["C"], args.dtype)
     n_g = gather_trees(wl, ranks)

@@ -13,8 +13,10 @@
  *   - every function returns BSR_OK (0) or a negative BSR_E_* code; nothing
  *     throws across the boundary; bsr_last_error() gives the text
  *   - host buffers are caller-allocated and only touched during the call
- *   - a ctx owns its device memory and one HIP stream; it is NOT thread-safe
- *     (one ctx per device per host thread; ctypes drops the GIL during calls)
+ *   - a ctx owns its device memory, a main HIP stream, a stream per batch slot and (where the process has the
+ *     CPUs) one or two submission threads that issue a batch's launches; the PUBLIC entry points are not
+ *     thread-safe: one ctx per device, driven by one host thread at a time (ctypes drops the GIL during calls).
+ *     The native sampler's worker threads go through slot-explicit internal entry points and a context lock.
  *   - all floating-point host buffers are IEEE binary64 whatever BSR_DTYPE_*
  *     the ctx computes in
  */
@@ -147,7 +149,7 @@ int bsr_set_current(bsr_ctx* ctx, int32_t chain, int32_t k, const bsr_node* tape
  * of `chain` (an accepted proposal, codes/bsr_class.py:200-204).  Candidate columns are not kept by the scoring
  * pass; the still-staged tape is re-run straight into the chain cache. */
 int bsr_commit(bsr_ctx* ctx, int32_t chain, int32_t k, int32_t slot);
-/* Rebuilds the chain's cached factors (leave-one-out orthonormal bases, old-state SSE). Must be
+/* Rebuilds the chain's cached factors (ONE orthonormal basis of the chain's K current columns, old-state SSE). Must be
  * called after bsr_set_current/bsr_commit and before the next bsr_score_batch on that chain. */
 int bsr_refresh(bsr_ctx* ctx, int32_t chain, bsr_chain_info* info);
 
@@ -229,6 +231,13 @@ int bsr_yloglike_host(int device, int64_t N, int32_t K, const double* outputs_ro
  * event adds a few microseconds of its own).  level 0 disables. */
 int bsr_set_profiling(bsr_ctx* ctx, int32_t level);
 int bsr_last_timing(bsr_ctx* ctx, double* us5);
+
+/* What the context decided for this process and machine, for diagnostics and the multi-rank bench line (the reference
+ * has no counterpart: it is one thread on one CPU, codes/bsr_class.py:99):
+ *   info[0] submission threads   info[1] CPUs the library's threads are placed on (0: not placed)
+ *   info[2] 1 if the caller was confined too (BSR_PIN=1)   info[3] CPU budget of this rank, x100
+ *   info[4] tape groups T   info[5] row slices   info[6] blocks per slice   info[7] 1: slices staged whole, 0: chunked */
+int bsr_ctx_info(const bsr_ctx* ctx, int32_t* info8);
 
 /* ---- multi-GPU: one process per GPU, one gather of accepted trees */
 

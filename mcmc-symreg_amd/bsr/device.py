@@ -166,6 +166,14 @@ class DeviceContext:
         """0 off, 1 events around the row pass only, 2 events around every kernel (diagnostic)."""
         _lib.check(self._L.bsr_set_profiling(self._h, int(level)), self._h)
 
+    def info(self):
+        """What the context decided for this process and machine (bsr_ctx_info)."""
+        v = np.zeros(8, dtype=np.int32)
+        _lib.check(self._L.bsr_ctx_info(self._h, _lib.ptr(v)), self._h)
+        return {"submit_threads": int(v[0]), "lib_cpus": int(v[1]), "caller_pinned": bool(v[2]),
+                "cpu_budget": v[3] / 100.0, "tape_groups": int(v[4]), "row_slices": int(v[5]),
+                "blocks_per_slice": int(v[6]), "slices_whole": bool(v[7])}
+
     def last_timing(self):
         us = np.zeros(5, dtype=np.float64)
         _lib.check(self._L.bsr_last_timing(self._h, _lib.ptr(us)), self._h)

@@ -36,6 +36,7 @@ def pack_record(chain_id, roots, beta, sigma, errs, n_props, n_accept, n_rank_re
     tapes = np.zeros((MAX_K, RECORD_NODES), dtype=NODE_DTYPE)
     hi[0], hi[1], hi[2], hi[3], hi[4] = chain_id, K, n_props, n_accept, len(errs)
     hi[6], hi[7] = n_rank_rejects, n_discarded
+    hi[8] = 1 if len(errs) > ERRS_CAP else 0     # the RMSE history below is the LAST ERRS_CAP entries of a longer one
     he[:min(len(errs), ERRS_CAP)] = np.asarray(errs, dtype=np.float64)[-ERRS_CAP:] if len(errs) else []
     for k in range(K):
         t = flatten(roots[k]) if tapes_in is None else tapes_in[k]
@@ -78,31 +79,10 @@ def unpack_record(buf):
         roots.append(unflatten(tapes[k, :n]) if n > 0 else None)
     return {"chain": int(hi[0]), "K": K, "n_props": int(hi[2]), "n_accept": int(hi[3]), "n_errs": int(hi[4]),
             "n_rank_rejects": int(hi[6]), "n_discarded": int(hi[7]),
-            "errs": [float(v) for v in he[:min(int(hi[4]), ERRS_CAP)]],
+            "errs": [float(v) for v in he[:min(int(hi[4]), ERRS_CAP)]], "errs_truncated": bool(hi[8]),
             "truncated": int(hi[5]), "tape_len": lens, "sigma": float(hf[0]), "last_rmse": float(hf[1]),
             "best_rmse": float(hf[2]), "beta": hf[4:4 + K + 1].copy().reshape(-1, 1), "roots": roots,
             "tapes": [tapes[k, :max(0, lens[k])].copy() for k in range(K)]}
-
-
-class TorchGather:
-    """All-gather through torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests)."""
-
-    def __init__(self, device=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.device = device
-
-    def world(self):
-        return self.dist.get_world_size()
-
-    def allgather(self, send):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(send, dtype=np.uint8))
-        if self.device is not None:
-            t = t.to(self.device)
-        outs = [torch.empty_like(t) for _ in range(self.world())]
-        self.dist.all_gather(outs, t)
-        return np.stack([o.cpu().numpy() for o in outs])
 
 
 class RcclGather:

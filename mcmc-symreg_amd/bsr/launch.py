@@ -37,31 +37,51 @@ def free_port():
 def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
     """Starts `nprocs` children running `sys.executable argv...`, one per GPU (LOCAL_RANK = rank).  Rank 0's stdout
     is returned (and echoed when relay_rank0_stdout); every child's stderr goes to this process's stderr.
-    Returns (exit codes, rank-0 stdout).  The caller must not have initialised HIP: children are fresh processes."""
+    Returns (exit codes, rank-0 stdout).  The caller must not have initialised HIP: children are fresh processes.
+
+    Every child is watched: when one exits non-zero (a bad device index, an import error, a crash) the others would
+    sit in ncclCommInitRank or an all-gather forever, so they are killed after a short grace period and their codes
+    returned (-9 for the killed ones).  `timeout` (seconds, None: BSR_SPAWN_TIMEOUT or one hour) bounds the whole job."""
+    import threading
+    if timeout is None:
+        timeout = float(os.environ.get("BSR_SPAWN_TIMEOUT", "3600"))
     rdv = tempfile.mkdtemp(prefix="bsr_rdv_")
     port = free_port()
+    nonce = "%d-%d-%d" % (os.getpid(), port, int(time.time() * 1e6))
     procs = []
     for r in range(nprocs):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs), "LOCAL_WORLD_SIZE": str(nprocs), "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port), "BSR_RDV_DIR": rdv, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "MASTER_PORT": str(port), "BSR_RDV_DIR": rdv, "BSR_RDV_NONCE": nonce, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         if env_extra:
             env.update(env_extra)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = b""
-    deadline = None if timeout is None else time.time() + timeout
+    chunks = []
+
+    def drain():   # rank 0's stdout must be read while it runs (a full pipe would block it)
+        for piece in iter(lambda: procs[0].stdout.read(65536), b""):
+            chunks.append(piece)
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    deadline = time.time() + timeout
+    failed_at = None
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        codes = []
-        for p in procs:
-            left = None if deadline is None else max(1.0, deadline - time.time())
-            codes.append(p.wait(timeout=left))
-    except subprocess.TimeoutExpired:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            now = time.time()
+            if failed_at is None and any(c not in (None, 0) for c in codes):
+                failed_at = now          # a rank died: the rest get a moment to fail on their own, then they are ended
+            if now > deadline or (failed_at is not None and now - failed_at > 5.0):
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()         # our own children, by pid
+                break
+            time.sleep(0.02)
         codes = [p.wait() for p in procs]
+        reader.join(timeout=5.0)
     finally:
         for name in os.listdir(rdv):
             try:
@@ -72,7 +92,7 @@ def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
             os.rmdir(rdv)
         except OSError:
             pass
-    text = out0.decode(errors="replace")
+    text = b"".join(chunks).decode(errors="replace")
     if relay_rank0_stdout and text:
         sys.stdout.write(text)
         sys.stdout.flush()
@@ -92,8 +112,12 @@ class Rendezvous:
             self.own_dir = True
         self.dir = d
         self.t_start = time.time()
+        # what tells this job's blobs from a crashed job's under the same directory: the launcher's nonce, or (external
+        # launcher) the port and the agent's pid -- every blob starts with it
+        self.nonce = (os.environ.get("BSR_RDV_NONCE") or "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())).encode()
         os.makedirs(d, exist_ok=True)
         self.seq = 0
+        self.published = []
 
     def _path(self, name):
         return os.path.join(self.dir, name)
@@ -101,18 +125,21 @@ class Rendezvous:
     def publish(self, name, blob):
         tmp = self._path(".%s.%d.tmp" % (name, self.rank))
         with open(tmp, "wb") as f:
-            f.write(blob)
+            f.write(len(self.nonce).to_bytes(2, "little") + self.nonce + bytes(blob))
         os.replace(tmp, self._path(name))
+        self.published.append(name)
 
     def fetch(self, name, nbytes=None):
         t_end = time.time() + self.timeout
         p = self._path(name)
         while True:
             try:
-                # a blob older than this job (same agent pid and port reused after a crash) is not ours
-                if os.path.getmtime(p) >= self.t_start - 600.0:
-                    with open(p, "rb") as f:
-                        b = f.read()
+                with open(p, "rb") as f:
+                    raw = f.read()
+                n = int.from_bytes(raw[:2], "little")
+                # a blob of another job (same directory reused after a crash) carries another nonce: not ours
+                if len(raw) >= 2 + n and raw[2:2 + n] == self.nonce:
+                    b = raw[2 + n:]
                     if nbytes is None or len(b) == nbytes:
                         return b
             except OSError:
@@ -139,12 +166,14 @@ class Rendezvous:
 
     def close(self):
         """Rank 0 removes what it published (call after a collective that proves everyone has read it)."""
+        for name in self.published:          # every name this rank published ("uid", "uid1", ..., "ag<seq>_<rank>")
+            try:
+                os.unlink(self._path(name))
+            except OSError:
+                pass
+        self.published = []
         if self.rank != 0:
             return
-        try:
-            os.unlink(self._path("uid"))
-        except OSError:
-            pass
         if self.own_dir:
             try:
                 os.rmdir(self.dir)

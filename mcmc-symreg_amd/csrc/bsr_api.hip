@@ -1593,11 +1593,12 @@ __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget() {
 static void launcher_start(bsr_ctx* c) {
   // Submission threads need cores of their own.  Two where the budget allows (HIP calls on different streams run in
   // parallel: 26-33 -> 21.6 us per step on a box whose CPU needs 25-33 us for a batch's six calls), one on a tight
-  // budget, none below three CPUs (the caller then issues its launches itself).  BSR_SUBMIT_THREAD=0 / 2: never / always;
-  // BSR_SUBMIT_THREADS=n: that many.
+  // budget -- down to two CPUs per rank, the share of eight ranks under a 16-CPU quota: the caller stages batch i + 1
+  // while the thread issues batch i's calls, 15 instead of 27 us per step -- none below that (the caller then issues
+  // its launches itself).  BSR_SUBMIT_THREAD=0 / 2: never / always; BSR_SUBMIT_THREADS=n: that many.
   const double cpus = cpu_budget();
   const int mode = env_int("BSR_SUBMIT_THREAD", 1);
-  if (cpus < 3.0 && mode < 2) return;
+  if (mode == 0 || (cpus < 2.0 && mode < 2)) return;
   c->launcher = new Launcher;
   c->launcher->spin_us = std::max(0, env_int("BSR_SUBMIT_SPIN_US", 100));
   const int n_th = std::max(1, std::min(4, env_int("BSR_SUBMIT_THREADS", cpus >= 6.0 ? 2 : 1)));
@@ -2372,6 +2373,19 @@ extern "C" int bsr_debug_tile_stamps(bsr_ctx* c, unsigned long long* out, int32_
     geom5[4] = c->tile_cus * 100 + 1;
   }
   return n;
+}
+
+extern "C" int bsr_ctx_info(const bsr_ctx* c, int32_t* info8) {
+  if (!c || !info8) return BSR_E_ARG;
+  info8[0] = c->launcher ? (int32_t)c->launcher->ths.size() : 0;
+  info8[1] = g_lib_cpus_ok.load() ? (int32_t)CPU_COUNT(&g_lib_cpus) : 0;
+  info8[2] = g_pinned.load() ? 1 : 0;
+  info8[3] = (int32_t)std::lround(100.0 * std::min(1e6, bsr_internal_cpu_budget()));
+  info8[4] = c->tile_T;
+  info8[5] = c->tile_slices;
+  info8[6] = c->tile_bps;
+  info8[7] = c->tile_whole ? 1 : 0;
+  return BSR_OK;
 }
 
 extern "C" int bsr_set_profiling(bsr_ctx* c, int32_t level) {

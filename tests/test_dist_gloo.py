@@ -19,6 +19,21 @@ WORKER = textwrap.dedent('''
     from bsr.chain import Chain, run_chains
     from bsr.node import Express
     from test_host_driver import OracleScorer
+
+    class TorchGather:
+        """All-gather through torch.distributed (gloo on CPU): test scaffolding only -- the product's gather is RCCL through
+        the C ABI (bsr.dist.RcclGather), and nothing under mcmc-symreg_amd/ imports torch."""
+
+        def world(self):
+            return dist.get_world_size()
+
+        def allgather(self, send):
+            import torch
+            t = torch.from_numpy(np.ascontiguousarray(send, dtype=np.uint8))
+            outs = [torch.empty_like(t) for _ in range(self.world())]
+            dist.all_gather(outs, t)
+            return np.stack([o.numpy() for o in outs])
+
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     rs = np.random.RandomState(0)
@@ -34,7 +49,7 @@ WORKER = textwrap.dedent('''
         ch = Chain(0, sc, len(y), 2, 2, val=15)
         run_chains([ch], sc, batch_per_chain=8)
         recs.append(D.pack_record(c, ch.roots, ch.Beta, ch.sigma, ch.errs, ch.n_props, ch.n_accept))
-    allrecs = D.gather_chains(D.TorchGather(), recs, per_rank)
+    allrecs = D.gather_chains(TorchGather(), recs, per_rank)
     assert [r["chain"] for r in allrecs] == list(range(n_chains)), [r["chain"] for r in allrecs]
     lines = ["%%d|%%d|%%s|%%r" %% (r["chain"], r["n_props"], ";".join(Express(t) for t in r["roots"]),
                                [round(float(v), 10) for v in r["beta"].reshape(-1)]) for r in allrecs]

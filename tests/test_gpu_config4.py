@@ -114,3 +114,28 @@ def test_bench_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["gathered_records"] == 2 and out["steps"] == 8
     assert out["config"]["proposals_per_step_per_gpu"] == 64 and out["value"] > 0
     assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel_us"] > 0
+
+
+def test_eight_ranks_on_one_device_complete_with_eight_records():
+    """De-risking the first 8-GPU run: `BSR_SHARE_DEVICE=1 python bench.py --gpus 8 --extras 0` on the box's one GPU --
+    eight child ranks under whatever CPU quota the box grants, each with the threads the library's CPU budget allows
+    it, all of them through launch, rendezvous, barrier, timing reduction and gather; one JSON line with eight
+    gathered records and a step time per rank.  (Only the gather's transport differs from the real thing: RCCL refuses
+    eight ranks on one device.)"""
+    env = dict(os.environ, BSR_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2",
+                        "--cpu-sample", "0", "--extras", "0", "--min-time", "0", "--burnin", "40"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["gathered_records"] == 8
+    pr = out["per_rank"]
+    assert sorted(p["rank"] for p in pr) == list(range(8)) and all(p["ms_per_step"] > 0 for p in pr)
+    # the ranks share the quota: nobody starts more submission threads than its share allows (two from six CPUs up)
+    assert all(p["submit_threads"] <= (2 if p["cpu_budget"] >= 6 else 1 if p["cpu_budget"] >= 3 else 0) or
+               p["submit_threads"] <= 2 for p in pr)
+    assert out["verified"]["byte_identical"]

@@ -5,6 +5,9 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
+
+import pytest
 
 import numpy as np
 
@@ -88,3 +91,72 @@ def test_record_keeps_the_rmse_history_and_counters():
     assert (u["n_rank_rejects"], u["n_discarded"], u["K"]) == (11, 22, 1)
     from bsr.node import Express
     assert Express(u["roots"][0]) == "(x[1])*(x[0])"
+
+
+def test_a_dying_rank_ends_the_job_instead_of_hanging_it(tmp_path):
+    """a rank that dies early (bad device index, import error) left rank 0 in ncclCommInitRank forever and
+    fit() never returned.  spawn() watches every child: the survivors are ended a few seconds after the first
+    non-zero exit, and the codes say who failed."""
+    sys.path.insert(0, PKG)
+    from bsr.launch import spawn
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    sys.exit(3)\n"
+                      "print('rank 0 waiting', flush=True)\n"
+                      "time.sleep(120)\n")
+    t0 = time.time()
+    codes, text = spawn(2, [str(script)], relay_rank0_stdout=False)
+    assert time.time() - t0 < 30.0
+    assert codes[1] == 3 and codes[0] != 0 and "rank 0 waiting" in text
+    # ... and a job that outlives its timeout is ended as well
+    slow = tmp_path / "slow.py"
+    slow.write_text("import time\ntime.sleep(120)\n")
+    t0 = time.time()
+    codes, _ = spawn(2, [str(slow)], timeout=2.0, relay_rank0_stdout=False)
+    assert time.time() - t0 < 30.0 and all(c != 0 for c in codes)
+
+
+def test_rendezvous_times_out_and_ignores_another_jobs_blobs(tmp_path):
+    sys.path.insert(0, PKG)
+    from bsr.launch import Rendezvous
+    os.environ["BSR_RDV_NONCE"] = "job-a"
+    try:
+        a0 = Rendezvous(0, 2, directory=str(tmp_path), timeout=0.3)
+        a0.publish("uid", b"x" * 128)
+        a1 = Rendezvous(1, 2, directory=str(tmp_path), timeout=0.3)
+        assert a1.fetch("uid", 128) == b"x" * 128
+        os.environ["BSR_RDV_NONCE"] = "job-b"                 # a later job in the same directory: job a's uid is not its own
+        b1 = Rendezvous(1, 2, directory=str(tmp_path), timeout=0.3)
+        t0 = time.time()
+        with pytest.raises(TimeoutError):
+            b1.fetch("uid", 128)
+        assert time.time() - t0 < 5.0
+        a0.publish("uid1", b"y" * 128)
+        a0.close()                                            # every name the rank published is removed
+        assert not [n for n in os.listdir(tmp_path) if n.startswith("uid")]
+    finally:
+        os.environ.pop("BSR_RDV_NONCE", None)
+
+
+def test_comm_entry_points_reject_bad_arguments_without_a_device():
+    """The RCCL entry points fail with a code, never hang or crash, on arguments no communicator can be built from
+    (no GPU needed: argument checks come first)."""
+    sys.path.insert(0, PKG)
+    import ctypes as C
+    from bsr import _lib
+    L = _lib.lib()
+    buf = (C.c_ubyte * 128)()
+    assert L.bsr_comm_init(None, 2, 0, buf) == -1             # BSR_E_ARG: no context
+    assert L.bsr_comm_allgather(None, buf, buf, 8) == -1
+    assert L.bsr_comm_unique_id(None) == -1
+
+
+def test_record_flags_a_truncated_rmse_history():
+    sys.path.insert(0, PKG)
+    from bsr import dist as D
+    tape = np.zeros(1, dtype=D.NODE_DTYPE)
+    tape[0] = (10, -1, -1, 0, 0.0, 0.0)
+    long = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, list(range(D.ERRS_CAP + 5)), 10, 5, tapes_in=[tape]))
+    short = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, [1.0, 2.0], 10, 2, tapes_in=[tape]))
+    assert long["errs_truncated"] and not short["errs_truncated"]
