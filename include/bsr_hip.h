@@ -123,10 +123,11 @@ int bsr_device_count(int* count);
  * max_batch bounds the proposals / tapes of one call and sizes the per-batch descriptor, partial-sum and result
  * blocks (O(max_batch * N / 1024) doubles).  Candidate columns are not stored by the scoring pass; the
  * max_batch * N column buffer of bsr_eval_tapes is allocated on its first use.
- * Side effect, once per process: the calling thread's CPU affinity is narrowed to one L3 domain of the host (the one
- * it is on; one per LOCAL_RANK when several ranks share the node), and the threads the library and the HIP runtime
- * start afterwards inherit it -- a batch crosses three threads, and across sockets that costs up to 20 % of the
- * pipelined rate.  BSR_PIN=0 leaves the affinity alone, BSR_PIN_CPUS gives the CPU list. */
+ * CPU placement: the threads the LIBRARY starts (submission threads, the native sampler's workers) are placed on one L3
+ * domain of the host (the one the creating thread is on; one per LOCAL_RANK when several ranks share the node) -- a
+ * batch crosses three threads, and across sockets that costs up to 20 % of the pipelined rate.  The caller's own
+ * affinity is never changed unless BSR_PIN=1 is set (then it is confined to the same CPUs, once per process);
+ * BSR_PIN=0: no placement at all; BSR_PIN_CPUS gives the CPU list. */
 int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor,
                    const double* y, int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype);
 int bsr_ctx_destroy(bsr_ctx* ctx);

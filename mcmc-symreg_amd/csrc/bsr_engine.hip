@@ -29,6 +29,13 @@
 
 namespace {
 
+// lgamma() stores the sign in the global `signgam`: a data race between the sampler's worker threads (found by the
+// ThreadSanitizer build, tests/native).  The reentrant form keeps it local.
+inline double lgamma_mt(double x) {
+  int sign = 0;
+  return lgamma_r(x, &sign);
+}
+
 const double kInf = std::numeric_limits<double>::infinity();
 const double kNaN = std::numeric_limits<double>::quiet_NaN();
 
@@ -168,7 +175,7 @@ inline double fdiv(double a, double b) {
 }
 inline double invgamma_pdf(double x, int a) {
   if (!(x > 0)) return 0.0;
-  return fexp(-(a + 1) * std::log(x) - std::lgamma((double)a) - 1.0 / x);
+  return fexp(-(a + 1) * std::log(x) - lgamma_mt((double)a) - 1.0 / x);
 }
 const double kSqrt2Pi = std::sqrt(2 * M_PI);
 inline double norm_pdf(double x, double loc, double scale) {
@@ -1748,7 +1755,8 @@ extern "C" int bsr_engine_chain_result(bsr_engine* e, int32_t chain, bsr_node* t
   }
   if (beta) memcpy(beta, c.Beta.data(), sizeof(double) * (e->K + 1));
   if (n_errs) *n_errs = (int32_t)c.errs.size();
-  if (errs) memcpy(errs, c.errs.data(), sizeof(double) * std::min<size_t>(c.errs.size(), (size_t)errs_cap));
+  if (errs && !c.errs.empty())   // (memcpy from a null data() is undefined even for zero bytes: UBSan, tests/native)
+    memcpy(errs, c.errs.data(), sizeof(double) * std::min<size_t>(c.errs.size(), (size_t)errs_cap));
   if (counters) {
     counters[0] = c.n_props;
     counters[1] = c.n_accept;

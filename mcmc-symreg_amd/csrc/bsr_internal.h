@@ -2,7 +2,10 @@
 // gfx950 (MI355X) only: wave64, no portability layer.
 #pragma once
 
+#ifndef BSR_HOST_ONLY   // (the sanitizer build of the host-side sampler compiles without HIP: tests/native/build_san.sh)
 #include <hip/hip_runtime.h>
+#endif
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/bsr_hip.h"
@@ -182,8 +185,10 @@ struct TileArgs {
   const T* cols[BSR_TILE_ARG_GROUPS][BSR_TILE_ARG_COLS];
 };
 #define BSR_TILE_STAMP_WORDS 8
+#ifndef BSR_HOST_ONLY
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
+#endif
 size_t tile_lds_bytes_max();
 int tile_qmax(int K);
 
@@ -245,6 +250,7 @@ struct RowPassArgs {
   int32_t* queue_clear;       // the counter set this launch zeroes for a later one
   FinArgs fin;                // residual pass only
 };
+#ifndef BSR_HOST_ONLY
 template <typename T>
 void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual);
 // the finalise step can ride behind the residual pass for these K (register budget of its 16-wave workgroups)
@@ -274,3 +280,4 @@ void launch_refresh_fast(hipStream_t st, const T* cols, T* Q, const T* y, int64_
                          const RefreshIn* d_in, RefreshPlan* d_plan, double* d_part, ChainB* ck,
                          ChainFitOut* fit_noicpt, ChainFitOut* fit_icpt);
 size_t refresh_part_doubles(int64_t N);
+#endif  // BSR_HOST_ONLY

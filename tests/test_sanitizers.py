@@ -1,0 +1,64 @@
+"""CPU-only sanitizer jobs over the product's threaded host code (GPU sanitizers are not available on the pool).
+
+The native sampler (csrc/bsr_engine.hip: worker threads, batches generated ahead, the context lock around the accept
+path) is compiled as plain C++ against tests/native/stub_scorer.cpp -- a CPU stand-in for the data side of the C ABI,
+test infrastructure only -- once with AddressSanitizer + UndefinedBehaviorSanitizer as a shared library that the
+Python package loads instead of libbsr_hip.so, once with ThreadSanitizer around a small driver:
+  * the reference's golden traces replay through the sanitized sampler bit for bit (the same test functions the GPU
+    box runs against the HIP library);
+  * eight chains on one, four and eight worker threads, with and without look-ahead batches, end in the same state,
+    with no data race reported.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "native", "build_san.sh")
+
+
+def _runtime(name):
+    out = subprocess.run(["gcc", "-print-file-name=%s" % name], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_thread_sanitizer_finds_no_race_and_grouping_does_not_change_the_chains(tmp_path):
+    if _runtime("libtsan.so") is None:
+        pytest.skip("libtsan not installed")
+    exe = str(tmp_path / "engine_tsan")
+    b = subprocess.run(["bash", BUILD, "tsan", exe], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-4000:]
+    outs = {}
+    for tag, env in (("g1", {"BSR_ENGINE_GROUPS": "1"}), ("g4", {"BSR_ENGINE_GROUPS": "4"}),
+                     ("g8", {"BSR_ENGINE_GROUPS": "8"}), ("g4_no_lookahead", {"BSR_ENGINE_GROUPS": "4", "BSR_ENGINE_LOOKAHEAD": "0"})):
+        r = subprocess.run([exe, "8", "300"], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", **env),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (tag, r.stderr[-3000:])
+        assert "ThreadSanitizer" not in r.stderr, (tag, r.stderr[:4000])
+        outs[tag] = r.stdout
+    assert len(outs["g1"].splitlines()) == 8
+    assert outs["g1"] == outs["g4"] == outs["g8"] == outs["g4_no_lookahead"]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_golden_traces_through_the_address_sanitized_sampler(tmp_path):
+    asan = _runtime("libasan.so")
+    if asan is None:
+        pytest.skip("libasan not installed")
+    lib = str(tmp_path / "libbsr_stub_asan.so")
+    b = subprocess.run(["bash", BUILD, "asan", lib], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-4000:]
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", BSR_LIB_PATH=lib, BSR_EXEMPT_DISCOVER="1")
+    # the GPU box's own trace tests of the C++ sampler, pointed at the sanitized CPU build
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_chain.py"), "-q", "-x",
+                        "-m", "gpu", "-p", "no:cacheprovider", "-s", "-k", "native_engine"],
+                       env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[:4000]
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
