@@ -52,6 +52,7 @@ struct BatchSlot {
   size_t code_words = 0, feat_words = 0, ln_words = 0;
   // tile pass (bsr_tile.hip): a second column stream with LDS slots instead of X columns sits behind the ln pairs
   bool tile = false;
+  bool tile_possible = false;   // stage_tapes: nothing rules the tile pass out for the staged batch (stage_tile decides)
   int tile_chains = 0;                // distinct chains of the batch (their basis columns are staged in LDS)
   std::vector<int32_t> chain_slot;    // chain -> index among the batch's chains, -1 if absent
   std::vector<int32_t> batch_chains;  // the batch's chains in first-seen order
@@ -1196,24 +1197,47 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       for (int t = nt; t < words * 4; ++t) pf[t >> 2] |= id0 << (16 * (t & 3));
     }
   }
+  s.tile_possible = c->tile_on && c->tile_ever && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK && !s.use_lds;
+  if (g_stream_stats) {
+    g_ss_batches.fetch_add(1, std::memory_order_relaxed);
+    g_ss_derived.fetch_add(s.derived_used, std::memory_order_relaxed);
+    g_ss_cols.fetch_add(s.nF, std::memory_order_relaxed);
+  }
+  return BSR_OK;
+}
+
+// Second half of staging a scoring batch for the tile pass: the tape groups, their LDS slot maps and column-pointer
+// tables, and the column stream in LDS slots; the descriptors learn their group and the slot of their chain's basis.
+// It needs nothing from the caller but what stage_tapes left in the slot, so it runs wherever the batch's launches
+// are issued -- on a submission thread where the context has one: 1.5 us off the caller's path per batch.
+static void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
+  std::vector<TapeLoc>& loc = s.loc_tmp;
+  const int tile_chains = s.tile_chains;
+  uint64_t* hc = s.h_streams();
+  uint64_t* hf = hc + s.code_words;
+  double* hl = reinterpret_cast<double*>(hf + s.feat_words);
+  uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + s.ln_words);  // the column stream in LDS slots
+  const size_t fw = s.feat_words;
+  s.tile = false;
+  if (!s.tile_possible || (int)loc.size() < n) return;
   // ---- tile pass: tape groups, their LDS slot maps and column-pointer tables, the column stream in LDS slots.
   // No tape may need more value-stack slots than the register stack holds.
-  if (c->tile_on && c->tile_ever && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK && !s.use_lds) {
+  {
     const int T = c->tile_T, K = c->K;
     const int cap = (n + T - 1) / T;   // tapes per group at most (keeps the groups' passes even)
     // tapes by cost, heaviest first (stable: equal costs keep batch order)
-    cost_order(s.order_tmp, s.order_keys, n, [&](int i) { return (*loc)[i].cost; });
+    cost_order(s.order_tmp, s.order_keys, n, [&](int i) { return loc[i].cost; });
     s.order_n = n;
     if ((int)s.grp_slot.size() < T * c->n_cols) s.grp_slot.resize((size_t)T * c->n_cols);
     std::fill(s.grp_slot.begin(), s.grp_slot.begin() + (size_t)T * c->n_cols, (int16_t)-1);
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long total_cost = 0;
-    for (int i = 0; i < n; ++i) total_cost += (*loc)[i].cost;
+    for (int i = 0; i < n; ++i) total_cost += loc[i].cost;
     const long share = total_cost / T + total_cost / (8 * T) + 1;   // an even share of the batch's cost and an eighth
     auto tape_cols = [&](int i, auto&& fn) {   // the columns tape i reads, in stream order
-      const uint64_t* pf = hf + (*loc)[i].feat_off;
-      for (int t = 0; t < (*loc)[i].nt; ++t) fn((int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu));
+      const uint64_t* pf = hf + loc[i].feat_off;
+      for (int t = 0; t < loc[i].nt; ++t) fn((int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu));
     };
     for (int oi = 0; oi < n; ++oi) {
       const int i = s.order_tmp[oi];
@@ -1227,19 +1251,19 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
         int best_new = 1 << 30;
         g = -1;
         for (int gi = 0; gi < T; ++gi) {
-          if (cnt[gi] >= cap || load[gi] + (*loc)[i].cost > share) continue;
+          if (cnt[gi] >= cap || load[gi] + loc[i].cost > share) continue;
           int n_new = 0;
           tape_cols(i, [&](int col) { if (s.grp_slot[(size_t)gi * c->n_cols + col] < 0) ++n_new; });
-          if (n_new < best_new || (n_new == best_new && load[gi] < load[g])) { best_new = n_new; g = gi; }
+          if (g < 0 || n_new < best_new || (n_new == best_new && load[gi] < load[g])) { best_new = n_new; g = gi; }
         }
         if (g < 0) {
           for (int gi = 0; gi < T; ++gi)
             if (cnt[gi] < cap && (g < 0 || load[gi] < load[g])) g = gi;
         }
       }
-      (*loc)[i].grp = g;
+      loc[i].grp = g;
       ++cnt[g];
-      load[g] += (*loc)[i].cost;
+      load[g] += loc[i].cost;
       tape_cols(i, [&](int col) {
         int16_t& sl = s.grp_slot[(size_t)g * c->n_cols + col];
         if (sl < 0) { sl = 0; ++ncol[g]; }
@@ -1296,7 +1320,7 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       s.tile_ring = ring;
       memset(hf2, 0, fw * 8);
       for (int i = 0; i < n; ++i) {
-        const TapeLoc& L = (*loc)[i];
+        const TapeLoc& L = loc[i];
         const uint64_t* pf = hf + L.feat_off;
         uint64_t* pf2 = hf2 + L.feat_off;
         const int16_t* map = s.grp_slot.data() + (size_t)L.grp * c->n_cols;
@@ -1308,12 +1332,12 @@ static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int
       }
     }
   }
-  if (g_stream_stats) {
-    g_ss_batches.fetch_add(1, std::memory_order_relaxed);
-    g_ss_derived.fetch_add(s.derived_used, std::memory_order_relaxed);
-    g_ss_cols.fetch_add(s.nF, std::memory_order_relaxed);
+  if (!s.tile) return;
+  PropDesc* hd = s.h_desc();
+  for (int i = 0; i < n; ++i) {
+    hd[i].grp = loc[i].grp;
+    hd[i].qslot = s.grp_nF[loc[i].grp] + 1 + s.chain_slot[hd[i].ck] * c->K;   // slot of the chain's basis in the group's LDS map
   }
-  return BSR_OK;
 }
 
 static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
@@ -1394,14 +1418,116 @@ static void launch_row_pass(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, const
 
 // Everything a staged batch puts on the GPU: upload, row pass, the kernels behind it, the event the waiter blocks on.
 struct TailJob {
-  int slot, P, n_part, spill_slots, nq;
+  int slot, P, spill_slots, nq;
   LaunchGeom g;
-  bool scoring, tile;
+  bool scoring, maybe_tile;
+  bool restage;   // false: a rescoring run over descriptors of the batch already staged (groups and streams stand)
   double rank_floor;
-  size_t in_bytes;
-  TileGeom tg;
 };
 static void launcher_push(bsr_ctx* c, const TailJob& job);
+
+// Geometry, schedule and tape records of a tile launch (after stage_tile): runs with the batch's launches.
+static int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
+  TileGeom& tg = *tgp;
+  memset(&tg, 0, sizeof tg);
+  PropDesc* hd = s.h_desc();
+  const int n_part = c->tile_slices + c->tile_left;
+  if (s.order_n != P) cost_order(s.order_tmp, s.order_keys, P, [&](int i) { return hd[i].cost; });
+  {
+    // geometry of this launch: the context's slices, the chunk the batch's columns leave room for, and the schedule:
+    // inside its group a tape goes -- heaviest first -- to the wave with the least work so far that still has a free
+    // set of sums (waves w, w+4, w+8, w+12 share a SIMD, but a light wave frees issue slots for its SIMD mates, so
+    // per-wave balance is what is worth having)
+    tg.T = c->tile_T;
+    tg.n_slices = c->tile_slices;
+    tg.bps = c->tile_bps;
+    tg.n_blocks = c->tile_blocks;
+    tg.n_left = c->tile_left;
+    tg.n_part = n_part;
+    tg.ncols = s.tile_ncols;
+    tg.ncols_fixed = s.tile_chains * c->K;
+    tg.chunk_blocks = s.tile_chunk;
+    tg.ring = s.tile_ring;
+    tg.qmax = c->tile_qmax;
+    int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];
+    int most = 0;
+    for (int gi = 0; gi < tg.T; ++gi) most = std::max(most, cnt_g[gi]);
+    const int per_pass = BSR_TILE_WAVES * tg.qmax;
+    tg.n_pass = std::max(1, (most + per_pass - 1) / per_pass);
+    const int slots_per_wave = tg.n_pass * tg.qmax;
+    const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
+    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
+    TapeRec* sc = s.h_sched();
+    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps ? most : 0;   // whole slice: the waves pull from the group's list
+    s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
+    for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
+    int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)
+    const uint64_t* hcodes = s.h_streams();
+    const uint64_t* hfeats = hcodes + s.code_words;
+    const double* hln = reinterpret_cast<const double*>(hfeats + s.feat_words);
+    const uint64_t* hfeats_lds = reinterpret_cast<const uint64_t*>(hln + s.ln_words);
+    s.wave_load.assign((size_t)tg.T * BSR_TILE_WAVES, 0.0);
+    s.wave_cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
+    for (int i = 0; i < P; ++i) {
+      const int p = s.order_tmp[i];
+      const PropDesc& D = hd[p];
+      const int grp = D.grp;
+      if (grp < 0 || grp >= tg.T) return fail(c, BSR_E_STATE, "tile schedule: tape group out of range");
+      size_t ri;
+      if (tg.per_group > 0) {
+        // the waves pull their tapes: where in the group's share of the record array a record sits does not matter
+        ri = (size_t)grp * tg.n_pass * per_pass + (size_t)s.wave_cnt[grp * BSR_TILE_WAVES]++;
+      } else {
+        int best = -1;
+        for (int w = 0; w < BSR_TILE_WAVES; ++w) {
+          const int idx = grp * BSR_TILE_WAVES + w;
+          if (s.wave_cnt[idx] >= slots_per_wave) continue;
+          if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
+        }
+        if (best < 0) return fail(c, BSR_E_STATE, "tile schedule: no free set of sums");
+        const int idx = grp * BSR_TILE_WAVES + best;
+        const int slot = s.wave_cnt[idx]++;
+        const int pass = slot / tg.qmax, q = slot % tg.qmax;
+        ri = (((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q;
+        s.wave_load[idx] += (double)D.cost;
+      }
+      left_idx[i] = (int32_t)ri;
+      // the tape's record: what the wave needs to start it, and the heads of its streams (a long tape reads on from them)
+      TapeRec& R = sc[ri];
+      R.p = p;
+      R.n_nodes = D.n_nodes;
+      R.chain = D.chain;
+      R.qslot = D.qslot;
+      R.s = D.s;
+      R.code0 = hcodes[D.code_off];
+      R.code1 = hcodes[D.code_off + 1];
+      R.f0 = hfeats_lds[D.feat_off];
+      R.f1 = hfeats_lds[D.feat_off + 1];
+      const double* pl = hln + 2 * (size_t)D.ln_off;
+      for (int t = 0; t < 3; ++t) {   // (the stream holds n_ln pairs and a padding pair)
+        R.ln[2 * t] = (t <= D.n_ln) ? pl[2 * t] : 1.0;
+        R.ln[2 * t + 1] = (t <= D.n_ln) ? pl[2 * t + 1] : 0.0;
+      }
+      R.code_off = D.code_off;
+      R.feat_off = D.feat_off;
+      R.ln_off = D.ln_off;
+      R.n_ln = D.n_ln;
+      R.n_term = D.n_term;
+      R.grp = grp;
+    }
+    if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
+      int32_t* glist = left_idx + P;
+      for (size_t i = 0; i < (size_t)tg.T * tg.per_group; ++i) glist[i] = -1;
+      int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < P; ++i) {
+        const int grp = hd[s.order_tmp[i]].grp;
+        glist[(size_t)grp * tg.per_group + fill[grp]++] = left_idx[i];
+      }
+    }
+  }
+  return BSR_OK;
+}
 
 static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   const long long t_issue0 = host_now();
@@ -1413,6 +1539,30 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       rc = BSR_E_HIP;
     }
   };
+  // the tile pass's half of the staging (groups, LDS slot maps, schedule, tape records), here with the launches: off
+  // the caller's thread where the context has submission threads
+  bool tile = false;
+  TileGeom tg;
+  memset(&tg, 0, sizeof tg);
+  if (j.maybe_tile) {
+    if (j.restage) stage_tile(c, s, j.P);
+    if (s.tile) {
+      rc = build_tile_launch(c, s, j.P, &tg);
+      tile = rc == BSR_OK;
+    }
+  }
+  const int n_part = tile ? tg.n_part : j.g.n_rb;   // partial records per proposal that k_solve reduces
+  if (j.maybe_tile && !tile) {   // the work-queue pass after all: its order of the tapes
+    PropDesc* hd = s.h_desc();
+    cost_order(s.order_tmp, s.order_keys, j.P, [&](int i) { return hd[i].cost; });
+    for (int i = 0; i < j.P; ++i) hd[i].order = s.order_tmp[i];
+  }
+  const size_t in_bytes = tile ? s.off_recs + s.recs_bytes : s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
+  if (rc != BSR_OK) {   // nothing was launched: the waiter sees the error
+    s.tail_rc = rc;
+    s.tail_gen.store(s.tail_wanted, std::memory_order_release);
+    return rc;
+  }
   {
     // upload + row pass on the slot's stream
     hipStream_t s0 = s.stream;
@@ -1421,33 +1571,33 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       // 16 KB) instead of a copy command: one HIP call fewer per batch.  The slot's previous batch has been waited
       // for, so nothing on the device reads the block now; the stores are globally ordered before the doorbell write
       // of the launch below (fence, then posted writes in order), and every kernel start invalidates the caches
-      memcpy(s.d_in, s.h_in, j.in_bytes);
+      memcpy(s.d_in, s.h_in, in_bytes);
       __builtin_ia32_sfence();   // drain the write-combining buffers before anything that rings the doorbell
       std::atomic_thread_fence(std::memory_order_seq_cst);
     } else {
       // (also when bsr_commit or a rescore left work on the slot's stream that nobody waited for -- it reads or writes
       // the device block: the copy command is ordered behind it, host stores would not be)
-      step(hipMemcpyAsync(s.d_in, s.h_in, j.in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
+      step(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
     }
     s.stream_dirty = false;   // this batch's completion covers everything before it on the stream
     if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
-    if (j.tile) {
+    if (tile) {
       const uint64_t* codes = s.d_streams();
       const uint64_t* feats = codes + s.code_words;
       const double* lnp = reinterpret_cast<const double*>(feats + s.feat_words);
       const uint64_t* feats_lds = reinterpret_cast<const uint64_t*>(lnp + s.ln_words);
       auto fill = [&](auto& a) {
         using TT = typename std::remove_reference<decltype(a)>::type;
-        a.g = j.tg;
+        a.g = tg;
         a.colsrc = (decltype(TT::colsrc))s.d_cols();
         a.cols_stride = s.cols_stride;
         a.N = c->N; a.codes = codes; a.feats = feats_lds; a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched();
         a.part = s.part1; a.P = j.P; a.K = c->K; a.stamps = c->d_stamps;
         for (int i = 0; i < 8; ++i) a.grp_nF[i] = s.grp_nF[i];
-        a.cols_in_args = (j.tg.T <= BSR_TILE_ARG_GROUPS && j.tg.ncols <= BSR_TILE_ARG_COLS) ? 1 : 0;
+        a.cols_in_args = (tg.T <= BSR_TILE_ARG_GROUPS && tg.ncols <= BSR_TILE_ARG_COLS) ? 1 : 0;
         for (int gi = 0; gi < BSR_TILE_ARG_GROUPS; ++gi)
           for (int i = 0; i < BSR_TILE_ARG_COLS; ++i)
-            a.cols[gi][i] = (a.cols_in_args && gi < j.tg.T && i < j.tg.ncols)
+            a.cols[gi][i] = (a.cols_in_args && gi < tg.T && i < tg.ncols)
                                 ? (decltype(a.cols[0][0]))s.h_cols()[(size_t)gi * s.cols_stride + i] : nullptr;
       };
       if (c->dtype == BSR_DTYPE_F64) {
@@ -1465,7 +1615,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
   }
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
-  launch_solve(st, s.d_desc(), c->d_ck, j.P, j.n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
+  launch_solve(st, s.d_desc(), c->d_ck, j.P, n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
@@ -1620,127 +1770,34 @@ static void launcher_stop(bsr_ctx* c) {
 }
 
 // Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
-static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring) {
+static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage = true) {
   PropDesc* hd = s.h_desc();
   int spill_slots = 0;
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
   LaunchGeom g = geometry(c, s, P);
-  const bool tile = scoring && s.tile;
-  const int n_part = tile ? c->tile_slices + c->tile_left : g.n_rb;   // partial records per proposal that k_solve reduces
+  // whether the batch takes the tile pass is decided where its launches are issued (stage_tile): room for either
+  const bool maybe_tile = scoring && s.tile_possible;
   {
     LaunchGeom gp = g;
-    gp.n_rb = std::max(g.n_rb, n_part);
+    if (maybe_tile) gp.n_rb = std::max(g.n_rb, c->tile_slices + c->tile_left);   // partial records per proposal
     int rc0 = ensure_partials(c, s, gp, P, spill_slots);
     if (rc0 != BSR_OK) return rc0;
   }
   int rc = BSR_OK;
-  TileGeom tg;
-  memset(&tg, 0, sizeof tg);
-  // work-queue order: heaviest tapes first (stable, so equal costs keep batch order)
-  if (s.order_n != P || !scoring) cost_order(s.order_tmp, s.order_keys, P, [&](int i) { return hd[i].cost; });
-  s.order_n = -1;   // (a rescoring run reuses the slot with other descriptors)
-  for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
-  if (tile) {
-    // geometry of this launch: the context's slices, the chunk the batch's columns leave room for, and the schedule:
-    // inside its group a tape goes -- heaviest first -- to the wave with the least work so far that still has a free
-    // set of sums (waves w, w+4, w+8, w+12 share a SIMD, but a light wave frees issue slots for its SIMD mates, so
-    // per-wave balance is what is worth having)
-    tg.T = c->tile_T;
-    tg.n_slices = c->tile_slices;
-    tg.bps = c->tile_bps;
-    tg.n_blocks = c->tile_blocks;
-    tg.n_left = c->tile_left;
-    tg.n_part = n_part;
-    tg.ncols = s.tile_ncols;
-    tg.ncols_fixed = s.tile_chains * c->K;
-    tg.chunk_blocks = s.tile_chunk;
-    tg.ring = s.tile_ring;
-    tg.qmax = c->tile_qmax;
-    int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];
-    int most = 0;
-    for (int gi = 0; gi < tg.T; ++gi) most = std::max(most, cnt_g[gi]);
-    const int per_pass = BSR_TILE_WAVES * tg.qmax;
-    tg.n_pass = std::max(1, (most + per_pass - 1) / per_pass);
-    const int slots_per_wave = tg.n_pass * tg.qmax;
-    const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
-    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
-    TapeRec* sc = s.h_sched();
-    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps ? most : 0;   // whole slice: the waves pull from the group's list
-    s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
-    for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
-    int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)
-    const uint64_t* hcodes = s.h_streams();
-    const uint64_t* hfeats = hcodes + s.code_words;
-    const double* hln = reinterpret_cast<const double*>(hfeats + s.feat_words);
-    const uint64_t* hfeats_lds = reinterpret_cast<const uint64_t*>(hln + s.ln_words);
-    s.wave_load.assign((size_t)tg.T * BSR_TILE_WAVES, 0.0);
-    s.wave_cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
-    for (int i = 0; i < P; ++i) {
-      const int p = s.order_tmp[i];
-      const PropDesc& D = hd[p];
-      const int grp = D.grp;
-      if (grp < 0 || grp >= tg.T) return fail(c, BSR_E_STATE, "tile schedule: tape group out of range");
-      size_t ri;
-      if (tg.per_group > 0) {
-        // the waves pull their tapes: where in the group's share of the record array a record sits does not matter
-        ri = (size_t)grp * tg.n_pass * per_pass + (size_t)s.wave_cnt[grp * BSR_TILE_WAVES]++;
-      } else {
-        int best = -1;
-        for (int w = 0; w < BSR_TILE_WAVES; ++w) {
-          const int idx = grp * BSR_TILE_WAVES + w;
-          if (s.wave_cnt[idx] >= slots_per_wave) continue;
-          if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
-        }
-        if (best < 0) return fail(c, BSR_E_STATE, "tile schedule: no free set of sums");
-        const int idx = grp * BSR_TILE_WAVES + best;
-        const int slot = s.wave_cnt[idx]++;
-        const int pass = slot / tg.qmax, q = slot % tg.qmax;
-        ri = (((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q;
-        s.wave_load[idx] += (double)D.cost;
-      }
-      left_idx[i] = (int32_t)ri;
-      // the tape's record: what the wave needs to start it, and the heads of its streams (a long tape reads on from them)
-      TapeRec& R = sc[ri];
-      R.p = p;
-      R.n_nodes = D.n_nodes;
-      R.chain = D.chain;
-      R.qslot = D.qslot;
-      R.s = D.s;
-      R.code0 = hcodes[D.code_off];
-      R.code1 = hcodes[D.code_off + 1];
-      R.f0 = hfeats_lds[D.feat_off];
-      R.f1 = hfeats_lds[D.feat_off + 1];
-      const double* pl = hln + 2 * (size_t)D.ln_off;
-      for (int t = 0; t < 3; ++t) {   // (the stream holds n_ln pairs and a padding pair)
-        R.ln[2 * t] = (t <= D.n_ln) ? pl[2 * t] : 1.0;
-        R.ln[2 * t + 1] = (t <= D.n_ln) ? pl[2 * t + 1] : 0.0;
-      }
-      R.code_off = D.code_off;
-      R.feat_off = D.feat_off;
-      R.ln_off = D.ln_off;
-      R.n_ln = D.n_ln;
-      R.n_term = D.n_term;
-      R.grp = grp;
-    }
-    if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
-      int32_t* glist = left_idx + P;
-      for (size_t i = 0; i < (size_t)tg.T * tg.per_group; ++i) glist[i] = -1;
-      int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < P; ++i) {
-        const int grp = hd[s.order_tmp[i]].grp;
-        glist[(size_t)grp * tg.per_group + fill[grp]++] = left_idx[i];
-      }
-    }
+  // work-queue order: heaviest tapes first (stable, so equal costs keep batch order); a batch that may take the tile
+  // pass gets its order where that is decided (issue_batch)
+  s.order_n = -1;
+  if (!maybe_tile) {
+    cost_order(s.order_tmp, s.order_keys, P, [&](int i) { return hd[i].cost; });
+    for (int i = 0; i < P; ++i) hd[i].order = s.order_tmp[i];
   }
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
   s.timed = c->prof;  // the level in force when the batch was enqueued decides which events exist at wait time
   TailJob job;
   job.slot = (int)(&s - c->slot);
-  job.P = P; job.n_part = n_part; job.g = g; job.spill_slots = spill_slots; job.nq = nq; job.scoring = scoring;
-  job.in_bytes = tile ? s.off_recs + s.recs_bytes : s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
-  job.tile = tile;
-  job.tg = tg;
+  job.P = P; job.g = g; job.spill_slots = spill_slots; job.nq = nq; job.scoring = scoring;
+  job.maybe_tile = maybe_tile;
+  job.restage = restage;
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
   job.rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
   s.flag_par ^= 1;   // this batch's list of flagged proposals; its k_solve empties the other one
@@ -2112,7 +2169,7 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
     D->ck = chain[i];
     D->qbase = col_ptr(c, c->Q, (int64_t)chain[i] * K);
     D->zout = nullptr;
-    D->qslot = s.grp_nF[loc[i].grp] + 1 + s.chain_slot[chain[i]] * K;   // slot of the chain's basis in the tape group's LDS map
+    D->qslot = 0;   // (tile pass: set with the tape's group by stage_tile)
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
     // the candidate is the tree it would replace, again (same canonical form): tell k_solve its column is in the span
@@ -2244,7 +2301,7 @@ extern "C" int bsr_score_wait(bsr_ctx* c, int32_t ticket, bsr_score* out) {
         D.s = std::ldexp(1.0, -e);
         s.h_desc()[j] = D;
       }
-      rc = enqueue(c, s, (int)redo.size(), true);   // (a descriptor keeps its tape group: the group's LDS slot map numbers its columns)
+      rc = enqueue(c, s, (int)redo.size(), true, false);   // (a descriptor keeps its tape group: the group's LDS slot map numbers its columns)
       if (rc == BSR_OK) rc = wait_slot(c, s);
       if (rc != BSR_OK) return rc;
       for (size_t j = 0; j < redo.size(); ++j) {
