@@ -171,6 +171,7 @@ struct bsr_ctx {
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
   std::vector<uint64_t> cur_hash;              // [chain*K+k] canonical hash of the current tree (0: unknown)
+  std::vector<int> cur_nonneg;                 // ... its nodes other than negations
   std::vector<std::vector<bsr_node>> cur_tape;  // ... and its tape, to confirm a hash match
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
@@ -280,6 +281,13 @@ extern "C" int bsr_device_count(int* count) {
 
 extern "C" const char* bsr_last_error(const bsr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// BSR_POISON=1 (debugging): device buffers that are handed out without a fill are filled with 0xFF bytes (NaN doubles,
+// -1 integers) -- a kernel that reads what nobody wrote shows at once instead of depending on what the allocator
+// happened to return.
+static void poison(void* p, size_t bytes) {
+  static const bool on = getenv("BSR_POISON") && atoi(getenv("BSR_POISON")) != 0;
+  if (on && p && bytes) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
+}
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -519,6 +527,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // less padding at the slice ends), but every group stages the slice's columns again: only while the data set is
     // L2-sized.  Everything here depends on the context alone.
     c->tile_on = env_int("BSR_TILE", 1);
+
     c->selfdup = env_int("BSR_SELFDUP", 1);
     c->reorder = env_int("BSR_REORDER", 1);
     c->chain_eval = env_int("BSR_CHAIN_EVAL", 1);
@@ -548,7 +557,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
     const size_t budget = tile_lds_bytes_max() - 1024;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      c->tile_cus = c->n_cu - c->aux_cus;
+      c->tile_cus = env_int("BSR_TILE_WGS", c->n_cu - c->aux_cus);
       auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
       auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
       // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):
@@ -592,7 +601,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
     }
     if (env_int("BSR_TILE_STAMPS", 0)) {
-      const size_t nb = (size_t)c->n_cu * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
+      const size_t nb = (size_t)std::max(c->n_cu, c->tile_cus) * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
       if (hipMalloc((void**)&c->d_stamps, nb) == hipSuccess) (void)hipMemset(c->d_stamps, 0, nb);
       else c->d_stamps = nullptr;
     }
@@ -609,29 +618,39 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     CK(hipMalloc(&c->Q, colb * n_chains * K));
     CK(hipMemsetAsync(c->Q, 0, colb * n_chains * K, c->stream));
     CK(hipMalloc((void**)&c->d_ck, sizeof(ChainB) * n_chains));
+  poison(c->d_ck, sizeof(ChainB) * n_chains);
     CK(hipMemsetAsync(c->d_ck, 0, sizeof(ChainB) * n_chains, c->stream));
     c->h_ck.resize((size_t)n_chains);
     c->ready.assign(n_chains, 0);
     c->col_set.assign((size_t)n_chains * K, 0);
     c->cur_hash.assign((size_t)n_chains * K, 0);
+    c->cur_nonneg.assign((size_t)n_chains * K, 0);
     c->cur_tape.assign((size_t)n_chains * K, std::vector<bsr_node>());
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
+  poison(c->d_fit, sizeof(ChainFitOut) * (n_chains + 1));
   c->h_fit.resize(n_chains + 1);
   CK(hipMalloc((void**)&c->d_fit_icpt, sizeof(ChainFitOut) * (n_chains + 1)));
+  poison(c->d_fit_icpt, sizeof(ChainFitOut) * (n_chains + 1));
   c->h_fit_icpt.resize(n_chains + 1);
   CK(hipMalloc((void**)&c->d_rin, sizeof(RefreshIn) * (n_chains + 1)));
+  poison(c->d_rin, sizeof(RefreshIn) * (n_chains + 1));
   c->h_rin.resize(n_chains + 1);
   CK(hipMalloc((void**)&c->d_plan, sizeof(RefreshPlan)));
+  poison(c->d_plan, sizeof(RefreshPlan));
   CK(hipHostMalloc((void**)&c->h_plan, sizeof(RefreshPlan)));
   CK(hipMalloc((void**)&c->d_rpart, refresh_part_doubles(N) * sizeof(double)));
+  poison(c->d_rpart, refresh_part_doubles(N) * sizeof(double));
   c->fast_refresh = env_int("BSR_FAST_REFRESH", 1);
   for (BatchSlot& s : c->slot) {
     CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     CK(hipMalloc((void**)&s.d_coef, sizeof(PropCoef) * (max_batch + 1)));
+    poison(s.d_coef, sizeof(PropCoef) * (max_batch + 1));
     s.flag_stride = (size_t)max_batch + 2;
     CK(hipMalloc((void**)&s.d_flagged, sizeof(int32_t) * (2 * (max_batch + 2) + 16)));   // two lists, alternating by batch; then k_finalize's arrival counter
     CK(hipMemset(s.d_flagged, 0, sizeof(int32_t) * (2 * (max_batch + 2) + 16)));
+    CK(hipMalloc((void**)&s.d_mh, sizeof(MhRes) * (max_batch + 1)));
+    poison(s.d_mh, sizeof(MhRes) * (max_batch + 1));
     CK(hipMalloc((void**)&s.queue, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     CK(hipMemset(s.queue, 0, (size_t)BSR_QUEUE_SETS * BSR_QUEUE_SET_INTS * sizeof(int32_t)));
     s.off_cols = ((size_t)c->n_cols * sizeof(int32_t) + 255) / 256 * 256;
@@ -640,7 +659,6 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     s.mh_cap = (size_t)max_batch;
     s.off_mh = s.off_sched;   // (the tile schedule lives behind the batch's streams: only what a batch uses is uploaded)
     s.off_desc = s.off_mh + (s.mh_cap * 8 * sizeof(double) + (2 * s.mh_cap + 2) * sizeof(int32_t) + 255) / 256 * 256;
-    CK(hipMalloc((void**)&s.d_mh, sizeof(MhRes) * (max_batch + 1)));
     CK(hipHostMalloc((void**)&s.h_ev, sizeof(bsr_event) * (max_batch + 1)));
     s.off_streams = s.off_desc + sizeof(PropDesc) * (max_batch + 1);
     s.chain_slot.assign(std::max(1, n_chains), -1);
@@ -672,8 +690,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Canonical form of the column a tape computes: children of + and * in a fixed order, negations at the root dropped
-// (the column then differs by sign only).  Two tapes with the same form compute bit-identical columns up to that sign.
+// Canonical form of the column a tape computes, up to sign: (sign, form) per subtree, such that the subtree's column is
+// sign x the form's column BIT FOR BIT on the device's arithmetic.  Negations travel to the root:
+//   neg A -> (-s, A);  A * B, A / B -> (sA sB, .);  1/A, A^3, sin A -> (sA, .);  A^2, cos A -> (+, .)
+//   a A + b (ln) -> (+, ln(sA a, b, A));  exp, log keep the operand's sign inside the form;
+//   A + B, A - B -> children ordered by form, the first one's sign in front, the other's relative sign in the form
+// (IEEE negation commutes with every rounded operation above; sin is odd and cos even in bsr_fastmath.h: the argument
+// reduction rounds symmetrically and the tables hold sin, cos of symmetric nodes).  Children of + and * in a fixed
+// order.  Two tapes with the same form compute the same column up to sign: a candidate with the form of the tree it
+// replaces lies in the span of the current columns exactly.  At K = 3 such candidates are 5.7 % of the real move mix --
+// 4.6 % the same tree again, 1.1 % the same tree with a negation moved (cos(-x), (-a) b, (-x)^3 y): before negations
+// travelled, those went through the residual step, one in almost every second batch.
 // Hash first (one pass over the postfix tape, a stack of hashes); the exact form, a string, only to confirm a match.
 static inline uint64_t mix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -683,69 +710,118 @@ static inline uint64_t mix64(uint64_t x) {
 }
 static inline bool is_commutative_op(int op) { return op == BSR_OP_ADD || op == BSR_OP_MUL; }
 static inline bool is_binary_op(int op);
+// what a unary operator does with its operand's sign: +1 passes it on (odd function), 0 drops it (even function),
+// -1 flips it (neg), 2: the sign stays inside the form
+static inline int unary_sign_rule(int op) {
+  switch (op) {
+    case BSR_OP_NEG: return -1;
+    case BSR_OP_INV: case BSR_OP_CUBIC: case BSR_OP_SIN: return 1;
+    case BSR_OP_SQUARE: case BSR_OP_COS: return 0;
+    default: return 2;   // ln (handled apart), exp, log
+  }
+}
 static uint64_t canon_hash(const bsr_node* t, int len) {
-  uint64_t h[BSR_MAX_STACK + 2], strip[BSR_MAX_STACK + 2];   // strip: the hash with leading negations removed
+  uint64_t h[BSR_MAX_STACK + 2];
+  int sg[BSR_MAX_STACK + 2];
   int sp = 0;
   for (int i = 0; i < len; ++i) {
     const int op = t[i].opcode;
     if (op == BSR_OP_TERMINAL) {
       if (sp > BSR_MAX_STACK) return 0;
-      h[sp] = strip[sp] = mix64(0x7465726Dull ^ ((uint64_t)(uint32_t)t[i].feature << 32));
+      h[sp] = mix64(0x7465726Dull ^ ((uint64_t)(uint32_t)t[i].feature << 32));
+      sg[sp] = 1;
       ++sp;
     } else if (is_binary_op(op)) {
       if (sp < 2) return 0;
       uint64_t l = h[sp - 2], r = h[sp - 1];
-      if (is_commutative_op(op) && l > r) std::swap(l, r);
+      int sl = sg[sp - 2], sr = sg[sp - 1];
       --sp;
-      h[sp - 1] = strip[sp - 1] = mix64(mix64(l ^ ((uint64_t)op << 56)) + 3 * r);
+      if (op == BSR_OP_MUL || op == BSR_OP_DIV) {
+        if (op == BSR_OP_MUL && l > r) std::swap(l, r);
+        h[sp - 1] = mix64(mix64(l ^ ((uint64_t)op << 56)) + 3 * r);
+        sg[sp - 1] = sl * sr;
+      } else {   // + and -: a - b is a + (-b)
+        if (op == BSR_OP_SUB) sr = -sr;
+        if (l > r) { std::swap(l, r); std::swap(sl, sr); }
+        const int rel = sl * sr;
+        h[sp - 1] = mix64(mix64(l ^ ((uint64_t)BSR_OP_ADD << 56)) + 3 * r + (rel < 0 ? 0x5A5Aull : 0));
+        sg[sp - 1] = sl;
+      }
     } else {
       if (sp < 1) return 0;
-      uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
       if (op == BSR_OP_LN) {
+        double av = t[i].a * sg[sp - 1];
         uint64_t a, b;
-        memcpy(&a, &t[i].a, 8);
+        memcpy(&a, &av, 8);
         memcpy(&b, &t[i].b, 8);
-        x = mix64(x ^ mix64(a) ^ (mix64(b) << 1));
+        uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
+        h[sp - 1] = mix64(x ^ mix64(a) ^ (mix64(b) << 1));
+        sg[sp - 1] = 1;
+        continue;
       }
-      strip[sp - 1] = (op == BSR_OP_NEG) ? strip[sp - 1] : x;
+      const int rule = unary_sign_rule(op);
+      if (rule == -1) { sg[sp - 1] = -sg[sp - 1]; continue; }
+      uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
+      if (rule == 2) { x = mix64(x + (sg[sp - 1] < 0 ? 0xA5A5ull : 0)); sg[sp - 1] = 1; }
+      else if (rule == 0) sg[sp - 1] = 1;
       h[sp - 1] = x;
     }
   }
-  return sp == 1 ? (strip[0] | 1ull) : 0;   // never 0: 0 means "no form"
+  return sp == 1 ? (h[0] | 1ull) : 0;   // never 0: 0 means "no form"
+}
+static inline int count_nonneg(const bsr_node* t, int len) {
+  int n = 0;
+  for (int q = 0; q < len; ++q) n += t[q].opcode != BSR_OP_NEG;
+  return n;
 }
 static std::string canon_form(const bsr_node* t, int len) {
-  std::vector<std::string> st, strip;
-  char buf[64];
+  std::vector<std::string> st;
+  std::vector<int> sg;
+  char buf[96];
   for (int i = 0; i < len; ++i) {
     const int op = t[i].opcode;
     if (op == BSR_OP_TERMINAL) {
       snprintf(buf, sizeof buf, "x%d", t[i].feature);
       st.push_back(buf);
-      strip.push_back(buf);
+      sg.push_back(1);
     } else if (is_binary_op(op)) {
       if (st.size() < 2) return std::string();
-      std::string r = st.back(); st.pop_back(); strip.pop_back();
-      std::string l = st.back(); st.pop_back(); strip.pop_back();
-      if (is_commutative_op(op) && r < l) std::swap(l, r);
-      snprintf(buf, sizeof buf, "(%d ", op);
-      st.push_back(buf + l + " " + r + ")");
-      strip.push_back(st.back());
+      std::string r = st.back(); st.pop_back();
+      std::string l = st.back(); st.pop_back();
+      int sr = sg.back(); sg.pop_back();
+      int sl = sg.back(); sg.pop_back();
+      if (op == BSR_OP_MUL || op == BSR_OP_DIV) {
+        if (op == BSR_OP_MUL && r < l) std::swap(l, r);
+        snprintf(buf, sizeof buf, "(%d ", op);
+        st.push_back(buf + l + " " + r + ")");
+        sg.push_back(sl * sr);
+      } else {
+        if (op == BSR_OP_SUB) sr = -sr;
+        if (r < l) { std::swap(l, r); std::swap(sl, sr); }
+        snprintf(buf, sizeof buf, "(%d ", (int)BSR_OP_ADD);
+        st.push_back(buf + l + (sl * sr < 0 ? " - " : " + ") + r + ")");
+        sg.push_back(sl);
+      }
     } else {
       if (st.empty()) return std::string();
       if (op == BSR_OP_LN) {
+        const double av = t[i].a * sg.back();
         uint64_t a, b;
-        memcpy(&a, &t[i].a, 8);
+        memcpy(&a, &av, 8);
         memcpy(&b, &t[i].b, 8);
         snprintf(buf, sizeof buf, "[%d %016llx %016llx ", op, (unsigned long long)a, (unsigned long long)b);
-      } else {
-        snprintf(buf, sizeof buf, "[%d ", op);
+        st.back() = buf + st.back() + "]";
+        sg.back() = 1;
+        continue;
       }
-      const std::string x = buf + st.back() + "]";
-      if (op != BSR_OP_NEG) strip.back() = x;
-      st.back() = x;
+      const int rule = unary_sign_rule(op);
+      if (rule == -1) { sg.back() = -sg.back(); continue; }
+      snprintf(buf, sizeof buf, "[%d%s ", op, (rule == 2 && sg.back() < 0) ? "-" : "");
+      st.back() = buf + st.back() + "]";
+      if (rule != 1) sg.back() = 1;
     }
   }
-  return st.size() == 1 ? strip[0] : std::string();
+  return st.size() == 1 ? st[0] : std::string();
 }
 
 static inline bool is_binary_op(int op) {
@@ -786,6 +862,7 @@ static int ensure_input(bsr_ctx* c, BatchSlot& s, size_t stream_words) {
   s.d_in = nullptr;
   s.h_in = nullptr;
   HIPCHK(c, hipMalloc((void**)&s.d_in, cap));
+  poison(s.d_in, cap);
   HIPCHK(c, hipHostMalloc((void**)&s.h_in, cap));
   s.in_cap = cap;
   return BSR_OK;
@@ -817,6 +894,7 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
     s.part1 = s.part2 = nullptr;
     const size_t cap = recs + recs / 2;
     HIPCHK(c, hipMalloc((void**)&s.part1, cap * BSR_P1_WORDS * sizeof(double)));
+    poison(s.part1, cap * BSR_P1_WORDS * sizeof(double));
     // K <= 3: the finalise step rides behind the residual pass in the same launch (its last workgroup to arrive runs
     // it).  The residual sums and the arrival counter then live in UNCACHED device memory: a store is visible once it
     // is acknowledged and a load never sees a cache, so the hand-over needs no cache write-back or invalidate under
@@ -830,7 +908,9 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
       (void)hipGetLastError();
       HIPCHK(c, hipMalloc((void**)&s.part2, cap * BSR_P2_WORDS * sizeof(double) + 64));
     }
-    HIPCHK(c, hipMemset(s.part2, 0, cap * BSR_P2_WORDS * sizeof(double) + 64));
+    // on the slot's stream: the slot streams do not wait for the null stream (hipStreamNonBlocking), and a fill that
+    // is still running when the batch's residual pass writes its records would wipe them
+    HIPCHK(c, hipMemsetAsync(s.part2, 0, cap * BSR_P2_WORDS * sizeof(double) + 64, s.stream));
     s.part_cap = cap;
   }
   if (spill_slots > 0) {
@@ -841,6 +921,7 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
       if (s.spill) HIPCHK(c, hipFree(s.spill));
       s.spill = nullptr;
       HIPCHK(c, hipMalloc(&s.spill, need));
+      poison(s.spill, need);
       s.spill_cap = need;
     }
   }
@@ -1243,7 +1324,10 @@ static void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       const int i = s.order_tmp[oi];
       int g = 0;
       if (T > 1 && c->tile_whole) {
-        g = oi % T;   // the slice sits in LDS whole: columns are cheap, balance the cost (LPT inside the group follows)
+        // the slice sits in LDS whole: columns are cheap, balance the cost -- dealt back and forth (0 1 1 0 ...), so that
+        // no group gets the heavier tape of every round (LPT inside the group follows)
+        const int r = oi / T, k = oi - r * T;
+        g = (r & 1) ? T - 1 - k : k;
       } else if (T > 1) {
         // chunked: every column of a group costs LDS (shorter chunks) and HBM traffic (the group streams it over all
         // rows), and the launch ends with its heaviest group: among the groups this tape does not lift above an even
@@ -1620,7 +1704,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
   // registers for the solver (K <= 3) and the hand-over memory is uncached (ensure_partials): one launch fewer
-  const bool fuse_fin = j.scoring && s.part2_uncached;
+  const bool fuse_fin = j.scoring && s.part2_uncached && residual_can_fuse_finalize(c->K) && c->no_lds;
   if (j.scoring) {
     FinArgs fin;
     memset(&fin, 0, sizeof fin);
@@ -1982,6 +2066,7 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
   c->cur_hash[(size_t)chain * c->K + k] = canon_hash(tape, len);
+  c->cur_nonneg[(size_t)chain * c->K + k] = count_nonneg(tape, len);
   c->cur_tape[(size_t)chain * c->K + k].assign(tape, tape + len);
   return BSR_OK;
 }
@@ -2041,6 +2126,7 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
       const bsr_node* t = s.rows_copy.data() + s.off_copy[idx];
       const int len = s.off_copy[idx + 1] - s.off_copy[idx];
       c->cur_hash[ck] = canon_hash(t, len);
+      c->cur_nonneg[ck] = count_nonneg(t, len);
       c->cur_tape[ck].assign(t, t + len);
     } else {
       c->cur_hash[ck] = 0;   // unknown: no shortcut for proposals on this tree
@@ -2178,14 +2264,13 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
       const bsr_node* t = rows + tape_off[i];
       const int len = tape_off[i + 1] - tape_off[i];
       const uint64_t h = c->cur_hash[ck];
-      // (the canonical form drops negations at the root and reorders operands: equal forms have equal node counts
-      // below the root's negations -- a cheap filter in front of the hash)
+      // (the canonical form drops negations and turns a - b into a + (-b): equal forms have equal node counts apart from
+      // the negations -- a cheap filter in front of the hash)
       const std::vector<bsr_node>& cur = c->cur_tape[ck];
-      int lc = (int)cur.size(), lt = len;
-      while (lc > 0 && cur[lc - 1].opcode == BSR_OP_NEG) --lc;
-      while (lt > 0 && t[lt - 1].opcode == BSR_OP_NEG) --lt;
+      const int lc = c->cur_nonneg[ck];
+      const int lt = count_nonneg(t, len);
       if (h != 0 && lc == lt && h == canon_hash(t, len) &&
-          canon_form(t, len) == canon_form(c->cur_tape[ck].data(), (int)c->cur_tape[ck].size()))
+          canon_form(t, len) == canon_form(cur.data(), (int)cur.size()))
         D->self_dup = 1;
     }
   }

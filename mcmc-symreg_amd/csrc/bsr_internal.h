@@ -122,7 +122,9 @@ struct RefreshPlan {  // per chain, device scratch handed from one refresh kerne
 
 // ---- tile-stationary row pass (bsr_tile.hip).  Fixed per context (so that a proposal's partial sums do not depend on
 // the batch it is scored in): rows per lane and block, the number of row slices and their block ranges.
+#ifndef BSR_TILE_WAVES
 #define BSR_TILE_WAVES 16                 // waves per workgroup (one workgroup per CU)
+#endif
 #define BSR_TILE_U 2                      // rows per lane and block: a block is 64 * U = 128 rows
 #define BSR_TILE_BLOCK (BSR_WAVE * BSR_TILE_U)
 #define BSR_TILE_NB 4                     // blocks per pass of a chain tape (2 NB values per lane in registers)

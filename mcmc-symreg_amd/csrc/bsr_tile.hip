@@ -326,44 +326,47 @@ __device__ __forceinline__ const T* const CONSTANT_AS* group_cols(const TileArgs
 // 896 units over 3 072 waves instead of a fifth block for some workgroups.  Their rows are in no workgroup's LDS:
 // columns are read through the launch's column-pointer table.
 template <typename T, int KQ>
-__device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileGeom& g, int lane, int wave) {
+__device__ __forceinline__ void leftover_unit(const TileArgs<T>& a, const TileGeom& g, int lane, int tk) {
   constexpr int U = BSR_TILE_U;
   constexpr int S = BSR_REG_STACK;
   using V2 = typename VecOf<T, 2>::type;
   // the tapes in cost order: index of the tape's record in the schedule (the index list sits behind the records)
   const int32_t CONSTANT_AS* left_idx = as_const(reinterpret_cast<const int32_t*>(a.sched + (size_t)g.T * g.n_pass * BSR_TILE_WAVES * g.qmax));
-  const int n_units = a.P * g.n_left, n_waves = (int)gridDim.x * BSR_TILE_WAVES;
-  for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units; tk += n_waves) {
-    const int ti = tk / g.n_left, bi = tk - ti * g.n_left;
-    const TapeRec CONSTANT_AS* rec = as_const(a.sched + left_idx[ti]);   // the ti-th most expensive tape
-    const int p = rec->p;
-    const int blk = g.n_slices * g.bps + bi;
-    const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
-    const uint64_t* pc = a.codes + rec->code_off;
-    const uint64_t* pf = a.feats + rec->feat_off;
-    const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
-    const int qslot = rec->qslot, grp = rec->grp;
-    const T* const CONSTANT_AS* colsrc = group_cols<T>(a, grp);   // the tape's group
-    const V2 yv = *reinterpret_cast<const V2*>(colsrc[a.grp_nF[grp & 7]] + row0);
-    V2 qv[KQ > 0 ? KQ : 1];
+  const int ti = tk / g.n_left, bi = tk - ti * g.n_left;
+  const TapeRec CONSTANT_AS* rec = as_const(a.sched + left_idx[ti]);   // the ti-th most expensive tape
+  const int p = rec->p;
+  const int blk = g.n_slices * g.bps + bi;
+  const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
+  const uint64_t* pc = a.codes + rec->code_off;
+  const uint64_t* pf = a.feats + rec->feat_off;
+  const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
+  const int qslot = rec->qslot, grp = rec->grp;
+  const T* const CONSTANT_AS* colsrc = group_cols<T>(a, grp);   // the tape's group
+  const V2 yv = *reinterpret_cast<const V2*>(colsrc[a.grp_nF[grp & 7]] + row0);
+  V2 qv[KQ > 0 ? KQ : 1];
 #pragma unroll
-    for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(colsrc[qslot + i] + row0);
-    TapeHead hd;
-    hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
-    hd.la = rec->ln[0]; hd.lb = rec->ln[1];
-    hd.ln_near = (const double*)rec->ln;
-    hd.n_ln = rec->n_ln;
-    hd.n_term = rec->n_term;
-    const double s = rec->s;
-    T z[U];
-    PtrCols<T, U> ldr{colsrc, row0};
-    run_tape_head<T, U, S, PtrCols<T, U>, false>(hd, pc, pf, pl, rec->n_nodes, ldr, z, (T*)nullptr, lane);
-    TapeAcc<KQ> A;
-    A.clear();
-    if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, s, row0, a.N);
-    else accumulate_v<T, KQ, true>(A, z, yv, qv, s, row0, a.N);
-    store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
-  }
+  for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(colsrc[qslot + i] + row0);
+  TapeHead hd;
+  hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+  hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+  hd.ln_near = (const double*)rec->ln;
+  hd.n_ln = rec->n_ln;
+  hd.n_term = rec->n_term;
+  const double s = rec->s;
+  T z[U];
+  PtrCols<T, U> ldr{colsrc, row0};
+  run_tape_head<T, U, S, PtrCols<T, U>, false>(hd, pc, pf, pl, rec->n_nodes, ldr, z, (T*)nullptr, lane);
+  TapeAcc<KQ> A;
+  A.clear();
+  if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<T, KQ, false>(A, z, yv, qv, s, row0, a.N);
+  else accumulate_v<T, KQ, true>(A, z, yv, qv, s, row0, a.N);
+  store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
+}
+// static deal (k_tile): unit u goes to wave u mod (workgroups x 16)
+template <typename T, int KQ>
+__device__ __forceinline__ void leftover_units(const TileArgs<T>& a, const TileGeom& g, int lane, int wave) {
+  const int n_units = a.P * g.n_left, n_waves = (int)gridDim.x * BSR_TILE_WAVES;
+  for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units; tk += n_waves) leftover_unit<T, KQ>(a, g, lane, tk);
 }
 
 // The row pass.  Workgroup = (row slice, tape group); wave w of group g runs the up to QMAX tapes the host's schedule
@@ -659,6 +662,12 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     // the next unit is requested now; its round trip hides under this one
     int nxt = 0;
     if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // The list is in cost order: a heavy tape on an even share of its SIMD's issue slots (four waves) would end long
+    // after the list has drained; the first tapes of the list run at raised priority instead.
+    if (idx < 4) __builtin_amdgcn_s_setprio(3);
+    else if (idx < 8) __builtin_amdgcn_s_setprio(2);
+    else if (idx < BSR_TILE_WAVES) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     const TapeRec CONSTANT_AS* rec = as_const(a.sched + ri);
     const int p = rec->p;
     const uint64_t* pc = a.codes + rec->code_off;
@@ -743,7 +752,20 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     idx = __builtin_amdgcn_readfirstlane(nxt);
   }
   TSTAMP(3);
-  if (g.n_left > 0) leftover_units<T, KQ>(a, g, lane, wave);
+  // the workgroup's share of the leftover units (unit u of the launch: workgroup u mod gridDim) through the same
+  // counter: the waves that run out of tapes first take them, heaviest tape first
+  if (g.n_left > 0) {
+    __builtin_amdgcn_s_setprio(0);
+    const int n_units = a.P * g.n_left;
+    for (;;) {
+      const int tk = (idx - n_items) * (int)gridDim.x + (int)blockIdx.x;
+      if (tk >= n_units) break;
+      int nx = 0;
+      if (lane == 0) nx = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      leftover_unit<T, KQ>(a, g, lane, tk);
+      idx = __builtin_amdgcn_readfirstlane(nx);
+    }
+  }
   TSTAMP(4);
   if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
 #undef TSTAMP

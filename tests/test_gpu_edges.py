@@ -402,6 +402,70 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
     assert run({"BSR_TILE": "0", "BSR_DERIVED": "0"}).tobytes() == rows.tobytes()
 
 
+@pytest.mark.parametrize("dtype", ["f64"])
+def test_a_repeat_with_a_negation_moved_scores_like_the_repeat_it_is(dtype, monkeypatch):
+    """Candidates that are the tree they would replace with a negation moved -- cos(-x), (-a) b, (-x)^3, 1/(-x),
+    sin(-x), a - b written -b + a, a (-A) + b as (-a) A + b -- compute the old column up to sign, bit for bit: the host
+    recognises them (canonical form with the signs carried to the root, bsr_api.hip) and k_solve takes w = 0 without the
+    residual step.  With the recognition off (BSR_SELFDUP=0) they go through the residual step: the same bytes."""
+    from bsr.tape import flatten
+    rs = np.random.RandomState(5)
+    N, d, K = 30000, 5, 3
+    X = rs.uniform(-2, 2, size=(N, d))
+    y = np.sin(X[:, 0]) * X[:, 1] + X[:, 2] - 0.5 * X[:, 3] + 0.05 * rs.standard_normal(N)
+    L = _leaf
+    cur = [
+        _bi("*", _un("cubic", _un("inv", _un("sin", L(0)))), _un("cos", L(1))),
+        _bi("+", _un("ln", _un("square", L(2)), 0.7, -0.2), _un("neg", L(3))),
+        _un("exp", _bi("*", L(4), L(0))),
+    ]
+    cands = [
+        # tree 0: every odd function passes the sign on, cos and the product swallow it
+        (0, _bi("*", _un("cubic", _un("inv", _un("sin", _un("neg", L(0))))), _un("cos", _un("neg", L(1))))),
+        (0, _bi("*", _un("cos", L(1)), _un("neg", _un("cubic", _un("inv", _un("sin", _un("neg", L(0)))))))),
+        (0, _un("neg", _bi("*", _un("cubic", _un("neg", _un("inv", _un("sin", L(0))))), _un("cos", L(1))))),
+        # tree 1: a sum with the signs of both children flipped, operands swapped; ln of a negated operand
+        (1, _un("neg", _bi("+", L(3), _un("neg", _un("ln", _un("square", _un("neg", L(2))), 0.7, -0.2))))),
+        (1, _bi("+", _un("neg", L(3)), _un("ln", _un("neg", _un("square", L(2))), -0.7, -0.2))),
+        # tree 2: exp keeps the sign of its operand inside: (-x4)(-x0) is x4 x0, (-x4) x0 is not
+        (2, _un("exp", _bi("*", _un("neg", L(4)), _un("neg", L(0))))),
+        (2, _un("exp", _bi("*", _un("neg", L(4)), L(0)))),
+        (2, _un("exp", _bi("*", L(0), L(4)))),
+    ]
+    tapes = [flatten(t) for _, t in cands]
+    ks = np.array([k for k, _ in cands], np.int32)
+    sig = np.full(len(cands), 1.3)
+    zeros = np.zeros(len(cands), np.int32)
+
+    def run(env):
+        for k in ("BSR_SELFDUP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _ctx(X, y, K=K, n_chains=1, max_batch=16, dtype=dtype)
+        for k in range(K):
+            c.set_current(0, k, flatten(cur[k]))
+        c.refresh(0)
+        out = c.score_batch(tapes, zeros, ks, sig).copy()
+        c.close()
+        return out
+    on = run({})
+    off = run({"BSR_SELFDUP": "0"})
+    assert on.tobytes() == off.tobytes()
+    # the repeats score what the current state scores (the same model): all equal among themselves, full rank
+    rep = [0, 1, 2, 3, 4, 5, 7]
+    assert (on["rank"][rep] == K).all()
+    assert np.ptp(on["sse"][rep]) <= 1e-9 * abs(on["sse"][0])
+    # ... and exp(-x4 x0) is another model
+    assert on["sse"][6] != on["sse"][0]
+    # the oracle agrees on every one of them
+    cur_cols = np.stack([_oracle_col(t, X) for t in cur], 1)
+    for i, (k, t) in enumerate(cands):
+        want = O.score_proposal(cur_cols, k, _oracle_col(t, X), y, sig[i])
+        assert want["rank"] == on["rank"][i]
+        assert np.isclose(on["loglik"][i], want["loglik"], rtol=1e-9, atol=0)
+
+
 def test_the_library_places_its_own_threads_and_leaves_the_caller_alone():
     """bsr_ctx_create places the library's own threads (submission threads) on one L3 domain of the host and does NOT
     touch the caller's affinity ("CPU placement"); BSR_PIN=1 confines the caller as well (bench.py asks for
