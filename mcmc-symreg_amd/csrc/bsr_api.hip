@@ -557,13 +557,27 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
     const size_t budget = tile_lds_bytes_max() - 1024;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      c->tile_cus = env_int("BSR_TILE_WGS", c->n_cu - c->aux_cus);
+      c->tile_cus = c->n_cu - c->aux_cus;
+      // Batches of at most four tapes per wave of ONE workgroup (64): a single tape group over slices of eight blocks
+      // -- what a chain tape evaluates in one pass -- where such a slice fits LDS whole for the widest batch.  Half as
+      // many workgroups as two groups over the same slices, each staging the slice once for all tapes and dealing four
+      // tapes per wave instead of two (C2: 96 workgroups, 26.5 us alone instead of 192 at 19.7, but 2 600 instead of
+      // 3 900 CU-us per batch: 11.7-11.9 instead of 12.7-13.3 us per pipelined step).  A launch narrower than the
+      // machine leaves the other CUs to the batches behind it.
+      const int long_slices = c->tile_blocks / 8;
+      // (from 32 slices on: a short data set keeps the many short slices -- one batch at a time is what it is scored in)
+      const bool long_ok = max_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
+                           worst_cols * (size_t)8 * BSR_TILE_BLOCK * c->esz <= budget && !getenv("BSR_TILE_T") &&
+                           !getenv("BSR_TILE_WGS") && env_int("BSR_TILE_LONG", 1);
+      if (long_ok) c->tile_cus = long_slices;
+      c->tile_cus = env_int("BSR_TILE_WGS", c->tile_cus);   // (test hook: workgroups of a launch)
       auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
       auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
       // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):
       // the largest T in {4, 2, 1} with a tape per wave at most -- fewer tapes per wave and longer slices (fewer lane
       // reductions, record fetches and decodes per row), while every group stages the slice's columns again
       int T = 0;
+      if (long_ok && fits_whole(1)) T = 1;
       for (int t = 4; t >= 1 && T == 0; t >>= 1)
         if (t <= (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES && c->tile_cus % t == 0 && fits_whole(t)) T = t;
       if (T == 0 && fits_whole(1)) T = 1;

@@ -412,6 +412,7 @@ def test_a_repeat_with_a_negation_moved_scores_like_the_repeat_it_is(dtype, monk
     rs = np.random.RandomState(5)
     N, d, K = 30000, 5, 3
     X = rs.uniform(-2, 2, size=(N, d))
+    X[:, 0] = rs.uniform(0.5, 2, size=N) * rs.choice([-1.0, 1.0], size=N)   # both signs, away from the pole of 1/sin
     y = np.sin(X[:, 0]) * X[:, 1] + X[:, 2] - 0.5 * X[:, 3] + 0.05 * rs.standard_normal(N)
     L = _leaf
     cur = [
