@@ -1,8 +1,21 @@
-bash tools/profile_bench.sh r02h_c2 --extras 0 > gpurun_out/prof_r02h_c2.log 2>&1
-bash tools/profile_bench.sh r02h_c3 --extras 0 --workload c3 > gpurun_out/prof_r02h_c3.log 2>&1
-bash tools/profile_bench.sh r02h_c5 --extras 0 --workload c5 > gpurun_out/prof_r02h_c5.log 2>&1
-python bench.py > gpurun_out/r02h_bench_default.json 2> gpurun_out/r02h_bench_default.err
-bash tools/pmc_tile.sh > gpurun_out/r02h_pmc_tile.log 2>&1
-BSR_TILE_STAMPS=1 python tools/tile_stamps.py > gpurun_out/r02h_wave_stamps.txt 2>&1
-BSR_SHARE_DEVICE=1 python bench.py --gpus 2 --steps 50 --warmup 5 --cpu-sample 0 > gpurun_out/r02h_bench_2ranks.json 2>/dev/null
-tail -c 600 gpurun_out/r02h_bench_default.json
+# The round's evidence set (GPU box): per-kernel stats, HBM traffic, instruction mix, wave stamps, the default bench line
+# and the N-rank lines on the one device.  usage: bash tools/probes/profile_set.sh r03a
+tag=${1:-r03a}
+bash tools/profile_bench.sh ${tag}_c2 --extras 0 > gpurun_out/prof_${tag}_c2.log 2>&1
+bash tools/profile_bench.sh ${tag}_c3 --extras 0 --workload c3 > gpurun_out/prof_${tag}_c3.log 2>&1
+bash tools/profile_bench.sh ${tag}_c5 --extras 0 --workload c5 > gpurun_out/prof_${tag}_c5.log 2>&1
+python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
+bash tools/pmc_tile.sh > gpurun_out/${tag}_pmc_tile.log 2>&1
+cp gpurun_out/pmc_tile.json gpurun_out/${tag}_pmc_tile_c2_B64.json
+BSR_TILE_STAMPS=1 python tools/tile_stamps.py > gpurun_out/${tag}_wave_stamps.txt 2>&1
+BSR_SHARE_DEVICE=1 python bench.py --gpus 2 --steps 50 --warmup 5 --cpu-sample 0 --extras 0 > gpurun_out/${tag}_bench_2ranks.json 2>/dev/null
+BSR_SHARE_DEVICE=1 python bench.py --gpus 8 --steps 50 --warmup 5 --cpu-sample 0 --extras 0 > gpurun_out/${tag}_bench_8ranks.json 2>/dev/null
+python tools/host_profile.py > gpurun_out/${tag}_host_profile.txt 2>&1
+for w in c2 c3 c5; do
+  cp gpurun_out/prof_${tag}_$w/kernel_stats.csv gpurun_out/${tag}_kernel_stats_bench_${w}_B64.csv
+  cp gpurun_out/prof_${tag}_$w/traffic.json gpurun_out/${tag}_traffic_${w}_B64.json
+  cp gpurun_out/prof_${tag}_$w/bench_stats.json gpurun_out/${tag}_${w}_B64_bench_under_rocprof.json
+  rm -rf gpurun_out/prof_${tag}_$w/stats gpurun_out/prof_${tag}_$w/fetch gpurun_out/prof_${tag}_$w/write
+done
+rm -rf gpurun_out/pt1 gpurun_out/pt2 gpurun_out/pt3 gpurun_out/pt4
+tail -c 600 gpurun_out/${tag}_bench_default.json
