@@ -568,9 +568,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // (from 32 slices on: a short data set keeps the many short slices -- one batch at a time is what it is scored in)
       const bool long_ok = max_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
                            worst_cols * (size_t)8 * BSR_TILE_BLOCK * c->esz <= budget && !getenv("BSR_TILE_T") &&
-                           !getenv("BSR_TILE_WGS") && env_int("BSR_TILE_LONG", 1);
+                           env_int("BSR_TILE_LONG", 1);
       if (long_ok) c->tile_cus = long_slices;
-      c->tile_cus = env_int("BSR_TILE_WGS", c->tile_cus);   // (test hook: workgroups of a launch)
       auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
       auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
       // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):

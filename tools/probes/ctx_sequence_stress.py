@@ -1,3 +1,8 @@
+"""Determinism stress: a sequence of freshly created contexts (K = 8, an ill-conditioned chain state whose scores
+move with the last bit of anything that is off) must refresh and score byte-identically every time.
+
+    python tools/probes/ctx_sequence_stress.py R [NB=2] [BSR_SELFDUP=0] ...   (GPU box; prints one line per context)
+"""
 import os, sys
 sys.path.insert(0, "mcmc-symreg_amd"); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
 import numpy as np
@@ -29,8 +34,7 @@ tapes[5] = flatten(neg); ks[5] = 0
 sig = rs.uniform(0.5, 2.0, size=B)
 zeros = np.zeros(B, np.int32)
 def run(env):
-    for k in ("BSR_SELFDUP", "BSR_FUSED_TAIL"):
-        os.environ.pop(k, None)
+    os.environ.pop("BSR_SELFDUP", None)
     os.environ.update(env)
     c = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
     for k in range(K):
@@ -55,19 +59,13 @@ def trial(name, envs, reps):
                 print(name, rep, env, "DIFFERENT at", len(d), "max rel %.3g" % np.abs(o["loglik"] / base["loglik"] - 1).max(), flush=True)
                 bad += 1
     print(name, "bad", bad, "of", reps * len(envs), flush=True)
-which = sys.argv[1] if len(sys.argv) > 1 else "all"
-if which in ("A", "all"): trial("A fused only", [{}], 12)
-if which in ("B", "all"): trial("B legacy only", [{"BSR_FUSED_TAIL": "0"}], 12)
-if which in ("C", "all"): trial("C legacy selfdup0", [{"BSR_FUSED_TAIL": "0", "BSR_SELFDUP": "0"}], 12)
-if which in ("D", "all"): trial("D fused selfdup0", [{"BSR_SELFDUP": "0"}], 12)
+which = sys.argv[1] if len(sys.argv) > 1 else "R"
 if which == "R":
     extra0 = dict(kv.split("=") for kv in sys.argv[2:])
     print("extra", extra0)
     for rep in range(12):
         extra = dict(extra0)
-        for k in ("BSR_SELFDUP", "BSR_FUSED_TAIL"):
-            os.environ.pop(k, None)
-        os.environ["BSR_FUSED_TAIL"] = "0"
+        os.environ.pop("BSR_SELFDUP", None)
         nb = int(extra.pop("NB", 2)) if "NB" in extra else 2
         os.environ.update(extra)
         c = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
