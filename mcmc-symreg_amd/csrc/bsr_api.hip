@@ -20,7 +20,9 @@
 #include <type_traits>
 #include <vector>
 
+#include <memory>
 #include "bsr_internal.h"
+#include "bsr_span.h"
 
 static thread_local std::string g_create_error;
 
@@ -104,6 +106,7 @@ struct BatchSlot {
   int tile_ncols = 0;                // most LDS columns of any group: sizes the LDS buffers
   int tile_chunk = 0;                // blocks staged at a time: the whole slice, or a chunk of the ring
   int tile_ring = 1;                 // LDS buffers the chunks travel through (LDS-DMA)
+  std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span_snap;   // [chain] the bases this batch was staged against
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
@@ -170,9 +173,11 @@ struct bsr_ctx {
   std::vector<double> x_lo, x_hi;  // per-feature range of X (host side; the native sampler's rank-gate predictor)
   std::vector<char> ready;       // chain factors valid
   std::vector<char> col_set;     // [chain*K+k] column initialised
-  std::vector<uint64_t> cur_hash;              // [chain*K+k] canonical hash of the current tree (0: unknown)
-  std::vector<int> cur_nonneg;                 // ... its nodes other than negations
-  std::vector<std::vector<bsr_node>> cur_tape;  // ... and its tape, to confirm a hash match
+  // structure of the chains' current trees (bsr_span.h): per tree its linear form, per chain the echelon basis of its K
+  // forms -- rebuilt on set_current / commit, handed to the batches in flight as immutable snapshots
+  std::vector<bsr_span::LinForm> cur_form;     // [chain*K+k]
+  std::vector<char> cur_form_ok;               // ... valid
+  std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span;   // [chain]
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
   int chain_eval = 1;   // BSR_CHAIN_EVAL: chain tapes take the register-resident pass of the tile kernel
@@ -636,9 +641,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     c->h_ck.resize((size_t)n_chains);
     c->ready.assign(n_chains, 0);
     c->col_set.assign((size_t)n_chains * K, 0);
-    c->cur_hash.assign((size_t)n_chains * K, 0);
-    c->cur_nonneg.assign((size_t)n_chains * K, 0);
-    c->cur_tape.assign((size_t)n_chains * K, std::vector<bsr_node>());
+    c->cur_form.assign((size_t)n_chains * K, bsr_span::LinForm());
+    c->cur_form_ok.assign((size_t)n_chains * K, 0);
+    c->span.assign((size_t)n_chains, std::shared_ptr<const bsr_span::SpanBasis>());
   }
   CK(hipMalloc((void**)&c->d_fit, sizeof(ChainFitOut) * (n_chains + 1)));
   poison(c->d_fit, sizeof(ChainFitOut) * (n_chains + 1));
@@ -703,138 +708,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Canonical form of the column a tape computes, up to sign: (sign, form) per subtree, such that the subtree's column is
-// sign x the form's column BIT FOR BIT on the device's arithmetic.  Negations travel to the root:
-//   neg A -> (-s, A);  A * B, A / B -> (sA sB, .);  1/A, A^3, sin A -> (sA, .);  A^2, cos A -> (+, .)
-//   a A + b (ln) -> (+, ln(sA a, b, A));  exp, log keep the operand's sign inside the form;
-//   A + B, A - B -> children ordered by form, the first one's sign in front, the other's relative sign in the form
-// (IEEE negation commutes with every rounded operation above; sin is odd and cos even in bsr_fastmath.h: the argument
-// reduction rounds symmetrically and the tables hold sin, cos of symmetric nodes).  Children of + and * in a fixed
-// order.  Two tapes with the same form compute the same column up to sign: a candidate with the form of the tree it
-// replaces lies in the span of the current columns exactly.  At K = 3 such candidates are 5.7 % of the real move mix --
-// 4.6 % the same tree again, 1.1 % the same tree with a negation moved (cos(-x), (-a) b, (-x)^3 y): before negations
-// travelled, those went through the residual step, one in almost every second batch.
-// Hash first (one pass over the postfix tape, a stack of hashes); the exact form, a string, only to confirm a match.
-static inline uint64_t mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-static inline bool is_commutative_op(int op) { return op == BSR_OP_ADD || op == BSR_OP_MUL; }
-static inline bool is_binary_op(int op);
-// what a unary operator does with its operand's sign: +1 passes it on (odd function), 0 drops it (even function),
-// -1 flips it (neg), 2: the sign stays inside the form
-static inline int unary_sign_rule(int op) {
-  switch (op) {
-    case BSR_OP_NEG: return -1;
-    case BSR_OP_INV: case BSR_OP_CUBIC: case BSR_OP_SIN: return 1;
-    case BSR_OP_SQUARE: case BSR_OP_COS: return 0;
-    default: return 2;   // ln (handled apart), exp, log
-  }
-}
-static uint64_t canon_hash(const bsr_node* t, int len) {
-  uint64_t h[BSR_MAX_STACK + 2];
-  int sg[BSR_MAX_STACK + 2];
-  int sp = 0;
-  for (int i = 0; i < len; ++i) {
-    const int op = t[i].opcode;
-    if (op == BSR_OP_TERMINAL) {
-      if (sp > BSR_MAX_STACK) return 0;
-      h[sp] = mix64(0x7465726Dull ^ ((uint64_t)(uint32_t)t[i].feature << 32));
-      sg[sp] = 1;
-      ++sp;
-    } else if (is_binary_op(op)) {
-      if (sp < 2) return 0;
-      uint64_t l = h[sp - 2], r = h[sp - 1];
-      int sl = sg[sp - 2], sr = sg[sp - 1];
-      --sp;
-      if (op == BSR_OP_MUL || op == BSR_OP_DIV) {
-        if (op == BSR_OP_MUL && l > r) std::swap(l, r);
-        h[sp - 1] = mix64(mix64(l ^ ((uint64_t)op << 56)) + 3 * r);
-        sg[sp - 1] = sl * sr;
-      } else {   // + and -: a - b is a + (-b)
-        if (op == BSR_OP_SUB) sr = -sr;
-        if (l > r) { std::swap(l, r); std::swap(sl, sr); }
-        const int rel = sl * sr;
-        h[sp - 1] = mix64(mix64(l ^ ((uint64_t)BSR_OP_ADD << 56)) + 3 * r + (rel < 0 ? 0x5A5Aull : 0));
-        sg[sp - 1] = sl;
-      }
-    } else {
-      if (sp < 1) return 0;
-      if (op == BSR_OP_LN) {
-        double av = t[i].a * sg[sp - 1];
-        uint64_t a, b;
-        memcpy(&a, &av, 8);
-        memcpy(&b, &t[i].b, 8);
-        uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
-        h[sp - 1] = mix64(x ^ mix64(a) ^ (mix64(b) << 1));
-        sg[sp - 1] = 1;
-        continue;
-      }
-      const int rule = unary_sign_rule(op);
-      if (rule == -1) { sg[sp - 1] = -sg[sp - 1]; continue; }
-      uint64_t x = mix64(h[sp - 1] ^ ((uint64_t)(op + 1) << 48));
-      if (rule == 2) { x = mix64(x + (sg[sp - 1] < 0 ? 0xA5A5ull : 0)); sg[sp - 1] = 1; }
-      else if (rule == 0) sg[sp - 1] = 1;
-      h[sp - 1] = x;
-    }
-  }
-  return sp == 1 ? (h[0] | 1ull) : 0;   // never 0: 0 means "no form"
-}
-static inline int count_nonneg(const bsr_node* t, int len) {
-  int n = 0;
-  for (int q = 0; q < len; ++q) n += t[q].opcode != BSR_OP_NEG;
-  return n;
-}
-static std::string canon_form(const bsr_node* t, int len) {
-  std::vector<std::string> st;
-  std::vector<int> sg;
-  char buf[96];
-  for (int i = 0; i < len; ++i) {
-    const int op = t[i].opcode;
-    if (op == BSR_OP_TERMINAL) {
-      snprintf(buf, sizeof buf, "x%d", t[i].feature);
-      st.push_back(buf);
-      sg.push_back(1);
-    } else if (is_binary_op(op)) {
-      if (st.size() < 2) return std::string();
-      std::string r = st.back(); st.pop_back();
-      std::string l = st.back(); st.pop_back();
-      int sr = sg.back(); sg.pop_back();
-      int sl = sg.back(); sg.pop_back();
-      if (op == BSR_OP_MUL || op == BSR_OP_DIV) {
-        if (op == BSR_OP_MUL && r < l) std::swap(l, r);
-        snprintf(buf, sizeof buf, "(%d ", op);
-        st.push_back(buf + l + " " + r + ")");
-        sg.push_back(sl * sr);
-      } else {
-        if (op == BSR_OP_SUB) sr = -sr;
-        if (r < l) { std::swap(l, r); std::swap(sl, sr); }
-        snprintf(buf, sizeof buf, "(%d ", (int)BSR_OP_ADD);
-        st.push_back(buf + l + (sl * sr < 0 ? " - " : " + ") + r + ")");
-        sg.push_back(sl);
-      }
-    } else {
-      if (st.empty()) return std::string();
-      if (op == BSR_OP_LN) {
-        const double av = t[i].a * sg.back();
-        uint64_t a, b;
-        memcpy(&a, &av, 8);
-        memcpy(&b, &t[i].b, 8);
-        snprintf(buf, sizeof buf, "[%d %016llx %016llx ", op, (unsigned long long)a, (unsigned long long)b);
-        st.back() = buf + st.back() + "]";
-        sg.back() = 1;
-        continue;
-      }
-      const int rule = unary_sign_rule(op);
-      if (rule == -1) { sg.back() = -sg.back(); continue; }
-      snprintf(buf, sizeof buf, "[%d%s ", op, (rule == 2 && sg.back() < 0) ? "-" : "");
-      st.back() = buf + st.back() + "]";
-      if (rule != 1) sg.back() = 1;
-    }
-  }
-  return st.size() == 1 ? st[0] : std::string();
+// A chain's current tree k changed (set_current / commit): its linear form and the chain's span basis (bsr_span.h).
+static void note_current_tree(bsr_ctx* c, int chain, int k, const bsr_node* t, int len) {
+  const size_t ck = (size_t)chain * c->K + k;
+  c->cur_form_ok[ck] = (t && len > 0 && bsr_span::lin_form(t, len, &c->cur_form[ck])) ? 1 : 0;
+  auto b = std::make_shared<bsr_span::SpanBasis>();
+  b->build(std::vector<bsr_span::LinForm>(c->cur_form.begin() + (size_t)chain * c->K, c->cur_form.begin() + (size_t)(chain + 1) * c->K),
+           std::vector<char>(c->cur_form_ok.begin() + (size_t)chain * c->K, c->cur_form_ok.begin() + (size_t)(chain + 1) * c->K));
+  c->span[chain] = b;
 }
 
 static inline bool is_binary_op(int op) {
@@ -1626,6 +1507,25 @@ static int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
   return BSR_OK;
 }
 
+// Which candidates of the batch lie in the span of their chain's current columns by construction (bsr_span.h): the
+// tree they would replace again, the same with a negation moved, a linear combination of current trees.  k_solve then
+// takes w = 0 without the residual step -- if its own one-pass figure agrees.  fp32 columns: only repeats up to sign
+// (bit-identical columns); a combination's rounding residue is above the cut there and goes through the residual step.
+static void mark_in_span(bsr_ctx* c, BatchSlot& s, int P) {
+  PropDesc* hd = s.h_desc();
+  if ((int)s.off_copy.size() < P + 1) return;
+  for (int i = 0; i < P; ++i) {
+    PropDesc& D = hd[i];
+    if (D.mode != BSR_MODE_SCORE || D.ck < 0 || (size_t)D.ck >= s.span_snap.size()) continue;
+    const bsr_span::SpanBasis* b = s.span_snap[D.ck].get();
+    if (!b) continue;
+    bsr_span::LinForm f;
+    if (!bsr_span::lin_form(s.rows_copy.data() + s.off_copy[i], s.off_copy[i + 1] - s.off_copy[i], &f)) continue;
+    const bool rep = D.k >= 0 && (size_t)D.k < b->forms.size() && b->known[D.k] && bsr_span::same_up_to_sign(f, b->forms[D.k]);
+    D.self_dup = (rep || (c->dtype == BSR_DTYPE_F64 && b->in_span(f))) ? 1 : 0;
+  }
+}
+
 static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   const long long t_issue0 = host_now();
   hipStream_t st = s.stream;
@@ -1641,6 +1541,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   bool tile = false;
   TileGeom tg;
   memset(&tg, 0, sizeof tg);
+  if (j.scoring && j.restage && c->selfdup) mark_in_span(c, s, j.P);
   if (j.maybe_tile) {
     if (j.restage) stage_tile(c, s, j.P);
     if (s.tile) {
@@ -2078,9 +1979,7 @@ extern "C" int bsr_set_current(bsr_ctx* c, int32_t chain, int32_t k, const bsr_n
   c->h_rin[chain].colflags[k] = s.h_out[0].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
-  c->cur_hash[(size_t)chain * c->K + k] = canon_hash(tape, len);
-  c->cur_nonneg[(size_t)chain * c->K + k] = count_nonneg(tape, len);
-  c->cur_tape[(size_t)chain * c->K + k].assign(tape, tape + len);
+  note_current_tree(c, chain, k, tape, len);
   return BSR_OK;
 }
 
@@ -2133,19 +2032,10 @@ int bsr_internal_commit(bsr_ctx* c, int si, int32_t chain, int32_t k, int32_t id
   c->h_rin[chain].colflags[k] = s.h_out[idx].flags & (BSR_F_INF | BSR_F_NAN);
   c->ready[chain] = 0;
   c->col_set[(size_t)chain * c->K + k] = 1;
-  {
-    const size_t ck = (size_t)chain * c->K + k;
-    if ((size_t)idx + 1 < s.off_copy.size()) {
-      const bsr_node* t = s.rows_copy.data() + s.off_copy[idx];
-      const int len = s.off_copy[idx + 1] - s.off_copy[idx];
-      c->cur_hash[ck] = canon_hash(t, len);
-      c->cur_nonneg[ck] = count_nonneg(t, len);
-      c->cur_tape[ck].assign(t, t + len);
-    } else {
-      c->cur_hash[ck] = 0;   // unknown: no shortcut for proposals on this tree
-      c->cur_tape[ck].clear();
-    }
-  }
+  if ((size_t)idx + 1 < s.off_copy.size())
+    note_current_tree(c, chain, k, s.rows_copy.data() + s.off_copy[idx], s.off_copy[idx + 1] - s.off_copy[idx]);
+  else
+    note_current_tree(c, chain, k, nullptr, 0);   // unknown: no shortcut for proposals on this chain's tree k
   return BSR_OK;
 }
 
@@ -2271,20 +2161,11 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
     D->qslot = 0;   // (tile pass: set with the tape's group by stage_tile)
     D->s = c->h_ck[chain[i]].s_k[which_k[i]];
     D->sigma = sigma[i];
-    // the candidate is the tree it would replace, again (same canonical form): tell k_solve its column is in the span
+    // (whether the candidate lies in the span of its chain's current columns by construction -- D->self_dup -- is worked
+    // out where the batch's launches are issued, against the bases snapshotted here: mark_in_span)
     if (c->selfdup) {
-      const size_t ck = (size_t)chain[i] * K + which_k[i];
-      const bsr_node* t = rows + tape_off[i];
-      const int len = tape_off[i + 1] - tape_off[i];
-      const uint64_t h = c->cur_hash[ck];
-      // (the canonical form drops negations and turns a - b into a + (-b): equal forms have equal node counts apart from
-      // the negations -- a cheap filter in front of the hash)
-      const std::vector<bsr_node>& cur = c->cur_tape[ck];
-      const int lc = c->cur_nonneg[ck];
-      const int lt = count_nonneg(t, len);
-      if (h != 0 && lc == lt && h == canon_hash(t, len) &&
-          canon_form(t, len) == canon_form(cur.data(), (int)cur.size()))
-        D->self_dup = 1;
+      if (s.span_snap.size() != c->span.size()) s.span_snap.resize(c->span.size());
+      if (s.span_snap[chain[i]].get() != c->span[chain[i]].get()) s.span_snap[chain[i]] = c->span[chain[i]];
     }
   }
   // keep the batch's tapes: bsr_commit makes one of them a current tree (its canonical form is needed then)

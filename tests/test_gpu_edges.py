@@ -467,6 +467,55 @@ def test_a_repeat_with_a_negation_moved_scores_like_the_repeat_it_is(dtype, monk
         assert np.isclose(on["loglik"][i], want["loglik"], rtol=1e-9, atol=0)
 
 
+def test_a_linear_combination_of_current_trees_scores_the_same_with_and_without_the_shortcut(monkeypatch):
+    """Candidates that are linear combinations of the chain's current trees (-x1 next to x1 + x1, x1 + x2 next to
+    x1 + x1 and -x2, cos(x3) + x2, the zero column x1 + -x1) lie in the span by construction: the host says so
+    (csrc/bsr_span.h) and k_solve takes w = 0 without the residual step.  With the recognition off they go through the
+    residual step: the same bytes.  The oracle agrees on rank and log-likelihood."""
+    from bsr.tape import flatten
+    rs = np.random.RandomState(9)
+    N, d, K = 30000, 5, 4
+    X = rs.uniform(-2, 2, size=(N, d))
+    y = X[:, 1] - 0.7 * X[:, 2] + np.cos(X[:, 3]) + 0.3 * X[:, 0] * X[:, 4] + 0.05 * rs.standard_normal(N)
+    L = _leaf
+    cur = [_bi("+", L(1), L(1)), _un("neg", L(2)), _un("cos", L(3)), _bi("*", L(0), L(4))]
+    cands = [
+        (0, _un("neg", L(1))),
+        (0, _bi("+", L(1), _un("neg", L(1)))),
+        (1, _bi("+", L(1), L(2))),
+        (2, _bi("+", _un("cos", L(3)), L(2))),
+        (1, _un("neg", _bi("+", L(2), L(2)))),
+        (3, _bi("+", _bi("*", L(4), L(0)), _un("ln", L(1), 2.5, 0.0))),
+        (3, _bi("+", _bi("*", L(4), L(0)), _un("ln", L(1), 2.5, 0.3))),   # + a constant: not in the span
+        (2, _un("sin", L(3))),
+    ]
+    tapes = [flatten(t) for _, t in cands]
+    ks = np.array([k for k, _ in cands], np.int32)
+    sig = np.full(len(cands), 0.9)
+    zeros = np.zeros(len(cands), np.int32)
+
+    def run(env):
+        monkeypatch.delenv("BSR_SELFDUP", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _ctx(X, y, K=K, n_chains=1, max_batch=16)
+        for k in range(K):
+            c.set_current(0, k, flatten(cur[k]))
+        c.refresh(0)
+        out = c.score_batch(tapes, zeros, ks, sig).copy()
+        c.close()
+        return out
+    on = run({})
+    off = run({"BSR_SELFDUP": "0"})
+    assert on.tobytes() == off.tobytes()
+    cur_cols = np.stack([_oracle_col(t, X) for t in cur], 1)
+    for i, (k, t) in enumerate(cands):
+        want = O.score_proposal(cur_cols, k, _oracle_col(t, X), y, sig[i])
+        assert want["rank"] == on["rank"][i], (i, want["rank"], on["rank"][i])
+        if want["rank"] == K:
+            assert np.isclose(on["loglik"][i], want["loglik"], rtol=1e-9, atol=0)
+
+
 def test_the_library_places_its_own_threads_and_leaves_the_caller_alone():
     """bsr_ctx_create places the library's own threads (submission threads) on one L3 domain of the host and does NOT
     touch the caller's affinity ("CPU placement"); BSR_PIN=1 confines the caller as well (bench.py asks for
