@@ -188,66 +188,81 @@ inline bool same_up_to_sign(const LinForm& f, const LinForm& g) {
 
 // Echelon basis of a chain's K forms.
 struct SpanBasis {
+  static constexpr int VCAP = 56;   // terms a working vector holds (K <= 8 forms of <= 6 terms and a candidate's)
+  struct Vec {                      // sorted by atom, no zero coefficient; inline storage: no allocation per candidate
+    int n = 0;
+    bool over = false;              // more terms than VCAP: the owner gives up (no claim)
+    uint64_t a[VCAP];
+    double c[VCAP];
+    double get(uint64_t at) const {
+      for (int i = 0; i < n; ++i)
+        if (a[i] == at) return c[i];
+      return 0.0;
+    }
+    double max_abs() const {
+      double m = 0.0;
+      for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(c[i]));
+      return m;
+    }
+    void from(const LinForm& f) {
+      n = f.n;
+      over = false;
+      for (int i = 0; i < f.n; ++i) { a[i] = f.atom[i]; c[i] = f.coef[i]; }
+    }
+  };
   struct Row {
     uint64_t pivot;
-    std::vector<std::pair<uint64_t, double>> t;   // sorted by atom; the pivot's coefficient is 1, no other row holds it
+    Vec t;   // the pivot's coefficient is 1, no other row holds it
   };
   std::vector<Row> rows;
   std::vector<LinForm> forms;   // the K forms themselves (same_up_to_sign against tree k)
   std::vector<char> known;      // form k is valid
 
-  static double get(const std::vector<std::pair<uint64_t, double>>& v, uint64_t a) {
-    for (const auto& p : v)
-      if (p.first == a) return p.second;
-    return 0.0;
-  }
-  // v -= c * r, exact zeros dropped, coefficients below 1e-12 of the largest seen treated as zero
-  static void axpy(std::vector<std::pair<uint64_t, double>>& v, double c, const std::vector<std::pair<uint64_t, double>>& r,
-                   double scale) {
-    std::vector<std::pair<uint64_t, double>> o;
-    o.reserve(v.size() + r.size());
-    size_t i = 0, j = 0;
-    while (i < v.size() || j < r.size()) {
+  // v -= x * r; coefficients below 1e-12 of `scale` are treated as zero
+  static void axpy(Vec& v, double x, const Vec& r, double scale) {
+    Vec o;
+    int i = 0, j = 0;
+    while (i < v.n || j < r.n) {
       uint64_t at;
-      double x;
-      if (j >= r.size() || (i < v.size() && v[i].first < r[j].first)) { at = v[i].first; x = v[i].second; ++i; }
-      else if (i >= v.size() || r[j].first < v[i].first) { at = r[j].first; x = -c * r[j].second; ++j; }
-      else { at = v[i].first; x = v[i].second - c * r[j].second; ++i; ++j; }
-      if (std::fabs(x) > 1e-12 * scale) o.emplace_back(at, x);
+      double y;
+      if (j >= r.n || (i < v.n && v.a[i] < r.a[j])) { at = v.a[i]; y = v.c[i]; ++i; }
+      else if (i >= v.n || r.a[j] < v.a[i]) { at = r.a[j]; y = -x * r.c[j]; ++j; }
+      else { at = v.a[i]; y = v.c[i] - x * r.c[j]; ++i; ++j; }
+      if (!(std::fabs(y) > 1e-12 * scale)) continue;
+      if (o.n == VCAP) { o.over = true; break; }
+      o.a[o.n] = at;
+      o.c[o.n] = y;
+      ++o.n;
     }
-    v.swap(o);
+    o.over = o.over || v.over || r.over;
+    v = o;
   }
-  void reduce(std::vector<std::pair<uint64_t, double>>& v, double scale) const {
+  void reduce(Vec& v, double scale) const {
     for (const Row& r : rows) {
-      const double c = get(v, r.pivot);
-      if (c != 0.0) axpy(v, c, r.t, scale);
+      const double x = v.get(r.pivot);
+      if (x != 0.0) axpy(v, x, r.t, scale);
     }
-  }
-  static double max_abs(const std::vector<std::pair<uint64_t, double>>& v) {
-    double m = 0.0;
-    for (const auto& p : v) m = std::max(m, std::fabs(p.second));
-    return m;
   }
   void add(const LinForm& f) {
-    std::vector<std::pair<uint64_t, double>> v;
-    for (int i = 0; i < f.n; ++i) v.emplace_back(f.atom[i], f.coef[i]);
-    const double scale = std::max(1.0, max_abs(v));
+    Vec v;
+    v.from(f);
+    const double scale = std::max(1.0, v.max_abs());
     reduce(v, scale);
-    if (v.empty()) return;
-    size_t best = 0;
-    for (size_t i = 1; i < v.size(); ++i)
-      if (std::fabs(v[i].second) > std::fabs(v[best].second)) best = i;
-    const double pc = v[best].second;
+    if (v.n == 0 || v.over) return;
+    int best = 0;
+    for (int i = 1; i < v.n; ++i)
+      if (std::fabs(v.c[i]) > std::fabs(v.c[best])) best = i;
+    const double pc = v.c[best];
     Row r;
-    r.pivot = v[best].first;
-    for (auto& p : v) p.second /= pc;
-    v[best].second = 1.0;
+    r.pivot = v.a[best];
+    for (int i = 0; i < v.n; ++i) v.c[i] /= pc;
+    v.c[best] = 1.0;
     r.t = v;
     for (Row& o : rows) {   // keep the basis fully reduced: the new pivot leaves the older rows
-      const double c = get(o.t, r.pivot);
-      if (c != 0.0) axpy(o.t, c, r.t, std::max(1.0, max_abs(o.t)));
+      const double x = o.t.get(r.pivot);
+      if (x != 0.0) axpy(o.t, x, r.t, std::max(1.0, o.t.max_abs()));
     }
-    rows.push_back(std::move(r));
+    rows.push_back(r);
   }
   void build(const std::vector<LinForm>& fs, const std::vector<char>& ok) {
     rows.clear();
@@ -255,14 +270,16 @@ struct SpanBasis {
     known = ok;
     for (size_t k = 0; k < fs.size(); ++k)
       if (ok[k]) add(fs[k]);
+    for (const Row& r : rows)
+      if (r.t.over) { rows.clear(); break; }   // a working vector overflowed: no claims from this basis
   }
   // the candidate's column is a linear combination of the chain's current columns (old column k included)
   bool in_span(const LinForm& f) const {
-    std::vector<std::pair<uint64_t, double>> v;
-    for (int i = 0; i < f.n; ++i) v.emplace_back(f.atom[i], f.coef[i]);
-    const double scale = std::max(1.0, max_abs(v));
+    Vec v;
+    v.from(f);
+    const double scale = std::max(1.0, v.max_abs());
     reduce(v, scale);
-    return max_abs(v) <= 1e-9 * scale;
+    return !v.over && v.max_abs() <= 1e-9 * scale;
   }
 };
 
