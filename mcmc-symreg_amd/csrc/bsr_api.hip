@@ -20,254 +20,29 @@
 #include <type_traits>
 #include <vector>
 
-#include <memory>
-#include "bsr_internal.h"
-#include "bsr_span.h"
+#include "bsr_ctx.h"
 
-static thread_local std::string g_create_error;
-
-struct TapeLoc {
-  int code_off, n_nodes, feat_off, ln_off, max_sp;
-  int n_stream;  // opcode-stream entries after fusing `terminal, +|*` pairs
-  int cost;      // rough relative cost of one sweep of the tape (orders the work queue: heaviest first)
-  int nt, nl;      // terminals in the column stream, (a, b) pairs in the ln stream
-  int grp;         // tile pass: the tape group that runs the tape (its LDS slot map numbers the tape's columns)
-  int acc_only;    // chain tape: one leading terminal, every other stream entry maps the accumulator to itself
-};
-
-// Everything one batch in flight owns.  Two slots let the host stage batch i+1 while the GPU scores batch i.
-// The input block is one pinned host buffer mirrored by one device buffer and uploaded with a single copy:
-//   [ feature list (d int32) | descriptors (max_batch + 1 PropDesc) | opcode words | column words | ln pairs ]
-struct BatchSlot {
-  uint8_t* h_in = nullptr;
-  uint8_t* d_in = nullptr;
-  size_t in_cap = 0;
-  size_t off_cols = 0, off_sched = 0, off_mh = 0, off_desc = 0, off_streams = 0;
-  int cols_stride = 0;   // entries between the tape groups' column-pointer tables
-  size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
-  size_t recs_bytes = 0; // ... of which this batch uses so many bytes
-  // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
-  MhRes* d_mh = nullptr;
-  bsr_event* h_ev = nullptr;   // pinned, written by k_events
-  int n_spans = 0;             // spans of the batch in flight (0: plain scoring)
-  size_t mh_cap = 0;           // proposals the MH block has room for
-  size_t code_words = 0, feat_words = 0, ln_words = 0;
-  // tile pass (bsr_tile.hip): a second column stream with LDS slots instead of X columns sits behind the ln pairs
-  bool tile = false;
-  bool tile_possible = false;   // stage_tapes: nothing rules the tile pass out for the staged batch (stage_tile decides)
-  int tile_chains = 0;                // distinct chains of the batch (their basis columns are staged in LDS)
-  std::vector<int32_t> chain_slot;    // chain -> index among the batch's chains, -1 if absent
-  std::vector<int32_t> batch_chains;  // the batch's chains in first-seen order
-  std::vector<double> wave_load;      // scratch of the tile schedule
-  std::vector<int> wave_cnt;
-  bsr_score* h_out = nullptr;
-  hipStream_t stream = nullptr;   // each slot has its own stream: the small solve/residual/finalise kernels of one
-                                  // batch overlap the row pass of the other
-  PropCoef* d_coef = nullptr;
-  int32_t* d_flagged = nullptr;  // two lists ([0] count, [1..] proposals k_solve hands to the residual pass), alternating by
-                                 // batch: each batch's k_solve empties the list the batch before it used
-  int flag_par = 0;
-  int32_t* flag_cur() const { return d_flagged + (size_t)flag_par * flag_stride; }
-  int32_t* flag_other() const { return d_flagged + (size_t)(flag_par ^ 1) * flag_stride; }
-  size_t flag_stride = 0;
-  double* part1 = nullptr;
-  double* part2 = nullptr;
-  bool part2_uncached = false;   // part2 and the arrival counter behind it are uncached memory: the finalise step is fused
-  size_t part_cap = 0;   // in (proposal,row block) records
-  void* spill = nullptr;
-  size_t spill_cap = 0;  // bytes
-  int32_t* queue = nullptr;  // ring of work-queue counter sets for the projection pass (zeroed once; every launch
-                             // takes the next set and clears the one half a ring ahead)
-  uint32_t queue_seq = 0;
-  hipEvent_t done = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int P = 0;
-  int nF = 0;
-  int derived_used = 0;  // derived columns the batch being staged refers to
-  bool use_lds = false;
-  int rb_rows = 512;
-  bool pending = false;
-  uint32_t gen = 0;         // bumped by every submission on this slot
-  uint32_t waited_gen = 0;  // generation whose results the last wait on this slot handed out
-  // submission thread (see Launcher): the generation whose solve / residual / finalise launches and `done` event have
-  // been issued, and the status of issuing them
-  std::atomic<uint32_t> tail_gen{0};
-  uint32_t tail_wanted = 0;
-  int tail_rc = 0;
-  int timed = 0;        // profiling level the pending batch was enqueued with
-  bool scored = false;  // holds a scored batch (bsr_commit may re-run its tapes)
-  std::vector<int32_t> slot_of;  // feature -> LDS slot of the batch being staged
-  std::vector<std::pair<int, int>> derived_cand;   // scratch of the derived-column choice
-  std::vector<int> derived_benefit;
-  // tile pass: per tape group, the columns its tapes read (ascending) -> LDS slots 0.., then y, then the chains' bases
-  std::vector<int16_t> grp_slot;     // [group][column] LDS slot or -1
-  std::vector<int32_t> grp_cols;     // scratch: columns of one group
-  int grp_nF[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // X columns per group (= the group's y slot)
-  int tile_ncols = 0;                // most LDS columns of any group: sizes the LDS buffers
-  int tile_chunk = 0;                // blocks staged at a time: the whole slice, or a chunk of the ring
-  int tile_ring = 1;                 // LDS buffers the chunks travel through (LDS-DMA)
-  std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span_snap;   // [chain] the bases this batch was staged against
-  std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
-  std::vector<int32_t> off_copy;
-  std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
-  std::vector<TapeLoc> loc_tmp;   // scratch of a submission
-  std::vector<uint32_t> order_keys;
-  int order_n = -1;              // tapes order_tmp is valid for (-1: not)
-  std::vector<bsr_node> rows_perm;   // tapes rewritten in fusing order (reorder_tape), at their batch offsets
-  std::vector<const bsr_node*> tape_src;   // per tape: where the streams are written from (the caller's rows, or rows_perm)
-  std::vector<int32_t> perm_kid, perm_stack;   // scratch of reorder_tape
-  bool stream_dirty = false;     // work on the slot's stream that no wait has covered yet (bsr_commit's re-run, a rescore's
-                                 // descriptor restore): the next batch's input block then goes by a copy command
-
-  int32_t* h_feat() const { return reinterpret_cast<int32_t*>(h_in); }
-  const void** h_cols() const { return reinterpret_cast<const void**>(h_in + off_cols); }
-  TapeRec* h_sched() const { return reinterpret_cast<TapeRec*>(h_in + off_recs); }
-  double* h_terms() const { return reinterpret_cast<double*>(h_in + off_mh); }
-  int32_t* h_mhflags() const { return reinterpret_cast<int32_t*>(h_in + off_mh + mh_cap * 8 * sizeof(double)); }
-  int32_t* h_spans() const { return h_mhflags() + mh_cap; }
-  const double* d_terms() const { return reinterpret_cast<const double*>(d_in + off_mh); }
-  const int32_t* d_mhflags() const { return reinterpret_cast<const int32_t*>(d_in + off_mh + mh_cap * 8 * sizeof(double)); }
-  const int32_t* d_spans() const { return d_mhflags() + mh_cap; }
-  const void* const* d_cols() const { return reinterpret_cast<const void* const*>(d_in + off_cols); }
-  const TapeRec* d_sched() const { return reinterpret_cast<const TapeRec*>(d_in + off_recs); }
-  PropDesc* h_desc() const { return reinterpret_cast<PropDesc*>(h_in + off_desc); }
-  uint64_t* h_streams() const { return reinterpret_cast<uint64_t*>(h_in + off_streams); }
-  const int32_t* d_feat() const { return reinterpret_cast<const int32_t*>(d_in); }
-  PropDesc* d_desc() const { return reinterpret_cast<PropDesc*>(d_in + off_desc); }
-  const uint64_t* d_streams() const { return reinterpret_cast<const uint64_t*>(d_in + off_streams); }
-};
-
-struct bsr_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int64_t N = 0, ld = 0;
-  int d = 0, K = 0, n_chains = 0, max_batch = 0, dtype = 0;
-  int n_cols = 0;          // columns of Xt: the d features, then (derived columns on) d per unary opcode of kDerivedOps
-  bool derived_ready = false;
-  int derived_max = 8;         // BSR_DERIVED_MAX: cap on the derived columns one batch may use
-  bool tile_ever = false;   // some batch of this context can take the tile pass
-  int n_cu = 256;
-  int tile_cus = 256;  // CUs the tile row pass runs on; the other n_cu - tile_cus serve the small kernels behind it
-  int aux_cus = 0;
-  int bar_write = 0;       // the host writes a batch's input block straight into device memory (large-BAR devices)
-  int wgs_per_cu = 5;  // resident 4-wave workgroups per CU the work-queue row pass is sized for (f64 kernels: 92 VGPRs -> 5)
-  size_t esz = 8;
-  bool has_y = false;
-  void* Xt = nullptr;
-  void* y = nullptr;
-  void* cur = nullptr;   // [chain][k][ld]
-  void* Q = nullptr;     // [chain][K][ld]: one orthonormal basis of the chain's K current columns
-  void* zbuf = nullptr;  // [max_batch][ld], allocated on the first bsr_eval_tapes that wants columns
-  ChainB* d_ck = nullptr;        // [chain]
-  std::vector<ChainB> h_ck;
-  ChainFitOut* d_fit = nullptr;  // [chain] no-intercept fit (also carries per-column max/flags) + 1 scratch slot
-  std::vector<ChainFitOut> h_fit;
-  ChainFitOut* d_fit_icpt = nullptr;   // [chain] intercept fit of the last refresh
-  std::vector<ChainFitOut> h_fit_icpt;
-  RefreshIn* d_rin = nullptr;          // [chain]
-  std::vector<RefreshIn> h_rin;        // host-tracked max|.| and inf/NaN flags of every current column
-  RefreshPlan* d_plan = nullptr;       // one scratch plan (refreshes are serialised on the main stream)
-  RefreshPlan* h_plan = nullptr;       // pinned
-  double* d_rpart = nullptr;
-  int fast_refresh = 1;
-  std::vector<double> x_lo, x_hi;  // per-feature range of X (host side; the native sampler's rank-gate predictor)
-  std::vector<char> ready;       // chain factors valid
-  std::vector<char> col_set;     // [chain*K+k] column initialised
-  // structure of the chains' current trees (bsr_span.h): per tree its linear form, per chain the echelon basis of its K
-  // forms -- rebuilt on set_current / commit, handed to the batches in flight as immutable snapshots
-  std::vector<bsr_span::LinForm> cur_form;     // [chain*K+k]
-  std::vector<char> cur_form_ok;               // ... valid
-  std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span;   // [chain]
-  int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
-  int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
-  int chain_eval = 1;   // BSR_CHAIN_EVAL: chain tapes take the register-resident pass of the tile kernel
-  BatchSlot slot[BSR_SLOTS];
-  int next_slot = 0;
-  int last_waited = -1;
-  std::mutex mu;  // commit / refresh / fit share the main stream and one set of staging buffers (bsr_internal_lock)
-  struct Launcher* launcher = nullptr;  // second submission thread (BSR_SUBMIT_THREAD, default on)
-  std::mutex err_mu;  // the error text may be written by worker threads
-  double* d_stage = nullptr;  // fp64 staging for column download in f32 mode
-  // tuning
-  int rb_rows = 512;
-  int target_wgs = 2048;
-  int rows_per_lane = 2;
-  int no_lds = 0;
-  // tile pass geometry, fixed for the life of the context (a proposal's partial sums must not depend on the batch)
-  int tile_on = 1;
-  int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
-  int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
-  bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
-  size_t tile_sched_cap = 0;
-  unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
-  // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
-  int prof = 0;
-  double last_us[5] = {0, 0, 0, 0, 0};
-  ncclComm_t comm = nullptr;
-  void* comm_buf = nullptr;
-  size_t comm_cap = 0;
-  std::string err;
-};
-
-struct bsr_ctx;
-static void set_err(bsr_ctx* c, const char* msg);
-#define HIPCHK(ctx, call)                                                                       \
-  do {                                                                                          \
-    hipError_t e_ = (call);                                                                     \
-    if (e_ != hipSuccess) {                                                                     \
-      char b_[512];                                                                             \
-      snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      set_err((ctx), b_);                                                                       \
-      return BSR_E_HIP;                                                                         \
-    }                                                                                           \
-  } while (0)
-
-// host-side cost of a submission, printed by bsr_ctx_destroy when BSR_HOST_PROF is set
-static std::atomic<long long> g_ns_stage{0}, g_ns_desc{0}, g_ns_enq{0}, g_n_sub{0};  // worker threads submit too
-static std::atomic<long long> g_ns_issue{0}, g_n_issue{0}, g_ns_wait{0}, g_n_wait{0};   // HIP calls of a batch; waits
-static const bool g_host_prof = getenv("BSR_HOST_PROF") != nullptr;
-// BSR_STREAM_STATS=1: what the staged batches hold, by stream opcode and evaluator (printed by bsr_ctx_destroy; the
-// instruction audit of the row pass prices a launch with it: tools/isa_audit.py)
-static const bool g_stream_stats = getenv("BSR_STREAM_STATS") != nullptr;
-static std::atomic<long long> g_ss_entries[2][16], g_ss_tapes[2], g_ss_batches{0}, g_ss_derived{0}, g_ss_cols{0};
-static inline long long host_now() {
-  return g_host_prof ? std::chrono::duration_cast<std::chrono::nanoseconds>(
-                           std::chrono::steady_clock::now().time_since_epoch()).count()
-                     : 0;
-}
-
-// Derived columns.  Most transcendental nodes of a proposal sit directly on a terminal (`sin(x3)`, `exp(x0)`), and the
-// row passes are bound by the vector instructions those nodes cost -- for every tape and row again.  The context
-// therefore keeps op(x_f) for every feature f and every unary opcode without parameters as extra columns behind X
-// (computed once, by the same device routines the interpreter runs: the values are bit-identical to an inline
-// evaluation), and the stream encoder turns `terminal f, op` into one terminal of column d*(1+m)+f.  What the pass
-// pays instead is the read of one more column per distinct (op, feature) of the batch -- bandwidth, which it has.
-static const int kDerivedOps[] = {BSR_OP_INV, BSR_OP_NEG, BSR_OP_SIN, BSR_OP_COS, BSR_OP_EXP, BSR_OP_SQUARE, BSR_OP_CUBIC,
-                                  BSR_OP_LOG};
-static const int kNumDerivedOps = (int)(sizeof(kDerivedOps) / sizeof(kDerivedOps[0]));
-static inline int derived_index(int opcode) {
-  for (int m = 0; m < kNumDerivedOps; ++m)
-    if (kDerivedOps[m] == opcode) return m;
-  return -1;
-}
+thread_local std::string g_create_error;
+std::atomic<long long> g_ns_stage{0}, g_ns_desc{0}, g_ns_enq{0}, g_n_sub{0};
+std::atomic<long long> g_ns_issue{0}, g_n_issue{0}, g_ns_wait{0}, g_n_wait{0};
+const bool g_host_prof = getenv("BSR_HOST_PROF") != nullptr;
+const bool g_stream_stats = getenv("BSR_STREAM_STATS") != nullptr;
+std::atomic<long long> g_ss_entries[2][16], g_ss_tapes[2], g_ss_batches{0}, g_ss_derived{0}, g_ss_cols{0};
 
 static void launcher_start(bsr_ctx* c);
 static void launcher_stop(bsr_ctx* c);
 static int build_derived(bsr_ctx* c);
 
-static void set_err(bsr_ctx* c, const char* msg) {
+void set_err(bsr_ctx* c, const char* msg) {
   std::lock_guard<std::mutex> lk(c->err_mu);
   c->err = msg;
 }
 
-static int fail(bsr_ctx* ctx, int code, const char* msg) {
+int fail(bsr_ctx* ctx, int code, const char* msg) {
   if (ctx) set_err(ctx, msg); else g_create_error = msg;
   return code;
 }
 
-static inline void* col_ptr(const bsr_ctx* c, void* base, int64_t col) {
-  return (char*)base + (size_t)col * c->ld * c->esz;
-}
 
 extern "C" int bsr_abi_version(void) { return BSR_ABI_VERSION; }
 
@@ -289,11 +64,11 @@ extern "C" const char* bsr_last_error(const bsr_ctx* ctx) { return ctx ? ctx->er
 // BSR_POISON=1 (debugging): device buffers that are handed out without a fill are filled with 0xFF bytes (NaN doubles,
 // -1 integers) -- a kernel that reads what nobody wrote shows at once instead of depending on what the allocator
 // happened to return.
-static void poison(void* p, size_t bytes) {
+void poison(void* p, size_t bytes) {
   static const bool on = getenv("BSR_POISON") && atoi(getenv("BSR_POISON")) != 0;
   if (on && p && bytes) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
 }
-static int env_int(const char* name, int dflt) {
+int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
@@ -371,90 +146,6 @@ static int upload_data(bsr_ctx* c, const double* X, const double* y) {
   }
   HIPCHK(c, hipFree(stage));
   return BSR_OK;
-}
-
-static std::atomic<bool> g_pinned{false};   // BSR_PIN=1: this process confined itself to the library's CPUs (choose_lib_cpus)
-// "0-7,128-135" -> CPU set; false when nothing parses
-static bool parse_cpulist(const char* txt, cpu_set_t* set) {
-  CPU_ZERO(set);
-  int n = 0;
-  for (const char* p = txt; p && *p;) {
-    while (*p == ',' || *p == ' ' || *p == '\n') ++p;
-    if (*p < '0' || *p > '9') break;
-    char* end = nullptr;
-    long a = strtol(p, &end, 10), b = a;
-    if (end && *end == '-') b = strtol(end + 1, &end, 10);
-    for (long i = a; i <= b && i < CPU_SETSIZE; ++i) {
-      CPU_SET((int)i, set);
-      ++n;
-    }
-    p = end;
-  }
-  return n > 0;
-}
-static bool l3_domain_of(int cpu, cpu_set_t* set) {
-  char path[128], buf[1024];
-  snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-  FILE* f = fopen(path, "r");
-  if (!f) return false;
-  const bool ok = fgets(buf, sizeof buf, f) != nullptr;
-  fclose(f);
-  return ok && parse_cpulist(buf, set);
-}
-// CPU placement.  A batch passes through the caller, a submission thread and (native sampler) a worker thread; left to
-// roam two sockets and sixteen L3 domains the pipelined step of the C2 bench measures anything from 17.9 to 21.6 us
-// run by run, with those threads inside ONE L3 domain (a CCX: 8 cores and their SMT siblings on the EPYC hosts of
-// MI355X boxes) 17.3 us every time (tools/probes/taskset_ab.sh).  The library therefore places ITS OWN threads
-// (submission threads, sampler workers: bsr_internal_place_thread, called by each of them) on the L3 domain the
-// context was created from -- with several ranks on the node (LOCAL_RANK / LOCAL_WORLD_SIZE) the domains of the
-// allowed CPUs are dealt evenly by local rank.  The CALLER's affinity is not touched: a drop-in library must not
-// narrow the CPU set of the host application's later threads.  A process that wants the whole effect for itself
-// (bench.py does) sets BSR_PIN=1: the calling thread is then confined too, once per process.  BSR_PIN=0: no placement
-// at all; BSR_PIN_CPUS="0-7,128-135": this list instead of an L3 domain.
-static cpu_set_t g_lib_cpus;
-static std::atomic<bool> g_lib_cpus_ok{false};
-static void choose_lib_cpus() {
-  static std::atomic<bool> done{false};
-  if (done.exchange(true)) return;
-  const int mode = env_int("BSR_PIN", -1);   // -1 (unset): the library's threads only; 0: nothing; 1: the caller as well
-  if (mode == 0) return;
-  cpu_set_t allowed, want;
-  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
-  CPU_ZERO(&want);
-  const char* list = getenv("BSR_PIN_CPUS");
-  if (list && *list) {
-    if (!parse_cpulist(list, &want)) return;
-  } else {
-    const int lr = env_int("LOCAL_RANK", -1), lw = env_int("LOCAL_WORLD_SIZE", env_int("WORLD_SIZE", 1));
-    if (lw > 1 && lr >= 0) {
-      std::vector<cpu_set_t> doms;
-      cpu_set_t seen;
-      CPU_ZERO(&seen);
-      for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
-        if (!CPU_ISSET(cpu, &allowed) || CPU_ISSET(cpu, &seen)) continue;
-        cpu_set_t dset;
-        if (!l3_domain_of(cpu, &dset)) return;
-        CPU_OR(&seen, &seen, &dset);
-        doms.push_back(dset);
-      }
-      if (doms.empty()) return;
-      const size_t nd = doms.size();
-      want = doms[nd >= (size_t)lw ? ((size_t)lr * nd) / (size_t)lw : (size_t)lr % nd];
-    } else {
-      const int cpu = sched_getcpu();
-      if (cpu < 0 || !l3_domain_of(cpu, &want)) return;
-    }
-  }
-  CPU_AND(&want, &want, &allowed);
-  if (CPU_COUNT(&want) < 4) return;   // not worth it (and a submission thread needs a core of its own)
-  g_lib_cpus = want;
-  g_lib_cpus_ok.store(true, std::memory_order_release);
-  if (mode == 1 && sched_setaffinity(0, sizeof want, &want) == 0) g_pinned.store(true);
-}
-// called by every thread the library starts: confines that thread (and nothing else) to the library's CPUs
-__attribute__((visibility("hidden"))) void bsr_internal_place_thread() {
-  if (!g_lib_cpus_ok.load(std::memory_order_acquire)) return;
-  (void)pthread_setaffinity_np(pthread_self(), sizeof g_lib_cpus, &g_lib_cpus);
 }
 
 extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X, const double* y,
@@ -718,36 +409,7 @@ static void note_current_tree(bsr_ctx* c, int chain, int k, const bsr_node* t, i
   c->span[chain] = b;
 }
 
-static inline bool is_binary_op(int op) {
-  return op == BSR_OP_ADD || op == BSR_OP_MUL || op == BSR_OP_SUB || op == BSR_OP_DIV;
-}
-
-static int check_tape(bsr_ctx* c, const bsr_node* t, int len, int* max_sp) {
-  if (len <= 0) return fail(c, BSR_E_TAPE, "empty tape");
-  if (len > BSR_MAX_TAPE) return fail(c, BSR_E_TOOBIG, "tape longer than BSR_MAX_TAPE");
-  int sp = 0, mx = 0;
-  for (int i = 0; i < len; ++i) {
-    const int op = t[i].opcode;
-    if (op == BSR_OP_TERMINAL) {
-      if (t[i].feature < 0 || t[i].feature >= c->d) return fail(c, BSR_E_TAPE, "terminal feature out of range");
-      ++sp;
-    } else if ((op >= 0 && op < BSR_OP_ADD) || op == BSR_OP_LOG) {
-      if (sp < 1) return fail(c, BSR_E_TAPE, "unary operator on empty stack");
-    } else if (is_binary_op(op)) {
-      if (sp < 2) return fail(c, BSR_E_TAPE, "binary operator needs two operands");
-      --sp;
-    } else {
-      return fail(c, BSR_E_TAPE, "unknown opcode");
-    }
-    mx = std::max(mx, sp);
-  }
-  if (sp != 1) return fail(c, BSR_E_TAPE, "tape does not reduce to one value");
-  if (mx > BSR_MAX_STACK) return fail(c, BSR_E_TOOBIG, "tape needs a deeper stack than BSR_MAX_STACK");
-  *max_sp = mx;
-  return BSR_OK;
-}
-
-static int ensure_input(bsr_ctx* c, BatchSlot& s, size_t stream_words) {
+int ensure_input(bsr_ctx* c, BatchSlot& s, size_t stream_words) {
   const size_t need = s.off_streams + stream_words * 8;
   if (need <= s.in_cap) return BSR_OK;
   const size_t cap = std::max(need, std::max(s.off_streams + (size_t)64 * 1024, s.in_cap * 2));
@@ -820,502 +482,6 @@ static int ensure_partials(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P,
     }
   }
   return BSR_OK;
-}
-
-// Operand order of the commutative operators in the streams.  A bare terminal (or a `terminal, unary op` pair that
-// became a derived column) as the SECOND operand of + or * fuses with the operator into one stream entry
-// (BSR_SOP_ADD_T / BSR_SOP_MUL_T) and needs no stack slot; as the first operand, with anything else second, it is
-// pushed and popped.  So where exactly the first operand is such a terminal the two subtrees trade places
-// (x3 + ln(x1) is written `x1 ln x3 +`): a + b == b + a and a * b == b * a bit for bit, the value of every row is
-// unchanged, and almost every tape of the real move mix becomes a chain (bsr_device.h: chain_eval).
-// `admitted(j)`: nodes j, j+1 are a `terminal, unary op` pair whose derived column this batch uses.
-// Writes the reordered tape to `out` (may alias nothing of `t`) and returns true, or returns false: order kept.
-template <typename Admitted>
-static bool reorder_tape(const bsr_node* t, int len, bsr_node* out, std::vector<int32_t>& kid, std::vector<int32_t>& stk,
-                         const Admitted& admitted) {
-  if (len < 4) return false;   // the shortest tape with something to swap: T, T, op, +
-  // pass 1: children of every node, "is one terminal entry" per subtree; is there anything to swap at all?
-  kid.resize((size_t)len * 2);
-  stk.clear();
-  bool any = false;
-  // kid[2j], kid[2j+1]: roots of the left / right subtree (-1: none); termlike(j): the subtree is one terminal entry
-  auto termlike = [&](int j) {
-    if (t[j].opcode == BSR_OP_TERMINAL) return true;
-    return j > 0 && t[j - 1].opcode == BSR_OP_TERMINAL && kid[2 * j] == j - 1 && kid[2 * j + 1] < 0 && admitted(j - 1);
-  };
-  for (int j = 0; j < len; ++j) {
-    const int op = t[j].opcode;
-    kid[2 * j] = kid[2 * j + 1] = -1;
-    if (op == BSR_OP_TERMINAL) {
-      stk.push_back(j);
-    } else if (op == BSR_OP_ADD || op == BSR_OP_MUL || op == BSR_OP_SUB || op == BSR_OP_DIV) {
-      if (stk.size() < 2) return false;
-      const int r = stk.back();
-      stk.pop_back();
-      const int l = stk.back();
-      kid[2 * j] = l;
-      kid[2 * j + 1] = r;
-      stk.back() = j;
-      if ((op == BSR_OP_ADD || op == BSR_OP_MUL) && termlike(l) && !termlike(r)) any = true;
-    } else {
-      if (stk.empty()) return false;
-      kid[2 * j] = stk.back();
-      stk.back() = j;
-    }
-  }
-  if (!any || stk.size() != 1) return false;
-  // pass 2: post-order walk from the root with the swapped child order (explicit stack; entry = node, or ~node once its
-  // children have been pushed)
-  int n_out = 0;
-  stk.clear();
-  stk.push_back(len - 1);
-  while (!stk.empty()) {
-    const int e = stk.back();
-    stk.pop_back();
-    if (e < 0) {
-      out[n_out++] = t[~e];
-      continue;
-    }
-    const int l = kid[2 * e], r = kid[2 * e + 1];
-    if (l < 0) {
-      out[n_out++] = t[e];
-      continue;
-    }
-    stk.push_back(~e);
-    if (r < 0) {
-      stk.push_back(l);
-    } else {
-      const int op = t[e].opcode;
-      const bool swap = (op == BSR_OP_ADD || op == BSR_OP_MUL) && termlike(l) && !termlike(r);
-      // popped first = evaluated first
-      if (swap) { stk.push_back(l); stk.push_back(r); }
-      else { stk.push_back(r); stk.push_back(l); }
-    }
-  }
-  return n_out == len;
-}
-
-// Tapes by cost, heaviest first, equal costs in batch order: one key per tape, sorted in place (std::stable_sort
-// allocates a buffer on every call: two of them were a tenth of the caller's time per batch).
-template <typename CostOf>
-static void cost_order(std::vector<int>& order, std::vector<uint32_t>& keys, int n, const CostOf& cost_of) {
-  keys.resize((size_t)n);
-  for (int i = 0; i < n; ++i) keys[i] = ((uint32_t)(65535 - std::min(65535, std::max(0, cost_of(i)))) << 16) | (uint32_t)(i & 0xFFFF);
-  std::sort(keys.begin(), keys.end());
-  order.resize((size_t)n);
-  for (int i = 0; i < n; ++i) order[i] = (int)(keys[i] & 0xFFFFu);
-}
-
-// Validates the tapes, chooses LDS staging, and writes the compact streams the interpreter reads into the slot's
-// pinned input block:
-//   opcode stream  : 4 bits per entry, 16 per 64-bit word, one padding word per tape; an entry is a tape node, or a
-//                    `terminal, +|*` pair fused into BSR_SOP_ADD_T / BSR_SOP_MUL_T
-//   column stream  : 16 bits per terminal in tape order (LDS slot when staging, else the X column), 4 per word,
-//                    padded with a valid id so the kernel may request one terminal past the end
-//   ln stream      : (a,b) per ln node in tape order plus one padding pair
-static int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* tape_off, int n,
-                       std::vector<TapeLoc>* loc, int tile_chains = 0) {
-  if (!rows || !tape_off || n <= 0) return fail(c, BSR_E_ARG, "null tapes / empty batch");
-  if (n > c->max_batch) return fail(c, BSR_E_TOOBIG, "batch larger than max_batch");
-  if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
-  loc->resize(n);
-  s.order_n = -1;
-  size_t cw = 0, fw = 0, lw = 0;
-  int max_fused_sp = 0;
-  std::fill(s.slot_of.begin(), s.slot_of.end(), -1);
-  // How many derived columns this batch may use.  A context that scores through the tile pass must keep the batch's
-  // columns inside LDS: the allowance is what the slice leaves after y, the chains' bases and every X column the tapes
-  // name (an upper bound of what stays in use).  Derived columns are admitted in tape order until it is spent; the
-  // values do not depend on which are (same routine either way), so neither do the results.
-  // (not with the LDS-staging variant of k_rows, BSR_NO_LDS=0: there the column count picks the row-block size, and the
-  // block size fixes the order of the sums)
-  const bool derive = c->derived_ready && c->n_cols > c->d && c->no_lds;
-  int allowance = derive ? c->n_cols : 0;
-  if (derive && c->tile_on && tile_chains > 0) {
-    int n_base = 0;
-    if (c->tile_whole) {   // (chunked contexts: the allowance does not depend on the batch's base columns)
-      for (int j = 0; j < tape_off[n]; ++j)
-        if (rows[j].opcode == BSR_OP_TERMINAL && rows[j].feature >= 0 && rows[j].feature < c->d &&
-            s.slot_of[rows[j].feature] < 0) {
-          s.slot_of[rows[j].feature] = 0;
-          ++n_base;
-        }
-      std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
-    }
-    const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
-    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
-    long room = (long)fit - fixed;
-    if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
-    // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
-    if (room >= 0) allowance = (int)std::min<long>(room, c->n_cols);
-    allowance = std::min(allowance, c->derived_max);
-  }
-  s.derived_used = 0;
-  // Which derived columns: the ones that save the most.  One pass over the batch adds up, per (op, feature), the
-  // interpreter cost of the op on every `terminal f, op` it would replace; the `allowance` best are admitted (ties: the
-  // lower column), a single cheap use (neg, square) is not worth a column.  -2 marks an admitted column until the main
-  // pass below gives it its place.
-  if (derive && allowance > 0) {
-    std::vector<std::pair<int, int>>& cand = s.derived_cand;   // (benefit, column)
-    cand.clear();
-    std::vector<int>& ben = s.derived_benefit;
-    if ((int)ben.size() < c->n_cols) ben.assign(c->n_cols, 0);
-    for (int j = 0; j + 1 < tape_off[n]; ++j) {
-      if (rows[j].opcode != BSR_OP_TERMINAL || rows[j].feature < 0 || rows[j].feature >= c->d) continue;
-      const int op = rows[j + 1].opcode, m = derived_index(op);
-      if (m < 0) continue;
-      const int dc = c->d * (1 + m) + rows[j].feature;
-      const int w = (op == BSR_OP_SIN || op == BSR_OP_COS) ? 77 : (op == BSR_OP_EXP) ? 59 : (op == BSR_OP_LOG) ? 90
-                    : (op == BSR_OP_INV) ? 35 : (op == BSR_OP_CUBIC) ? 23 : 3;   // the operator's cost (stage_tapes' cost model)
-      if (ben[dc] == 0) cand.push_back({0, dc});
-      ben[dc] += w;
-    }
-    // (a `terminal, op` pair that straddles two tapes cannot occur: a tape never ends in a terminal unless it is one)
-    for (auto& cd : cand) {
-      cd.first = ben[cd.second];
-      ben[cd.second] = 0;
-    }
-    std::sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
-      return a.first != b.first ? a.first > b.first : a.second < b.second;
-    });
-    // worth a column: one use of cubic or anything dearer where the slice is staged from L2; where it streams from HBM
-    // (8 bytes per row and group that uses it), an operator of 17 instructions or more per value
-    const int worth = c->tile_whole ? 15 : 35;
-    for (size_t q = 0; q < cand.size() && (int)q < allowance; ++q)
-      if (cand[q].first >= worth) s.slot_of[cand[q].second] = -2;
-  }
-  // Pass 1: validation, sizes, the columns in use.  A tape whose fused encoding still pushes more than one terminal
-  // (it is not a chain) is tried once more with its commutative operands in fusing order (reorder_tape): few tapes
-  // get there, so the reordering costs the batch next to nothing.
-  if ((int)s.tape_src.size() < n) s.tape_src.resize((size_t)n);
-  for (int i = 0; i < n; ++i) {
-    const int len = tape_off[i + 1] - tape_off[i];
-    TapeLoc& L = (*loc)[i];
-    const bsr_node* t = rows + tape_off[i];
-    int rc = check_tape(c, t, len, &L.max_sp);
-    if (rc != BSR_OK) return rc;
-    int nt = 0, nl = 0, fmx = 0, n_push = 0;
-    auto scan = [&](const bsr_node* tp) {
-      nt = nl = fmx = n_push = 0;
-      int fsp = 0;  // stack depth with `terminal, +|*` pairs fused (what the kernels run)
-      for (int j = 0; j < len; ++j) {
-        if (tp[j].opcode == BSR_OP_TERMINAL) {
-          ++nt;
-          int col = tp[j].feature;
-          if (derive && j + 1 < len) {   // `terminal, unary op` -> the op's derived column
-            const int m = derived_index(tp[j + 1].opcode);
-            if (m >= 0) {
-              const int dc = c->d * (1 + m) + col;
-              if (s.slot_of[dc] == -2 || s.slot_of[dc] == 0) {   // admitted above
-                if (s.slot_of[dc] == -2) ++s.derived_used;
-                col = dc;
-                ++j;
-              }
-            }
-          }
-          s.slot_of[col] = 0;
-          const int nxt = (j + 1 < len) ? tp[j + 1].opcode : -1;
-          if (nt > 1 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) ++j; else { ++fsp; ++n_push; }
-        } else if (tp[j].opcode == BSR_OP_LN) {
-          ++nl;
-        } else if (is_binary_op(tp[j].opcode)) {
-          --fsp;
-        }
-        fmx = std::max(fmx, fsp);
-      }
-    };
-    scan(t);
-    s.tape_src[i] = t;
-    if (c->reorder && n_push > 1 && len >= 4) {
-      auto admitted = [&](int j) {   // nodes j, j+1: `terminal, unary op` served by a derived column of this batch
-        if (!derive || j + 1 >= len) return false;
-        const int m = derived_index(t[j + 1].opcode), f = t[j].feature;
-        if (m < 0 || f < 0 || f >= c->d) return false;
-        const int sl = s.slot_of[c->d * (1 + m) + f];
-        return sl == -2 || sl == 0;
-      };
-      if ((int)s.rows_perm.size() < tape_off[n]) {
-        // (pointers into the copy handed out for earlier tapes must survive: size it once for the whole batch)
-        std::vector<bsr_node> grown((size_t)tape_off[n]);
-        for (int q = 0; q < i; ++q)
-          if (s.tape_src[q] != rows + tape_off[q]) {
-            memcpy(grown.data() + tape_off[q], s.tape_src[q], (size_t)(tape_off[q + 1] - tape_off[q]) * sizeof(bsr_node));
-            s.tape_src[q] = grown.data() + tape_off[q];
-          }
-        s.rows_perm.swap(grown);
-      }
-      if (reorder_tape(t, len, s.rows_perm.data() + tape_off[i], s.perm_kid, s.perm_stack, admitted)) {
-        s.tape_src[i] = s.rows_perm.data() + tape_off[i];
-        scan(s.tape_src[i]);
-      }
-    }
-    max_fused_sp = std::max(max_fused_sp, fmx);
-    L.n_nodes = len;
-    L.code_off = (int)cw;
-    L.feat_off = (int)fw;
-    L.ln_off = (int)lw;
-    cw += (size_t)(len + 15) / 16 + 1;
-    fw += (size_t)(nt + 1 + 3) / 4 + 1;
-    lw += (size_t)nl + 1;
-  }
-  const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t)) / 8 + 32;
-  int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw + rec_words);
-  if (rc != BSR_OK) return rc;
-  s.off_recs = (s.off_streams + (cw + 2 * fw + 2 * lw) * 8 + 127) / 128 * 128;
-  s.recs_bytes = 0;
-  // columns of X referenced by this batch -> LDS slots (ascending feature order)
-  s.nF = 0;
-  int32_t* hfeat = s.h_feat();
-  for (int f = 0; f < c->n_cols; ++f)
-    if (s.slot_of[f] == 0) {
-      s.slot_of[f] = s.nF;
-      hfeat[s.nF++] = f;
-    }
-  const size_t lds_budget = 64 * 1024;
-  s.use_lds = false;
-  s.rb_rows = c->rb_rows;
-  if (!c->no_lds) {
-    for (int rb = c->rb_rows; rb >= 64 * c->rows_per_lane && rb >= 256; rb >>= 1) {
-      if ((size_t)(s.nF + 1) * rb * c->esz <= lds_budget) {
-        s.use_lds = true;
-        s.rb_rows = rb;
-        break;
-      }
-    }
-  }
-  s.tile = false;
-  s.tile_chains = tile_chains;
-  s.code_words = cw;
-  s.feat_words = fw;
-  s.ln_words = 2 * lw;
-  uint64_t* hc = s.h_streams();
-  uint64_t* hf = hc + cw;
-  double* hl = reinterpret_cast<double*>(hf + fw);
-  uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + 2 * lw);  // tile pass: the column stream in LDS slots
-  memset(hc, 0, (cw + fw) * 8);
-  for (int i = 0; i < n; ++i) {
-    const TapeLoc L = (*loc)[i];
-    uint64_t* pc = hc + L.code_off;
-    uint64_t* pf = hf + L.feat_off;
-    double* pl = hl + 2 * (size_t)L.ln_off;
-    const bsr_node* tsrc = s.tape_src[i];
-    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 23;
-    int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
-    uint8_t ss_codes[64];
-    int ss_n = 0;
-    for (int j = 0; j < L.n_nodes; ++j) {
-      const bsr_node& r = tsrc[j];
-      int code = r.opcode & 15;
-      if (r.opcode == BSR_OP_TERMINAL) {
-        int col = r.feature;
-        if (derive && j + 1 < L.n_nodes) {   // the column pass 1 admitted for `terminal, unary op` (slot assigned)
-          const int m = derived_index(tsrc[j + 1].opcode);
-          if (m >= 0 && s.slot_of[c->d * (1 + m) + col] >= 0) {
-            col = c->d * (1 + m) + col;
-            ++j;
-          }
-        }
-        const uint64_t id = (uint64_t)(s.use_lds ? s.slot_of[col] : col);
-        pf[nt >> 2] |= id << (16 * (nt & 3));
-        ++nt;
-        // a terminal consumed at once by + or * (the lighter child in the tape's heavy-child-first order) becomes
-        // one stream entry: acc = acc op X[:,f], no push/pop
-        const int nxt = (j + 1 < L.n_nodes) ? tsrc[j + 1].opcode : -1;
-        if (ns > 0 && (nxt == BSR_OP_ADD || nxt == BSR_OP_MUL)) {
-          code = (nxt == BSR_OP_ADD) ? BSR_SOP_ADD_T : BSR_SOP_MUL_T;
-          ++j;
-        } else {
-          ++sp;
-          ++n_push;
-        }
-      } else if (r.opcode == BSR_OP_LN) {
-        pl[2 * nl] = r.a;
-        pl[2 * nl + 1] = r.b;
-        ++nl;
-      } else if (is_binary_op(r.opcode)) {
-        --sp;
-        ++n_stack_ops;
-      }
-      mx = std::max(mx, sp);
-      pc[ns >> 4] |= (uint64_t)code << (4 * (ns & 15));
-      ++ns;
-      if (g_stream_stats) ss_codes[ss_n < 64 ? ss_n++ : 63] = (uint8_t)code;
-      // vector instructions per 64 rows of the tile pass's chain evaluator, in halves (ISA listing of k_tile1 / k_tile):
-      // a fused terminal 1.5 (its reads are LDS work), neg / square 1.5, ln 2.5, cubic 11.5, inv 17.5, exp 29.5,
-      // sin / cos 38.5 (31 of arithmetic, the huge-argument test, the call's register moves), log 45, a pushed terminal or
-      // a popping operator 3 (operand copies of the stack machine); each includes ~0.5 for its decode.  The base 11.5
-      // is the projection sums (7), the pass's set-up and the block's share of the lane reduction.
-      cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 3
-              : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 6 : 0)
-              : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 77
-              : (r.opcode == BSR_OP_EXP) ? 59 : (r.opcode == BSR_OP_LOG) ? 90
-              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 35 : (r.opcode == BSR_OP_CUBIC) ? 23
-              : (r.opcode == BSR_OP_LN) ? 5 : is_binary_op(r.opcode) ? 6 : 3;
-    }
-    (*loc)[i].n_stream = ns;
-    (*loc)[i].nt = nt;
-    (*loc)[i].nl = nl;
-    (*loc)[i].grp = 0;
-    (*loc)[i].cost = cost;
-    (*loc)[i].max_sp = mx;
-    (*loc)[i].acc_only = (c->chain_eval && n_push == 1 && n_stack_ops == 0) ? 1 : 0;
-    if (g_stream_stats) {
-      const int kind = (*loc)[i].acc_only ? 0 : 1;
-      g_ss_tapes[kind].fetch_add(1, std::memory_order_relaxed);
-      for (int q = 0; q < ss_n; ++q) g_ss_entries[kind][ss_codes[q]].fetch_add(1, std::memory_order_relaxed);
-    }
-    pl[2 * nl] = 1.0;
-    pl[2 * nl + 1] = 0.0;
-    if (!s.use_lds) {  // padding ids must name a valid column: repeat the first terminal's
-      const uint64_t id0 = pf[0] & 0xFFFFu;
-      const int words = (nt + 1 + 3) / 4 + 1;
-      for (int t = nt; t < words * 4; ++t) pf[t >> 2] |= id0 << (16 * (t & 3));
-    }
-  }
-  s.tile_possible = c->tile_on && c->tile_ever && tile_chains > 0 && max_fused_sp - 1 <= BSR_REG_STACK && !s.use_lds;
-  if (g_stream_stats) {
-    g_ss_batches.fetch_add(1, std::memory_order_relaxed);
-    g_ss_derived.fetch_add(s.derived_used, std::memory_order_relaxed);
-    g_ss_cols.fetch_add(s.nF, std::memory_order_relaxed);
-  }
-  return BSR_OK;
-}
-
-// Second half of staging a scoring batch for the tile pass: the tape groups, their LDS slot maps and column-pointer
-// tables, and the column stream in LDS slots; the descriptors learn their group and the slot of their chain's basis.
-// It needs nothing from the caller but what stage_tapes left in the slot, so it runs wherever the batch's launches
-// are issued -- on a submission thread where the context has one: 1.5 us off the caller's path per batch.
-static void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
-  std::vector<TapeLoc>& loc = s.loc_tmp;
-  const int tile_chains = s.tile_chains;
-  uint64_t* hc = s.h_streams();
-  uint64_t* hf = hc + s.code_words;
-  double* hl = reinterpret_cast<double*>(hf + s.feat_words);
-  uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + s.ln_words);  // the column stream in LDS slots
-  const size_t fw = s.feat_words;
-  s.tile = false;
-  if (!s.tile_possible || (int)loc.size() < n) return;
-  // ---- tile pass: tape groups, their LDS slot maps and column-pointer tables, the column stream in LDS slots.
-  // No tape may need more value-stack slots than the register stack holds.
-  {
-    const int T = c->tile_T, K = c->K;
-    const int cap = (n + T - 1) / T;   // tapes per group at most (keeps the groups' passes even)
-    // tapes by cost, heaviest first (stable: equal costs keep batch order)
-    cost_order(s.order_tmp, s.order_keys, n, [&](int i) { return loc[i].cost; });
-    s.order_n = n;
-    if ((int)s.grp_slot.size() < T * c->n_cols) s.grp_slot.resize((size_t)T * c->n_cols);
-    std::fill(s.grp_slot.begin(), s.grp_slot.begin() + (size_t)T * c->n_cols, (int16_t)-1);
-    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long total_cost = 0;
-    for (int i = 0; i < n; ++i) total_cost += loc[i].cost;
-    const long share = total_cost / T + total_cost / (8 * T) + 1;   // an even share of the batch's cost and an eighth
-    auto tape_cols = [&](int i, auto&& fn) {   // the columns tape i reads, in stream order
-      const uint64_t* pf = hf + loc[i].feat_off;
-      for (int t = 0; t < loc[i].nt; ++t) fn((int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu));
-    };
-    for (int oi = 0; oi < n; ++oi) {
-      const int i = s.order_tmp[oi];
-      int g = 0;
-      if (T > 1 && c->tile_whole) {
-        // the slice sits in LDS whole: columns are cheap, balance the cost -- dealt back and forth (0 1 1 0 ...), so that
-        // no group gets the heavier tape of every round (LPT inside the group follows)
-        const int r = oi / T, k = oi - r * T;
-        g = (r & 1) ? T - 1 - k : k;
-      } else if (T > 1) {
-        // chunked: every column of a group costs LDS (shorter chunks) and HBM traffic (the group streams it over all
-        // rows), and the launch ends with its heaviest group: among the groups this tape does not lift above an even
-        // share of the cost, the one that needs the fewest new columns for it; failing that, the lightest
-        int best_new = 1 << 30;
-        g = -1;
-        for (int gi = 0; gi < T; ++gi) {
-          if (cnt[gi] >= cap || load[gi] + loc[i].cost > share) continue;
-          int n_new = 0;
-          tape_cols(i, [&](int col) { if (s.grp_slot[(size_t)gi * c->n_cols + col] < 0) ++n_new; });
-          if (g < 0 || n_new < best_new || (n_new == best_new && load[gi] < load[g])) { best_new = n_new; g = gi; }
-        }
-        if (g < 0) {
-          for (int gi = 0; gi < T; ++gi)
-            if (cnt[gi] < cap && (g < 0 || load[gi] < load[g])) g = gi;
-        }
-      }
-      loc[i].grp = g;
-      ++cnt[g];
-      load[g] += loc[i].cost;
-      tape_cols(i, [&](int col) {
-        int16_t& sl = s.grp_slot[(size_t)g * c->n_cols + col];
-        if (sl < 0) { sl = 0; ++ncol[g]; }
-      });
-    }
-    // slots in ascending column order per group; the group's table: X columns, y, every chain's basis
-    const void** hcols = s.h_cols();
-    int max_ncols = 0;
-    for (int g = 0; g < T; ++g) {
-      int nf = 0;
-      for (int col = 0; col < c->n_cols; ++col) {
-        int16_t& sl = s.grp_slot[(size_t)g * c->n_cols + col];
-        if (sl < 0) continue;
-        sl = (int16_t)nf;
-        hcols[(size_t)g * s.cols_stride + nf] = col_ptr(c, c->Xt, col);
-        ++nf;
-      }
-      s.grp_nF[g] = nf;
-      hcols[(size_t)g * s.cols_stride + nf] = c->y;
-      for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
-        for (int k = 0; k < K; ++k)
-          hcols[(size_t)g * s.cols_stride + nf + 1 + ci * K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * K + k);
-      max_ncols = std::max(max_ncols, nf + 1 + tile_chains * K);
-    }
-    // the whole slice in LDS at once, or chunks through two buffers (f32: one, staged through registers): as many
-    // blocks as fit, a whole number of chain passes where there is room for one
-    const size_t budget = tile_lds_bytes_max() - 1024;
-    const size_t per_block = (size_t)max_ncols * BSR_TILE_BLOCK * c->esz;
-    int chunk = 0, ring = 1;
-    static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hooks: chunks of at most this many blocks,
-    static const int force_ring = env_int("BSR_TILE_RING", 0);     // a ring of this many buffers
-    if (per_block * (size_t)c->tile_bps <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
-      chunk = c->tile_bps;
-    } else if (c->esz == 4) {   // f32: one buffer, staged through registers
-      chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / per_block);
-      if (chunk >= BSR_TILE_NB) chunk = chunk / BSR_TILE_NB * BSR_TILE_NB;
-      if (force_chunk > 0) chunk = std::min(chunk, force_chunk);
-    } else {
-      // a ring of buffers, ring - 1 chunks in flight while the waves compute on one: what is in flight keeps HBM busy,
-      // so prefer the deepest ring that still leaves chunks of two blocks (a chain pass of four values per lane)
-      const int room = (int)(budget / per_block);   // blocks of all columns LDS holds
-      if (room >= 8) { ring = 4; chunk = room / 4 >= BSR_TILE_NB ? BSR_TILE_NB : 2; }
-      else if (room >= 6) { ring = 3; chunk = 2; }
-      else if (room >= 4) { ring = 2; chunk = 2; }
-      else if (room >= 2) { ring = 2; chunk = 1; }
-      if (force_ring >= 2 && force_ring <= 4 && room >= force_ring) { ring = force_ring; chunk = std::max(1, std::min(room / ring, BSR_TILE_NB)); }
-      if (force_chunk > 0 && chunk > 0) chunk = std::min(chunk, force_chunk);
-      chunk = std::min(chunk, c->tile_bps);
-    }
-    if (chunk >= 1 && max_ncols < 32768) {
-      s.tile = true;
-      s.tile_ncols = max_ncols;
-      s.tile_chunk = chunk;
-      s.tile_ring = ring;
-      memset(hf2, 0, fw * 8);
-      for (int i = 0; i < n; ++i) {
-        const TapeLoc& L = loc[i];
-        const uint64_t* pf = hf + L.feat_off;
-        uint64_t* pf2 = hf2 + L.feat_off;
-        const int16_t* map = s.grp_slot.data() + (size_t)L.grp * c->n_cols;
-        const int words = (L.nt + 1 + 3) / 4 + 1;   // the padding ids repeat the first terminal's
-        for (int t = 0; t < words * 4; ++t) {
-          const int col = (int)((pf[t >> 2] >> (16 * (t & 3))) & 0xFFFFu);
-          pf2[t >> 2] |= (uint64_t)(uint16_t)map[col] << (16 * (t & 3));
-        }
-      }
-    }
-  }
-  if (!s.tile) return;
-  PropDesc* hd = s.h_desc();
-  for (int i = 0; i < n; ++i) {
-    hd[i].grp = loc[i].grp;
-    hd[i].qslot = s.grp_nF[loc[i].grp] + 1 + s.chain_slot[hd[i].ck] * c->K;   // slot of the chain's basis in the group's LDS map
-  }
 }
 
 static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
@@ -1403,109 +569,6 @@ struct TailJob {
   double rank_floor;
 };
 static void launcher_push(bsr_ctx* c, const TailJob& job);
-
-// Geometry, schedule and tape records of a tile launch (after stage_tile): runs with the batch's launches.
-static int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
-  TileGeom& tg = *tgp;
-  memset(&tg, 0, sizeof tg);
-  PropDesc* hd = s.h_desc();
-  const int n_part = c->tile_slices + c->tile_left;
-  if (s.order_n != P) cost_order(s.order_tmp, s.order_keys, P, [&](int i) { return hd[i].cost; });
-  {
-    // geometry of this launch: the context's slices, the chunk the batch's columns leave room for, and the schedule:
-    // inside its group a tape goes -- heaviest first -- to the wave with the least work so far that still has a free
-    // set of sums (waves w, w+4, w+8, w+12 share a SIMD, but a light wave frees issue slots for its SIMD mates, so
-    // per-wave balance is what is worth having)
-    tg.T = c->tile_T;
-    tg.n_slices = c->tile_slices;
-    tg.bps = c->tile_bps;
-    tg.n_blocks = c->tile_blocks;
-    tg.n_left = c->tile_left;
-    tg.n_part = n_part;
-    tg.ncols = s.tile_ncols;
-    tg.ncols_fixed = s.tile_chains * c->K;
-    tg.chunk_blocks = s.tile_chunk;
-    tg.ring = s.tile_ring;
-    tg.qmax = c->tile_qmax;
-    int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];
-    int most = 0;
-    for (int gi = 0; gi < tg.T; ++gi) most = std::max(most, cnt_g[gi]);
-    const int per_pass = BSR_TILE_WAVES * tg.qmax;
-    tg.n_pass = std::max(1, (most + per_pass - 1) / per_pass);
-    const int slots_per_wave = tg.n_pass * tg.qmax;
-    const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
-    if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
-    TapeRec* sc = s.h_sched();
-    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps ? most : 0;   // whole slice: the waves pull from the group's list
-    s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
-    for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
-    int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)
-    const uint64_t* hcodes = s.h_streams();
-    const uint64_t* hfeats = hcodes + s.code_words;
-    const double* hln = reinterpret_cast<const double*>(hfeats + s.feat_words);
-    const uint64_t* hfeats_lds = reinterpret_cast<const uint64_t*>(hln + s.ln_words);
-    s.wave_load.assign((size_t)tg.T * BSR_TILE_WAVES, 0.0);
-    s.wave_cnt.assign((size_t)tg.T * BSR_TILE_WAVES, 0);
-    for (int i = 0; i < P; ++i) {
-      const int p = s.order_tmp[i];
-      const PropDesc& D = hd[p];
-      const int grp = D.grp;
-      if (grp < 0 || grp >= tg.T) return fail(c, BSR_E_STATE, "tile schedule: tape group out of range");
-      size_t ri;
-      if (tg.per_group > 0) {
-        // the waves pull their tapes: where in the group's share of the record array a record sits does not matter
-        ri = (size_t)grp * tg.n_pass * per_pass + (size_t)s.wave_cnt[grp * BSR_TILE_WAVES]++;
-      } else {
-        int best = -1;
-        for (int w = 0; w < BSR_TILE_WAVES; ++w) {
-          const int idx = grp * BSR_TILE_WAVES + w;
-          if (s.wave_cnt[idx] >= slots_per_wave) continue;
-          if (best < 0 || s.wave_load[idx] < s.wave_load[grp * BSR_TILE_WAVES + best]) best = w;
-        }
-        if (best < 0) return fail(c, BSR_E_STATE, "tile schedule: no free set of sums");
-        const int idx = grp * BSR_TILE_WAVES + best;
-        const int slot = s.wave_cnt[idx]++;
-        const int pass = slot / tg.qmax, q = slot % tg.qmax;
-        ri = (((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q;
-        s.wave_load[idx] += (double)D.cost;
-      }
-      left_idx[i] = (int32_t)ri;
-      // the tape's record: what the wave needs to start it, and the heads of its streams (a long tape reads on from them)
-      TapeRec& R = sc[ri];
-      R.p = p;
-      R.n_nodes = D.n_nodes;
-      R.chain = D.chain;
-      R.qslot = D.qslot;
-      R.s = D.s;
-      R.code0 = hcodes[D.code_off];
-      R.code1 = hcodes[D.code_off + 1];
-      R.f0 = hfeats_lds[D.feat_off];
-      R.f1 = hfeats_lds[D.feat_off + 1];
-      const double* pl = hln + 2 * (size_t)D.ln_off;
-      for (int t = 0; t < 3; ++t) {   // (the stream holds n_ln pairs and a padding pair)
-        R.ln[2 * t] = (t <= D.n_ln) ? pl[2 * t] : 1.0;
-        R.ln[2 * t + 1] = (t <= D.n_ln) ? pl[2 * t + 1] : 0.0;
-      }
-      R.code_off = D.code_off;
-      R.feat_off = D.feat_off;
-      R.ln_off = D.ln_off;
-      R.n_ln = D.n_ln;
-      R.n_term = D.n_term;
-      R.grp = grp;
-    }
-    if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
-      int32_t* glist = left_idx + P;
-      for (size_t i = 0; i < (size_t)tg.T * tg.per_group; ++i) glist[i] = -1;
-      int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < P; ++i) {
-        const int grp = hd[s.order_tmp[i]].grp;
-        glist[(size_t)grp * tg.per_group + fill[grp]++] = left_idx[i];
-      }
-    }
-  }
-  return BSR_OK;
-}
 
 // Which candidates of the batch lie in the span of their chain's current columns by construction (bsr_span.h): the
 // tree they would replace again, the same with a negation moved, a linear combination of current trees.  k_solve then
@@ -2435,63 +1498,3 @@ extern "C" int bsr_last_timing(bsr_ctx* c, double* us5) {
   return BSR_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// RCCL: one communicator per process/GPU, one all-gather of fixed-size accepted-tree records.
-extern "C" int bsr_comm_unique_id(void* id128) {
-  if (!id128) return BSR_E_ARG;
-  static_assert(sizeof(ncclUniqueId) <= BSR_COMM_ID_BYTES, "ncclUniqueId larger than BSR_COMM_ID_BYTES");
-  ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return BSR_E_COMM;
-  memset(id128, 0, BSR_COMM_ID_BYTES);
-  memcpy(id128, &id, sizeof id);
-  return BSR_OK;
-}
-
-extern "C" int bsr_comm_init(bsr_ctx* c, int32_t nranks, int32_t rank, const void* id128) {
-  if (!c || !id128 || nranks <= 0 || rank < 0 || rank >= nranks) return BSR_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof id);
-  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
-  if (r != ncclSuccess) {
-    c->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
-    c->comm = nullptr;
-    return BSR_E_COMM;
-  }
-  return BSR_OK;
-}
-
-extern "C" int bsr_comm_allgather(bsr_ctx* c, const void* send, void* recv, int64_t bytes_per_rank) {
-  if (!c || !send || !recv || bytes_per_rank <= 0) return BSR_E_ARG;
-  if (!c->comm) return fail(c, BSR_E_STATE, "bsr_comm_allgather: communicator not initialised");
-  HIPCHK(c, hipSetDevice(c->device));
-  int nranks = 0;
-  ncclCommCount(c->comm, &nranks);
-  const size_t need = (size_t)bytes_per_rank * (nranks + 1);
-  if (need > c->comm_cap) {
-    if (c->comm_buf) HIPCHK(c, hipFree(c->comm_buf));
-    c->comm_buf = nullptr;
-    HIPCHK(c, hipMalloc(&c->comm_buf, need));
-    c->comm_cap = need;
-  }
-  char* dsend = (char*)c->comm_buf;
-  char* drecv = dsend + bytes_per_rank;
-  HIPCHK(c, hipMemcpyAsync(dsend, send, bytes_per_rank, hipMemcpyHostToDevice, c->stream));
-  ncclResult_t r = ncclAllGather(dsend, drecv, (size_t)bytes_per_rank, ncclChar, c->comm, c->stream);
-  if (r != ncclSuccess) {
-    c->err = std::string("ncclAllGather: ") + ncclGetErrorString(r);
-    return BSR_E_COMM;
-  }
-  HIPCHK(c, hipMemcpyAsync(recv, drecv, (size_t)bytes_per_rank * nranks, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return BSR_OK;
-}
-
-extern "C" int bsr_comm_destroy(bsr_ctx* c) {
-  if (!c) return BSR_E_ARG;
-  if (c->comm) {
-    ncclCommDestroy(c->comm);
-    c->comm = nullptr;
-  }
-  return BSR_OK;
-}

@@ -413,7 +413,7 @@ __device__ __forceinline__ WorkItem map_work(int n_rb, int n_pg, int w) {
 }
 
 // Evaluates one tape on the lane's U rows.  The tape arrives as three compact streams built by the host from the
-// bsr_node rows (bsr_api.hip: stage_tapes): 4-bit opcodes (16 per 64-bit word; `terminal, +|*` pairs arrive fused as
+// bsr_node rows (bsr_stage.hip: stage_tapes): 4-bit opcodes (16 per 64-bit word; `terminal, +|*` pairs arrive fused as
 // BSR_SOP_ADD_T / BSR_SOP_MUL_T), 16-bit column ids of the terminals
 // in tape order (4 per word) and the (a,b) pairs of the ln nodes.  They are read through the constant address space
 // (scalar loads) a whole word at a time, so the node loop itself is register-only: opcode, stack pointer and every

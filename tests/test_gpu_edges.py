@@ -406,7 +406,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 def test_a_repeat_with_a_negation_moved_scores_like_the_repeat_it_is(dtype, monkeypatch):
     """Candidates that are the tree they would replace with a negation moved -- cos(-x), (-a) b, (-x)^3, 1/(-x),
     sin(-x), a - b written -b + a, a (-A) + b as (-a) A + b -- compute the old column up to sign, bit for bit: the host
-    recognises them (canonical form with the signs carried to the root, bsr_api.hip) and k_solve takes w = 0 without the
+    recognises them (canonical form with the signs carried to the root, csrc/bsr_span.h) and k_solve takes w = 0 without the
     residual step.  With the recognition off (BSR_SELFDUP=0) they go through the residual step: the same bytes."""
     from bsr.tape import flatten
     rs = np.random.RandomState(5)

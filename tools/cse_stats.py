@@ -4,7 +4,7 @@ oracle as the scorer -- the same batch generation as tools/shape_stats.py).
 
 Every batch is B speculative proposals of ONE chain state: most candidates are the current tree with one subtree
 changed, so subtrees repeat across the batch's tapes.  Per batch, with the interpreter's cost of a node (the staging
-cost model of csrc/bsr_api.hip: stage_tapes, in half-instructions per row pair): total cost of all nodes; cost of the
+cost model of csrc/bsr_stage.hip: stage_tapes, in half-instructions per row pair): total cost of all nodes; cost of the
 DISTINCT subtrees (each computed once per batch -- the upper bound of any CSE: it ignores the column an intermediate
 would have to be stored in and read from); the part of the difference that derived columns (`terminal, unary op`
 pairs, admitted up to 8 per batch) already take.
@@ -22,7 +22,7 @@ for p in ("mcmc-symreg_amd", "oracle", "tests", ""):
 
 import numpy as np
 
-# cost of one node in the interpreter (half vector instructions per row pair; csrc/bsr_api.hip: stage_tapes)
+# cost of one node in the interpreter (half vector instructions per row pair; csrc/bsr_stage.hip: stage_tapes)
 COST = {"inv": 35, "ln": 5, "neg": 3, "sin": 77, "cos": 77, "exp": 59, "square": 3, "cubic": 23, "+": 6, "*": 6,
         "sub": 6, "div": 40, "log": 90}
 LOAD = 2       # a terminal: one LDS read

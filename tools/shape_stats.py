@@ -2,7 +2,7 @@
 """Stream-shape statistics of the real move mix (CPU only; test/tool infrastructure, uses the oracle as the scorer).
 
 Reproduces bench.py's batch generation (burn-in, frozen chain state, B speculative proposals per batch) with a CPU
-stand-in for the data side at a reduced N, encodes every tape the way csrc/bsr_api.hip: stage_tapes does
+stand-in for the data side at a reduced N, encodes every tape the way csrc/bsr_stage.hip: stage_tapes does
 (`terminal f, unary op` -> derived column, `terminal, +|*` -> fused entry) and prints how often each stream shape
 occurs -- the input of tools/gen_shapes.py (the straight-line evaluators of csrc/bsr_shapes.h).
 
