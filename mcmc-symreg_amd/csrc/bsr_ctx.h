@@ -111,6 +111,7 @@ struct BatchSlot {
   int tile_chunk = 0;                // blocks staged at a time: the whole slice, or a chunk of the ring
   int tile_ring = 1;                 // LDS buffers the chunks travel through (LDS-DMA)
   std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span_snap;   // [chain] the bases this batch was staged against
+  uint64_t bar_readback = 0;         // (sink of the read that closes a BAR upload)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
   std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
