@@ -725,7 +725,9 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       using std::integral_constant;
       while (NBIG > 4 && nb - b >= NBIG) pass(integral_constant<int, NBIG>{}, integral_constant<bool, true>{}, NBIG);
       while (nb - b >= 4) pass(integral_constant<int, 4>{}, integral_constant<bool, true>{}, 4);
-      if (b < nb) pass(integral_constant<int, 4>{}, integral_constant<bool, false>{}, nb - b);
+      // (what is left: a full pass of two blocks costs two blocks; a partial pass of four would cost four)
+      if (nb - b >= 2) pass(integral_constant<int, 2>{}, integral_constant<bool, true>{}, 2);
+      if (b < nb) pass(integral_constant<int, 2>{}, integral_constant<bool, false>{}, nb - b);
     } else {
       // Two blocks per interpreter pass (4 rows per lane): the scalar decode of a node is paid once per 256 rows.  The
       // per-lane sums still grow block by block in row order, so the result does not depend on the pairing.
