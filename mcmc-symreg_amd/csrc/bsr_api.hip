@@ -260,7 +260,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // tapes per wave instead of two (C2: 96 workgroups, 26.5 us alone instead of 192 at 19.7, but 2 600 instead of
       // 3 900 CU-us per batch: 11.7-11.9 instead of 12.7-13.3 us per pipelined step).  A launch narrower than the
       // machine leaves the other CUs to the batches behind it.
-      const int long_bps = 8;   // (6, 5, 4 and 10 blocks per slice measured 1.2-2.4 us per step slower: tools/probes/r03_bps.sh)
+      const int long_bps = 8;   // (6, 5, 4 and 10 blocks per slice measured 1.2-2.4 us per step slower, interleaved in one box)
       const int long_slices = c->tile_blocks / long_bps;
       // (from 32 slices on: a short data set keeps the many short slices -- one batch at a time is what it is scored in)
       const bool long_ok = max_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
