@@ -482,7 +482,6 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
                                               int lane) {
   const uint64_t CONSTANT_AS* cw = as_const(codes);
   const uint64_t CONSTANT_AS* fw = as_const(feats);
-  const double CONSTANT_AS* lp = as_const(lnp);
   RegStack<T, U, S> st;
   st.spill = spill;
   st.lane = lane;
@@ -664,7 +663,6 @@ __device__ __forceinline__ void chain_eval(const TapeHead& hd, const uint64_t* c
   static_assert(U % 4 == 0, "the out-of-line routines take four values");
   const uint64_t CONSTANT_AS* cw = as_const(codes);
   const uint64_t CONSTANT_AS* fw = as_const(feats);
-  const double CONSTANT_AS* lp = as_const(lnp);
   const LdsPass<T, NB, FULL> ldr{sx, rb_rows, off, nb};
   uint64_t code = hd.code0, code_next = hd.code1;
   uint64_t fhead = hd.f0, fnext = hd.f1;

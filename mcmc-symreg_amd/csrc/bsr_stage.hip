@@ -291,7 +291,6 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
   uint64_t* hc = s.h_streams();
   uint64_t* hf = hc + cw;
   double* hl = reinterpret_cast<double*>(hf + fw);
-  uint64_t* hf2 = reinterpret_cast<uint64_t*>(hl + 2 * lw);  // tile pass: the column stream in LDS slots
   memset(hc, 0, (cw + fw) * 8);
   for (int i = 0; i < n; ++i) {
     const TapeLoc L = (*loc)[i];

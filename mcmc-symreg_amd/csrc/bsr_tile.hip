@@ -408,7 +408,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const bool multi = g.chunk_blocks < g.bps;   // the slice does not fit LDS whole: two buffers, LDS-DMA
   const int buf_elems = (multi && sizeof(T) == 8) ? g.ncols * chunk_rows : 0;   // one buffer of the ring (f32: one buffer at all)
   const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
-  const PropDesc CONSTANT_AS* dsc = as_const(a.desc);
   const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
   const int y_slot = a.grp_nF[tg & 7];
   const int ncols = y_slot + 1 + (g.ncols_fixed);   // the group's LDS columns
