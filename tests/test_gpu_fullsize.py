@@ -206,3 +206,36 @@ def test_fullsize_real_mix_values_against_the_oracle(N, d, K, deep):
     assert n_full >= B // 2
     note_exempt("full-size real mix N=%d d=%d K=%d" % (N, d, K), n_exempt, n_full)
     scorer.close()
+
+
+@pytest.mark.parametrize("K", [3, 8])
+def test_the_span_shortcut_changes_no_byte_on_the_real_move_mix(K, monkeypatch):
+    """BASELINE configs[1], [2] at full size: twelve batches of the real move mix, drawn from a burnt-in chain state,
+    scored with the host's span analysis on (candidates inside the span of the current columns by construction skip the
+    residual step, csrc/bsr_span.h) and off (they go through it): byte-identical scores.  At K = 8 a dozen candidates per
+    batch take the shortcut."""
+    from bsr.chain import Chain, DeviceScorer, run_chains
+    N, d = 100_000, 10
+    X, y = synth(N, d)
+
+    def run(env):
+        monkeypatch.delenv("BSR_SELFDUP", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scorer = DeviceScorer(X, y, K, n_chains=1, max_batch=72)
+        np.random.seed(1000)
+        ch = Chain(0, scorer, N, d, K, val=10 ** 9)
+        run_chains([ch], scorer, batch_per_chain=32, max_props=200)
+        outs = []
+        for _ in range(12):
+            cands = ch.generate(64)
+            outs.append(scorer.ctx.score_batch([c.tape for c in cands], [0] * 64, [c.k for c in cands],
+                                               [c.new_sigma for c in cands]).copy())
+            ch.rng_state = ch._end_state
+        scorer.close()
+        return outs
+    on = run({})
+    off = run({"BSR_SELFDUP": "0"})
+    for a, b in zip(on, off):
+        assert a.tobytes() == b.tobytes()
+    assert sum(int((a["rank"] == K).sum()) for a in on) > 6 * 64
