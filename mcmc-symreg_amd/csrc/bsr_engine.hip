@@ -1523,11 +1523,12 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   }
   // tracing wants proposals in chain order: keep one group then
   // A group's cycle is serial (generate, submit, wait for the batch's dependent kernels, consume), so the batches in
-  // flight are what hides it.  Up to eight groups (a worker thread each) while K <= 4: 8 chains at K = 3 run at
-  // 1.55 M consumed proposals/s in eight groups against 1.14 M in four; at K = 8, where k_solve and k_finalize take
-  // 25 us per launch whatever its size, eight launches of 32 proposals lose 6 % against four of 64
-  // (tools/probes/engine_groups.sh).  Four also when the process has fewer than a dozen CPUs to itself.
-  const int dflt_groups = (e->K <= 4 && bsr_internal_cpu_budget() >= 12.0) ? 8 : 4;
+  // flight are what hides it: four groups (a worker thread each) with a second, lookahead batch per group (below).
+  // 8 chains x 32 at K = 3, N = 100k, consumed proposals/s (tools/probes/engine_lookahead_ab.sh, three rounds in one
+  // box): 4 groups with lookahead 1.69-1.82 M, 8 groups with 1.49-1.63 M, 8 without 1.56-1.69 M (round 2's default),
+  // 4 without 1.44-1.45 M.  At K = 8, where k_solve takes 27 us per launch whatever its size, eight launches of 32
+  // proposals lose against four of 64 anyway.
+  const int dflt_groups = 4;
   const int max_groups = std::max(1, std::min<int>(BSR_MAX_INFLIGHT, getenv("BSR_ENGINE_GROUPS") ? atoi(getenv("BSR_ENGINE_GROUPS")) : dflt_groups));
   const int n_groups = trace ? 1 : std::max(1, std::min<int>(max_groups, (int)live.size()));
   // One worker thread per group (each with its own batch slots and HIP streams): proposal generation, staging and the
