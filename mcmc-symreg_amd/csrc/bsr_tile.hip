@@ -175,7 +175,30 @@ __device__ __forceinline__ void store_partial(const TapeAcc<KQ>& A, double* o, i
   const int slot = ((lane >> 3) & 2) | (lane >> 5);   // rows 0, 1, 2, 3 of the wave hold values 0, 2, 1, 3 (in arithmetic:
                                                       // a table would be a memory load and a pointer kept in registers)
   double g0[8], lo0, hi0;
-  if constexpr (KQ <= 6) {  // everything fits one group: c[0..KQ-1] at 0.., a0 at 6, a1 at 7
+  if constexpr (KQ == 3) {
+    // five sums: (c0 c1) and (c2 a0) through the swap network, a1 on its own (its partner lanes come by ds_swizzle);
+    // every total is combined in the order of the general network below -- halves, rows 16 apart, then lane ^ 1, 2,
+    // 4, 8 -- so the bits are the same, for a third fewer vector instructions than eight padded slots
+    double v0 = A.c[0], v1 = A.c[1], v2 = A.c[2], v3 = A.a0, v4 = A.a1, v5 = A.a1;
+    swap32(v0, v1);
+    swap32(v2, v3);
+    swap32(v4, v5);
+    double w0 = v0 + v1, w1 = v2 + v3;
+    const double w2 = v4 + v5;                       // every lane: a1 over both halves
+    swap16(w0, w1);
+    lo0 = row_sum16_swz(w0 + w1);                     // rows 0, 1, 2, 3: c0, c2, c1, a0
+    hi0 = row_sum16_swz(w2 + swz_xor_f64<16>(w2));    // every row: a1
+    const double amax = wave_max_swz_hi(A.amax);
+    if ((lane & 15) == 0) o[slot < 3 ? slot : 8] = lo0;
+    if (lane == 0) {
+      o[3] = 0.0; o[4] = 0.0; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+      o[9] = hi0;
+    }
+    if (lane == 63) {
+      o[10] = amax;
+      o[11] = 0.0;
+    }
+  } else if constexpr (KQ <= 6) {  // everything fits one group: c[0..KQ-1] at 0.., a0 at 6, a1 at 7
 #pragma unroll
     for (int i = 0; i < 6; ++i) g0[i] = (i < KQ) ? A.c[i < KQ ? i : 0] : 0.0;
     g0[6] = A.a0;
