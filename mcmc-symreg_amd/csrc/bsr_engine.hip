@@ -26,6 +26,7 @@
 
 #include "../../include/bsr_hip.h"
 #include "bsr_internal.h"
+#include "bsr_span.h"
 
 namespace {
 
@@ -944,6 +945,10 @@ struct ChainS {
   LegacyRng rng;
   std::vector<Tree> roots;
   std::vector<std::vector<bsr_node>> tapes;
+  // structure of the current trees (bsr_span.h): per tree k the echelon basis of the OTHER trees' linear forms, and
+  // whether those siblings are dependent among themselves -- rank-gate speculation (predict_gate_reject)
+  std::vector<bsr_span::SpanBasis> sib_basis;
+  std::vector<char> sib_dependent;
   std::vector<Tree> last_roots;  // `Roots` as built before the latest newProp (codes/bsr_class.py:180-182)
   std::vector<double> siga, sigb, Beta, errs;
   std::vector<double> fs_old_s, fs_old_p;
@@ -1028,6 +1033,7 @@ int refresh_chain(bsr_engine* e, ChainS& c) {
   return BSR_OK;
 }
 
+void rebuild_sibling_spans(ChainS& c, int K);
 int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   const int K = e->K;
   c.sigma = invgamma_rvs(c.rng, 1);
@@ -1056,6 +1062,7 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.def_ema.assign(K, 0.0);
   c.ckey.assign(K, 0);
   for (int k = 0; k < K; ++k) c.ckey[k] = canon_key(c.roots[k]);
+  rebuild_sibling_spans(c, K);
   int rc = refresh_chain(e, c);
   if (rc != BSR_OK) return rc;
   c.Beta.assign(K + 1, 0.0);
@@ -1137,7 +1144,26 @@ Iv tree_range(const Tree& t, int i, const double* xlo, const double* xhi, double
   }
 }
 
-bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k) {
+// the sibling bases of a chain (after initialisation and after every accepted move)
+void rebuild_sibling_spans(ChainS& c, int K) {
+  std::vector<bsr_span::LinForm> forms((size_t)K);
+  std::vector<char> ok((size_t)K, 0);
+  for (int j = 0; j < K; ++j)
+    ok[j] = (j < (int)c.tapes.size() && !c.tapes[j].empty() &&
+             bsr_span::lin_form(c.tapes[j].data(), (int)c.tapes[j].size(), &forms[j])) ? 1 : 0;
+  c.sib_basis.assign((size_t)K, bsr_span::SpanBasis());
+  c.sib_dependent.assign((size_t)K, 0);
+  for (int k = 0; k < K; ++k) {
+    std::vector<char> okk = ok;
+    okk[k] = 0;
+    c.sib_basis[k].build(forms, okk);
+    int known = 0;
+    for (int j = 0; j < K; ++j) known += okk[j];
+    c.sib_dependent[k] = (int)c.sib_basis[k].rows.size() < known ? 1 : 0;
+  }
+}
+
+bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k, const std::vector<bsr_node>& tape) {
   if (!e->predict_gate) return false;
   if (c.def_ema[k] > 0.9) return true;   // a state in which (nearly) every candidate for k is rejected
   if (e->K < 2) return false;
@@ -1147,6 +1173,13 @@ bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k) {
     if (c.ckey[i] == key) return true;                      // repeats a sibling
     for (int j = i + 1; j < e->K; ++j)
       if (j != k && c.ckey[i] == c.ckey[j]) return true;    // two siblings repeat each other
+  }
+  // linear structure: the siblings are dependent among themselves, or the candidate is a linear combination of them
+  // (`x1 + x6` next to `x1 + x1` and `-x6`): the new matrix has rank < K whatever the numbers are
+  if ((size_t)k < c.sib_basis.size()) {
+    if (c.sib_dependent[k]) return true;
+    bsr_span::LinForm f;
+    if (!tape.empty() && bsr_span::lin_form(tape.data(), (int)tape.size(), &f) && c.sib_basis[k].in_span(f)) return true;
   }
   if (!e->x_lo) return false;
   double sib = 0.0;
@@ -1185,7 +1218,7 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     cd.action = mv.action;
     flatten(cd.tree, cd.tree.root, cd.tape);
     cd.before_u = c.rng;
-    cd.pred_def = predict_gate_reject(e, c, cd.tree, k);
+    cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape);
     cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
     {  // the scalar terms of codes/funcs.py:1230-1296 that do not depend on the score
       fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &cd.sn_s, &cd.sn_p);
@@ -1341,6 +1374,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.roots[k] = cd.tree;
     c.ckey[k] = canon_key(cd.tree);
     c.tapes[k] = cd.tape;
+    rebuild_sibling_spans(c, K);
     c.sigma = cd.new_sigma;
     c.siga[k] = cd.new_sa2;
     c.sigb[k] = cd.new_sb2;
@@ -1511,6 +1545,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::vector<ChainS*> chains;
     Lane lane[2];
     double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
+    double evt_ema = 0.0;   // share of this group's chain batches that ended in an event lately (lookahead pays while it is low)
   };
   auto is_live = [&](const ChainS& c) { return c.inited && !c.done && (max_props < 0 || c.n_props < max_props); };
   std::vector<ChainS*> live;
@@ -1542,7 +1577,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // (accept, gate verdict against the speculation) makes the chain's share of the second one void -- it is skipped
   // when it arrives, and the chain generates afresh from the state behind the event: the sequence of consumed
   // proposals is the reference's whatever is thrown away (codes/funcs.py:1300-1303, :1226-1228).
-  const bool lookahead = threaded && (getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) != 0 : true);
+  // On by default for K <= 4: at K = 5 and 8, where the tail kernels make the GPU the bound, it measured 2-7 % slower
+  // even when skipped adaptively (below).
+  const bool lookahead = threaded && (getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) != 0 : e->K <= 4);
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
   for (int gi = 0; gi < n_groups; ++gi) {
@@ -1661,6 +1698,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       const bool more_ahead = O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0;
       bool broke = false;
       r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke);
+      g.evt_ema = 0.9 * g.evt_ema + (broke ? 0.1 : 0.0);
       if (broke && O.inflight && i < O.valid.size()) O.valid[i] = 0;   // what was generated behind these is void
       if (r != BSR_OK) return r;
     }
@@ -1675,7 +1713,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       int cur = 0;
       int r = submit(g, 0, false);
       while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK && g.lane[cur].inflight) {
-        if (lookahead) {
+        // a lookahead batch is consumed only if the batch in front of it ends as speculated: while more than half of
+        // the group's chain batches end in an event (K = 8: six in seven) it would mostly be scored for nothing
+        if (lookahead && g.evt_ema < 0.5) {
           r = submit(g, cur ^ 1, true);
           if (r != BSR_OK) break;
         }
