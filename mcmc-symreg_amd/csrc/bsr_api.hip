@@ -303,6 +303,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // a data set of which not even one block of a narrow group (eight features or all of them, y, one chain's basis)
     // fits two LDS buffers never takes the tile pass: the work-queue row pass (bsr_kernels.hip: k_rows) serves it
     c->tile_ever = c->tile_on && (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * 2 * BSR_TILE_BLOCK * c->esz <= budget;
+    // The chunked kernel is built for data sets much larger than LDS (N = 1M: 30 blocks per CU).  A short data set whose
+    // slices miss LDS only because its widest batch would carry many chains' bases (8 chains at K = 8: 75 columns at
+    // N = 100k -- 3 blocks per CU) is better served by the work-queue pass: the native sampler's batches there (two
+    // chains, 32 proposals each) measured 0.66-0.69 M consumed proposals/s through it against 0.55 M through k_tile.
+    if (!c->tile_whole && c->tile_blocks < 8 * c->n_cu) c->tile_ever = false;
     // derived columns pay where the slice sits in LDS whole (a derived column is then one more column staged from L2);
     // a chunked pass would stream each of them from HBM (N = 1M: 8 MB per column and group), the work-queue pass for
     // every tape again
