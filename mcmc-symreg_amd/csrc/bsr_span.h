@@ -277,7 +277,8 @@ struct SpanBasis {
   bool in_span(const LinForm& f) const {
     Vec v;
     v.from(f);
-    const double scale = std::max(1.0, v.max_abs());
+    const double scale = v.max_abs();   // relative to the candidate's own coefficients (a form of tiny ones is not "zero")
+    if (scale == 0.0) return true;      // the zero column
     reduce(v, scale);
     return !v.over && v.max_abs() <= 1e-9 * scale;
   }

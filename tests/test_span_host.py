@@ -87,6 +87,8 @@ def test_constructed_cases(shim):
         (1, _bi("+", _un("ln", x(5), 0.8234, 0.0783), x(4)), 2),    # operands of + order-free
         (0, _un("sin", x(3)), 0),
         (3, _bi("+", x(1), x(2)), 0),
+        (3, _un("ln", x(2), 1e-12, 0.0), 0),                       # a tiny multiple of a column outside the span is outside
+        (3, _un("ln", x(1), 1e-12, 0.0), 1),                       # ... of one inside, inside
     ]
     got = _check(shim, cur, [t for _, t, _ in cands], [k for k, _, _ in cands])
     assert got.tolist() == [w for _, _, w in cands]
