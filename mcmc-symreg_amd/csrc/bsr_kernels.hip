@@ -18,6 +18,7 @@
 //
 // Everything is deterministic: partial sums are written per (proposal,row block) and reduced in a fixed order.
 // Compiled with -ffp-contract=off so that a*x+b keeps numpy's two roundings; accumulations use explicit fma().
+#include <algorithm>
 #include "bsr_internal.h"
 
 #include <cstdlib>
@@ -36,6 +37,7 @@
 //                  (allcal / set_current).
 //   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
+#define BSR_RESID_WGS 32u   // workgroups of the residual pass at most (16 waves each; see MODE_RESIDUAL in k_rows)
 #ifndef BSR_SOLVE_WAVES
 #define BSR_SOLVE_WAVES 4   // k_solve: proposals (waves) per workgroup (measured at C2 / K=8, us per step: 4: 17.3 / 27.2,
                            // 8: 17.9 / 29.7, 16: 19.7 / 37.7 -- tools/probes/lib_ab.sh)
@@ -355,8 +357,19 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
     }
   } else {
     if (MODE == MODE_RESIDUAL) {
-      if (active)
+      if constexpr (FAT) {
+        // the launch is capped at BSR_RESID_WGS workgroups (an empty list -- nineteen batches in twenty -- then costs a few
+        // microseconds at any N instead of 0.1 us per row block's workgroup: 25 us at N = 1M); its virtual workgroups
+        // stride over the row blocks
+        const int n_vwg = ((n_rb + 7) / 8) * 8;
+        for (int vw = vwg; vw < n_vwg; vw += (int)gridDim.x * 4) {
+          const WorkItem w2 = map_work(n_rb, n_pg, vw);
+          if (!w2.valid) continue;
+          for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], w2.rb, (int64_t)w2.rb * rb_rows);
+        }
+      } else if (active) {
         for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], wi.rb, (int64_t)wi.rb * rb_rows);
+      }
     } else {
       for (int pi = wave; pi < pg; pi += BSR_WG_WAVES) {
         const int p = wi.pgi * pg + pi;
@@ -1321,8 +1334,8 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   dim3 grid((unsigned)(((g.n_rb + 7) / 8) * 8 * g.n_pg)), block(BSR_WG_WAVES * BSR_WAVE);
   if (!a.feat_list && MODE == MODE_PROJECT) grid.x = (unsigned)g.dyn_wgs;  // work-queue launch
   if (MODE == MODE_RESIDUAL) grid.x = (unsigned)(((g.n_rb + 7) / 8) * 8);   // one (virtual) workgroup per row block, flagged list
-  if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape)
-    grid.x /= 4;
+  if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape), at most BSR_RESID_WGS
+    grid.x = std::min<unsigned>(grid.x / 4, BSR_RESID_WGS);
     block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
   }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
