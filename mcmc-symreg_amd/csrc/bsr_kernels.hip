@@ -37,7 +37,9 @@
 //                  (allcal / set_current).
 //   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
+#ifndef BSR_RESID_WGS
 #define BSR_RESID_WGS 32u   // workgroups of the residual pass at most (16 waves each; see MODE_RESIDUAL in k_rows)
+#endif
 #ifndef BSR_SOLVE_WAVES
 #define BSR_SOLVE_WAVES 4   // k_solve: proposals (waves) per workgroup (measured at C2 / K=8, us per step: 4: 17.3 / 27.2,
                            // 8: 17.9 / 29.7, 16: 19.7 / 37.7 -- tools/probes/lib_ab.sh)
