@@ -29,7 +29,7 @@ if [ -x "$objdump" ]; then
   tmp="$(mktemp -d)"
   cp "$obj/bsr_tile.o" "$tmp/t.o"
   (cd "$tmp" && "$objdump" --offloading t.o > /dev/null && "$objdump" -d t.o.*gfx950 |
-     awk '/^[0-9a-f]+ <.*>:$/ { name = $2; n[name] += 0 } /\<scratch_(load|store)/ { n[name]++ } END { for (k in n) print k, n[k] }') \
+     awk '/^[0-9a-f]+ <.*>:$/ { name = $2; n[name] += 0 } /[ \t]scratch_(load|store)/ { n[name]++ } END { for (k in n) print k, n[k] }') \
     | sort > "$obj/bsr_tile.scratch_ops.txt" || true
   rm -rf "$tmp"
 fi

@@ -51,6 +51,11 @@ def test_tile_row_pass_has_no_scratch():
         counts[name.strip("<>:")] = int(cnt)
     for n in names:
         assert counts.get(n) == 0, (n, counts.get(n))
+    # the chunked kernel (config 5) keeps a few registers of its prologue / epilogue in scratch (K = 3: 12 instructions,
+    # none inside the chunk loop); more than that would be a regression
+    for n, cnt in counts.items():
+        if "6k_tileIdLi3EE" in n or "6k_tileIdLi2EE" in n or "6k_tileIdLi1EE" in n:
+            assert cnt <= 16, (n, cnt)
 
 
 def test_default_work_queue_row_pass_has_no_scratch():
