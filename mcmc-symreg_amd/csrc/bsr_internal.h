@@ -130,7 +130,9 @@ struct RefreshPlan {  // per chain, device scratch handed from one refresh kerne
 #define BSR_TILE_NB 4                     // blocks per pass of a chain tape (2 NB values per lane in registers)
 #define BSR_TILE_ARG_GROUPS 4
 #define BSR_TILE_ARG_COLS 32
-#define BSR_TILE_QMAX 2                   // tapes (sets of per-lane sums) per wave and pass: with four, the sums, a pass of
+#ifndef BSR_TILE_QMAX
+#define BSR_TILE_QMAX 2
+#endif                                    // tapes (sets of per-lane sums) per wave and pass: with four, the sums, a pass of
                                           // values and its operand columns no longer fit 128 registers (K = 3: 17 spilled)
 struct TileGeom {
   int T;                // tape groups: workgroup w serves slice w % n_slices with the tapes of group w / n_slices

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
       else accumulate_v<T, KQ, true>(A[qq], zz, yv, qv, s, row0, a.N);                 \
     }                                                                                  \
     break;
-          switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) }
+          switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) BSR_ACC_CASE(2) BSR_ACC_CASE(3) }
 #undef BSR_ACC_CASE
         };
         int b = 0;
