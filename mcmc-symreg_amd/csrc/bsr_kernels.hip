@@ -363,11 +363,15 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
         // the launch is capped at BSR_RESID_WGS workgroups (an empty list -- nineteen batches in twenty -- then costs a few
         // microseconds at any N instead of 0.1 us per row block's workgroup: 25 us at N = 1M); its virtual workgroups
         // stride over the row blocks
+        // ... and (row block, flagged proposal) pairs are dealt to ALL waves of the launch, a row block's proposals to
+        // neighbouring waves: one flagged proposal keeps every wave busy, not one wave in four
         const int n_vwg = ((n_rb + 7) / 8) * 8;
-        for (int vw = vwg; vw < n_vwg; vw += (int)gridDim.x * 4) {
+        const int n_units = n_vwg * n_flag;
+        const int n_waves = (int)gridDim.x * 4 * BSR_WG_WAVES;
+        for (int u = (int)blockIdx.x * 4 * BSR_WG_WAVES + wave_raw; u < n_units; u += n_waves) {
+          const int vw = u / n_flag, pi = u - vw * n_flag;
           const WorkItem w2 = map_work(n_rb, n_pg, vw);
-          if (!w2.valid) continue;
-          for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], w2.rb, (int64_t)w2.rb * rb_rows);
+          if (w2.valid) run_task(flagged[1 + pi], w2.rb, (int64_t)w2.rb * rb_rows);
         }
       } else if (active) {
         for (int pi = wave; pi < n_flag; pi += BSR_WG_WAVES) run_task(flagged[1 + pi], wi.rb, (int64_t)wi.rb * rb_rows);
