@@ -40,6 +40,7 @@ inline uint64_t mix64(uint64_t x) {
 
 struct LinForm {
   int n = 0;                 // terms, sorted by atom, no zero coefficient
+  bool approx = false;       // the form stands for the tape's column to ROUNDING only (an inverse of an inverse was undone)
   uint64_t atom[LF_CAP];
   double coef[LF_CAP];
 };
@@ -107,6 +108,12 @@ inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 2
   LinForm st[28];
   if (max_stack > 26) max_stack = 26;
   int sp = 0;
+  // 1/(1/A) is A to rounding (the moves stack an inverse on an inverse often enough: `1/[1/[x30]]`): the atoms made
+  // by `inv` of a plain +-atom remember it, and an inverse on top of one gives it back
+  constexpr int INV_CAP = 8;
+  uint64_t inv_of[INV_CAP], inv_base[INV_CAP];
+  int n_inv = 0;
+  bool undone = false;
   for (int i = 0; i < len; ++i) {
     const int op = t[i].opcode;
     if (op == BSR_OP_TERMINAL) {
@@ -163,7 +170,23 @@ inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 2
       int s;
       as_atom(st[sp - 1], &h, &s);
       const int rule = unary_sign_rule(op);
+      const bool plain = st[sp - 1].n == 1 && (st[sp - 1].coef[0] == 1.0 || st[sp - 1].coef[0] == -1.0);
+      if (op == BSR_OP_INV && plain) {
+        int hit = -1;
+        for (int q = 0; q < n_inv; ++q)
+          if (inv_of[q] == h) hit = q;
+        if (hit >= 0) {   // 1/(s * 1/B) = s B
+          set_atom(st[sp - 1], inv_base[hit], (double)s);
+          undone = true;
+          continue;
+        }
+      }
       uint64_t x = mix64(h ^ ((uint64_t)(op + 1) << 48));
+      if (op == BSR_OP_INV && plain && n_inv < INV_CAP) {
+        inv_of[n_inv] = x;
+        inv_base[n_inv] = h;
+        ++n_inv;
+      }
       if (rule == 2) { x = mix64(x + (s < 0 ? 0xA5A5ull : 0)); s = 1; }
       else if (rule == 0) s = 1;
       set_atom(st[sp - 1], x, (double)s);
@@ -173,11 +196,13 @@ inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 2
   }
   if (sp != 1) return false;
   *out = st[0];
+  out->approx = undone;
   return true;
 }
 
 // f == +-g term by term (the column of one is the column of the other up to sign, bit for bit)
 inline bool same_up_to_sign(const LinForm& f, const LinForm& g) {
+  if (f.approx || g.approx) return false;
   if (f.n != g.n) return false;
   if (f.n == 0) return true;
   const double r = (f.coef[0] == g.coef[0]) ? 1.0 : -1.0;

@@ -485,6 +485,7 @@ def test_a_linear_combination_of_current_trees_scores_the_same_with_and_without_
         (1, _bi("+", L(1), L(2))),
         (2, _bi("+", _un("cos", L(3)), L(2))),
         (1, _un("neg", _bi("+", L(2), L(2)))),
+        (1, _un("inv", _un("inv", L(2)))),                      # x2 to rounding: in the span of -x2
         (3, _bi("+", _bi("*", L(4), L(0)), _un("ln", L(1), 2.5, 0.0))),
         (3, _bi("+", _bi("*", L(4), L(0)), _un("ln", L(1), 2.5, 0.3))),   # + a constant: not in the span
         (2, _un("sin", L(3))),

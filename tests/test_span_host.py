@@ -87,6 +87,10 @@ def test_constructed_cases(shim):
         (1, _bi("+", _un("ln", x(5), 0.8234, 0.0783), x(4)), 2),    # operands of + order-free
         (0, _un("sin", x(3)), 0),
         (3, _bi("+", x(1), x(2)), 0),
+        (5, _un("inv", _un("inv", x(6))), 1),                    # 1/(1/x6) is -(-x6), to rounding: in the span, not a bit-exact repeat
+        (5, _un("inv", _un("neg", _un("inv", _un("neg", x(6))))), 1),
+        (3, _bi("+", _un("inv", _un("inv", x(1))), x(6)), 1),       # x1 + x6 with an inverse undone
+        (5, _un("inv", _un("inv", _un("inv", x(6)))), 0),          # 1/x6 is not in the span
         (3, _un("ln", x(2), 1e-12, 0.0), 0),                       # a tiny multiple of a column outside the span is outside
         (3, _un("ln", x(1), 1e-12, 0.0), 1),                       # ... of one inside, inside
     ]
