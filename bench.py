@@ -84,10 +84,11 @@ def launch_children(args):
     """--gpus N without a launcher: N fresh child processes, one per device.  Nothing here touches HIP."""
     from bsr.launch import spawn
     argv = [os.path.abspath(__file__)] + sys.argv[1:]
-    codes, text = spawn(args.gpus, argv)
+    # the run itself is as long as it is; the start-up (rendezvous, ncclCommInitRank) is what can hang: bounded alone
+    codes, text = spawn(args.gpus, argv, init_timeout=float(os.environ.get("BSR_INIT_TIMEOUT", "900")))
     bad = [c for c in codes if c != 0]
     if bad:
-        sys.stderr.write("bench.py: rank exit codes %r\n" % (codes,))
+        sys.stderr.write("bench.py: rank exit codes %r%s\n" % (list(codes), (" -- " + codes.reason) if codes.reason else ""))
         return max(abs(c) for c in bad) or 1
     return 0
 

@@ -136,13 +136,17 @@ def connect(ctx, rank, world, rdv=None):
     from .launch import Rendezvous
     rdv = rdv or Rendezvous(rank, world)
     if os.environ.get("BSR_SHARE_DEVICE") == "1":
-        return FileGather(rdv), rdv
+        g = FileGather(rdv)
+        g.allgather(np.zeros(8, dtype=np.uint8))
+        rdv.mark_up()
+        return g, rdv
     global _N_CONNECTS
     name = "uid" if _N_CONNECTS == 0 else "uid%d" % _N_CONNECTS      # every rank connects in the same order
     _N_CONNECTS += 1
     uid = rdv.broadcast(name, lambda: ctx.comm_unique_id().tobytes(), nbytes=128)
     g = RcclGather(ctx, world, rank, np.frombuffer(uid, dtype=np.uint8))
     g.allgather(np.zeros(8, dtype=np.uint8))      # first collective: everyone holds the id now
+    rdv.mark_up()
     rdv.close()
     return g, rdv
 

@@ -34,17 +34,32 @@ def free_port():
     return port
 
 
-def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
+class ExitCodes(list):
+    """The ranks' exit codes, plus why spawn() ended them where it did: `timed_out` is None, "job" (the whole job
+    outlived `timeout`) or "init" (the ranks did not all get through rendezvous and communicator set-up in
+    `init_timeout`); `reason` says so in words."""
+    timed_out = None
+    reason = ""
+
+
+def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True, init_timeout=None):
     """Starts `nprocs` children running `sys.executable argv...`, one per GPU (LOCAL_RANK = rank).  Rank 0's stdout
     is returned (and echoed when relay_rank0_stdout); every child's stderr goes to this process's stderr.
     Returns (exit codes, rank-0 stdout).  The caller must not have initialised HIP: children are fresh processes.
 
     Every child is watched: when one exits non-zero (a bad device index, an import error, a crash) the others would
     sit in ncclCommInitRank or an all-gather forever, so they are killed after a short grace period and their codes
-    returned (-9 for the killed ones).  `timeout` (seconds, None: BSR_SPAWN_TIMEOUT or one hour) bounds the whole job."""
+    returned (-9 for the killed ones).
+
+    `timeout` (seconds) bounds the WHOLE job; None means no limit -- a long fit is not a hang -- unless
+    BSR_SPAWN_TIMEOUT is set.  What can hang without anyone dying is the start: a rank waiting for a unique id that
+    never comes, ncclCommInitRank on a stale one.  `init_timeout` (seconds; None: not watched) bounds that phase alone:
+    every rank leaves a marker in the rendezvous directory once its first collective has returned (bsr.dist.connect),
+    and ranks that have not all done so in time are ended.  Either way the returned codes say what happened
+    (`ExitCodes.timed_out`, `.reason`) and a line goes to stderr: a timeout does not look like a crash."""
     import threading
-    if timeout is None:
-        timeout = float(os.environ.get("BSR_SPAWN_TIMEOUT", "3600"))
+    if timeout is None and os.environ.get("BSR_SPAWN_TIMEOUT"):
+        timeout = float(os.environ["BSR_SPAWN_TIMEOUT"])
     rdv = tempfile.mkdtemp(prefix="bsr_rdv_")
     port = free_port()
     nonce = "%d-%d-%d" % (os.getpid(), port, int(time.time() * 1e6))
@@ -64,8 +79,11 @@ def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
             chunks.append(piece)
     reader = threading.Thread(target=drain, daemon=True)
     reader.start()
-    deadline = time.time() + timeout
+    t_start = time.time()
+    deadline = None if timeout is None else t_start + timeout
+    init_deadline = None if init_timeout is None else t_start + init_timeout
     failed_at = None
+    timed_out, reason = None, ""
     try:
         while True:
             codes = [p.poll() for p in procs]
@@ -74,13 +92,28 @@ def spawn(nprocs, argv, env_extra=None, timeout=None, relay_rank0_stdout=True):
             now = time.time()
             if failed_at is None and any(c not in (None, 0) for c in codes):
                 failed_at = now          # a rank died: the rest get a moment to fail on their own, then they are ended
-            if now > deadline or (failed_at is not None and now - failed_at > 5.0):
+            if init_deadline is not None:
+                if all(os.path.exists(os.path.join(rdv, "up_%d" % r)) for r in range(nprocs)):
+                    init_deadline = None     # everyone is through its first collective: the job runs as long as it runs
+                elif now > init_deadline:
+                    timed_out = "init"
+                    reason = ("spawn: not every rank got through rendezvous and communicator set-up within %.0f s "
+                              "(init_timeout); ending %d ranks" % (init_timeout, nprocs))
+            if deadline is not None and now > deadline and timed_out is None:
+                timed_out = "job"
+                reason = "spawn: the job outlived its timeout of %.0f s (timeout= / BSR_SPAWN_TIMEOUT); ending %d ranks" % (
+                    timeout, nprocs)
+            if timed_out or (failed_at is not None and now - failed_at > 5.0):
                 for p in procs:
                     if p.poll() is None:
                         p.kill()         # our own children, by pid
                 break
             time.sleep(0.02)
-        codes = [p.wait() for p in procs]
+        codes = ExitCodes(p.wait() for p in procs)
+        codes.timed_out, codes.reason = timed_out, reason
+        if reason:
+            sys.stderr.write("bsr.launch." + reason + "\n")
+            sys.stderr.flush()
         reader.join(timeout=5.0)
     finally:
         for name in os.listdir(rdv):
@@ -113,8 +146,11 @@ class Rendezvous:
         self.dir = d
         self.t_start = time.time()
         # what tells this job's blobs from a crashed job's under the same directory: the launcher's nonce, or (external
-        # launcher) the port and the agent's pid -- every blob starts with it
-        self.nonce = (os.environ.get("BSR_RDV_NONCE") or "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())).encode()
+        # launcher: port, agent pid and -- what changes when an elastic agent restarts its workers under the same pid and
+        # port -- the run id and restart count) -- every blob starts with it
+        self.nonce = (os.environ.get("BSR_RDV_NONCE") or "%s-%d-%s-%s" % (
+            os.environ.get("MASTER_PORT", "0"), os.getppid(), os.environ.get("TORCHELASTIC_RUN_ID", ""),
+            os.environ.get("TORCHELASTIC_RESTART_COUNT", ""))).encode()
         os.makedirs(d, exist_ok=True)
         self.seq = 0
         self.published = []
@@ -163,6 +199,16 @@ class Rendezvous:
         self.seq += 1
         self.publish("ag%d_%d" % (seq, self.rank), bytes(blob))
         return [self.fetch("ag%d_%d" % (seq, r), len(blob)) for r in range(self.world)]
+
+    def mark_up(self):
+        """This rank's first collective has returned: the start-up phase spawn() may bound (init_timeout) is over."""
+        if self.own_dir:      # (an external launcher's job: nobody reads the marker)
+            return
+        try:
+            with open(self._path("up_%d" % self.rank), "wb") as f:
+                f.write(self.nonce)
+        except OSError:
+            pass
 
     def close(self):
         """Rank 0 removes what it published (call after a collective that proves everyone has read it)."""

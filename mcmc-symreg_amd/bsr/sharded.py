@@ -91,9 +91,14 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
         if ops is not None:
             w = op_weights if op_weights is not None else [1.0 / len(ops)] * len(ops)
             argv += ["--ops", ",".join(ops), "--op-weights", ",".join(repr(float(v)) for v in w)]
-        codes, _ = spawn(len(devices), argv, env_extra=env, timeout=timeout, relay_rank0_stdout=False)
+        # no limit on the fit itself unless the caller (or BSR_SPAWN_TIMEOUT) sets one; the start-up -- rendezvous and
+        # ncclCommInitRank, the one place ranks can hang without dying -- is bounded on its own
+        codes, _ = spawn(len(devices), argv, env_extra=env, timeout=timeout, relay_rank0_stdout=False,
+                         init_timeout=float(os.environ.get("BSR_INIT_TIMEOUT", "900")) if len(devices) > 1 else None)
+        if getattr(codes, "timed_out", None):
+            raise TimeoutError("bsr.sharded: %s (rank exit codes %r)" % (codes.reason, list(codes)))
         if any(c != 0 for c in codes):
-            raise RuntimeError("bsr.sharded: rank exit codes %r" % (codes,))
+            raise RuntimeError("bsr.sharded: rank exit codes %r" % (list(codes),))
         raw = np.load(out)
         return [D.unpack_record(raw[i]) for i in range(raw.shape[0])]
     finally:

@@ -1158,7 +1158,7 @@ void rebuild_sibling_spans(ChainS& c, int K) {
     okk[k] = 0;
     c.sib_basis[k].build(forms, okk);
     int known = 0;
-    for (int j = 0; j < K; ++j) known += okk[j];
+    for (int j = 0; j < K; ++j) known += (okk[j] && !forms[j].inexact) ? 1 : 0;   // (the basis takes only forms that stand for their columns)
     c.sib_dependent[k] = (int)c.sib_basis[k].rows.size() < known ? 1 : 0;
   }
 }

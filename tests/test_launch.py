@@ -115,6 +115,57 @@ def test_a_dying_rank_ends_the_job_instead_of_hanging_it(tmp_path):
     t0 = time.time()
     codes, _ = spawn(2, [str(slow)], timeout=2.0, relay_rank0_stdout=False)
     assert time.time() - t0 < 30.0 and all(c != 0 for c in codes)
+    assert codes.timed_out == "job" and "outlived its timeout of 2 s" in codes.reason   # told apart from a crash
+
+
+def test_only_the_start_up_is_bounded_by_default(tmp_path, monkeypatch):
+    """timeout=None used to mean "one hour", after which a long multi-GPU fit was killed with nothing to
+    say why.  None is no limit again (BSR_SPAWN_TIMEOUT sets one); what is bounded is the phase that can hang without
+    anyone dying -- rendezvous and communicator set-up -- through the markers the ranks leave once their first
+    collective has returned."""
+    sys.path.insert(0, PKG)
+    from bsr.launch import spawn
+    monkeypatch.delenv("BSR_SPAWN_TIMEOUT", raising=False)
+    # ranks that come up (marker written) and then work for longer than init_timeout: left alone
+    up = tmp_path / "up.py"
+    up.write_text("import os, time\n"     # (what Rendezvous.mark_up does, without the package's import time)
+                  "open(os.path.join(os.environ['BSR_RDV_DIR'], 'up_' + os.environ['RANK']), 'wb').close()\n"
+                  "time.sleep(3.0)\n")
+    t0 = time.time()
+    codes, _ = spawn(2, [str(up)], init_timeout=1.5, relay_rank0_stdout=False)
+    assert list(codes) == [0, 0] and codes.timed_out is None and time.time() - t0 >= 3.0
+    # ranks stuck in their start-up (no marker): ended after init_timeout, and the codes say why
+    stuck = tmp_path / "stuck.py"
+    stuck.write_text("import time\ntime.sleep(120)\n")
+    t0 = time.time()
+    codes, _ = spawn(2, [str(stuck)], init_timeout=1.5, relay_rank0_stdout=False)
+    assert time.time() - t0 < 30.0 and all(c != 0 for c in codes)
+    assert codes.timed_out == "init" and "communicator set-up within 2 s" in codes.reason
+    # BSR_SPAWN_TIMEOUT bounds the whole job where the caller gave no timeout
+    monkeypatch.setenv("BSR_SPAWN_TIMEOUT", "1.5")
+    codes, _ = spawn(1, [str(stuck)], relay_rank0_stdout=False)
+    assert codes.timed_out == "job"
+
+
+def test_an_elastic_restart_does_not_read_the_previous_attempts_blobs(tmp_path, monkeypatch):
+    """under an external launcher the nonce was the port and the agent's pid -- the same after the agent
+    restarts its workers, so a non-zero rank could fetch the previous attempt's unique id and hang in
+    ncclCommInitRank.  The run id and the restart count are part of it now."""
+    sys.path.insert(0, PKG)
+    from bsr.launch import Rendezvous
+    monkeypatch.delenv("BSR_RDV_NONCE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    a0 = Rendezvous(0, 2, directory=str(tmp_path), timeout=0.3)
+    a0.publish("uid", b"x" * 128)
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    b1 = Rendezvous(1, 2, directory=str(tmp_path), timeout=0.3)
+    with pytest.raises(TimeoutError):
+        b1.fetch("uid", 128)
+    b0 = Rendezvous(0, 2, directory=str(tmp_path), timeout=0.3)
+    b0.publish("uid", b"y" * 128)
+    assert b1.fetch("uid", 128) == b"y" * 128
 
 
 def test_rendezvous_times_out_and_ignores_another_jobs_blobs(tmp_path):
