@@ -283,8 +283,17 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
           c->aux_cus = 0;
           continue;
         }
-        T = want;
-        while (T > 4) T = (T + 1) / 2;
+        // fp64: the streaming kernel (bsr_stream.hip) -- four sets of sums per wave at K <= 4, so ONE tape group takes a
+        // batch of 64 and every column streams from HBM once per launch; BSR_STREAM=0: the chunked k_tile as before
+        c->tile_stream = c->dtype == BSR_DTYPE_F64 && env_int("BSR_STREAM", 1) != 0;
+        if (c->tile_stream) {
+          c->tile_qmax = stream_qmax(std::max(1, K));
+          T = 1;
+          while (T < 8 && T * BSR_TILE_WAVES * c->tile_qmax < max_batch) T *= 2;
+        } else {
+          T = want;
+          while (T > 4) T = (T + 1) / 2;
+        }
       }
       T = std::max(1, std::min(8, env_int("BSR_TILE_T", T)));
       while (c->tile_whole && T > 1 && (c->tile_cus % T) != 0) --T;   // (chunked: n_cu / T slices, a CU or two may idle)
@@ -295,6 +304,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // goes out as single (tape, block) units dealt to the waves of the launch (bsr_tile.hip: leftover_units)
       c->tile_bps = c->tile_blocks / c->tile_slices;
       c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
+      if (c->tile_stream) {
+        // every WHOLE block in a slice, the first tile_long slices one block longer; the block that holds row N (N not a
+        // multiple of 128) goes out as (tape, block) units behind the loop: nothing in the loop masks rows
+        const int whole = (int)(N / BSR_TILE_BLOCK);
+        c->tile_bps = whole / c->tile_slices;
+        c->tile_long = whole - c->tile_bps * c->tile_slices;
+        c->tile_left = c->tile_blocks - whole;
+      }
       break;
     }
     c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
@@ -667,17 +684,24 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         a.cols_stride = s.cols_stride;
         a.N = c->N; a.codes = codes; a.feats = feats_lds; a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched();
         a.part = s.part1; a.P = j.P; a.K = c->K; a.stamps = c->d_stamps;
+        a.srec = s.tile_stream ? reinterpret_cast<const StreamRec*>(s.d_in + s.off_recs + s.srec_off) : nullptr;
         for (int i = 0; i < 8; ++i) a.grp_nF[i] = s.grp_nF[i];
-        a.cols_in_args = (tg.T <= BSR_TILE_ARG_GROUPS && tg.ncols <= BSR_TILE_ARG_COLS) ? 1 : 0;
-        for (int gi = 0; gi < BSR_TILE_ARG_GROUPS; ++gi)
-          for (int i = 0; i < BSR_TILE_ARG_COLS; ++i)
-            a.cols[gi][i] = (a.cols_in_args && gi < tg.T && i < tg.ncols)
-                                ? (decltype(a.cols[0][0]))s.h_cols()[(size_t)gi * s.cols_stride + i] : nullptr;
+        // the groups' column tables inside the argument block: 128 pointers dealt to 1, 2 or 4 groups
+        constexpr int n_arg = BSR_TILE_ARG_GROUPS * BSR_TILE_ARG_COLS;
+        a.arg_stride = tg.T == 1 ? n_arg : tg.T == 2 ? n_arg / 2 : BSR_TILE_ARG_COLS;
+        a.cols_in_args = (tg.T <= BSR_TILE_ARG_GROUPS && tg.ncols <= a.arg_stride) ? 1 : 0;
+        auto* flat = &a.cols[0][0];
+        for (int i = 0; i < n_arg; ++i) flat[i] = nullptr;
+        if (a.cols_in_args)
+          for (int gi = 0; gi < tg.T; ++gi)
+            for (int i = 0; i < tg.ncols; ++i)
+              flat[gi * a.arg_stride + i] = (decltype(a.cols[0][0]))s.h_cols()[(size_t)gi * s.cols_stride + i];
       };
       if (c->dtype == BSR_DTYPE_F64) {
         TileArgs<double> a;
         fill(a);
-        launch_tile<double>(s0, a);
+        if (s.tile_stream) launch_stream(s0, a);
+        else launch_tile<double>(s0, a);
       } else {
         TileArgs<float> a;
         fill(a);
@@ -1496,7 +1520,7 @@ extern "C" int bsr_ctx_info(const bsr_ctx* c, int32_t* info8) {
   info8[4] = c->tile_T;
   info8[5] = c->tile_slices;
   info8[6] = c->tile_bps;
-  info8[7] = c->tile_whole ? 1 : 0;
+  info8[7] = c->tile_whole ? 1 : (c->tile_stream ? 2 : 0);   // 1: whole slices in LDS (k_tile1), 2: streaming kernel, 0: chunked k_tile / k_rows
   return BSR_OK;
 }
 

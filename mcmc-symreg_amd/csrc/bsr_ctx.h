@@ -50,6 +50,7 @@ struct BatchSlot {
   int cols_stride = 0;   // entries between the tape groups' column-pointer tables
   size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
   size_t recs_bytes = 0; // ... of which this batch uses so many bytes
+  size_t srec_off = 0;   // streaming kernel: its StreamRecs, so many bytes behind off_recs
   // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
   MhRes* d_mh = nullptr;
   bsr_event* h_ev = nullptr;   // pinned, written by k_events
@@ -110,6 +111,7 @@ struct BatchSlot {
   int tile_ncols = 0;                // most LDS columns of any group: sizes the LDS buffers
   int tile_chunk = 0;                // blocks staged at a time: the whole slice, or a chunk of the ring
   int tile_ring = 1;                 // LDS buffers the chunks travel through (LDS-DMA)
+  bool tile_stream = false;          // the batch takes the streaming kernel (bsr_stream.hip: k_stream), not k_tile
   std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span_snap;   // [chain] the bases this batch was staged against
   uint64_t bar_readback = 0;         // (sink of the read that closes a BAR upload)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
@@ -203,6 +205,8 @@ struct bsr_ctx {
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
   bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
+  bool tile_stream = false; // chunked fp64 context: the streaming kernel (bsr_stream.hip) with its own geometry -- every
+  int tile_long = 0;        // block in a slice, the first tile_long slices one block longer, no leftover units
   size_t tile_sched_cap = 0;
   unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
   // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel

@@ -199,6 +199,29 @@ static __device__ __forceinline__ double sincos_big(double x, double fast, int w
   const double lib = which ? cos(x) : sin(x);
   return (fabs(x) < BSR_SINCOS_LIMIT) ? fast : lib;
 }
+// The same without a call on the ordinary path.  A kernel with LDS-DMA copies in flight cannot afford calls in its hot
+// loop: every device function starts with s_waitcnt vmcnt(0) (the calling convention), which waits for the copies the
+// wave issued for chunks it will not touch for microseconds.  The huge / non-finite lanes still go out of line: then, and
+// only then, the wave pays that wait.
+static __device__ __attribute__((noinline)) double sincos_big_call(double x, double fast, int which) {
+  return sincos_big(x, fast, which);
+}
+template <int U>
+__device__ __forceinline__ void sincos_vals(double (&v)[U], int which) {
+  bool small = true;
+  double f[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    small = small && (fabs(v[u]) < BSR_SINCOS_LIMIT);   // false for NaN
+    f[u] = bsr_sincos(v[u], which, bsr_lds_tab);
+  }
+  if (__builtin_amdgcn_ballot_w64(!small) != 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = sincos_big_call(v[u], f[u], which);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = f[u];
+}
 static __device__ __attribute__((noinline)) double2 sin_rows(double2 v) {
   const bool small = fabs(v.x) < BSR_SINCOS_LIMIT && fabs(v.y) < BSR_SINCOS_LIMIT;  // false for NaN
   const double2 f = make_double2(bsr_sincos(v.x, 0, bsr_lds_tab), bsr_sincos(v.y, 0, bsr_lds_tab));
@@ -315,7 +338,9 @@ template <> __device__ __forceinline__ float op_cube<float>(float x) {
 
 // Register stack accessed with a wave-uniform switch: no dynamic VGPR indexing, no scratch.  S slots live in VGPRs,
 // deeper entries (Strahler number of the tree > S+1, rare) go to a per-wave global spill area.
-template <typename T, int U, int S>
+// SPILL = false: the caller guarantees that no tape needs more than S slots (the deeper path -- vector memory -- is not
+// even generated: a kernel that counts its own LDS-DMA copies must not find loads of the compiler's among them).
+template <typename T, int U, int S, bool SPILL = true>
 struct RegStack {
   T s[S][U];
   T* spill;  // per-wave: slot-major [slot][64*U]
@@ -335,10 +360,12 @@ struct RegStack {
 #undef X
         default: __builtin_unreachable();
       }
-    } else {
+    } else if constexpr (SPILL) {
       T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
 #pragma unroll
       for (int u = 0; u < U; ++u) q[u] = v[u];
+    } else {
+      __builtin_unreachable();
     }
   }
   __device__ __forceinline__ void pop(int sp, T (&v)[U]) {
@@ -356,10 +383,12 @@ struct RegStack {
 #undef X
         default: __builtin_unreachable();
       }
-    } else {
+    } else if constexpr (SPILL) {
       const T* q = spill + (size_t)(sp - S) * (BSR_WAVE * U) + lane * U;
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = q[u];
+    } else {
+      __builtin_unreachable();
     }
   }
 };
@@ -476,13 +505,14 @@ struct LnFeed {
 };
 
 // QUAD: the out-of-line routines take four values per call (a caller short of registers asks for pairs).
-template <typename T, int U, int S, typename Loader, bool QUAD = true>
+// INL (fp64): sin, cos, exp and the protected division inline -- for callers that must not call (sincos_vals above).
+template <typename T, int U, int S, typename Loader, bool QUAD = true, bool INL = false>
 __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t* codes, const uint64_t* feats,
                                               const double* lnp, int n, const Loader& ldr, T (&acc)[U], T* spill,
                                               int lane) {
   const uint64_t CONSTANT_AS* cw = as_const(codes);
   const uint64_t CONSTANT_AS* fw = as_const(feats);
-  RegStack<T, U, S> st;
+  RegStack<T, U, S, !INL> st;   // (INL callers stay within the register stack)
   st.spill = spill;
   st.lane = lane;
   uint64_t code = hd.code0, code_next = hd.code1;
@@ -515,6 +545,9 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
         if (op == BSR_OP_SUB) {
 #pragma unroll
           for (int u = 0; u < U; ++u) acc[u] = lhs[u] - acc[u];
+        } else if constexpr (INL) {  // BSR_OP_DIV, protected like inv
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = (acc[u] == (T)0) ? (T)0 : lhs[u] / acc[u];
         } else {  // BSR_OP_DIV
           if constexpr (U % 4 == 0 && QUAD) {
 #pragma unroll
@@ -589,13 +622,26 @@ __device__ __forceinline__ void run_tape_head(const TapeHead& hd, const uint64_t
           for (int u = 0; u < U; ++u) acc[u] = -acc[u];
           break;
         case BSR_OP_SIN:
-          BSR_CALL_ROWS(sin_rows)
+          if constexpr (INL && sizeof(T) == 8) {
+            sincos_vals<U>(acc, 0);
+          } else {
+            BSR_CALL_ROWS(sin_rows)
+          }
           break;
         case BSR_OP_COS:
-          BSR_CALL_ROWS(cos_rows)
+          if constexpr (INL && sizeof(T) == 8) {
+            sincos_vals<U>(acc, 1);
+          } else {
+            BSR_CALL_ROWS(cos_rows)
+          }
           break;
         case BSR_OP_EXP:
-          BSR_CALL_ROWS(exp_rows)
+          if constexpr (INL && sizeof(T) == 8) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = op_exp<T>(acc[u]);
+          } else {
+            BSR_CALL_ROWS(exp_rows)
+          }
           break;
         case BSR_OP_SQUARE:
 #pragma unroll

@@ -141,6 +141,7 @@ struct TileGeom {
   int n_blocks;         // ceil(N / BSR_TILE_BLOCK)
   int chunk_blocks;     // blocks staged in LDS at a time: bps (the whole slice, staged once), or fewer: the slice then
   int ring;             // streams through a ring of `ring` buffers (2..4) by LDS-DMA, ring - 1 chunks ahead
+  int n_long;           // the first n_long slices hold bps + 1 blocks (streaming geometry: every block in a slice, n_left = 0)
   int n_left;           // blocks behind the last slice (n_blocks - n_slices * bps): (tape, block) units dealt to the waves
   int n_pass;           // passes over the slice (tapes per wave beyond the sets of sums)
   int qmax;             // sets of sums per wave of the launched kernel (tile_qmax(K))
@@ -167,14 +168,27 @@ struct TapeRec {
 };
 static_assert(sizeof(TapeRec) == 128, "one tape record per 128 bytes");
 
+// The streaming kernel's view of a tape (bsr_stream.hip): what its scalar-register interpreter needs, 32 bytes, one per
+// (wave, set of sums) in schedule order and one of padding behind the last.
+struct StreamRec {
+  int32_t meta;         // bits 0..4: stream entries - 1, bit 5: fast (a chain of <= 16 entries, <= 8 terminals, <= 3 ln
+                        // nodes), bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
+  int32_t p;            // proposal index, -1: none
+  double s;             // prescale of the candidate column
+  uint64_t code;        // the first 16 stream entries, 4 bits each
+  uint64_t slots;       // LDS slots of the first 8 terminals, 8 bits each; 0xFF behind the last
+};
+static_assert(sizeof(StreamRec) == 32, "one scalar load per tape");
+
 template <typename T>
 struct TileArgs {
   TileGeom g;
   const T* const* colsrc;     // [T][cols_stride] global column pointers (device memory): a tape group's X columns in LDS
   int cols_stride;            // slot order, its y, the basis columns of the batch's chains
-  int cols_in_args;           // the groups' tables are also in `cols` below (at most 4 groups of at most 32 columns): the
+  int cols_in_args;           // the groups' tables are also in `cols` below (T groups of arg_stride columns, 128 in all): the
                               // table in memory was written microseconds ago and misses every cache, the argument block
                               // is on its way to the workgroup anyway
+  int arg_stride;             // columns per group of `cols` (32 for up to four groups; 64 for two, 128 for one)
   int grp_nF[8];              // X columns per tape group (= the LDS slot of its y)
   int64_t N;
   const uint64_t* codes;
@@ -182,6 +196,7 @@ struct TileArgs {
   const double* lnp;
   const PropDesc* desc;
   const TapeRec* sched;       // [T][n_pass][BSR_TILE_WAVES][qmax] the waves' tapes (host: cost-balanced)
+  const StreamRec* srec;      // the same schedule as StreamRecs (streaming kernel), else null
   double* part;               // [P][n_part][BSR_P1_WORDS]
   int P;
   int K;
@@ -192,9 +207,13 @@ struct TileArgs {
 #ifndef BSR_HOST_ONLY
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
+void launch_stream(hipStream_t st, const TileArgs<double>& a);   // bsr_stream.hip: fp64 slices that stream through LDS
 #endif
 size_t tile_lds_bytes_max();
 int tile_qmax(int K);
+size_t stream_ln_bytes(int qt);   // LDS the streaming kernel needs behind its ring
+int stream_qmax(int K);           // its sets of sums per wave
+#define BSR_STREAM_UNITS_MAX 64   // (column, block) pieces of a chunk the streaming kernel's waves can copy (4 per wave)
 
 struct LaunchGeom {
   int rb_rows;      // rows per row block (multiple of 256)

@@ -258,7 +258,8 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     fw += (size_t)(nt + 1 + 3) / 4 + 1;
     lw += (size_t)nl + 1;
   }
-  const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t)) / 8 + 32;
+  const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t) +
+                            (c->tile_stream ? (c->tile_sched_cap + 2) * sizeof(StreamRec) : 0)) / 8 + 32;
   int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw + rec_words);
   if (rc != BSR_OK) return rc;
   s.off_recs = (s.off_streams + (cw + 2 * fw + 2 * lw) * 8 + 127) / 128 * 128;
@@ -472,7 +473,23 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
     int chunk = 0, ring = 1;
     static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hooks: chunks of at most this many blocks,
     static const int force_ring = env_int("BSR_TILE_RING", 0);     // a ring of this many buffers
-    if (per_block * (size_t)c->tile_bps <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
+    s.tile_stream = false;
+    if (c->tile_stream) {
+      // the streaming kernel: chunks of one 128-row block through the deepest ring LDS holds (what is in flight keeps HBM
+      // busy); two-block chunks where even four of those fit (a narrow batch).  Its waves copy at most 64 (column, block)
+      // pieces per chunk; a wider batch takes k_tile over the same slices (the same sums, bit for bit).
+      const int room = (int)((budget - stream_ln_bytes(c->tile_qmax)) / per_block);
+      static const int two = env_int("BSR_STREAM_CB2", 0);   // (two-block chunks: four sets of sums then spill; kept for K >= 5 experiments)
+      if (room >= 8 && two) { ring = 4; chunk = 2; }
+      else if (room >= 4) { ring = 4; chunk = 1; }
+      else if (room >= 2) { ring = room; chunk = 1; }
+      if (force_chunk > 0 && chunk > 0) chunk = std::min(chunk, std::min(force_chunk, 2));
+      if (force_ring >= 2 && force_ring <= 4 && chunk > 0 && room >= force_ring * chunk) ring = force_ring;
+      s.tile_stream = chunk > 0 && max_ncols * chunk <= BSR_STREAM_UNITS_MAX;
+      if (!s.tile_stream) { chunk = 0; ring = 1; }
+    }
+    if (s.tile_stream) {
+    } else if (per_block * (size_t)(c->tile_bps + (c->tile_long > 0 ? 1 : 0)) <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
       chunk = c->tile_bps;
     } else if (c->esz == 4) {   // f32: one buffer, staged through registers
       chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / per_block);
@@ -534,12 +551,13 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
     tg.bps = c->tile_bps;
     tg.n_blocks = c->tile_blocks;
     tg.n_left = c->tile_left;
+    tg.n_long = c->tile_long;
     tg.n_part = n_part;
     tg.ncols = s.tile_ncols;
     tg.ncols_fixed = s.tile_chains * c->K;
     tg.chunk_blocks = s.tile_chunk;
     tg.ring = s.tile_ring;
-    tg.qmax = c->tile_qmax;
+    tg.qmax = s.tile_stream ? c->tile_qmax : tile_qmax(c->K);   // (a streaming context's batch that takes k_tile after all)
     int cnt_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < P; ++i) ++cnt_g[hd[i].grp & 7];
     int most = 0;
@@ -588,7 +606,9 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       TapeRec& R = sc[ri];
       R.p = p;
       R.n_nodes = D.n_nodes;
-      R.chain = D.chain;
+      // bit 1: the streaming kernel's scalar-register interpreter takes the tape (a chain of at most 16 entries, 8
+      // terminals in slots below 255, 3 ln nodes)
+      R.chain = D.chain | ((D.chain && D.n_nodes <= 16 && D.n_term <= 8 && D.n_ln <= 3 && tg.ncols < 255) ? 2 : 0);
       R.qslot = D.qslot;
       R.s = D.s;
       R.code0 = hcodes[D.code_off];
@@ -606,6 +626,33 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       R.n_ln = D.n_ln;
       R.n_term = D.n_term;
       R.grp = grp;
+    }
+    s.srec_off = 0;
+    if (s.tile_stream) {
+      // the streaming kernel's 32-byte view of every set of sums, in schedule order, one record of padding behind the
+      // last (a wave requests the next tape's program while it adds up this one's rows)
+      s.srec_off = (s.recs_bytes + 31) / 32 * 32;
+      StreamRec* sr = reinterpret_cast<StreamRec*>(reinterpret_cast<char*>(sc) + s.srec_off);
+      for (size_t i = 0; i <= n_sched; ++i) {
+        StreamRec& Q = sr[i];
+        memset(&Q, 0, sizeof Q);
+        Q.p = -1;
+        if (i == n_sched || sc[i].p < 0) continue;
+        const TapeRec& R = sc[i];
+        const bool fast = (R.chain & 2) != 0;
+        Q.p = R.p;
+        Q.meta = ((R.n_nodes - 1) & 31) | (fast ? 32 : 0) | 64 | ((R.qslot & 0xFF) << 8);
+        Q.s = R.s;
+        Q.code = R.code0;
+        uint64_t slots = 0;
+        for (int t = 0; t < 8; ++t) {
+          const uint64_t w = (t < 4) ? R.f0 : R.f1;
+          const uint64_t id = (w >> (16 * (t & 3))) & 0xFFu;
+          slots |= ((t < R.n_term) ? id : (uint64_t)0xFF) << (8 * t);
+        }
+        Q.slots = slots;
+      }
+      s.recs_bytes = s.srec_off + (n_sched + 1) * sizeof(StreamRec);
     }
     if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
       int32_t* glist = left_idx + P;

@@ -1,0 +1,374 @@
+// Streaming row pass for data sets far larger than LDS (BASELINE configs[4]: N = 1M, d = 50): the projection pass of the
+// scoring path (allcal + the O(N) part of ylogLike / the rank gate, codes/funcs.py:175-220, 1147-1174, 1212-1226) for
+// fp64 contexts whose row slices do not fit LDS whole.
+//
+// One workgroup of 16 waves per CU owns a row slice and one tape group; a wave keeps the per-lane sums of its QT tapes
+// (a static, cost-balanced schedule written by the host) in registers over the whole slice, and the slice travels
+// HBM -> LDS through a ring of R buffers filled by LDS-DMA, R - 1 chunks ahead of the one the waves compute on.  What
+// k_tile (bsr_tile.hip) paid per (tape, chunk) and this kernel does not:
+//   * a tape's program -- 4-bit opcodes, 8-bit LDS slots of its terminals, prescale, basis slot -- sits in scalar
+//     registers for the life of the wave (k_tile re-read a 128-byte record per tape and chunk, and its compiler-made
+//     scalar spills were vector instructions: 34 per (tape, 128 rows) for one fused operand; tools/probes/op_costs);
+//   * y and the basis columns are read from LDS once per chunk and wave, not once per tape, and before the tapes run;
+//   * the operand of the next `acc op= column` entry is requested one entry ahead;
+//   * a wave's DMA pieces take their source from scalar registers (a column base per piece, loaded once) and ONE vector
+//     offset that advances by a chunk: no per-piece lane reads.
+// Chunks are one or two 128-row blocks.  With all 64 tapes in ONE group (four per wave at K <= 4) every column is
+// streamed once per launch (k_tile's two groups both streamed the columns they shared: 1.38x the algorithmic bytes).
+//
+// Tapes the fast interpreter does not take (not a chain, more than 16 entries, 8 terminals or 3 ln nodes) run through
+// the stack machine of bsr_device.h on the same staged rows -- one copy of it behind the unrolled tapes.  Nothing in the
+// loop is a call (sin, cos, exp inline; only their huge-argument lanes and the extension operator `log` go out of line):
+// every device function starts with s_waitcnt vmcnt(0), which would wait for the wave's copies in flight.  Either way the values of a row and the order
+// of every sum are those of the other row passes: per lane the blocks of the slice in order, the lane's two rows of a
+// block in order; one lane reduction per (tape, slice) in the fixed network of reduce_store.  What is summed in which
+// order depends on the context's slices only, never on the batch.
+#include "bsr_tile_common.h"
+
+namespace {
+
+// the scalar state of one tape of a wave: a StreamRec (bsr_internal.h), 32 bytes the host packs per (wave, set of sums)
+struct TapeS {
+  int meta;             // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5: the fast interpreter takes it,
+                        // bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
+  double s;             // prescale
+  uint64_t code;        // 16 entries x 4 bits (entry 0: the leading terminal)
+  uint64_t slots;       // LDS slots of its terminals in stream order, 8 bits each; 0xFF: none
+  __device__ __forceinline__ bool fast() const { return (meta & 32) != 0; }
+  __device__ __forceinline__ bool any() const { return (meta & 64) != 0; }
+  __device__ __forceinline__ int n() const { return (meta & 31) + 1; }
+  __device__ __forceinline__ int qslot() const { return (meta >> 8) & 0xFF; }
+};
+__device__ __forceinline__ TapeS load_tape(const StreamRec CONSTANT_AS* r) {
+  TapeS t;
+  t.meta = r->meta;
+  t.s = r->s;
+  t.code = r->code;
+  t.slots = r->slots;
+  return t;
+}
+
+template <int CB>
+__device__ __forceinline__ void lds_pairs(const double* col, double (&v)[2 * CB]) {
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const double2 p = *reinterpret_cast<const double2*>(col + j * BSR_TILE_BLOCK);
+    v[2 * j] = p.x;
+    v[2 * j + 1] = p.y;
+  }
+}
+
+// acc <- log|acc| through the out-of-line routine of bsr_device.h (an extension operator: the one call left in the loop)
+#define BSR_STREAM_CALL(f)                                                              \
+  if constexpr (CB == 2) {                                                              \
+    double4 v = make_double4(acc[0], acc[1], acc[2], acc[3]);                           \
+    v = f(v);                                                                           \
+    acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;                             \
+  } else {                                                                              \
+    double2 v = make_double2(acc[0], acc[1]);                                           \
+    v = f(v);                                                                           \
+    acc[0] = v.x; acc[1] = v.y;                                                         \
+  }
+
+// A chain tape on the lane's rows of one chunk: entry 0 loads the leading terminal, every other entry maps the
+// accumulator to the accumulator.  `lane_col`: the lane's pair in block 0 of column 0 of the chunk's buffer;
+// `ln_tab`: the tape's (a, b) pairs in LDS.
+template <int CB>
+__device__ __forceinline__ void chain_fast(const TapeS& t, const double* lane_col, int chunk_rows, const double2* ln_tab,
+                                           double (&acc)[2 * CB]) {
+  constexpr int U = 2 * CB;
+  uint64_t code = t.code >> 4, sl = t.slots;
+  lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, acc);
+  sl >>= 8;
+  double pre[U];
+  if ((sl & 0xFF) != 0xFF) lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);
+  int lk = 0;
+  const int n = t.n();
+  for (int i = 1; i < n; ++i) {
+    const int op = (int)(code & 15u);
+    code >>= 4;
+    switch (op) {
+      case BSR_SOP_ADD_T:
+      case BSR_SOP_MUL_T: {
+        if (op == BSR_SOP_ADD_T) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
+        }
+        sl >>= 8;
+        if ((sl & 0xFF) != 0xFF) lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);   // the next operand, one entry ahead
+      } break;
+      case BSR_OP_INV:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = (acc[u] == 0.0) ? 0.0 : 1.0 / acc[u];
+        break;
+      case BSR_OP_LN: {
+        const double2 ab = ln_tab[lk];   // every lane reads the same 16 bytes: a broadcast
+        ++lk;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = ab.x * acc[u] + ab.y;   // two roundings (contraction is off)
+      } break;
+      case BSR_OP_NEG:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = -acc[u];
+        break;
+#ifndef BSR_X_NOTRANS
+      case BSR_OP_SIN:   // inline: a call would wait for the wave's LDS-DMA copies in flight (bsr_device.h: sincos_vals)
+        sincos_vals<U>(acc, 0);
+        break;
+      case BSR_OP_COS:
+        sincos_vals<U>(acc, 1);
+        break;
+      case BSR_OP_EXP:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = op_exp<double>(acc[u]);
+        break;
+      case BSR_OP_LOG:
+        BSR_STREAM_CALL(log_rows)
+        break;
+#endif
+      case BSR_OP_SQUARE:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
+        break;
+      case BSR_OP_CUBIC:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = op_cube<double>(acc[u]);
+        break;
+      default:  // a chain holds no other entry
+        break;
+    }
+  }
+}
+
+// one chunk's rows of one tape into its sums (the order of accumulate_v, bsr_tile_common.h); every row lies below N
+template <int KQ, int CB>
+__device__ __forceinline__ void add_chunk(TapeAcc<KQ>& A, const double (&z)[2 * CB], const double (&yv)[2 * CB],
+                                          const double (&qv)[KQ > 0 ? KQ : 1][2 * CB], double s, int nbc) {
+  constexpr int U = 2 * CB;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (CB == 1 || u < 2 * nbc) {   // (a chunk cut short by the end of the slice: its second block is not there)
+      const double zs = z[u] * s;
+      A.amax = max_abs(A.amax, z[u]);
+      A.a0 = fma(zs, zs, A.a0);
+      A.a1 = fma(zs, yv[u], A.a1);
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) A.c[i] = fma(qv[i][u], zs, A.c[i]);
+    }
+  }
+}
+
+// The block that holds row N (N not a multiple of 128) belongs to no slice: it goes out as (tape, block) units with a
+// partial record of their own, rows beyond N masked, columns read through L2 (leftover_unit, bsr_tile_common.h) -- a call,
+// behind the loop, when none of the wave's copies is in flight any more.
+template <int KQ>
+__device__ __attribute__((noinline)) void leftover_call(const TileArgs<double>* ka, int lane, int tk) {
+  const uint64_t v = (uint64_t)(size_t)ka;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  using AT = TileArgs<double> CONSTANT_AS;   // (read field by field through scalar loads: no copy of the block)
+  const AT& a = *(const AT*)(size_t)(((uint64_t)hi << 32) | lo);
+  leftover_unit<double, KQ, AT, TileGeom CONSTANT_AS>(a, a.g, lane, tk);
+}
+
+template <int KQ, int QT, int CB, bool STAMPS>
+__global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<double> a) {
+  constexpr int U = 2 * CB;
+  constexpr int NUMAX = BSR_STREAM_UNITS_MAX / BSR_TILE_WAVES;   // DMA pieces per wave and chunk at most
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* sx = reinterpret_cast<double*>(smem);   // [ring][ncols][chunk_rows], then the waves' ln pairs
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_slices = a.g.n_slices;
+  const int tg = blockIdx.x / n_slices, slice = blockIdx.x - tg * n_slices;
+  const int b0 = slice * a.g.bps + min(slice, a.g.n_long);            // the first n_long slices hold one block more
+  const int nb = a.g.bps + (slice < a.g.n_long ? 1 : 0);
+  const int n_chunks = (nb + CB - 1) / CB;
+  constexpr int chunk_rows = CB * BSR_TILE_BLOCK;
+  const int R = a.g.ring;
+  const int buf_elems = a.g.ncols * chunk_rows;
+  const double* const CONSTANT_AS* colsrc = group_cols<double>(a, tg);
+  const int y_slot = a.grp_nF[tg & 7];
+  const int ncols = y_slot + 1 + a.g.ncols_fixed;
+  double2* ln_all = reinterpret_cast<double2*>(sx + (size_t)R * buf_elems);
+  unsigned long long* stamp = STAMPS ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
+#define TSTAMP(i) do { if (STAMPS && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  TSTAMP(0);
+  if (STAMPS && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+  tables_to_lds();  // visible after the first barrier below
+  unsigned long long busy = 0, t_busy = 0;
+
+  // the wave's DMA pieces: piece k copies unit u = wave + 16 k of every chunk -- (column u / CB, block u % CB of the
+  // chunk) -- to byte u * 1024 of the ring buffer; its column base sits in scalar registers
+  const int n_units = ncols * CB;
+  uint64_t src[NUMAX];
+#pragma unroll
+  for (int k = 0; k < NUMAX; ++k) {
+    const int u = wave + BSR_TILE_WAVES * k;
+    src[k] = 0;
+    if (u < n_units) src[k] = (uint64_t)(size_t)(colsrc[u / CB] + (int64_t)(b0 + u % CB) * BSR_TILE_BLOCK);
+  }
+  const int n_mine = (n_units - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // pieces of a whole chunk (n_units > wave: >= 16 columns... or 0)
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sx;
+  // pieces of chunk j: all of them, or (two-block chunks, a slice of an odd number of blocks: its last chunk) those of block 0
+  auto pieces = [&](int j) {
+    if (CB == 1 || (j + 1) * CB <= nb) return n_mine > 0 ? n_mine : 0;
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < NUMAX; ++k) n += ((wave + BSR_TILE_WAVES * k) < n_units && ((wave + BSR_TILE_WAVES * k) % CB) == 0) ? 1 : 0;
+    return n;
+  };
+  auto issue = [&](int j) {
+    const bool cut = CB == 2 && (j + 1) * CB > nb;   // only block 0 of the chunk exists
+    const uint32_t buf = lds0 + (uint32_t)((j % R) * buf_elems) * 8u;
+    const uint32_t voff = (uint32_t)lane * 16u + (uint32_t)j * (uint32_t)(chunk_rows * 8);
+#pragma unroll
+    for (int k = 0; k < NUMAX; ++k) {
+      const int u = wave + BSR_TILE_WAVES * k;
+      if (u < n_units && !(cut && (u % CB) != 0)) {
+        const uint32_t la = buf + (uint32_t)u * 1024u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src[k]), "s"(la) : "memory", "m0");
+      }
+    }
+  };
+
+  for (int pass = 0; pass < a.g.n_pass; ++pass) {
+    const TapeRec* my = a.sched + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT;
+    // the wave's tapes: ln pairs into LDS, sums cleared; their programs (StreamRec, 32 bytes) are read again for every
+    // chunk by one scalar load each, requested under the sums of the tape before
+    const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
+    TapeAcc<KQ> A[QT];
+    double2* ln_mine = ln_all + (size_t)wave * QT * 3;
+    if (pass != 0) __syncthreads();   // everyone is done with the last chunks (and the ln pairs) of the pass before
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const TapeRec CONSTANT_AS* rec = as_const(my + q);
+      A[q].clear();
+      if (lane == 0) {   // (scalar loads and LDS stores: no vector memory operation next to the copies' counter)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ln_mine[q * 3 + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
+      }
+    }
+    for (int j = 0; j < min(R - 1, n_chunks); ++j) issue(j);
+    for (int ci = 0; ci < n_chunks; ++ci) {
+      {
+        int later = 0;
+        for (int j = ci + 1; j < min(ci + R - 1, n_chunks); ++j) later += pieces(j);
+        dma_wait_left(later);
+      }
+      __syncthreads();   // chunk ci has landed for everyone; everyone is done with chunk ci - 1
+      if (ci + R - 1 < n_chunks) issue(ci + R - 1);
+      if (ci == 0 && pass == 0) TSTAMP(1);
+      if (STAMPS) t_busy = __builtin_amdgcn_s_memtime();
+      const double* cur = sx + (size_t)(ci % R) * buf_elems;
+      const double* lane_col = cur + 2 * lane;
+      const int nbc = (CB == 1) ? 1 : min(CB, nb - ci * CB);
+      // y (and below: the basis columns) of the lane's rows, once for all tapes of the wave
+      double yv[U];
+      lds_pairs<CB>(lane_col + y_slot * chunk_rows, yv);
+      double qv[KQ > 0 ? KQ : 1][U];
+      int q_have = -1;
+      TapeS nx = load_tape(sr);
+#pragma unroll 1
+      for (int q = 0; q < QT; ++q) {
+        const TapeS t = nx;
+        if (!t.any()) {
+          nx = load_tape(sr + q + 1);
+          continue;
+        }
+        if (t.qslot() != q_have) {   // (tapes of one chain share the basis: read once)
+          q_have = t.qslot();
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (q_have + i) * chunk_rows, qv[i]);
+        }
+        double z[U];
+        if (t.fast()) {
+          chain_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * 3, z);
+        } else {
+          // Any other tape (not a chain; longer than the scalar registers hold): the stack machine of bsr_device.h on
+          // the same rows, its routines inline too; the tape's full record is read for it.
+          const TapeRec CONSTANT_AS* rec = as_const(my + q);
+          TapeHead hd;
+          hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+          hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+          hd.ln_near = (const double*)rec->ln;
+          hd.n_ln = rec->n_ln;
+          hd.n_term = rec->n_term;
+          LdsCols<double, U> ldr{cur, chunk_rows, 2 * lane};
+          run_tape_head<double, U, BSR_REG_STACK, LdsCols<double, U>, false, true>(
+              hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, z,
+              (double*)nullptr, lane);
+        }
+        nx = load_tape(sr + q + 1);   // the next tape's program travels under this tape's sums (one record of padding behind the last)
+        switch (q) {
+#define BSR_ADD_CASE(qq) case qq: if constexpr (qq < QT) add_chunk<KQ, CB>(A[qq], z, yv, qv, t.s, nbc); break;
+          BSR_ADD_CASE(0) BSR_ADD_CASE(1) BSR_ADD_CASE(2) BSR_ADD_CASE(3)
+#undef BSR_ADD_CASE
+        }
+      }
+      if (STAMPS) busy += __builtin_amdgcn_s_memtime() - t_busy;
+      if (ci == 0 && pass == 0) TSTAMP(2);
+    }
+    if (pass == a.g.n_pass - 1) TSTAMP(3);
+    if (STAMPS && lane == 0) stamp[5] = busy;
+    __syncthreads();   // everyone is done with the ring: its first bytes serve as the reductions' scratch
+    reduce_store<KQ, QT>(A, my, a.part, a.g.n_part, slice, sx + (size_t)wave * (QT * (KQ + 2) + 12), lane);
+  }
+  // the block that holds row N, if N is not a multiple of 128: unit u of the launch goes to wave u mod (workgroups x 16)
+  if (a.g.n_left > 0) {
+    const int n_units_left = a.P * a.g.n_left, n_waves = (int)gridDim.x * BSR_TILE_WAVES;
+    for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units_left; tk += n_waves)
+      leftover_call<KQ>((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), lane, tk);
+  }
+  TSTAMP(4);
+  if (STAMPS && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#undef TSTAMP
+}
+
+template <int KQ, int QT, int CB, bool STAMPS>
+void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(tile_lds_bytes_max() - 1024));
+    attr = true;
+  }
+  const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
+  hipLaunchKernelGGL((k_stream<KQ, QT, CB, STAMPS>), grid, block, lds, st, a);
+}
+template <int KQ, int QT>
+void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
+  if (a.stamps) {   // diagnostics build of the kernel (BSR_TILE_STAMPS=1): per-wave clock samples
+    if (a.g.chunk_blocks == 2) launch_one<KQ, QT, 2, true>(st, a, lds);
+    else launch_one<KQ, QT, 1, true>(st, a, lds);
+    return;
+  }
+  if (a.g.chunk_blocks == 2) launch_one<KQ, QT, 2, false>(st, a, lds);
+  else launch_one<KQ, QT, 1, false>(st, a, lds);
+}
+
+}  // namespace
+
+// bytes of LDS behind the ring: three (a, b) pairs per tape of every wave
+size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof(double2); }
+
+// sets of sums per wave of the streaming kernel: four while the sums of four tapes, a chunk's y and basis values and
+// the routines' temporaries fit 128 registers (K <= 4), else two
+int stream_qmax(int K) { return K <= 4 ? 4 : 2; }
+
+void launch_stream(hipStream_t st, const TileArgs<double>& a) {
+  const TileGeom& g = a.g;
+  const size_t lds = (size_t)g.ring * g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(double) + stream_ln_bytes(g.qmax);
+  switch (a.K) {
+    case 1: launch_cb<1, 4>(st, a, lds); break;
+    case 2: launch_cb<2, 4>(st, a, lds); break;
+    case 3: launch_cb<3, 4>(st, a, lds); break;
+    case 4: launch_cb<4, 4>(st, a, lds); break;
+    case 5: launch_cb<5, 2>(st, a, lds); break;
+    case 6: launch_cb<6, 2>(st, a, lds); break;
+    case 7: launch_cb<7, 2>(st, a, lds); break;
+    default: launch_cb<8, 2>(st, a, lds); break;
+  }
+}
