@@ -331,7 +331,7 @@ def attach_traffic(out, name, B, C, dtype):
     tpath = tpaths[-1] if tpaths else ""
     if C == WORKLOADS[name]["chains"] and dtype == "f64" and tpath:
         recs = [(rec.get("launches", 0), rec) for kname, rec in json.load(open(tpath)).items()
-                if "k_rows" in kname or "k_tile" in kname]
+                if "k_rows" in kname or "k_tile" in kname or "k_stream" in kname]
         if recs:   # the scoring pass is the kernel with (by far) the most launches; the others filled derived columns
             rec = max(recs, key=lambda t: t[0])[1]
             out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
@@ -344,7 +344,7 @@ def attach_traffic(out, name, B, C, dtype):
         best = None
         for row in csv.DictReader(open(spaths[-1])):
             kn = row.get("Name", "")
-            if "k_tile" in kn or ("k_rows" in kn and ", 0>" in kn):
+            if "k_tile" in kn or "k_stream" in kn or ("k_rows" in kn and ", 0>" in kn):
                 if best is None or int(row["Calls"]) > int(best["Calls"]):
                     best = row
         if best:

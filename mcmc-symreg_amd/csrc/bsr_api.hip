@@ -514,6 +514,7 @@ static void fill_desc_tape(PropDesc* D, const TapeLoc& L) {
   D->feat_off = L.feat_off;
   D->ln_off = L.ln_off;
   D->spill_need = std::max(0, L.max_sp - 1 - 2);  // sized for the smallest register stack (2 slots at 8 rows/lane)
+  D->max_sp = L.max_sp;
   D->cost = L.cost;
   D->chain = L.acc_only;
   D->grp = L.grp;

@@ -58,6 +58,7 @@ struct PropDesc {
   int32_t K;
   int32_t ck;           // index into the ChainB array (chain)
   int32_t spill_need;   // stack slots beyond the register stack
+  int32_t max_sp;       // values the fused encoding holds at once (the accumulator included): 1 for a chain
   int32_t order;        // entry i: index of the i-th most expensive tape of the batch (work-queue order)
   int32_t cost;         // host's estimate of the tape's cost per sweep (sort key for `order`)
   int32_t qslot;        // tile pass: LDS slot of the chain's first basis column (K consecutive slots)
@@ -173,10 +174,10 @@ static_assert(sizeof(TapeRec) == 128, "one tape record per 128 bytes");
 struct StreamRec {
   int32_t meta;         // bits 0..4: stream entries - 1, bit 5: fast (a chain of <= 16 entries, <= 8 terminals, <= 3 ln
                         // nodes), bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
-  int32_t p;            // proposal index, -1: none
+  int32_t first;        // LDS slot of the leading terminal
   double s;             // prescale of the candidate column
   uint64_t code;        // the first 16 stream entries, 4 bits each
-  uint64_t slots;       // LDS slots of the first 8 terminals, 8 bits each; 0xFF behind the last
+  uint64_t slots;       // LDS slots of terminals 2..8, 8 bits each, in stream order
 };
 static_assert(sizeof(StreamRec) == 32, "one scalar load per tape");
 

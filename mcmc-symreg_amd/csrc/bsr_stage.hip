@@ -480,7 +480,7 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       // pieces per chunk; a wider batch takes k_tile over the same slices (the same sums, bit for bit).
       const int room = (int)((budget - stream_ln_bytes(c->tile_qmax)) / per_block);
       static const int two = env_int("BSR_STREAM_CB2", 0);   // (two-block chunks: four sets of sums then spill; kept for K >= 5 experiments)
-      if (room >= 8 && two) { ring = 4; chunk = 2; }
+      if (room >= 4 && two) { ring = std::min(4, room / 2); chunk = 2; }
       else if (room >= 4) { ring = 4; chunk = 1; }
       else if (room >= 2) { ring = room; chunk = 1; }
       if (force_chunk > 0 && chunk > 0) chunk = std::min(chunk, std::min(force_chunk, 2));
@@ -606,9 +606,9 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       TapeRec& R = sc[ri];
       R.p = p;
       R.n_nodes = D.n_nodes;
-      // bit 1: the streaming kernel's scalar-register interpreter takes the tape (a chain of at most 16 entries, 8
-      // terminals in slots below 255, 3 ln nodes)
-      R.chain = D.chain | ((D.chain && D.n_nodes <= 16 && D.n_term <= 8 && D.n_ln <= 3 && tg.ncols < 255) ? 2 : 0);
+      // bit 1: the streaming kernel's scalar-register interpreter takes the tape (at most 16 entries, 8 terminals in
+      // slots below 255, 3 ln nodes, one value on the stack below the accumulator)
+      R.chain = D.chain | ((D.n_nodes <= 16 && D.n_term <= 8 && D.n_ln <= 3 && D.max_sp <= 2 && tg.ncols < 255) ? 2 : 0);
       R.qslot = D.qslot;
       R.s = D.s;
       R.code0 = hcodes[D.code_off];
@@ -627,6 +627,25 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       R.n_term = D.n_term;
       R.grp = grp;
     }
+    static const int dump = env_int("BSR_SCHED_DUMP", 0);   // diagnostics: the schedule's loads (cost model units) per wave
+    if (dump && tg.per_group == 0) {
+      std::string line = "sched T=" + std::to_string(tg.T) + " qmax=" + std::to_string(tg.qmax) + " costs:";
+      for (int i = 0; i < P; ++i) line += " " + std::to_string(hd[s.order_tmp[i]].cost);
+      line += " | wave loads:";
+      for (size_t i = 0; i < s.wave_load.size(); ++i) line += " " + std::to_string((int)s.wave_load[i]);
+      fprintf(stderr, "%s\n", line.c_str());
+      for (int w = 0; w < BSR_TILE_WAVES * tg.T; ++w) {
+        std::string l2 = "  wave " + std::to_string(w) + ":";
+        for (int q = 0; q < tg.qmax; ++q) {
+          const TapeRec& R = sc[(size_t)w * tg.qmax + q];
+          if (R.p < 0) continue;
+          char b[96];
+          snprintf(b, sizeof b, " [cost %d n %d chain %d code %llx]", hd[R.p].cost, R.n_nodes, R.chain, (unsigned long long)R.code0);
+          l2 += b;
+        }
+        fprintf(stderr, "%s\n", l2.c_str());
+      }
+    }
     s.srec_off = 0;
     if (s.tile_stream) {
       // the streaming kernel's 32-byte view of every set of sums, in schedule order, one record of padding behind the
@@ -636,19 +655,18 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       for (size_t i = 0; i <= n_sched; ++i) {
         StreamRec& Q = sr[i];
         memset(&Q, 0, sizeof Q);
-        Q.p = -1;
         if (i == n_sched || sc[i].p < 0) continue;
         const TapeRec& R = sc[i];
         const bool fast = (R.chain & 2) != 0;
-        Q.p = R.p;
         Q.meta = ((R.n_nodes - 1) & 31) | (fast ? 32 : 0) | 64 | ((R.qslot & 0xFF) << 8);
         Q.s = R.s;
         Q.code = R.code0;
+        Q.first = (int32_t)(R.f0 & 0xFFu);
         uint64_t slots = 0;
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 1; t < 8; ++t) {
           const uint64_t w = (t < 4) ? R.f0 : R.f1;
           const uint64_t id = (w >> (16 * (t & 3))) & 0xFFu;
-          slots |= ((t < R.n_term) ? id : (uint64_t)0xFF) << (8 * t);
+          slots |= ((t < R.n_term) ? id : (uint64_t)0) << (8 * (t - 1));
         }
         Q.slots = slots;
       }

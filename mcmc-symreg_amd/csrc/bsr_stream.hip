@@ -25,26 +25,33 @@
 // order depends on the context's slices only, never on the batch.
 #include "bsr_tile_common.h"
 
+int env_int(const char* name, int dflt);   // bsr_api.hip
+
 namespace {
 
-// the scalar state of one tape of a wave: a StreamRec (bsr_internal.h), 32 bytes the host packs per (wave, set of sums)
+// the scalar state of one tape of a wave: a StreamRec (bsr_internal.h), 32 bytes the host packs per (wave, set of sums),
+// fetched by ONE scalar load
 struct TapeS {
-  int meta;             // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5: the fast interpreter takes it,
+  uint32_t meta;        // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5: the fast interpreter takes it,
                         // bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
+  uint32_t first;       // LDS slot of the leading terminal
   double s;             // prescale
   uint64_t code;        // 16 entries x 4 bits (entry 0: the leading terminal)
-  uint64_t slots;       // LDS slots of its terminals in stream order, 8 bits each; 0xFF: none
+  uint64_t slots;       // LDS slots of the terminals behind the first, in stream order, 8 bits each
   __device__ __forceinline__ bool fast() const { return (meta & 32) != 0; }
   __device__ __forceinline__ bool any() const { return (meta & 64) != 0; }
-  __device__ __forceinline__ int n() const { return (meta & 31) + 1; }
-  __device__ __forceinline__ int qslot() const { return (meta >> 8) & 0xFF; }
+  __device__ __forceinline__ int n() const { return (int)(meta & 31) + 1; }
+  __device__ __forceinline__ int qslot() const { return (int)((meta >> 8) & 0xFF); }
 };
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ TapeS load_tape(const StreamRec CONSTANT_AS* r) {
+  const u32x8 w = *reinterpret_cast<const u32x8 CONSTANT_AS*>(r);
   TapeS t;
-  t.meta = r->meta;
-  t.s = r->s;
-  t.code = r->code;
-  t.slots = r->slots;
+  t.meta = w[0];
+  t.first = w[1];
+  t.s = __hiloint2double((int)w[3], (int)w[2]);
+  t.code = ((uint64_t)w[5] << 32) | w[4];
+  t.slots = ((uint64_t)w[7] << 32) | w[6];
   return t;
 }
 
@@ -70,36 +77,65 @@ __device__ __forceinline__ void lds_pairs(const double* col, double (&v)[2 * CB]
     acc[0] = v.x; acc[1] = v.y;                                                         \
   }
 
-// A chain tape on the lane's rows of one chunk: entry 0 loads the leading terminal, every other entry maps the
-// accumulator to the accumulator.  `lane_col`: the lane's pair in block 0 of column 0 of the chunk's buffer;
-// `ln_tab`: the tape's (a, b) pairs in LDS.
+// A tape on the lane's rows of one chunk, from scalar registers: entry 0 loads the leading terminal; `acc op= column`
+// entries and unary operators map the accumulator to the accumulator (a chain tape holds nothing else); a terminal that
+// is not fused pushes the accumulator into ONE saved register set, a binary operator pops it -- expressions like
+// (x0 + x1) * (x2 + x3) cost two moves more than a chain, not a trip through the general stack machine (measured at
+// ten times a chain's time per tape: tools/probes/op_costs).  Same operators, same operand order as run_tape_head.
+// `lane_col`: the lane's pair in block 0 of column 0 of the chunk's buffer; `ln_tab`: the tape's (a, b) pairs in LDS.
 template <int CB>
-__device__ __forceinline__ void chain_fast(const TapeS& t, const double* lane_col, int chunk_rows, const double2* ln_tab,
-                                           double (&acc)[2 * CB]) {
+__device__ __forceinline__ void tape_fast(const TapeS& t, const double* lane_col, int chunk_rows, const double2* ln_tab,
+                                          double (&acc)[2 * CB]) {
   constexpr int U = 2 * CB;
-  uint64_t code = t.code >> 4, sl = t.slots;
-  lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, acc);
-  sl >>= 8;
-  double pre[U];
-  if ((sl & 0xFF) != 0xFF) lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);
+  uint64_t code = t.code >> 4, sl = t.slots;   // (the leading terminal's values arrive in acc: the caller requested them a tape ahead)
+  // (no operand requested ahead of its entry: carried around the loop, the compiler copies such registers on every
+  // entry and waits for the read it was meant to hide -- 450 cycles per entry measured; at its use the read costs one LDS
+  // round trip, which the SIMD's other waves fill)
+  double s0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s0[u] = 0.0;
   int lk = 0;
   const int n = t.n();
   for (int i = 1; i < n; ++i) {
     const int op = (int)(code & 15u);
     code >>= 4;
     switch (op) {
-      case BSR_SOP_ADD_T:
-      case BSR_SOP_MUL_T: {
-        if (op == BSR_SOP_ADD_T) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
-        }
+      case BSR_SOP_ADD_T: {
+        double pre[U];
+        lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);
         sl >>= 8;
-        if ((sl & 0xFF) != 0xFF) lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);   // the next operand, one entry ahead
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] + pre[u];
       } break;
+      case BSR_SOP_MUL_T: {
+        double pre[U];
+        lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, pre);
+        sl >>= 8;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = acc[u] * pre[u];
+      } break;
+      case BSR_OP_TERMINAL: {   // push
+#pragma unroll
+        for (int u = 0; u < U; ++u) s0[u] = acc[u];
+        lds_pairs<CB>(lane_col + (int)(sl & 0xFF) * chunk_rows, acc);
+        sl >>= 8;
+      } break;
+      case BSR_OP_ADD:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = s0[u] + acc[u];
+        break;
+      case BSR_OP_MUL:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = s0[u] * acc[u];
+        break;
+      case BSR_OP_SUB:
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = s0[u] - acc[u];
+        break;
+      case BSR_OP_DIV:   // protected like inv
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = (acc[u] == 0.0) ? 0.0 : s0[u] / acc[u];
+        break;
       case BSR_OP_INV:
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = (acc[u] == 0.0) ? 0.0 : 1.0 / acc[u];
@@ -114,7 +150,6 @@ __device__ __forceinline__ void chain_fast(const TapeS& t, const double* lane_co
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = -acc[u];
         break;
-#ifndef BSR_X_NOTRANS
       case BSR_OP_SIN:   // inline: a call would wait for the wave's LDS-DMA copies in flight (bsr_device.h: sincos_vals)
         sincos_vals<U>(acc, 0);
         break;
@@ -128,16 +163,13 @@ __device__ __forceinline__ void chain_fast(const TapeS& t, const double* lane_co
       case BSR_OP_LOG:
         BSR_STREAM_CALL(log_rows)
         break;
-#endif
       case BSR_OP_SQUARE:
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
         break;
-      case BSR_OP_CUBIC:
+      default:  // BSR_OP_CUBIC
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = op_cube<double>(acc[u]);
-        break;
-      default:  // a chain holds no other entry
         break;
     }
   }
@@ -201,47 +233,52 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   unsigned long long busy = 0, t_busy = 0;
 
   // the wave's DMA pieces: piece k copies unit u = wave + 16 k of every chunk -- (column u / CB, block u % CB of the
-  // chunk) -- to byte u * 1024 of the ring buffer; its column base sits in scalar registers
+  // chunk) -- to byte u * 1024 of the ring buffer.  Column bases are fetched from the group's table when a chunk is
+  // requested (scalar loads, issued in front of the barrier the wave waits at anyway): held in scalar registers for the
+  // life of the kernel they were spilled, and every reload of a spilled scalar is a vector instruction.
   const int n_units = ncols * CB;
-  uint64_t src[NUMAX];
-#pragma unroll
-  for (int k = 0; k < NUMAX; ++k) {
-    const int u = wave + BSR_TILE_WAVES * k;
-    src[k] = 0;
-    if (u < n_units) src[k] = (uint64_t)(size_t)(colsrc[u / CB] + (int64_t)(b0 + u % CB) * BSR_TILE_BLOCK);
-  }
-  const int n_mine = (n_units - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES;   // pieces of a whole chunk (n_units > wave: >= 16 columns... or 0)
+  const int n_mine = max(0, (n_units - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES);   // the wave's pieces of a whole chunk
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sx;
-  // pieces of chunk j: all of them, or (two-block chunks, a slice of an odd number of blocks: its last chunk) those of block 0
-  auto pieces = [&](int j) {
-    if (CB == 1 || (j + 1) * CB <= nb) return n_mine > 0 ? n_mine : 0;
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < NUMAX; ++k) n += ((wave + BSR_TILE_WAVES * k) < n_units && ((wave + BSR_TILE_WAVES * k) % CB) == 0) ? 1 : 0;
-    return n;
-  };
-  auto issue = [&](int j) {
-    const bool cut = CB == 2 && (j + 1) * CB > nb;   // only block 0 of the chunk exists
-    const uint32_t buf = lds0 + (uint32_t)((j % R) * buf_elems) * 8u;
-    const uint32_t voff = (uint32_t)lane * 16u + (uint32_t)j * (uint32_t)(chunk_rows * 8);
+  const uint32_t buf_bytes = (uint32_t)buf_elems * 8u, ring_bytes = buf_bytes * (uint32_t)R;
+  // (two-block chunks: u % 2 == wave % 2 for every piece of the wave; the last chunk of a slice of an odd number of
+  // blocks holds block 0 only: the odd waves then copy nothing)
+  auto pieces = [&](int j) { return (CB == 2 && (j + 1) * CB > nb && (wave & 1)) ? 0 : n_mine; };
+  struct Bases { uint64_t p[NUMAX]; };
+  auto fetch_bases = [&]() {
+    Bases B;
 #pragma unroll
     for (int k = 0; k < NUMAX; ++k) {
-      const int u = wave + BSR_TILE_WAVES * k;
-      if (u < n_units && !(cut && (u % CB) != 0)) {
-        const uint32_t la = buf + (uint32_t)u * 1024u;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src[k]), "s"(la) : "memory", "m0");
+      int u = min(wave + BSR_TILE_WAVES * k, n_units - 1);   // (a piece the wave does not have reads a valid entry)
+      asm volatile("" : "+s"(u));   // (not loop-invariant to the compiler: hoisted, the bases would live -- spilled -- in
+                                    // scalar registers for the whole kernel again)
+      B.p[k] = (uint64_t)(size_t)colsrc[u / CB];
+    }
+    return B;
+  };
+  // chunk j into the ring buffer at byte `boff` of the ring
+  auto issue = [&](int j, uint32_t boff, const Bases& B) {
+    int np = pieces(j);
+    asm volatile("" : "+s"(np));   // (compared where it is used: precomputed, the four conditions are four spilled lane masks)
+    const uint32_t buf = lds0 + boff + (uint32_t)wave * 1024u;
+    const uint32_t voff = (uint32_t)lane * 16u + (uint32_t)(b0 + j * CB + (CB == 2 ? (wave & 1) : 0)) * 1024u;
+#pragma unroll
+    for (int k = 0; k < NUMAX; ++k) {
+      if (k < np) {
+        const uint32_t la = buf + (uint32_t)k * (BSR_TILE_WAVES * 1024u);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(B.p[k]), "s"(la) : "memory", "m0");
       }
     }
   };
+  const int n_fixed = a.g.ncols_fixed;   // == KQ: every tape of the batch projects on the same basis (slots y_slot + 1 ..)
 
   for (int pass = 0; pass < a.g.n_pass; ++pass) {
     const TapeRec* my = a.sched + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT;
     // the wave's tapes: ln pairs into LDS, sums cleared; their programs (StreamRec, 32 bytes) are read again for every
     // chunk by one scalar load each, requested under the sums of the tape before
-    const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
     TapeAcc<KQ> A[QT];
     double2* ln_mine = ln_all + (size_t)wave * QT * 3;
     if (pass != 0) __syncthreads();   // everyone is done with the last chunks (and the ln pairs) of the pass before
+    const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       const TapeRec CONSTANT_AS* rec = as_const(my + q);
@@ -251,41 +288,78 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         for (int j = 0; j < 3; ++j) ln_mine[q * 3 + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
       }
     }
-    for (int j = 0; j < min(R - 1, n_chunks); ++j) issue(j);
+    uint32_t issue_off = 0;   // where in the ring the next chunk to be requested goes
+    {
+      const Bases B = fetch_bases();
+      for (int j = 0; j < min(R - 1, n_chunks); ++j) {
+        issue(j, issue_off, B);
+        issue_off += buf_bytes;
+      }
+    }
+    if (issue_off == ring_bytes) issue_off = 0;
+    uint32_t cur_off = 0;     // ... and where the chunk the waves compute on sits
     for (int ci = 0; ci < n_chunks; ++ci) {
+      const Bases B = fetch_bases();   // (for the request behind the barrier; the loads return while the wave waits there)
       {
-        int later = 0;
-        for (int j = ci + 1; j < min(ci + R - 1, n_chunks); ++j) later += pieces(j);
+        // copies complete in order: chunk ci has landed when at most the pieces of the chunks requested behind it are
+        // still in flight
+        int later;
+        if (CB == 1) {
+          later = n_mine * min(R - 2, n_chunks - 1 - ci);
+        } else {
+          later = 0;
+          for (int j = ci + 1; j < min(ci + R - 1, n_chunks); ++j) later += pieces(j);
+        }
         dma_wait_left(later);
       }
       __syncthreads();   // chunk ci has landed for everyone; everyone is done with chunk ci - 1
-      if (ci + R - 1 < n_chunks) issue(ci + R - 1);
+      if (ci + R - 1 < n_chunks) {
+        issue(ci + R - 1, issue_off, B);
+        issue_off += buf_bytes;
+        if (issue_off == ring_bytes) issue_off = 0;
+      }
       if (ci == 0 && pass == 0) TSTAMP(1);
       if (STAMPS) t_busy = __builtin_amdgcn_s_memtime();
-      const double* cur = sx + (size_t)(ci % R) * buf_elems;
+      const double* cur = reinterpret_cast<const double*>(smem + cur_off);
+      cur_off += buf_bytes;
+      if (cur_off == ring_bytes) cur_off = 0;
       const double* lane_col = cur + 2 * lane;
       const int nbc = (CB == 1) ? 1 : min(CB, nb - ci * CB);
-      // y (and below: the basis columns) of the lane's rows, once for all tapes of the wave
+      // One-block chunks: y (and below: the basis columns) of the lane's rows are read once for all tapes of the wave.
+      // Two-block chunks: every tape reads them again when its values are ready -- held across the tapes they are 32
+      // registers, which with four sets of sums and the evaluation's temporaries is more than a wave has.
+      constexpr bool HOLD = CB == 1;
       double yv[U];
-      lds_pairs<CB>(lane_col + y_slot * chunk_rows, yv);
       double qv[KQ > 0 ? KQ : 1][U];
       int q_have = -1;
+      int nfx = n_fixed;
+      asm volatile("" : "+s"(nfx));
+      if (HOLD) {
+        lds_pairs<CB>(lane_col + y_slot * chunk_rows, yv);
+        if (nfx == KQ) {
+          q_have = y_slot + 1;
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (y_slot + 1 + i) * chunk_rows, qv[i]);
+        }
+      }
       TapeS nx = load_tape(sr);
 #pragma unroll 1
       for (int q = 0; q < QT; ++q) {
         const TapeS t = nx;
-        if (!t.any()) {
-          nx = load_tape(sr + q + 1);
-          continue;
-        }
-        if (t.qslot() != q_have) {   // (tapes of one chain share the basis: read once)
+        nx = load_tape(sr + q + 1);   // the next tape's program: its scalar load returns under this tape's first LDS wait
+                                      // (one record of padding behind the last).  (Tried: the programs in one vector
+                                      // register, read by v_readlane -- no memory round trip, eight vector instructions
+                                      // per tape: 108 -> 132 us.  Vector issue is what this kernel has least of.)
+        if (!t.any()) continue;
+        double z[U];
+        lds_pairs<CB>(lane_col + (int)t.first * chunk_rows, z);
+        if (HOLD && nfx != KQ && t.qslot() != q_have) {   // (tapes of one chain share the basis: read once)
           q_have = t.qslot();
 #pragma unroll
           for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (q_have + i) * chunk_rows, qv[i]);
         }
-        double z[U];
         if (t.fast()) {
-          chain_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * 3, z);
+          tape_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * 3, z);
         } else {
           // Any other tape (not a chain; longer than the scalar registers hold): the stack machine of bsr_device.h on
           // the same rows, its routines inline too; the tape's full record is read for it.
@@ -296,12 +370,25 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
           hd.ln_near = (const double*)rec->ln;
           hd.n_ln = rec->n_ln;
           hd.n_term = rec->n_term;
-          LdsCols<double, U> ldr{cur, chunk_rows, 2 * lane};
-          run_tape_head<double, U, BSR_REG_STACK, LdsCols<double, U>, false, true>(
-              hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, z,
-              (double*)nullptr, lane);
+          // (one block at a time: the stack machine's registers -- three stack slots, operand and result per value --
+          // are what a two-block pass would spill, and a spill in this loop is a vector load next to the copies' counter)
+#pragma unroll 1
+          for (int jb = 0; jb < CB; ++jb) {
+            double zb[2];
+            LdsCols<double, 2> ldr{cur, chunk_rows, jb * BSR_TILE_BLOCK + 2 * lane};
+            run_tape_head<double, 2, BSR_REG_STACK, LdsCols<double, 2>, false, true>(
+                hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, zb,
+                (double*)nullptr, lane);
+            if (CB == 1 || jb == 0) { z[0] = zb[0]; z[1] = zb[1]; }
+            else { z[U - 2] = zb[0]; z[U - 1] = zb[1]; }
+          }
         }
-        nx = load_tape(sr + q + 1);   // the next tape's program travels under this tape's sums (one record of padding behind the last)
+        if (!HOLD) {
+          lds_pairs<CB>(lane_col + y_slot * chunk_rows, yv);
+          const int qs = t.qslot();
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (qs + i) * chunk_rows, qv[i]);
+        }
         switch (q) {
 #define BSR_ADD_CASE(qq) case qq: if constexpr (qq < QT) add_chunk<KQ, CB>(A[qq], z, yv, qv, t.s, nbc); break;
           BSR_ADD_CASE(0) BSR_ADD_CASE(1) BSR_ADD_CASE(2) BSR_ADD_CASE(3)
@@ -354,18 +441,31 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
 // bytes of LDS behind the ring: three (a, b) pairs per tape of every wave
 size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof(double2); }
 
-// sets of sums per wave of the streaming kernel: four while the sums of four tapes, a chunk's y and basis values and
-// the routines' temporaries fit 128 registers (K <= 4), else two
-int stream_qmax(int K) { return K <= 4 ? 4 : 2; }
+// sets of sums per wave of the streaming kernel (BSR_STREAM_QT overrides: 2 or 4): four while the sums of four tapes, a
+// chunk's y and basis values and the routines' temporaries fit 128 registers (K <= 4), else two
+int stream_qmax(int K) {
+  static const int forced = env_int("BSR_STREAM_QT", 0);
+  if (forced == 2 || (forced == 4 && K <= 4)) return forced;
+  return K <= 4 ? 4 : 2;
+}
 
 void launch_stream(hipStream_t st, const TileArgs<double>& a) {
   const TileGeom& g = a.g;
   const size_t lds = (size_t)g.ring * g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(double) + stream_ln_bytes(g.qmax);
+  if (g.qmax == 4) {
+    switch (a.K) {
+      case 1: launch_cb<1, 4>(st, a, lds); break;
+      case 2: launch_cb<2, 4>(st, a, lds); break;
+      case 3: launch_cb<3, 4>(st, a, lds); break;
+      default: launch_cb<4, 4>(st, a, lds); break;
+    }
+    return;
+  }
   switch (a.K) {
-    case 1: launch_cb<1, 4>(st, a, lds); break;
-    case 2: launch_cb<2, 4>(st, a, lds); break;
-    case 3: launch_cb<3, 4>(st, a, lds); break;
-    case 4: launch_cb<4, 4>(st, a, lds); break;
+    case 1: launch_cb<1, 2>(st, a, lds); break;
+    case 2: launch_cb<2, 2>(st, a, lds); break;
+    case 3: launch_cb<3, 2>(st, a, lds); break;
+    case 4: launch_cb<4, 2>(st, a, lds); break;
     case 5: launch_cb<5, 2>(st, a, lds); break;
     case 6: launch_cb<6, 2>(st, a, lds); break;
     case 7: launch_cb<7, 2>(st, a, lds); break;

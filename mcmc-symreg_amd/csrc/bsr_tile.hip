@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
         const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
         const int n_nodes = rec->n_nodes;
         const double s = rec->s;
-        const bool chain = rec->chain != 0;
+        const bool chain = (rec->chain & 1) != 0;   // (bit 1: the streaming kernel's own flag)
         const T* sq = cur + (size_t)rec->qslot * chunk_rows;
         TapeHead hd;
         hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
     const double* pl = a.lnp + 2 * (size_t)rec->ln_off;
     const int n_nodes = rec->n_nodes;
     const double s = rec->s;
-    const bool chain = rec->chain != 0;
+    const bool chain = (rec->chain & 1) != 0;   // (bit 1: the streaming kernel's own flag)
     const T* sq = sx + (size_t)rec->qslot * chunk_rows;
     TapeHead hd;
     hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;

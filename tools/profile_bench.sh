@@ -34,7 +34,7 @@ for name in ("fetch", "write"):
             seen.add((k, r["Dispatch_Id"])); n[k] += 1
     for k in acc:
         # the projection pass: the tile kernel (bsr_tile.hip) or, where it does not apply, k_rows<..., PROJECT>
-        if "k_tile" in k or ("k_rows" in k and ", 0>" in k):
+        if "k_tile" in k or "k_stream" in k or ("k_rows" in k and ", 0>" in k):
             res.setdefault(k, {})[name] = acc[k] / n[k]; res[k]["launches_" + name] = n[k]
 summary = {}
 for k, v in res.items():

@@ -82,6 +82,8 @@ def main():
     if (st[:, :, 5][ok] > 0).any():   # chunked kernel: cycles a wave ran tapes, the rest of 1->3 it waited (copies, barriers)
         busy = st[:, :, 5].astype(np.float64) / mhz
         stat("running tapes (sum over chunks)", busy[ok])
+        print("  running tapes by wave index (mean over workgroups, us): " +
+              " ".join("%.0f" % np.mean([busy[w][i] for w in range(n) if ok[w][i]]) for i in range(busy.shape[1]) if ok[:, i].any()))
         per = np.array([busy[w][ok[w]].max() / max(1e-9, busy[w][ok[w]].mean()) for w in range(n) if ok[w].any()])
         print("busy imbalance inside a workgroup (busiest wave / mean wave): median %.2f  max %.2f" % (np.median(per), per.max()))
     stat("wave lifetime (0->4)", d(0, 4))

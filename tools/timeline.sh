@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(f)))
 ev = []
 for r in rows:
     n = r["Kernel_Name"]
-    short = "tile" if "k_tile" in n else "solve" if n.startswith("k_solve") else "finalize" if n.startswith("k_finalize") else \
+    short = "tile" if ("k_tile" in n or "k_stream" in n) else "solve" if n.startswith("k_solve") else "finalize" if n.startswith("k_finalize") else \
             "residual" if ("k_rows" in n and ", 1>" in n) else "rows" if "k_rows" in n else "events" if "k_events" in n else "other"
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, r.get("Queue_Id", "?")))
 ev.sort()
