@@ -105,7 +105,10 @@ class Ranks:
     def device(self):
         if os.environ.get("BSR_SHARE_DEVICE") == "1":
             return 0
-        return self.local if self.world > 1 else 0
+        if self.world <= 1:
+            return 0
+        from bsr.dist import local_device          # (a launcher may have narrowed the visible devices to this rank's own)
+        return local_device(self.local)
 
     def connect(self):
         """One small context per rank that lives as long as the process and owns the RCCL communicator."""
@@ -352,6 +355,43 @@ def attach_traffic(out, name, B, C, dtype):
             out["roofline"]["kernel_stats_source"] = os.path.relpath(spaths[-1], ROOT)
 
 
+def attach_valu(out, name, B, C, dtype, n_cu_used=None):
+    """The secondary bound ("state honestly"): instruction issue of the row pass from the committed counter
+    run of this same command (tools/pmc_tile.sh).  On gfx950 a SIMD issues one fp64 vector instruction per ~4.4 cycles
+    and the CU's ONE scalar unit about one scalar instruction (SALU, branch, scalar load) per cycle for all sixteen
+    waves (tools/micro/fp64_issue.hip, issue_mix.hip): both floors are stated, with the share of the kernel's time they
+    account for."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_tile_%s_B%d.json" % (name, B))))
+    if not (C == WORKLOADS[name]["chains"] and dtype == "f64" and paths):
+        return
+    recs = json.load(open(paths[-1]))
+    if not recs:
+        return
+    kname, rec = max(recs.items(), key=lambda kv: kv[1].get("launches", 0))
+    valu = rec.get("SQ_INSTS_VALU")
+    if not valu:
+        return
+    clock_ghz = 2.3
+    waves = rec.get("SQ_WAVES", 0)
+    n_cu = n_cu_used or max(1, int(round(waves / 16.0)))
+    scalar = rec.get("SQ_INSTS_SALU", 0) + rec.get("SQ_INSTS_BRANCH", 0) + rec.get("SQ_INSTS_SMEM", 0)
+    fp64 = rec.get("SQ_INSTS_VALU_ADD_F64", 0) + rec.get("SQ_INSTS_VALU_MUL_F64", 0) + rec.get("SQ_INSTS_VALU_FMA_F64", 0)
+    kern_us = out["roofline"].get("kernel_us_rocprofv3") or out["roofline"]["kernel_us"]
+    valu_us = valu * 4.4 / (4.0 * n_cu) / (clock_ghz * 1e3)
+    scalar_us = scalar * 1.2 / n_cu / (clock_ghz * 1e3)
+    out["roofline"]["valu"] = {
+        "kernel": kname, "insts": valu, "fp64_insts": fp64, "fp64_share": round(fp64 / valu, 3),
+        "scalar_insts": scalar, "cus": n_cu,
+        "issue_cycles": int(valu * 4.4 / (4.0 * n_cu)),                 # per SIMD, at 4.4 cycles per fp64 vector instruction
+        "valu_floor_us": round(valu_us, 1), "scalar_floor_us": round(scalar_us, 1),
+        "busy_frac": round(valu_us / kern_us, 3), "scalar_busy_frac": round(scalar_us / kern_us, 3),
+        "lds_bank_conflict_frac": (round(rec["SQ_LDS_BANK_CONFLICT"] / rec["SQ_LDS_IDX_ACTIVE"], 3)
+                                   if rec.get("SQ_LDS_IDX_ACTIVE") else None),
+        "wait_frac": round(rec["SQ_WAIT_ANY"] / rec["SQ_WAVE_CYCLES"], 3) if rec.get("SQ_WAVE_CYCLES") else None,
+        "source": os.path.relpath(paths[-1], ROOT)}
+
+
 def gather_trees(wl, ranks):
     """The one exchange of the path: every chain's current (accepted) trees, all-gathered over RCCL."""
     import numpy as np
@@ -459,6 +499,20 @@ def f32_leg(args, ranks):
     return res
 
 
+def unpinned_leg(args):
+    """The headline workload once more WITHOUT BSR_PIN=1 (this script confines itself to the library's CPUs; a drop-in
+    caller does not): a child process, after this one's contexts are closed."""
+    import subprocess
+    env = dict(os.environ)
+    env["BSR_PIN"] = "0"
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras", "0", "--cpu-sample", "0", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--min-time", str(min(args.min_time, 0.5))]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "env_knobs": d.get("env_knobs"),
+            "caller_cpus": d["per_rank"][0]["caller_cpus"], "verified": d.get("verified")}
+
+
 def main():
     args = parse_args()
     knobs = refuse_debug_knobs()
@@ -491,7 +545,8 @@ def main():
     # actually gets: DESIGN 6)
     info = wl["ctx"].info()
     mine = {"rank": ranks.rank, "ms_per_step": 1e3 * tr["elapsed_local"] / tr["n_steps"], "submit_threads": info["submit_threads"],
-            "lib_cpus": info["lib_cpus"], "cpu_budget": info["cpu_budget"], "caller_cpus": len(os.sched_getaffinity(0))}
+            "lib_cpus": info["lib_cpus"], "cpu_budget": info["cpu_budget"], "caller_cpus": len(os.sched_getaffinity(0)),
+            "gpu_numa_node": info["gpu_numa_node"]}
     if ranks.world > 1:
         import numpy as np
         vec = np.array([mine["rank"], mine["ms_per_step"], mine["submit_threads"], mine["lib_cpus"], mine["cpu_budget"],
@@ -503,6 +558,9 @@ def main():
         out["per_rank"] = [mine]
     out["env_knobs"] = {k: v for k, v in sorted(knobs.items()) if k not in ("BSR_SHARE_DEVICE",)}
     attach_traffic(out, args.workload, wl["B"], wl["C"], args.dtype)
+    attach_valu(out, args.workload, wl["B"], wl["C"], args.dtype)
+    # which row pass and geometry the context chose (tests/test_gpu_regimes.py pins it per BASELINE config)
+    out["config"]["geometry"] = {k: info[k] for k in ("row_pass", "tape_groups", "row_slices", "blocks_per_slice")}
     n_g = gather_trees(wl, ranks)
     if n_g is not None:
         out["gathered_records"] = n_g
@@ -530,6 +588,9 @@ def main():
                 s2["verified"] = t2["verified"]
                 s2["steps"] = steps2
                 attach_traffic(s2, name, w2["B"], w2["C"], args.dtype)
+                attach_valu(s2, name, w2["B"], w2["C"], args.dtype)
+                i2 = w2["ctx"].info()
+                s2["config"]["geometry"] = {k: i2[k] for k in ("row_pass", "tape_groups", "row_slices", "blocks_per_slice")}
                 if ranks.world > 1:
                     s2["gathered_records"] = gather_trees(w2, ranks)
                 ex[name] = s2
@@ -549,8 +610,17 @@ def main():
         if ranks.world == 1:
             try:
                 ex["c5_f32"] = f32_leg(args, ranks)
+                import glob
+                sw = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp32_chain_sweep.json")))
+                if sw:   # the chain-level sweep (tools/fp32_chain_sweep.py: decisions per consumed proposal, N = 1e4 .. 1e6)
+                    ex["c5_f32"]["chain_sweep"] = json.load(open(sw[-1]))["rows"]
+                    ex["c5_f32"]["chain_sweep_source"] = os.path.relpath(sw[-1], ROOT)
             except Exception as exc:
                 ex["c5_f32"] = {"error": repr(exc)}
+            try:
+                ex["c2_unpinned"] = unpinned_leg(args)
+            except Exception as exc:
+                ex["c2_unpinned"] = {"error": repr(exc)}
         out["extra"] = ex
     if ranks.rank == 0:
         print(json.dumps(out))

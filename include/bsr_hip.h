@@ -240,6 +240,11 @@ int bsr_last_timing(bsr_ctx* ctx, double* us5);
  *   info[4] tape groups T   info[5] row slices   info[6] blocks per slice   info[7] 1: slices staged whole, 0: chunked */
 int bsr_ctx_info(const bsr_ctx* ctx, int32_t* info8);
 
+/* Where this process's library threads were placed (once per process, by the first bsr_ctx_create; csrc/bsr_place.h):
+ *   info[0] 1 if a placement was made   info[1] its CPUs   info[2] NUMA node of the context's GPU as sysfs reports it
+ *   (/sys/bus/pci/devices/<bdf>/numa_node; -1: unknown, -2: no placement)   info[3] 1 if the caller was confined too */
+int bsr_place_info(int32_t* info4);
+
 /* ---- multi-GPU: one process per GPU, one gather of accepted trees */
 
 #define BSR_COMM_ID_BYTES 128

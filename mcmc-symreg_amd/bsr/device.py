@@ -170,7 +170,9 @@ class DeviceContext:
         """What the context decided for this process and machine (bsr_ctx_info)."""
         v = np.zeros(8, dtype=np.int32)
         _lib.check(self._L.bsr_ctx_info(self._h, _lib.ptr(v)), self._h)
-        return {"submit_threads": int(v[0]), "lib_cpus": int(v[1]), "caller_pinned": bool(v[2]),
+        pl = np.zeros(4, dtype=np.int32)
+        _lib.check(self._L.bsr_place_info(_lib.ptr(pl)), self._h)
+        return {"gpu_numa_node": int(pl[2]),"submit_threads": int(v[0]), "lib_cpus": int(v[1]), "caller_pinned": bool(v[2]),
                 "cpu_budget": v[3] / 100.0, "tape_groups": int(v[4]), "row_slices": int(v[5]),
                 "blocks_per_slice": int(v[6]), "slices_whole": int(v[7]) == 1, "streaming": int(v[7]) == 2,
                 "row_pass": {1: "k_tile1", 2: "k_stream"}.get(int(v[7]), "k_tile/k_rows")}

@@ -125,6 +125,22 @@ class SoloGather:
         return np.ascontiguousarray(send, dtype=np.uint8).reshape(1, -1)
 
 
+def local_device(local_rank, n_visible=None):
+    """HIP device index of a local rank.  One process per GPU sees either all GPUs of the node (device = LOCAL_RANK) or --
+    a launcher that narrows HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank -- just its own, renumbered from 0:
+    LOCAL_RANK modulo the number of visible devices serves both (and refuses a process that sees none)."""
+    if n_visible is None:
+        import ctypes as C
+        from . import _lib
+        n = C.c_int(0)
+        _lib.check(_lib.lib().bsr_device_count(C.byref(n)), None)
+        n_visible = n.value
+    if n_visible <= 0:
+        raise RuntimeError("no HIP device visible to local rank %d (HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r)"
+                           % (local_rank, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+    return int(local_rank) % int(n_visible)
+
+
 _N_CONNECTS = 0
 
 

@@ -130,7 +130,7 @@ def main(argv=None):
     from .launch import rank_env
     rank, world, local = rank_env()
     devs = [int(v) for v in os.environ.get("BSR_DEVICES", "").split(",") if v != ""]
-    device = devs[local] if local < len(devs) else local
+    device = devs[local] if local < len(devs) else D.local_device(local)
     X = np.load(os.path.join(args.data, "X.npy"))
     y = np.load(os.path.join(args.data, "y.npy"))
     seeds = [int(s) for s in np.load(os.path.join(args.data, "seeds.npy"))]

@@ -152,7 +152,6 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
                               int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype) {
   if (!out) return BSR_E_ARG;
   *out = nullptr;
-  choose_lib_cpus();   // (BSR_PIN=1: before the first HIP call of the process, if this is it)
   if (!X || N <= 0 || d <= 0 || d > 65536) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
   if (K < 0 || K > BSR_MAX_K || n_chains < 0 || max_batch <= 0)
     return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad K/n_chains/max_batch");
@@ -160,6 +159,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
     return fail(nullptr, BSR_E_NODEVICE, "bsr_ctx_create: no such HIP device");
+  choose_lib_cpus(device);   // (once per process: an L3 domain of this device's NUMA node)
   bsr_ctx* c = new bsr_ctx();
   c->device = device;
   c->N = N;
@@ -1522,6 +1522,15 @@ extern "C" int bsr_ctx_info(const bsr_ctx* c, int32_t* info8) {
   info8[5] = c->tile_slices;
   info8[6] = c->tile_bps;
   info8[7] = c->tile_whole ? 1 : (c->tile_stream ? 2 : 0);   // 1: whole slices in LDS (k_tile1), 2: streaming kernel, 0: chunked k_tile / k_rows
+  return BSR_OK;
+}
+
+extern "C" int bsr_place_info(int32_t* info4) {
+  if (!info4) return BSR_E_ARG;
+  info4[0] = g_lib_cpus_ok.load() ? 1 : 0;
+  info4[1] = info4[0] ? (int32_t)CPU_COUNT(&g_lib_cpus) : 0;
+  info4[2] = g_lib_numa;
+  info4[3] = g_pinned.load() ? 1 : 0;
   return BSR_OK;
 }
 

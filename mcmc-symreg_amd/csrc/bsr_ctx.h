@@ -290,4 +290,5 @@ inline void cost_order(std::vector<int>& order, std::vector<uint32_t>& keys, int
 extern std::atomic<bool> g_pinned;       // BSR_PIN=1: this process confined itself to the library's CPUs
 extern cpu_set_t g_lib_cpus;
 extern std::atomic<bool> g_lib_cpus_ok;
-BSR_HID void choose_lib_cpus();
+BSR_HID void choose_lib_cpus(int device);
+extern int g_lib_numa;

@@ -1,0 +1,75 @@
+"""Which row pass -- and which geometry -- every BASELINE configuration selects.  The parity tests compare values; a
+context that silently fell back to the work-queue pass (k_rows) would pass all of them and cost 2-3x.  bsr_ctx_info
+exposes what the context decided (one decision per context, for its life: a proposal's partial sums must not depend on
+the batch); this test pins it, and scores a batch to make sure the chosen kernel is the one that runs (the profiling
+timer of the row pass only ticks for the pass that was launched)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from bsr.device import DeviceContext
+from bsr.node import Node
+from bsr.tape import flatten
+
+
+def leaf(f):
+    n = Node(1)
+    n.type = 0
+    n.feature = np.array([f])
+    return n
+
+
+def un(op, c, a=None, b=None):
+    n = Node(0)
+    n.type, n.operator, n.left, n.a, n.b = 1, op, c, a, b
+    c.parent = n
+    return n
+
+
+def bi(op, l, r):
+    n = Node(0)
+    n.type, n.operator, n.left, n.right = 2, op, l, r
+    l.parent = r.parent = n
+    return n
+
+
+# (name, N, d, K, chains, max_batch, dtype) -> expected (row_pass, tape_groups, row_slices, blocks_per_slice)
+CASES = [
+    ("C2", 100_000, 10, 3, 1, 64, "f64", ("k_tile1", 1, 97, 8)),
+    ("C3", 100_000, 10, 8, 1, 64, "f64", ("k_tile1", 1, 192, 4)),
+    ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1", None, None, None)),
+    ("C5", 1_000_000, 50, 3, 1, 64, "f64", ("k_stream", 1, 256, 30)),
+    ("C5 f32", 1_000_000, 50, 3, 1, 64, "f32", ("k_tile/k_rows", None, None, None)),
+]
+
+
+@pytest.mark.parametrize("name,N,d,K,chains,max_batch,dtype,want", CASES, ids=[c[0] for c in CASES])
+def test_the_regime_each_baseline_config_selects(name, N, d, K, chains, max_batch, dtype, want):
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    ctx = DeviceContext(X, y, K=K, n_chains=chains, max_batch=max_batch, dtype=dtype)
+    try:
+        info = ctx.info()
+        assert info["row_pass"] == want[0], (name, info)
+        for key, w in zip(("tape_groups", "row_slices", "blocks_per_slice"), want[1:]):
+            if w is not None:
+                assert info[key] == w, (name, key, info)
+        assert info["streaming"] == (want[0] == "k_stream") and info["slices_whole"] == (want[0] == "k_tile1")
+        # ... and the kernel runs: one batch through it
+        pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cos', leaf(4)),
+                un('cubic', leaf(5)), bi('+', leaf(6), leaf(7)), un('inv', un('ln', un('square', leaf(8)), 1.0, 1.0)),
+                un('square', leaf(9))]
+        for c in range(chains):
+            for k in range(K):
+                ctx.set_current(c, k, flatten(pool[k]))
+            ctx.refresh(c)
+        B = min(max_batch, 32)
+        tapes = [flatten(bi('+', un('sin', leaf(i % d)), leaf((i + 1) % d))) for i in range(B)]
+        ctx.set_profiling(1)
+        res = ctx.score_batch(tapes, np.arange(B, dtype=np.int32) % chains, np.arange(B, dtype=np.int32) % K, np.full(B, 0.8))
+        assert (res["rank"] == K).all() and np.isfinite(res["loglik"]).all()
+        assert ctx.last_timing()[0] > 0.0
+    finally:
+        ctx.close()

@@ -211,3 +211,49 @@ def test_record_flags_a_truncated_rmse_history():
     long = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, list(range(D.ERRS_CAP + 5)), 10, 5, tapes_in=[tape]))
     short = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, [1.0, 2.0], 10, 2, tapes_in=[tape]))
     assert long["errs_truncated"] and not short["errs_truncated"]
+
+
+def test_a_rank_whose_communicator_fails_ends_the_job_with_its_error_text(tmp_path):
+    """VERDICT r3 (de-risking the first N > 1 run): ncclCommInitRank failing on ONE rank -- a stale unique id, a GPU
+    RCCL cannot open -- must surface as BSR_E_COMM with RCCL's text on that rank's stderr and end the whole job with
+    non-zero codes, not leave the other ranks in the first collective.  The C ABI cannot fail on demand here (no GPU),
+    so a stand-in context raises what bsr._lib.check makes of the C return code; everything above it is the product's
+    (bsr.dist.connect, bsr.launch.spawn)."""
+    sys.path.insert(0, PKG)
+    from bsr.launch import spawn
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from bsr import dist as D, _lib\n"
+        "from bsr.launch import rank_env\n"
+        "rank, world, _ = rank_env()\n"
+        "class Ctx:\n"
+        "    def comm_unique_id(self):\n"
+        "        return np.zeros(128, dtype=np.uint8)\n"
+        "    def comm_init(self, n, r, uid):\n"
+        "        if r == 1:\n"
+        "            raise _lib.BsrError(-7, 'ncclCommInitRank: unhandled system error')   # what check() raises for BSR_E_COMM\n"
+        "    def comm_allgather(self, send):\n"
+        "        time.sleep(120)      # rank 0 sits in the first collective\n"
+        "D.connect(Ctx(), rank, world)\n" % PKG)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r)\nfrom bsr.launch import spawn\n"
+                        "codes, _ = spawn(2, [%r], relay_rank0_stdout=False, init_timeout=60)\nprint(list(codes))"
+                        % (PKG, str(script))], capture_output=True, text=True, timeout=120)
+    assert time.time() - t0 < 60.0
+    assert "BSR_E_COMM (-7): ncclCommInitRank: unhandled system error" in r.stderr, r.stderr[-800:]
+    codes = eval(r.stdout.strip().splitlines()[-1])
+    assert codes[1] == 1 and codes[0] != 0
+
+
+def test_local_device_follows_a_narrowed_device_list():
+    sys.path.insert(0, PKG)
+    from bsr.dist import local_device
+    assert [local_device(r, 8) for r in range(8)] == list(range(8))      # the whole node visible: device = LOCAL_RANK
+    assert [local_device(r, 1) for r in range(8)] == [0] * 8              # one GPU per rank visible: its index is 0
+    assert [local_device(r, 4) for r in (4, 5, 6, 7)] == [0, 1, 2, 3]    # half a node per launcher group
+    with pytest.raises(RuntimeError):
+        local_device(0, 0)
