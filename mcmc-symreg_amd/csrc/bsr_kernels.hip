@@ -37,6 +37,7 @@
 //                  (allcal / set_current).
 //   MODE_RESIDUAL: w = s z - Q c for the proposals k_solve flagged; |w|^2 and w.y -> part[(p,rb)][2].
 enum { MODE_PROJECT = 0, MODE_RESIDUAL = 1 };
+int env_int(const char* name, int dflt);   // bsr_api.hip
 #ifndef BSR_RESID_WGS
 #define BSR_RESID_WGS 32u   // workgroups of the residual pass at most (16 waves each; see MODE_RESIDUAL in k_rows)
 #endif
@@ -1341,7 +1342,11 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
   if (!a.feat_list && MODE == MODE_PROJECT) grid.x = (unsigned)g.dyn_wgs;  // work-queue launch
   if (MODE == MODE_RESIDUAL) grid.x = (unsigned)(((g.n_rb + 7) / 8) * 8);   // one (virtual) workgroup per row block, flagged list
   if (MODE == MODE_RESIDUAL && !a.feat_list) {   // four of them per 16-wave workgroup (RowsShape), at most BSR_RESID_WGS
-    grid.x = std::min<unsigned>(grid.x / 4, BSR_RESID_WGS);
+    // (a data set far beyond the caches -- N = 1M: 977 row blocks -- is bound by what each CU can pull from HBM, ~25 GB/s:
+    // 32 workgroups measured ~100 us whenever a proposal was flagged, 21 us on average with one batch in five flagging;
+    // BSR_RESID_WGS_BIG workgroups there, whose empty launch costs a microsecond more)
+    static const unsigned big = (unsigned)env_int("BSR_RESID_WGS_BIG", 128);
+    grid.x = std::min<unsigned>(grid.x / 4, g.n_rb >= 512 ? std::max(big, BSR_RESID_WGS) : BSR_RESID_WGS);
     block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
   }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
