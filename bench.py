@@ -602,7 +602,7 @@ def main():
         except Exception as exc:
             ex["c4_native_engine"] = {"error": repr(exc)}
         try:
-            ex["c2_native_engine"] = engine_leg(args, ranks, chains=1, batch=64, seconds=2.0)
+            ex["c2_native_engine"] = engine_leg(args, ranks, chains=1, batch=32, seconds=2.0)   # (BSR.fit's default batch)
             # what a single chain CONSUMES next to what the headline scores (speculative batches of a frozen state):
             out["consumed_per_s"] = ex["c2_native_engine"]["value"]
         except Exception as exc:

@@ -65,7 +65,10 @@ extern "C" const char* bsr_last_error(const bsr_ctx* ctx) { return ctx ? ctx->er
 // -1 integers) -- a kernel that reads what nobody wrote shows at once instead of depending on what the allocator
 // happened to return.
 void poison(void* p, size_t bytes) {
-  static const bool on = getenv("BSR_POISON") && atoi(getenv("BSR_POISON")) != 0;
+  // (read at every allocation, not once per process: tests/test_gpu_ctx_sequence.py interleaves poisoned and clean lives
+  // of the same blocks)
+  const char* v = getenv("BSR_POISON");
+  const bool on = v && atoi(v) != 0;
   if (on && p && bytes) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
 }
 int env_int(const char* name, int dflt) {
@@ -302,7 +305,9 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       c->tile_slices = std::max(1, c->tile_cus / T);
       // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
       // goes out as single (tape, block) units dealt to the waves of the launch (bsr_tile.hip: leftover_units)
-      c->tile_bps = c->tile_blocks / c->tile_slices;
+      // ... of WHOLE blocks: the block that holds row N (N not a multiple of 128) is always a leftover unit, the only place
+      // that masks rows
+      c->tile_bps = (int)(N / BSR_TILE_BLOCK) / c->tile_slices;
       c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
       if (c->tile_stream) {
         // every WHOLE block in a slice, the first tile_long slices one block longer; the block that holds row N (N not a

@@ -1571,7 +1571,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // host thread leaves the GPU two thirds idle.  K == 1 keeps the single-threaded ticket path (its rescoring step
   // drains every slot).
   const int want_threads = getenv("BSR_ENGINE_THREADS") ? atoi(getenv("BSR_ENGINE_THREADS")) : 1;
-  const bool threaded = n_groups > 1 && e->K > 1 && want_threads != 0;
+  // (a single group -- one chain -- takes the same path on the caller's thread: what it gains is the lookahead batch;
+  // served by the plain ticket loop below it sat out every batch's time on the GPU, 0.32 M consumed proposals/s at C2)
+  const bool threaded = !trace && e->K > 1 && want_threads != 0;
   // A SECOND batch per group, generated while the first is on the GPU on the assumption that the first ends as
   // speculated (four in five do): a worker used to wait 63 % of its time for its batch.  An event in the first batch
   // (accept, gate verdict against the speculation) makes the chain's share of the second one void -- it is skipped

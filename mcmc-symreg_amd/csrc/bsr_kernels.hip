@@ -447,6 +447,31 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
 }
 
 
+// 1/x and 1/sqrt(x) for the Jacobi rotations: the hardware estimate and two Newton steps (a few roundings, not correctly
+// rounded -- a rotation only has to be orthogonal to rounding, which cs^2 + sn^2 = 1 +- a few ulp is; the singular values
+// themselves are measured with IEEE sqrt afterwards).  The IEEE division and square root are ~14 and ~20 dependent
+// instructions each, five of them per rotation: two thirds of what a rotation costs a wave that runs alone.
+__device__ __forceinline__ double rot_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rot_rsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  return r;
+}
+// (cs, sn) of the rotation that annihilates gamma between columns of squared norms alpha and beta
+__device__ __forceinline__ void rot_coeffs(double alpha, double beta, double gamma, double* cs, double* sn) {
+  const double zeta = (beta - alpha) * rot_rcp(2.0 * gamma);
+  const double s1 = fma(zeta, zeta, 1.0);
+  const double tt = copysign(1.0, zeta) * rot_rcp(fabs(zeta) + s1 * rot_rsq(s1));
+  *cs = rot_rsq(fma(tt, tt, 1.0));
+  *sn = *cs * tt;
+}
+
 // entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
 __device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
   if (m == K - 1) return (i < K) ? in.c[i < K ? i : 0] : rho;
@@ -509,10 +534,9 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
         // sqrt(alpha beta): both compared in squares (two dependent square roots fewer per rotation)
         const double ab = alpha * beta, g2 = gamma * gamma;
         if (ab > 0.0 && g2 > 1e-34 * ab) {
-          off = fmax(off, g2 / ab);
-          const double zeta = (beta - alpha) / (2.0 * gamma);
-          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+          off = fmax(off, g2 * rot_rcp(ab));
+          double cs, sn;
+          rot_coeffs(alpha, beta, gamma, &cs, &sn);
 #pragma unroll
           for (int i = 0; i < M; ++i) {
             const double wa = W[i][a], wb = W[i][b];
@@ -645,10 +669,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
       const double alpha = low ? mine : theirs, beta = low ? theirs : mine;
       const double ab = alpha * beta, g2 = gamma * gamma;   // squared criteria: see solve_regs
       if (ab > 0.0 && g2 > 1e-34 * ab) {
-        off = fmax(off, g2 / ab);
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        off = fmax(off, g2 * rot_rcp(ab));
+        double cs, sn;
+        rot_coeffs(alpha, beta, gamma, &cs, &sn);
         const double sp = low ? -sn : sn;  // low column: cs*W - sn*Wp ; high column: sn*Wp + cs*W
 #pragma unroll
         for (int i = 0; i < M; ++i) W[i] = cs * W[i] + sp * Wp[i];

@@ -57,7 +57,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const bool multi = g.chunk_blocks < g.bps + (g.n_long > 0 ? 1 : 0);   // the slice does not fit LDS whole: two buffers, LDS-DMA
   const int buf_elems = (multi && sizeof(T) == 8) ? g.ncols * chunk_rows : 0;   // one buffer of the ring (f32: one buffer at all)
-  const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
   const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
   const int y_slot = a.grp_nF[tg & 7];
   const int ncols = y_slot + 1 + (g.ncols_fixed);   // the group's LDS columns
@@ -176,12 +175,13 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile(TileArgs<T> a
           V2 qv[KQ > 0 ? KQ : 1];
 #pragma unroll
           for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * chunk_rows + off);
-          const bool whole = blk < n_full;   // wave-uniform
+          // (every block of a slice lies below row N whole: the block that holds row N is a leftover unit -- the context's
+          // geometry sees to it, bsr_api.hip -- so nothing in these loops masks rows: nine scalar instructions and a branch
+          // per block at C2, a quarter of the kernel's scalar work)
 #define BSR_ACC_CASE(qq)                                                               \
   case qq:                                                                             \
     if constexpr (qq < QMAX) {                                                         \
-      if (whole) accumulate_v<T, KQ, false>(A[qq], zz, yv, qv, s, row0, a.N);          \
-      else accumulate_v<T, KQ, true>(A[qq], zz, yv, qv, s, row0, a.N);                 \
+      accumulate_v<T, KQ, false>(A[qq], zz, yv, qv, s, row0, a.N);                     \
     }                                                                                  \
     break;
           switch (q) { BSR_ACC_CASE(0) BSR_ACC_CASE(1) BSR_ACC_CASE(2) BSR_ACC_CASE(3) }
@@ -271,7 +271,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   const int y_slot = a.grp_nF[tg & 7];
   const int ncols = y_slot + 1 + g.ncols_fixed;
   const T* sy = sx + (size_t)y_slot * chunk_rows;
-  const int n_full = (int)(a.N / BSR_TILE_BLOCK);   // blocks that lie below row N whole
   // the group's tapes in cost order: indices of their records
   const int32_t CONSTANT_AS* list = as_const(reinterpret_cast<const int32_t*>(a.sched + (size_t)g.T * g.n_pass * BSR_TILE_WAVES * g.qmax) +
                                              a.P + (size_t)tg * g.per_group);
@@ -341,8 +340,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
       V2 qv[KQ > 0 ? KQ : 1];
 #pragma unroll
       for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(sq + (size_t)i * chunk_rows + off);
-      if (b0 + b < n_full) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
-      else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
+      accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);   // (slices hold whole blocks only: see k_tile)
     };
     int b = 0;
     if (chain) {
@@ -355,7 +353,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
         chain_eval<T, NB, FULL>(hd, pc, pf, pl, n_nodes, sx, chunk_rows, off, pn, z);
         const T* yp = sy + off;
         const T* qp = sq + off;
-        const bool whole = b0 + b + pn <= n_full;   // no block of the pass reaches beyond row N
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
           if (FULL || jb < pn) {
@@ -365,8 +362,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
 #pragma unroll
             for (int i = 0; i < KQ; ++i) qv[i] = *reinterpret_cast<const V2*>(qp + (size_t)i * chunk_rows + jb * BSR_TILE_BLOCK);
             const int64_t row0 = (int64_t)(b0 + b + jb) * BSR_TILE_BLOCK + 2 * lane;
-            if (whole || b0 + b + jb < n_full) accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
-            else accumulate_v<T, KQ, true>(A, zz, yv, qv, s, row0, a.N);
+            accumulate_v<T, KQ, false>(A, zz, yv, qv, s, row0, a.N);
           }
         }
         b += pn;
