@@ -325,10 +325,10 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       if (cur_off == ring_bytes) cur_off = 0;
       const double* lane_col = cur + 2 * lane;
       const int nbc = (CB == 1) ? 1 : min(CB, nb - ci * CB);
-      // One-block chunks: y (and below: the basis columns) of the lane's rows are read once for all tapes of the wave.
-      // Two-block chunks: every tape reads them again when its values are ready -- held across the tapes they are 32
+      // One-block chunks, K <= 3: y (and below: the basis columns) of the lane's rows are read once for all tapes of the
+      // wave.  Two-block chunks, or more basis columns: every tape reads them again when its values are ready -- held across the tapes they are 32
       // registers, which with four sets of sums and the evaluation's temporaries is more than a wave has.
-      constexpr bool HOLD = CB == 1;
+      constexpr bool HOLD = CB == 1 && KQ <= 3;   // (K >= 4: the basis values alone are 16+ registers per block)
       double yv[U];
       double qv[KQ > 0 ? KQ : 1][U];
       int q_have = -1;

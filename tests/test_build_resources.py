@@ -69,3 +69,54 @@ def test_default_work_queue_row_pass_has_no_scratch():
         seen += 1
         assert r["ScratchSize [bytes/lane]"] == 0, (n, r)
     assert seen >= 16
+
+
+def _loop_of(kernel_lines):
+    """The chunk loop of a streaming kernel: between the last two s_barrier instructions."""
+    bars = [i for i, l in enumerate(kernel_lines) if "s_barrier" in l]
+    assert len(bars) >= 3, bars
+    return kernel_lines[bars[-2]:bars[-1]]
+
+
+def test_streaming_row_pass_keeps_compiler_memory_traffic_out_of_its_chunk_loop():
+    """k_stream (config 5) counts its own LDS-DMA copies with s_waitcnt vmcnt(n).  Anything the COMPILER adds to the
+    loop that touches vector memory -- a spilled register's scratch load, the s_waitcnt vmcnt(0) behind it, a device
+    function call (every callee starts with s_waitcnt vmcnt(0)) -- makes the wave wait for the copies it issued for
+    chunks it will not touch for microseconds (measured: one spilled register in the loop cost the two-block variant
+    25 %).  Pinned for every default variant (one-block chunks; K = 1..4 four sets of sums per wave, K = 5..8 two): no
+    spilled vector register at all; inside the chunk loop at most the handful of scratch accesses and waits of the
+    general stack machine's dynamically indexed slots (the path of tapes too long for the scalar-register
+    interpreter), and no call but the cold ones (huge-argument sin/cos, the extension operator log)."""
+    rep = _report("bsr_stream")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(CSRC, "build", "bsr_stream.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("no llvm-objdump / object file")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(obj, os.path.join(tmp, "t.o"))
+        subprocess.run([objdump, "--offloading", "t.o"], cwd=tmp, check=True, capture_output=True)
+        dev = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert dev, os.listdir(tmp)
+        text = subprocess.run([objdump, "-d", dev[0]], cwd=tmp, check=True, capture_output=True, text=True).stdout
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None:
+            cur.append(line)
+    seen = 0
+    for K in range(1, 9):
+        qt = 4 if K <= 4 else 2
+        name = [n for n in funcs if "8k_streamILi%dELi%dELi1ELb0E" % (K, qt) in n]
+        assert len(name) == 1, (K, name)
+        r = rep[name[0]]
+        assert r["VGPRs Spill"] == 0 and r["VGPRs"] <= 128, (name[0], r)
+        loop = _loop_of(funcs[name[0]])
+        n_scratch = sum("scratch_" in l for l in loop)
+        n_vm = sum("vmcnt" in l for l in loop)
+        n_call = sum("s_swappc" in l for l in loop)
+        assert n_scratch <= 6 and n_vm <= 5 and n_call <= 10, (name[0], n_scratch, n_vm, n_call)
+        seen += 1
+    assert seen == 8
