@@ -172,11 +172,12 @@ static_assert(sizeof(TapeRec) == 128, "one tape record per 128 bytes");
 // The streaming kernel's view of a tape (bsr_stream.hip): what its scalar-register interpreter needs, 32 bytes, one per
 // (wave, set of sums) in schedule order and one of padding behind the last.
 struct StreamRec {
-  int32_t meta;         // bits 0..4: stream entries - 1, bit 5: fast (a chain of <= 16 entries, <= 8 terminals, <= 3 ln
-                        // nodes), bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
-  int32_t first;        // LDS slot of the leading terminal
+  int32_t meta;         // bits 0..4: stream entries - 1, bits 5 and 31: fast (<= 16 entries, <= 8 terminals, <= 3 ln nodes,
+                        // one value below the accumulator, no `log`), bit 6: there is a tape, bits 8..15: LDS slot of the
+                        // chain's first basis column
+  int32_t first;        // LDS slot of the leading terminal x 1024
   double s;             // prescale of the candidate column
-  uint64_t code;        // the first 16 stream entries, 4 bits each
+  uint64_t code;        // fast tapes: the entries behind the leading terminal, 4 bits each: operator + 1, 0 behind the last
   uint64_t slots;       // LDS slots of terminals 2..8, 8 bits each, in stream order
 };
 static_assert(sizeof(StreamRec) == 32, "one scalar load per tape");

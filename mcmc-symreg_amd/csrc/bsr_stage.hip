@@ -657,11 +657,19 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
         memset(&Q, 0, sizeof Q);
         if (i == n_sched || sc[i].p < 0) continue;
         const TapeRec& R = sc[i];
-        const bool fast = (R.chain & 2) != 0;
-        Q.meta = ((R.n_nodes - 1) & 31) | (fast ? 32 : 0) | 64 | ((R.qslot & 0xFF) << 8);
+        bool fast = (R.chain & 2) != 0;
+        // the entries behind the leading terminal as operator + 1, 0 behind the last (bsr_stream_asm.h); `log`, which
+        // would need code 16, sends its tape to the stack machine
+        uint64_t enc = 0;
+        for (int e = 1; fast && e < R.n_nodes; ++e) {
+          const int op = (int)((R.code0 >> (4 * e)) & 15u);
+          if (op == BSR_OP_LOG) fast = false;
+          enc |= (uint64_t)((op + 1) & 15) << (4 * (e - 1));
+        }
+        Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : 0) | 64 | ((R.qslot & 0xFF) << 8);
         Q.s = R.s;
-        Q.code = R.code0;
-        Q.first = (int32_t)(R.f0 & 0xFFu);
+        Q.code = fast ? enc : 0;
+        Q.first = (int32_t)(R.f0 & 0xFFu) << 10;   // (its byte offset in a buffer of one-block chunks)
         uint64_t slots = 0;
         for (int t = 1; t < 8; ++t) {
           const uint64_t w = (t < 4) ? R.f0 : R.f1;

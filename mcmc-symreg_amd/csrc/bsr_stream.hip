@@ -24,6 +24,8 @@
 // block in order; one lane reduction per (tape, slice) in the fixed network of reduce_store.  What is summed in which
 // order depends on the context's slices only, never on the batch.
 #include "bsr_tile_common.h"
+#include "bsr_stream_asm.h"
+#include "bsr_stream_chunk_asm.h"
 
 int env_int(const char* name, int dflt);   // bsr_api.hip
 
@@ -32,11 +34,11 @@ namespace {
 // the scalar state of one tape of a wave: a StreamRec (bsr_internal.h), 32 bytes the host packs per (wave, set of sums),
 // fetched by ONE scalar load
 struct TapeS {
-  uint32_t meta;        // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5: the fast interpreter takes it,
-                        // bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
-  uint32_t first;       // LDS slot of the leading terminal
+  uint32_t meta;        // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5 and bit 31: the fast
+                        // interpreter takes it, bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
+  uint32_t first;       // LDS slot of the leading terminal x 1024 (its byte offset in a buffer of one-block chunks)
   double s;             // prescale
-  uint64_t code;        // 16 entries x 4 bits (entry 0: the leading terminal)
+  uint64_t code;        // the entries behind the leading terminal, 4 bits each: operator + 1, 0 = end (bsr_stream_asm.h)
   uint64_t slots;       // LDS slots of the terminals behind the first, in stream order, 8 bits each
   __device__ __forceinline__ bool fast() const { return (meta & 32) != 0; }
   __device__ __forceinline__ bool any() const { return (meta & 64) != 0; }
@@ -87,7 +89,7 @@ template <int CB>
 __device__ __forceinline__ void tape_fast(const TapeS& t, const double* lane_col, int chunk_rows, const double2* ln_tab,
                                           double (&acc)[2 * CB]) {
   constexpr int U = 2 * CB;
-  uint64_t code = t.code >> 4, sl = t.slots;   // (the leading terminal's values arrive in acc: the caller requested them a tape ahead)
+  uint64_t code = t.code, sl = t.slots;   // (the leading terminal's values arrive in acc)
   // (no operand requested ahead of its entry: carried around the loop, the compiler copies such registers on every
   // entry and waits for the read it was meant to hide -- 450 cycles per entry measured; at its use the read costs one LDS
   // round trip, which the SIMD's other waves fill)
@@ -97,7 +99,7 @@ __device__ __forceinline__ void tape_fast(const TapeS& t, const double* lane_col
   int lk = 0;
   const int n = t.n();
   for (int i = 1; i < n; ++i) {
-    const int op = (int)(code & 15u);
+    const int op = (int)(code & 15u) - 1;
     code >>= 4;
     switch (op) {
       case BSR_SOP_ADD_T: {
@@ -160,9 +162,6 @@ __device__ __forceinline__ void tape_fast(const TapeS& t, const double* lane_col
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = op_exp<double>(acc[u]);
         break;
-      case BSR_OP_LOG:
-        BSR_STREAM_CALL(log_rows)
-        break;
       case BSR_OP_SQUARE:
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = acc[u] * acc[u];
@@ -205,8 +204,41 @@ __device__ __attribute__((noinline)) void leftover_call(const TileArgs<double>* 
   leftover_unit<double, KQ, AT, TileGeom CONSTANT_AS>(a, a.g, lane, tk);
 }
 
-template <int KQ, int QT, int CB, bool STAMPS>
+// A tape the fast interpreters do not take, on the lane's two rows of one block of the staged chunk.  Out of line on
+// purpose: the stack machine keeps its deeper values in scratch memory, and with scratch accesses anywhere in the chunk
+// loop the compiler guards every register they might still be writing with s_waitcnt vmcnt(0) -- which is also the counter
+// of the wave's LDS-DMA copies in flight.  A call drains that counter too (every callee starts by waiting for everything),
+// but only when such a tape comes by.
+__device__ __attribute__((noinline)) double2 generic_block(const TileArgs<double>* ka, const TapeRec* recp, const double* cur,
+                                                           int row0, int lane) {
+  // (both pointers are the same in every lane: made scalar by hand, so that the records are read by scalar loads)
+  const uint64_t v = (uint64_t)(size_t)ka, r = (uint64_t)(size_t)recp;
+  const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)v), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const uint32_t rlo = __builtin_amdgcn_readfirstlane((uint32_t)r), rhi = __builtin_amdgcn_readfirstlane((uint32_t)(r >> 32));
+  using AT = TileArgs<double> CONSTANT_AS;
+  const AT& a = *(const AT*)(size_t)(((uint64_t)vhi << 32) | vlo);
+  const TapeRec CONSTANT_AS* rec = (const TapeRec CONSTANT_AS*)(size_t)(((uint64_t)rhi << 32) | rlo);
+  TapeHead hd;
+  hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+  hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+  hd.ln_near = (const double*)rec->ln;
+  hd.n_ln = rec->n_ln;
+  hd.n_term = rec->n_term;
+  double zb[2];
+  LdsCols<double, 2> ldr{cur, BSR_TILE_BLOCK * (int)a.g.chunk_blocks, row0};
+  run_tape_head<double, 2, BSR_REG_STACK, LdsCols<double, 2>, false, true>(
+      hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, zb,
+      (double*)nullptr, lane);
+  return make_double2(zb[0], zb[1]);
+}
+
+template <int KQ, int QT, int CB, bool STAMPS, int MODE>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<double> a) {
+  // MODE 0: the C++ interpreter (tape_fast); 1: the assembly interpreter, a tape at a time (bsr_stream_asm.h);
+  // 2: a wave's four tapes of a chunk in one block of assembly (bsr_stream_chunk_asm.h: K = 3, every tape on one basis)
+  constexpr bool ASM = MODE == 1;
+  static_assert(MODE == 0 || CB == 1, "the assembly interpreters take one block at a time");
+  static_assert(MODE != 2 || (KQ == 3 && QT == 4), "the chunk block is written for K = 3, four tapes per wave");
   constexpr int U = 2 * CB;
   constexpr int NUMAX = BSR_STREAM_UNITS_MAX / BSR_TILE_WAVES;   // DMA pieces per wave and chunk at most
   extern __shared__ __align__(16) unsigned char smem[];
@@ -277,6 +309,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     // chunk by one scalar load each, requested under the sums of the tape before
     TapeAcc<KQ> A[QT];
     double2* ln_mine = ln_all + (size_t)wave * QT * 3;
+    const uint32_t ln_lds = lds0 + ring_bytes + (uint32_t)wave * (QT * 48u);   // (its LDS address, for the assembly interpreter)
     if (pass != 0) __syncthreads();   // everyone is done with the last chunks (and the ln pairs) of the pass before
     const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
 #pragma unroll
@@ -321,6 +354,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       if (ci == 0 && pass == 0) TSTAMP(1);
       if (STAMPS) t_busy = __builtin_amdgcn_s_memtime();
       const double* cur = reinterpret_cast<const double*>(smem + cur_off);
+      const uint32_t lc = lds0 + cur_off + (uint32_t)lane * 16u;   // LDS address of the lane's pair in column 0
       cur_off += buf_bytes;
       if (cur_off == ring_bytes) cur_off = 0;
       const double* lane_col = cur + 2 * lane;
@@ -328,7 +362,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       // One-block chunks, K <= 3: y (and below: the basis columns) of the lane's rows are read once for all tapes of the
       // wave.  Two-block chunks, or more basis columns: every tape reads them again when its values are ready -- held across the tapes they are 32
       // registers, which with four sets of sums and the evaluation's temporaries is more than a wave has.
-      constexpr bool HOLD = CB == 1 && KQ <= 3;   // (K >= 4: the basis values alone are 16+ registers per block)
+      // (the assembly interpreter's fixed registers leave no room for them either)
+      constexpr bool HOLD = CB == 1 && KQ <= 3 && !ASM;   // (K >= 4: the basis values alone are 16+ registers per block)
       double yv[U];
       double qv[KQ > 0 ? KQ : 1][U];
       int q_have = -1;
@@ -342,6 +377,50 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
           for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (y_slot + 1 + i) * chunk_rows, qv[i]);
         }
       }
+      if constexpr (MODE == 2) {
+        // the four tapes of the wave in one block of assembly; sin, cos, exp and tapes for the stack machine come back
+        // here, and the block is entered again where it left (`resume`)
+        uint32_t resume = 0, st, sv[5];
+        double z0, z1, s00, s01;
+        asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
+                          "=v"(sv[4]));   // (no value yet: nothing to initialise)
+        const uint32_t yo = (uint32_t)y_slot << 10;
+        for (;;) {
+          asm volatile(BSR_STREAM_CHUNK_ASM_K3
+                       : [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [sa0] "+v"(A[0].a0),
+                         [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax),
+                         [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [sa1] "+v"(A[1].a0),
+                         [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax),
+                         [ca2] "+v"(A[2].c[0]), [cb2] "+v"(A[2].c[1]), [cc2] "+v"(A[2].c[2]), [sa2] "+v"(A[2].a0),
+                         [sb2] "+v"(A[2].a1), [am2] "+v"(A[2].amax),
+                         [ca3] "+v"(A[3].c[0]), [cb3] "+v"(A[3].c[1]), [cc3] "+v"(A[3].c[2]), [sa3] "+v"(A[3].a0),
+                         [sb3] "+v"(A[3].a1), [am3] "+v"(A[3].amax),
+                         [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]),
+                         [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)
+                       : [resume] "s"(resume), [lc] "v"(lc), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo)
+                       : BSR_STREAM_CHUNK_CLOBBERS);
+          if (st == 0) break;
+          const uint32_t what = st & 15u;
+          if (what == 1) {
+            const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
+                                             my + (st >> 4), cur, 2 * lane, lane);
+            z0 = zb.x;
+            z1 = zb.y;
+          } else if (what == BSR_OP_EXP + 1) {
+            z0 = op_exp<double>(z0);
+            z1 = op_exp<double>(z1);
+          } else {
+            double zz[2] = {z0, z1};
+            sincos_vals<2>(zz, what == BSR_OP_COS + 1 ? 1 : 0);
+            z0 = zz[0];
+            z1 = zz[1];
+          }
+          resume = __builtin_amdgcn_readfirstlane(st);
+        }
+        if (STAMPS) busy += __builtin_amdgcn_s_memtime() - t_busy;
+        if (ci == 0 && pass == 0) TSTAMP(2);
+        continue;
+      }
       TapeS nx = load_tape(sr);
 #pragma unroll 1
       for (int q = 0; q < QT; ++q) {
@@ -352,35 +431,51 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
                                       // per tape: 108 -> 132 us.  Vector issue is what this kernel has least of.)
         if (!t.any()) continue;
         double z[U];
-        lds_pairs<CB>(lane_col + (int)t.first * chunk_rows, z);
+        if (!(ASM && t.fast())) lds_pairs<CB>(lane_col + (int)(t.first >> 10) * chunk_rows, z);
         if (HOLD && nfx != KQ && t.qslot() != q_have) {   // (tapes of one chain share the basis: read once)
           q_have = t.qslot();
 #pragma unroll
           for (int i = 0; i < KQ; ++i) lds_pairs<CB>(lane_col + (q_have + i) * chunk_rows, qv[i]);
         }
-        if (t.fast()) {
+        if (ASM && __builtin_expect(t.fast(), 1)) {
+          if constexpr (ASM) {
+            // the interpreter of bsr_stream_asm.h; sin, cos and exp come back here with the state in the operands
+            // (the state of a tape that left for sin / cos / exp travels in five vector registers: tied scalar operands
+            // carried around this loop do not compile -- "illegal VGPR to SGPR copy")
+            const uint64_t code = t.code, sl = t.slots;
+            const uint32_t lnp = ln_lds + (uint32_t)q * 48u, first = t.first;
+            uint32_t resume = 0, st, sv[5];
+            double s00, s01;
+            asm volatile("" : "=v"(z[0]), "=v"(z[1]), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]),
+                              "=v"(sv[3]), "=v"(sv[4]));   // (no value yet: nothing to initialise)
+            for (;;) {
+              asm volatile(BSR_STREAM_INTERP_ASM
+                           : [z0] "+v"(z[0]), [z1] "+v"(z[1]), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]),
+                             [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)
+                           : [resume] "s"(resume), [first] "s"(first), [lc] "v"(lc), [code] "s"(code), [sl] "s"(sl),
+                             [ln] "s"(lnp)
+                           : BSR_STREAM_INTERP_CLOBBERS);
+              if (st == 0) break;
+              if (st == BSR_OP_EXP + 1) {
+                z[0] = op_exp<double>(z[0]);
+                z[1] = op_exp<double>(z[1]);
+              } else {
+                sincos_vals<2>(reinterpret_cast<double(&)[2]>(z), st == BSR_OP_COS + 1 ? 1 : 0);
+              }
+              resume = 1;
+            }
+          }
+        } else if (t.fast()) {
           tape_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * 3, z);
         } else {
-          // Any other tape (not a chain; longer than the scalar registers hold): the stack machine of bsr_device.h on
-          // the same rows, its routines inline too; the tape's full record is read for it.
-          const TapeRec CONSTANT_AS* rec = as_const(my + q);
-          TapeHead hd;
-          hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
-          hd.la = rec->ln[0]; hd.lb = rec->ln[1];
-          hd.ln_near = (const double*)rec->ln;
-          hd.n_ln = rec->n_ln;
-          hd.n_term = rec->n_term;
-          // (one block at a time: the stack machine's registers -- three stack slots, operand and result per value --
-          // are what a two-block pass would spill, and a spill in this loop is a vector load next to the copies' counter)
+          // Any other tape (not a chain; longer than the scalar registers hold, or with a `log`): the stack machine of
+          // bsr_device.h on the same rows, one block at a time, out of line (generic_block above)
 #pragma unroll 1
           for (int jb = 0; jb < CB; ++jb) {
-            double zb[2];
-            LdsCols<double, 2> ldr{cur, chunk_rows, jb * BSR_TILE_BLOCK + 2 * lane};
-            run_tape_head<double, 2, BSR_REG_STACK, LdsCols<double, 2>, false, true>(
-                hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, zb,
-                (double*)nullptr, lane);
-            if (CB == 1 || jb == 0) { z[0] = zb[0]; z[1] = zb[1]; }
-            else { z[U - 2] = zb[0]; z[U - 1] = zb[1]; }
+            const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), my + q, cur,
+                                             jb * BSR_TILE_BLOCK + 2 * lane, lane);
+            if (CB == 1 || jb == 0) { z[0] = zb.x; z[1] = zb.y; }
+            else { z[U - 2] = zb.x; z[U - 1] = zb.y; }
           }
         }
         if (!HOLD) {
@@ -414,26 +509,39 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
 #undef TSTAMP
 }
 
-template <int KQ, int QT, int CB, bool STAMPS>
+template <int KQ, int QT, int CB, bool STAMPS, int MODE>
 void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(tile_lds_bytes_max() - 1024));
     attr = true;
   }
   const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  hipLaunchKernelGGL((k_stream<KQ, QT, CB, STAMPS>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((k_stream<KQ, QT, CB, STAMPS, MODE>), grid, block, lds, st, a);
 }
 template <int KQ, int QT>
 void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
-  if (a.stamps) {   // diagnostics build of the kernel (BSR_TILE_STAMPS=1): per-wave clock samples
-    if (a.g.chunk_blocks == 2) launch_one<KQ, QT, 2, true>(st, a, lds);
-    else launch_one<KQ, QT, 1, true>(st, a, lds);
+  // BSR_STREAM_ASM=0: the C++ interpreter (tape_fast) on one-block chunks too -- the cross-check of the assembly ones;
+  // 1: the assembly interpreter a tape at a time; default: the wave's four tapes in one block where it applies (K = 3,
+  // one chain's basis behind y), else 1
+  static const int asm_mode = env_int("BSR_STREAM_ASM", 2);
+  const bool chunk_block = KQ == 3 && QT == 4 && asm_mode >= 2 && a.g.ncols_fixed == KQ;
+  if (a.g.chunk_blocks == 2) {
+    if (a.stamps) launch_one<KQ, QT, 2, true, 0>(st, a, lds);
+    else launch_one<KQ, QT, 2, false, 0>(st, a, lds);
     return;
   }
-  if (a.g.chunk_blocks == 2) launch_one<KQ, QT, 2, false>(st, a, lds);
-  else launch_one<KQ, QT, 1, false>(st, a, lds);
+  if constexpr (KQ == 3 && QT == 4) {
+    if (chunk_block) {
+      if (a.stamps) launch_one<KQ, QT, 1, true, 2>(st, a, lds);   // (BSR_TILE_STAMPS=1: per-wave clock samples)
+      else launch_one<KQ, QT, 1, false, 2>(st, a, lds);
+      return;
+    }
+  }
+  if (a.stamps) launch_one<KQ, QT, 1, true, 1>(st, a, lds);
+  else if (asm_mode >= 1) launch_one<KQ, QT, 1, false, 1>(st, a, lds);
+  else launch_one<KQ, QT, 1, false, 0>(st, a, lds);
 }
 
 }  // namespace

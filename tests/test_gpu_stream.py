@@ -64,3 +64,64 @@ def test_streaming_pass_against_the_oracle_and_itself(N, d, K):
             assert one.tobytes() == res[i:i + 1].tobytes(), i
     finally:
         ctx.close()
+
+
+_INTERP_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "mcmc-symreg_amd")); sys.path.insert(0, os.path.join(sys.argv[1], "tools", "probes"))
+import stream_check as S
+from bsr.device import DeviceContext
+from bsr.tape import flatten
+leaf, un, bi = S.leaf, S.un, S.bi
+N, d, K, B = 200_077, 40, 3, 64
+rs = np.random.RandomState(5)
+X = rs.uniform(-3, 3, size=(N, d))
+X[::977, 3] = 0.0                      # zeros for the protected divisions
+X[::1013, 4] = 1e200                   # overflow in the cube, huge arguments for sin / cos
+y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
+assert ctx.info()["row_pass"] == "k_stream", ctx.info()
+for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5))]):
+    ctx.set_current(0, k, flatten(t))
+ctx.refresh(0)
+trees = S.make_tapes(d, 40)
+x = leaf
+trees += [bi('sub', x(1), x(2)), bi('div', x(1), x(3)), bi('div', bi('+', x(1), x(2)), un('neg', x(3))), un('inv', x(3)),
+          un('cubic', x(4)), un('cubic', bi('*', x(4), x(4))), un('sin', x(4)), un('cos', bi('+', x(4), x(1))),
+          un('log', x(3)), un('exp', un('log', bi('sub', x(6), x(7)))), bi('sub', un('exp', x(8)), un('sin', un('cos', x(9)))),
+          bi('div', un('ln', x(10), 0.5, 2.0), un('ln', un('ln', x(11), 1.5, -1.0), -0.25, 0.75)),
+          un('square', bi('sub', un('cubic', x(12)), un('inv', x(13)))), bi('*', un('neg', x(14)), un('neg', x(15))),
+          un('exp', un('exp', un('neg', un('square', x(16))))), bi('+', bi('+', bi('+', x(17), x(18)), x(19)), x(20)),
+          un('sin', un('sin', un('sin', x(21)))), bi('div', x(22), bi('sub', x(22), x(22))),
+          un('inv', un('inv', un('inv', x(23)))), bi('sub', un('square', x(24)), un('square', x(25))),
+          bi('*', un('ln', x(26), 2.0, 0.0), x(27)), un('neg', un('neg', x(28))), un('cos', un('neg', x(29))),
+          un('cubic', un('cubic', x(30)))]
+trees = trees[:B]
+tapes = [flatten(t) for t in trees]
+n = len(tapes)
+with np.errstate(all="ignore"):
+    res = ctx.score_batch(tapes, np.zeros(n, dtype=np.int32), (np.arange(n) % K).astype(np.int32), np.full(n, 0.8)).copy()
+np.save(sys.argv[2], np.frombuffer(res.tobytes(), dtype=np.uint8))
+ctx.close()
+"""
+
+
+def test_the_three_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path):
+    """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
+    time (1) or a wave's four tapes in one block of assembly (2, the default at K = 3).  The assembly restates the
+    instruction sequences the compiler emits for the C++ -- division, cube, ln, the fused operands -- so every score of a
+    batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
+    sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran."""
+    import subprocess
+    out = {}
+    for mode in ("0", "1", "2"):
+        path = str(tmp_path / ("res%s.npy" % mode))
+        env = dict(os.environ, BSR_STREAM_ASM=mode)
+        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, (mode, p.stderr[-2000:])
+        out[mode] = np.load(path)
+    assert out["0"].size > 0
+    assert (out["0"] == out["1"]).all(), np.nonzero(out["0"] != out["1"])[0][:20]
+    assert (out["0"] == out["2"]).all(), np.nonzero(out["0"] != out["2"])[0][:20]
