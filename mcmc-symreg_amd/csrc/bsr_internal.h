@@ -214,7 +214,8 @@ void launch_stream(hipStream_t st, const TileArgs<double>& a);   // bsr_stream.h
 size_t tile_lds_bytes_max();
 int tile_qmax(int K);
 size_t stream_ln_bytes(int qt);   // LDS the streaming kernel needs behind its ring
-int stream_qmax(int K);           // its sets of sums per wave
+int stream_qmax(int K);
+bool stream_chunk_block(int K, int ncols_fixed);           // its sets of sums per wave
 #define BSR_STREAM_UNITS_MAX 64   // (column, block) pieces of a chunk the streaming kernel's waves can copy (4 per wave)
 
 struct LaunchGeom {

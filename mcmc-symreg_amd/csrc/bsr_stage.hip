@@ -146,6 +146,8 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
     long room = (long)fit - fixed;
     if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
+    // (streaming contexts too: trading derived columns for a deeper LDS ring -- 3 buffers instead of 2 in the batches
+    // of 49+ columns -- measured slower, 95.8 against 91.6 us: a derived column saves more than the ring's depth)
     // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
     if (room >= 0) allowance = (int)std::min<long>(room, c->n_cols);
     allowance = std::min(allowance, c->derived_max);
@@ -299,7 +301,9 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     uint64_t* pf = hf + L.feat_off;
     double* pl = hl + 2 * (size_t)L.ln_off;
     const bsr_node* tsrc = s.tape_src[i];
-    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = 23;
+    // (the cost model's unit differs by row pass: see the two tables below)
+    const bool stream_costs = c->tile_stream != 0;
+    int nt = 0, nl = 0, ns = 0, sp = 0, mx = 0, cost = stream_costs ? 73 : 23;
     int n_push = 0, n_stack_ops = 0;   // chain tape: one push (the leading terminal), no operator that pops
     uint8_t ss_codes[64];
     int ss_n = 0;
@@ -345,13 +349,30 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
       // sin / cos 38.5 (31 of arithmetic, the huge-argument test, the call's register moves), log 45, a pushed terminal or
       // a popping operator 3 (operand copies of the stack machine); each includes ~0.5 for its decode.  The base 11.5
       // is the projection sums (7), the pass's set-up and the block's share of the lane reduction.
-      cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 3
-              : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 6 : 0)
-              : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 77
-              : (r.opcode == BSR_OP_EXP) ? 59 : (r.opcode == BSR_OP_LOG) ? 90
-              : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 35 : (r.opcode == BSR_OP_CUBIC) ? 23
-              : (r.opcode == BSR_OP_LN) ? 5 : is_binary_op(r.opcode) ? 6 : 3;
+      if (!stream_costs) {
+        cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 3
+                : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 6 : 0)
+                : (r.opcode == BSR_OP_SIN || r.opcode == BSR_OP_COS) ? 77
+                : (r.opcode == BSR_OP_EXP) ? 59 : (r.opcode == BSR_OP_LOG) ? 90
+                : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 35 : (r.opcode == BSR_OP_CUBIC) ? 23
+                : (r.opcode == BSR_OP_LN) ? 5 : is_binary_op(r.opcode) ? 6 : 3;
+      } else {
+        // The streaming pass (bsr_stream.hip, its assembly interpreter): a wave's time, not its vector instructions --
+        // half-microseconds per tape over a 30-block slice, from batches of one shape (tools/probes/op_costs, round 4):
+        // a leaf 36.5 us of fetching the program, reading y and the basis and adding up (the base, 73); a fused
+        // terminal +2.0, neg / square +2.5, ln +3.0, a pushed terminal or a popping operator +4, cubic +6, inv +11,
+        // exp +14, cos +19, sin +20.  With the tile pass's table (an operator 3 to 77 against a base of 23) the
+        // schedule gave tapes with a sin a wave almost to themselves: busiest wave / mean wave 1.50 measured.
+        cost += (code == BSR_SOP_ADD_T || code == BSR_SOP_MUL_T) ? 4
+                : (r.opcode == BSR_OP_TERMINAL) ? (ns > 1 ? 8 : 0)
+                : (r.opcode == BSR_OP_SIN) ? 40 : (r.opcode == BSR_OP_COS) ? 38
+                : (r.opcode == BSR_OP_EXP) ? 28 : (r.opcode == BSR_OP_LOG) ? 400   // (log: the stack machine, out of line)
+                : (r.opcode == BSR_OP_INV || r.opcode == BSR_OP_DIV) ? 22 : (r.opcode == BSR_OP_CUBIC) ? 12
+                : (r.opcode == BSR_OP_LN) ? 6 : is_binary_op(r.opcode) ? 8 : 5;
+      }
     }
+    // (a tape the streaming pass hands to the stack machine: a call, scratch-indexed stack slots -- four times a chain's time)
+    if (stream_costs && (ns > 16 || nt > 8 || nl > 3 || mx > 2)) cost *= 4;
     (*loc)[i].n_stream = ns;
     (*loc)[i].nt = nt;
     (*loc)[i].nl = nl;
@@ -479,7 +500,11 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       // busy); two-block chunks where even four of those fit (a narrow batch).  Its waves copy at most 64 (column, block)
       // pieces per chunk; a wider batch takes k_tile over the same slices (the same sums, bit for bit).
       const int room = (int)((budget - stream_ln_bytes(c->tile_qmax)) / per_block);
-      static const int two = env_int("BSR_STREAM_CB2", 0);   // (two-block chunks: four sets of sums then spill; kept for K >= 5 experiments)
+      // two-block chunks (half the barriers and hand-overs per row) where the kernel evaluates them a block at a time --
+      // the chunk block of assembly; the C++ interpreter would hold four values per lane and tape, and spills
+      // (BSR_STREAM_CB2: 0 never, 1 always, default: by that rule)
+      static const int two_env = env_int("BSR_STREAM_CB2", -1);
+      const bool two = two_env >= 0 ? two_env != 0 : stream_chunk_block(K, tile_chains * K);
       if (room >= 4 && two) { ring = std::min(4, room / 2); chunk = 2; }
       else if (room >= 4) { ring = 4; chunk = 1; }
       else if (room >= 2) { ring = room; chunk = 1; }
@@ -627,6 +652,16 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       R.n_term = D.n_term;
       R.grp = grp;
     }
+    static const int gdump = env_int("BSR_GEOM_DUMP", 0);   // diagnostics: a batch's geometry, once per distinct one
+    if (gdump) {
+      static int last = -1;
+      const int key = tg.ring * 1000000 + tg.chunk_blocks * 100000 + tg.ncols * 100 + tg.T;
+      if (key != last) {
+        last = key;
+        fprintf(stderr, "geometry: stream %d ring %d chunk_blocks %d ncols %d (fixed %d) T %d qmax %d passes %d\n",
+                (int)s.tile_stream, tg.ring, tg.chunk_blocks, tg.ncols, tg.ncols_fixed, tg.T, tg.qmax, tg.n_pass);
+      }
+    }
     static const int dump = env_int("BSR_SCHED_DUMP", 0);   // diagnostics: the schedule's loads (cost model units) per wave
     if (dump && tg.per_group == 0) {
       std::string line = "sched T=" + std::to_string(tg.T) + " qmax=" + std::to_string(tg.qmax) + " costs:";
@@ -669,7 +704,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
         Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : 0) | 64 | ((R.qslot & 0xFF) << 8);
         Q.s = R.s;
         Q.code = fast ? enc : 0;
-        Q.first = (int32_t)(R.f0 & 0xFFu) << 10;   // (its byte offset in a buffer of one-block chunks)
+        Q.first = (int32_t)(R.f0 & 0xFFu) << (tg.chunk_blocks == 2 ? 11 : 10);   // (its byte offset in a chunk buffer)
         uint64_t slots = 0;
         for (int t = 1; t < 8; ++t) {
           const uint64_t w = (t < 4) ? R.f0 : R.f1;

@@ -28,6 +28,7 @@
 #include "bsr_stream_chunk_asm.h"
 
 int env_int(const char* name, int dflt);   // bsr_api.hip
+int stream_qmax(int K);
 
 namespace {
 
@@ -36,7 +37,7 @@ namespace {
 struct TapeS {
   uint32_t meta;        // bits 0..4: stream entries - 1 (a fast tape holds at most 16), bit 5 and bit 31: the fast
                         // interpreter takes it, bit 6: there is a tape, bits 8..15: LDS slot of the chain's first basis column
-  uint32_t first;       // LDS slot of the leading terminal x 1024 (its byte offset in a buffer of one-block chunks)
+  uint32_t first;       // byte offset of the leading terminal's column in a chunk buffer (LDS slot x 1024 x blocks per chunk)
   double s;             // prescale
   uint64_t code;        // the entries behind the leading terminal, 4 bits each: operator + 1, 0 = end (bsr_stream_asm.h)
   uint64_t slots;       // LDS slots of the terminals behind the first, in stream order, 8 bits each
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   // MODE 0: the C++ interpreter (tape_fast); 1: the assembly interpreter, a tape at a time (bsr_stream_asm.h);
   // 2: a wave's four tapes of a chunk in one block of assembly (bsr_stream_chunk_asm.h: K = 3, every tape on one basis)
   constexpr bool ASM = MODE == 1;
-  static_assert(MODE == 0 || CB == 1, "the assembly interpreters take one block at a time");
+  static_assert(MODE != 1 || CB == 1, "the tape-at-a-time assembly interpreter takes one-block chunks");
   static_assert(MODE != 2 || (KQ == 3 && QT == 4), "the chunk block is written for K = 3, four tapes per wave");
   constexpr int U = 2 * CB;
   constexpr int NUMAX = BSR_STREAM_UNITS_MAX / BSR_TILE_WAVES;   // DMA pieces per wave and chunk at most
@@ -384,26 +385,39 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         double z0, z1, s00, s01;
         asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
                           "=v"(sv[4]));   // (no value yet: nothing to initialise)
-        const uint32_t yo = (uint32_t)y_slot << 10;
+        const uint32_t yo = (uint32_t)y_slot << (CB == 2 ? 11 : 10);
+        const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
+        // (two-block chunks: the same block of assembly on either half -- a lane's rows reach its sums in the order of
+        // one-block chunks, block by block: the same sums bit for bit, with half the barriers)
+#pragma unroll 1
+        for (int jb = 0; jb < nbc; ++jb) {
+        const uint32_t lcb = lc + (uint32_t)jb * 1024u;
+        resume = 0;
         for (;;) {
-          asm volatile(BSR_STREAM_CHUNK_ASM_K3
-                       : [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [sa0] "+v"(A[0].a0),
-                         [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax),
-                         [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [sa1] "+v"(A[1].a0),
-                         [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax),
-                         [ca2] "+v"(A[2].c[0]), [cb2] "+v"(A[2].c[1]), [cc2] "+v"(A[2].c[2]), [sa2] "+v"(A[2].a0),
-                         [sb2] "+v"(A[2].a1), [am2] "+v"(A[2].amax),
-                         [ca3] "+v"(A[3].c[0]), [cb3] "+v"(A[3].c[1]), [cc3] "+v"(A[3].c[2]), [sa3] "+v"(A[3].a0),
-                         [sb3] "+v"(A[3].a1), [am3] "+v"(A[3].amax),
-                         [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]),
-                         [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)
-                       : [resume] "s"(resume), [lc] "v"(lc), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo)
-                       : BSR_STREAM_CHUNK_CLOBBERS);
+#define BSR_SC_OPERANDS \
+                       : [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [sa0] "+v"(A[0].a0), \
+                         [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
+                         [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [sa1] "+v"(A[1].a0), \
+                         [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax), \
+                         [ca2] "+v"(A[2].c[0]), [cb2] "+v"(A[2].c[1]), [cc2] "+v"(A[2].c[2]), [sa2] "+v"(A[2].a0), \
+                         [sb2] "+v"(A[2].a1), [am2] "+v"(A[2].amax), \
+                         [ca3] "+v"(A[3].c[0]), [cb3] "+v"(A[3].c[1]), [cc3] "+v"(A[3].c[2]), [sa3] "+v"(A[3].a0), \
+                         [sb3] "+v"(A[3].a1), [am3] "+v"(A[3].amax), \
+                         [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]), \
+                         [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st) \
+                       : [resume] "s"(resume), [lc] "v"(lcb), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds) \
+                       : BSR_STREAM_CHUNK_CLOBBERS
+          if constexpr (CB == 2) {
+            asm volatile(BSR_STREAM_CHUNK2_ASM_K3 BSR_SC_OPERANDS);
+          } else {
+            asm volatile(BSR_STREAM_CHUNK_ASM_K3 BSR_SC_OPERANDS);
+          }
+#undef BSR_SC_OPERANDS
           if (st == 0) break;
           const uint32_t what = st & 15u;
           if (what == 1) {
             const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
-                                             my + (st >> 4), cur, 2 * lane, lane);
+                                             my + (st >> 4), cur, jb * BSR_TILE_BLOCK + 2 * lane, lane);
             z0 = zb.x;
             z1 = zb.y;
           } else if (what == BSR_OP_EXP + 1) {
@@ -416,6 +430,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
             z1 = zz[1];
           }
           resume = __builtin_amdgcn_readfirstlane(st);
+        }
         }
         if (STAMPS) busy += __builtin_amdgcn_s_memtime() - t_busy;
         if (ci == 0 && pass == 0) TSTAMP(2);
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
                                       // per tape: 108 -> 132 us.  Vector issue is what this kernel has least of.)
         if (!t.any()) continue;
         double z[U];
-        if (!(ASM && t.fast())) lds_pairs<CB>(lane_col + (int)(t.first >> 10) * chunk_rows, z);
+        if (!(ASM && t.fast())) lds_pairs<CB>(lane_col + (int)(t.first >> (CB == 2 ? 11 : 10)) * chunk_rows, z);
         if (HOLD && nfx != KQ && t.qslot() != q_have) {   // (tapes of one chain share the basis: read once)
           q_have = t.qslot();
 #pragma unroll
@@ -528,6 +543,13 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   static const int asm_mode = env_int("BSR_STREAM_ASM", 2);
   const bool chunk_block = KQ == 3 && QT == 4 && asm_mode >= 2 && a.g.ncols_fixed == KQ;
   if (a.g.chunk_blocks == 2) {
+    if constexpr (KQ == 3 && QT == 4) {
+      if (chunk_block) {
+        if (a.stamps) launch_one<KQ, QT, 2, true, 2>(st, a, lds);
+        else launch_one<KQ, QT, 2, false, 2>(st, a, lds);
+        return;
+      }
+    }
     if (a.stamps) launch_one<KQ, QT, 2, true, 0>(st, a, lds);
     else launch_one<KQ, QT, 2, false, 0>(st, a, lds);
     return;
@@ -551,6 +573,13 @@ size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof
 
 // sets of sums per wave of the streaming kernel (BSR_STREAM_QT overrides: 2 or 4): four while the sums of four tapes, a
 // chunk's y and basis values and the routines' temporaries fit 128 registers (K <= 4), else two
+// whether a batch of this shape takes the chunk block of assembly (K = 3, four sets of sums per wave, one chain's basis):
+// then two-block chunks cost nothing but LDS (bsr_stage.hip: stage_tile's geometry)
+bool stream_chunk_block(int K, int ncols_fixed) {
+  static const int asm_mode = env_int("BSR_STREAM_ASM", 2);
+  return K == 3 && stream_qmax(3) == 4 && asm_mode >= 2 && ncols_fixed == K;
+}
+
 int stream_qmax(int K) {
   static const int forced = env_int("BSR_STREAM_QT", 0);
   if (forced == 2 || (forced == 4 && K <= 4)) return forced;

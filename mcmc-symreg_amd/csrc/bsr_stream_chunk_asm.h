@@ -33,18 +33,18 @@
   "s_or_b32 s26, s24, s10\n\t"                   \
   "s_setpc_b64 s[26:27]\n\t"
 
-#define BSR_SC_SLOT_ADDR                         \
+#define BSR_SC_SLOT_ADDR(SH)                     \
   "s_and_b32 s10, s22, 0xff\n\t"                 \
   "s_lshr_b64 s[22:23], s[22:23], 8\n\t"         \
-  "v_lshl_add_u32 v20, s10, 10, %[lc]\n\t"
+  "v_lshl_add_u32 v20, s10, " SH ", %[lc]\n\t"
 
 #define BSR_SC_BIN(ins, neg)                                                     \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   ins " v[0:1], v[4:5], " neg "v[0:1]\n\t"                                       \
   ins " v[2:3], v[6:7], " neg "v[2:3]\n\t"                                       \
   BSR_SC_DISPATCH
-#define BSR_SC_BIN_T(ins)                                                        \
-  BSR_SC_SLOT_ADDR                                                               \
+#define BSR_SC_BIN_T(ins, SH)                                                    \
+  BSR_SC_SLOT_ADDR(SH)                                                             \
   "ds_read_b128 v[8:11], v20\n\t"                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   ins " v[0:1], v[0:1], v[8:9]\n\t"                                              \
@@ -85,6 +85,98 @@
   "s_nop 1\n\t"                                                        \
   "v_cndmask_b32_e32 " xhi ", v17, v15, vcc\n\t"                       \
   "v_cndmask_b32_e32 " xlo ", v16, v14, vcc\n\t"
+
+
+// sin / cos / exp of bsr_fastmath.h (bsr_sincos, bsr_exp behind op_exp of bsr_device.h) for one value, operation by
+// operation in the order of the C++ (every one a correctly rounded IEEE operation: the same bits).  Constants: read by
+// scalar loads from the table itself -- the operator slots that only hold a branch carry 64 bytes of data behind it --
+// into s[36:59]; an instruction takes ONE scalar operand, so the second constant of a fused multiply-add goes through
+// a vector register first, as in the compiler's code.  Temporaries: v[8:19], v[22:39] -- the y and basis values are
+// read again behind the operator.  %[tab]: LDS address of the tables (bsr_tables.h layout).
+//   sincos constants: s[36:37] 128/pi, s[38:43] pi/128 in three parts, s[44:49] -1/5040, 1/120, -1/6, s[50:53] -1/720, 1/24,
+//                     s[54:55] 2^-26, s[56:57] the limit of the fast path
+#define BSR_SC_SINCOS(x, xlo, xhi, joff, tiny)                          \
+  "v_mul_f64 v[8:9], " x ", s[36:37]\n\t"                               \
+  "v_rndne_f64_e32 v[8:9], v[8:9]\n\t"                                  \
+  "v_fma_f64 v[10:11], -v[8:9], s[38:39], " x "\n\t"                    \
+  "v_mul_f64 v[12:13], v[8:9], s[40:41]\n\t"                            \
+  "v_fma_f64 v[14:15], v[8:9], s[40:41], -v[12:13]\n\t"                 \
+  "v_add_f64 v[16:17], v[10:11], -v[12:13]\n\t"       /* r */           \
+  "v_add_f64 v[18:19], v[10:11], -v[16:17]\n\t"                         \
+  "v_add_f64 v[18:19], v[18:19], -v[12:13]\n\t"       /* e */           \
+  "v_add_f64 v[18:19], v[18:19], -v[14:15]\n\t"                         \
+  "v_fma_f64 v[18:19], -v[8:9], s[42:43], v[18:19]\n\t" /* rl */        \
+  "v_cvt_i32_f64_e32 v20, v[8:9]\n\t"                                   \
+  joff                                                                  \
+  "v_and_b32_e32 v20, 0xff, v20\n\t"                                    \
+  "v_lshl_add_u32 v20, v20, 5, %[tab]\n\t"                              \
+  "ds_read_b128 v[32:35], v20\n\t"                    /* S, Sl */       \
+  "ds_read_b128 v[36:39], v20 offset:16\n\t"          /* C, Cl */       \
+  "v_mul_f64 v[22:23], v[16:17], v[16:17]\n\t"        /* z */           \
+  "v_mov_b64_e32 v[24:25], s[46:47]\n\t"                                \
+  "v_fma_f64 v[24:25], v[22:23], s[44:45], v[24:25]\n\t"                \
+  "v_fma_f64 v[24:25], v[22:23], v[24:25], s[48:49]\n\t"                \
+  "v_mul_f64 v[24:25], v[22:23], v[24:25]\n\t"        /* ps */          \
+  "v_mov_b64_e32 v[26:27], s[52:53]\n\t"                                \
+  "v_fma_f64 v[26:27], v[22:23], s[50:51], v[26:27]\n\t"                \
+  "v_fma_f64 v[26:27], v[22:23], v[26:27], -0.5\n\t"                    \
+  "v_mul_f64 v[26:27], v[22:23], v[26:27]\n\t"        /* pc */          \
+  "v_mul_f64 v[30:31], v[16:17], v[24:25]\n\t"        /* r ps */        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                            \
+  "v_mul_f64 v[28:29], v[32:33], v[26:27]\n\t"        /* u = S pc */    \
+  "v_fma_f64 v[28:29], v[36:37], v[30:31], v[28:29]\n\t"                \
+  "v_add_f64 v[28:29], v[28:29], v[34:35]\n\t"                          \
+  "v_fma_f64 v[28:29], v[38:39], v[16:17], v[28:29]\n\t"                \
+  "v_fma_f64 v[28:29], v[36:37], v[18:19], v[28:29]\n\t"                \
+  "v_fma_f64 v[28:29], v[36:37], v[16:17], v[28:29]\n\t"                \
+  "v_add_f64 v[28:29], v[32:33], v[28:29]\n\t"                          \
+  tiny
+// (sin of a tiny argument is the argument itself)
+#define BSR_SC_SIN_TINY(x, xlo, xhi)                                    \
+  "v_cmp_lt_f64_e64 vcc, |" x "|, s[54:55]\n\t"                         \
+  "s_nop 1\n\t"                                                         \
+  "v_cndmask_b32_e32 " xlo ", v28, " xlo ", vcc\n\t"                    \
+  "v_cndmask_b32_e32 " xhi ", v29, " xhi ", vcc\n\t"
+#define BSR_SC_COS_MOVE(x)                                              \
+  "v_mov_b64_e32 " x ", v[28:29]\n\t"
+//   exp constants: s[36:37] 64/ln2, s[38:41] ln2/64 in two parts, s[42:49] 1/720, 1/120, 1/24, 1/6, s[50:51] 710,
+//                  s[52:53] -760, s[54:55] 200
+#define BSR_SC_EXP(x, xlo, xhi)                                         \
+  "v_min_f64 v[10:11], " x ", s[50:51]\n\t"                             \
+  "v_max_f64 v[10:11], v[10:11], s[52:53]\n\t"                          \
+  "v_mul_f64 v[8:9], v[10:11], s[36:37]\n\t"                            \
+  "v_rndne_f64_e32 v[8:9], v[8:9]\n\t"                                  \
+  "v_fma_f64 v[10:11], -v[8:9], s[38:39], v[10:11]\n\t"                 \
+  "v_fma_f64 v[10:11], -v[8:9], s[40:41], v[10:11]\n\t" /* r */         \
+  "v_cvt_i32_f64_e32 v20, v[8:9]\n\t"                                   \
+  "v_and_b32_e32 v22, 63, v20\n\t"                                      \
+  "v_lshl_add_u32 v22, v22, 4, %[tab]\n\t"                              \
+  "ds_read_b128 v[32:35], v22 offset:8192\n\t"        /* T, Tl */       \
+  "v_mov_b64_e32 v[12:13], s[44:45]\n\t"                                \
+  "v_fma_f64 v[12:13], v[10:11], s[42:43], v[12:13]\n\t"                \
+  "v_fma_f64 v[12:13], v[10:11], v[12:13], s[46:47]\n\t"                \
+  "v_fma_f64 v[12:13], v[10:11], v[12:13], s[48:49]\n\t"                \
+  "v_fma_f64 v[12:13], v[10:11], v[12:13], 0.5\n\t"   /* q */           \
+  "v_mul_f64 v[14:15], v[10:11], v[10:11]\n\t"                          \
+  "v_fma_f64 v[14:15], v[14:15], v[12:13], v[10:11]\n\t" /* p */        \
+  "v_ashrrev_i32_e32 v20, 6, v20\n\t"                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                            \
+  "v_fma_f64 v[14:15], v[32:33], v[14:15], v[34:35]\n\t"                \
+  "v_add_f64 v[14:15], v[32:33], v[14:15]\n\t"        /* m */           \
+  "v_ldexp_f64 v[14:15], v[14:15], v20\n\t"                             \
+  "v_cmp_le_f64_e64 vcc, " x ", s[54:55]\n\t"                           \
+  "s_nop 1\n\t"                                                         \
+  "v_cndmask_b32_e32 " xlo ", v30, v14, vcc\n\t"   /* (v[30:31]: 1e10 -- a literal next to vcc is one scalar operand too many) */ \
+  "v_cndmask_b32_e32 " xhi ", v31, v15, vcc\n\t"
+// y and the basis columns again (the operator above used their registers), then on with the tape
+#define BSR_SC_RELOAD_YQ(O1, O2, O3)                                    \
+  "v_add_u32_e32 v20, %[yo], %[lc]\n\t"                                 \
+  "ds_read_b128 v[24:27], v20\n\t"                                      \
+  "ds_read_b128 v[28:31], v20 offset:" O1 "\n\t"                        \
+  "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"                        \
+  "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"
+#define BSR_SC_QUAD(a, b, c, d, e, f, g, h)                             \
+  ".p2align 6\n\t.quad " a ", " b ", " c ", " d ", " e ", " f ", " g ", " h "\n\t"
 
 // where `end` goes for tape q (its add-up code, in front of the table), and the tape's ln pairs
 #define BSR_SC_TAPE_REGS(q)                                                      \
@@ -142,7 +234,7 @@
   "s_cbranch_scc1 .Lsc_acc" #q "_%=\n\t"                                         \
   "s_branch .Lsc_state%=\n\t"
 
-#define BSR_STREAM_CHUNK_ASM_K3                                                  \
+#define BSR_STREAM_CHUNK_ASM_K3_(SH, O1, O2, O3)                                 \
   "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
   "s_getpc_b64 s[24:25]\n"                                                       \
   ".Lsc_pc%=:\n\t"                                                               \
@@ -151,9 +243,9 @@
   "s_mov_b32 s27, s25\n\t"                                                       \
   "v_add_u32_e32 v20, %[yo], %[lc]\n\t"   /* y and the basis columns of the lane's rows, once for the four tapes */ \
   "ds_read_b128 v[24:27], v20\n\t"                                               \
-  "ds_read_b128 v[28:31], v20 offset:1024\n\t"                                   \
-  "ds_read_b128 v[32:35], v20 offset:2048\n\t"                                   \
-  "ds_read_b128 v[36:39], v20 offset:3072\n\t"                                   \
+  "ds_read_b128 v[28:31], v20 offset:" O1 "\n\t"                                 \
+  "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"                                 \
+  "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"                                 \
   "s_cmp_lg_u32 %[resume], 0\n\t"                                                \
   "s_cbranch_scc1 .Lsc_resume%=\n\t"                                             \
   BSR_SC_TAPE(0, 1) BSR_SC_TAPE(1, 2) BSR_SC_TAPE(2, 3) BSR_SC_TAPE(3, 4)        \
@@ -198,26 +290,32 @@
   "v_xor_b32_e32 v1, 0x80000000, v1\n\t"                                         \
   "v_xor_b32_e32 v3, 0x80000000, v3\n\t"                                         \
   BSR_SC_DISPATCH                                                                \
-  BSR_SC_SLOT("4") BSR_SC_LEAVE("4") /* sin */                                   \
-  BSR_SC_SLOT("5") BSR_SC_LEAVE("5") /* cos */                                   \
-  BSR_SC_SLOT("6") BSR_SC_LEAVE("6") /* exp */                                   \
+  BSR_SC_SLOT("4") "s_branch .Lsc_sin%=\n\t"   /* + 128/pi, pi/128 in three parts, -1/5040, 1/120, -1/6, -1/720 */ \
+  BSR_SC_QUAD("0x40445F306DC9C883", "0x3F9921FB54442D18", "0x3C31A62633145C07", "0xB8BF1976B7ED8FBC",                \
+              "0xBF2A01A01A01A01A", "0x3F81111111111111", "0xBFC5555555555555", "0xBF56C16C16C16C17")                \
+  BSR_SC_SLOT("5") "s_branch .Lsc_cos%=\n\t"   /* + 1/24, 2^-26, 2^20 pi/2 (BSR_SINCOS_LIMIT) */ \
+  BSR_SC_QUAD("0x3FA5555555555555", "0x3E50000000000000", "0x413921FB00000000", "0", "0", "0", "0", "0")             \
+  BSR_SC_SLOT("6") "s_branch .Lsc_exp%=\n\t"   /* + 64/ln2, ln2/64 in two parts, 1/720, 1/120, 1/24, 1/6, 710 */ \
+  BSR_SC_QUAD("0x40571547652B82FE", "0x3F862E42FEFA39EF", "0x3C1ABC9E3B39803F", "0x3F56C16C16C16C17",                \
+              "0x3F81111111111111", "0x3FA5555555555555", "0x3FC5555555555555", "0x4086300000000000")                \
   BSR_SC_SLOT("7") /* square */                                                  \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "v_mul_f64 v[0:1], v[0:1], v[0:1]\n\t"                                         \
   "v_mul_f64 v[2:3], v[2:3], v[2:3]\n\t"                                         \
   BSR_SC_DISPATCH                                                                \
-  BSR_SC_SLOT("8") "s_branch .Lsc_cube%=\n\t"                                    \
+  BSR_SC_SLOT("8") "s_branch .Lsc_cube%=\n\t"   /* + -760, 200 */               \
+  BSR_SC_QUAD("0xC087C00000000000", "0x4069000000000000", "0", "0", "0", "0", "0", "0")                              \
   BSR_SC_SLOT("9") BSR_SC_BIN("v_add_f64", "")                                   \
   BSR_SC_SLOT("10") BSR_SC_BIN("v_mul_f64", "")                                  \
   BSR_SC_SLOT("11") /* terminal: the accumulator becomes the saved value */      \
-  BSR_SC_SLOT_ADDR                                                               \
+  BSR_SC_SLOT_ADDR(SH)                                                           \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "v_mov_b64_e32 v[4:5], v[0:1]\n\t"                                             \
   "v_mov_b64_e32 v[6:7], v[2:3]\n\t"                                             \
   "ds_read_b128 v[0:3], v20\n\t"                                                 \
   BSR_SC_DISPATCH                                                                \
-  BSR_SC_SLOT("12") BSR_SC_BIN_T("v_add_f64")                                    \
-  BSR_SC_SLOT("13") BSR_SC_BIN_T("v_mul_f64")                                    \
+  BSR_SC_SLOT("12") BSR_SC_BIN_T("v_add_f64", SH)                                 \
+  BSR_SC_SLOT("13") BSR_SC_BIN_T("v_mul_f64", SH)                                 \
   BSR_SC_SLOT("14") BSR_SC_BIN("v_add_f64", "-") /* sub */                       \
   BSR_SC_SLOT("15") /* div, protected like inv */                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
@@ -235,7 +333,43 @@
   BSR_SC_CUBE("v[0:1]", "v0", "v1")                                              \
   BSR_SC_CUBE("v[2:3]", "v2", "v3")                                              \
   BSR_SC_DISPATCH                                                                \
-  ".Lsc_leave%=:\n\t"   /* sin, cos, exp: out with the state; which tape: the offset of its add-up code */ \
+  ".Lsc_sin%=:\n\t"                                                              \
+  "s_movk_i32 s12, 4\n\t"                                                        \
+  "s_load_dwordx16 s[36:51], s[24:25], 576\n\t"                                  \
+  "s_load_dwordx8 s[52:59], s[24:25], 704\n\t"                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  "v_cmp_nlt_f64_e64 s[8:9], |v[0:1]|, s[56:57]\n\t"   /* huge, infinite, NaN: the caller's (library) routine */ \
+  "v_cmp_nlt_f64_e64 vcc, |v[2:3]|, s[56:57]\n\t"                                \
+  "s_or_b64 vcc, vcc, s[8:9]\n\t"                                                \
+  "s_cbranch_vccnz .Lsc_leave%=\n\t"                                             \
+  BSR_SC_SINCOS("v[0:1]", "v0", "v1", "", BSR_SC_SIN_TINY("v[0:1]", "v0", "v1")) \
+  BSR_SC_SINCOS("v[2:3]", "v2", "v3", "", BSR_SC_SIN_TINY("v[2:3]", "v2", "v3")) \
+  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  BSR_SC_DISPATCH                                                                \
+  ".Lsc_cos%=:\n\t"                                                              \
+  "s_movk_i32 s12, 5\n\t"                                                        \
+  "s_load_dwordx16 s[36:51], s[24:25], 576\n\t"                                  \
+  "s_load_dwordx8 s[52:59], s[24:25], 704\n\t"                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  "v_cmp_nlt_f64_e64 s[8:9], |v[0:1]|, s[56:57]\n\t"                             \
+  "v_cmp_nlt_f64_e64 vcc, |v[2:3]|, s[56:57]\n\t"                                \
+  "s_or_b64 vcc, vcc, s[8:9]\n\t"                                                \
+  "s_cbranch_vccnz .Lsc_leave%=\n\t"                                             \
+  BSR_SC_SINCOS("v[0:1]", "v0", "v1", "v_add_u32_e32 v20, 64, v20\n\t", BSR_SC_COS_MOVE("v[0:1]")) \
+  BSR_SC_SINCOS("v[2:3]", "v2", "v3", "v_add_u32_e32 v20, 64, v20\n\t", BSR_SC_COS_MOVE("v[2:3]")) \
+  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  BSR_SC_DISPATCH                                                                \
+  ".Lsc_exp%=:\n\t"                                                              \
+  "s_load_dwordx16 s[36:51], s[24:25], 832\n\t"                                  \
+  "s_load_dwordx4 s[52:55], s[24:25], 1088\n\t"                                  \
+  "v_mov_b32_e32 v30, 0x20000000\n\t"   /* 1e10: what the clipped exp returns beyond 200 (and for NaN) */ \
+  "v_mov_b32_e32 v31, 0x4202a05f\n\t"                                            \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  BSR_SC_EXP("v[0:1]", "v0", "v1")                                               \
+  BSR_SC_EXP("v[2:3]", "v2", "v3")                                               \
+  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  BSR_SC_DISPATCH                                                                \
+  ".Lsc_leave%=:\n\t"   /* sin, cos of huge arguments: out with the state; which tape: the offset of its add-up code */ \
   "s_sub_u32 s10, s28, s24\n\t"                                                  \
   "v_mov_b32_e32 %[sv0], s20\n\t"                                                \
   "v_mov_b32_e32 %[sv1], s21\n\t"                                                \
@@ -260,9 +394,14 @@
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"
 
+// one-block chunks: a column of the buffer is 1024 bytes; two-block chunks: 2048 (the block's half picked by %[lc])
+#define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_K3_("10", "1024", "2048", "3072")
+#define BSR_STREAM_CHUNK2_ASM_K3 BSR_STREAM_CHUNK_ASM_K3_("11", "2048", "4096", "6144")
+
 #define BSR_STREAM_CHUNK_CLOBBERS                                                                                      \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17",   \
-  "v18", "v19", "v20", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", \
+  "v18", "v19", "v20", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", \
   "v38", "v39", "s8", "s9", "s10", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", \
-  "s24", "s25", "s26", "s27", "s28", "s29", "vcc", "scc", "memory"
+  "s24", "s25", "s26", "s27", "s28", "s29", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", \
+  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc", "memory"
 // clang-format on

