@@ -236,10 +236,12 @@ __device__ __attribute__((noinline)) double2 generic_block(const TileArgs<double
 template <int KQ, int QT, int CB, bool STAMPS, int MODE>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<double> a) {
   // MODE 0: the C++ interpreter (tape_fast); 1: the assembly interpreter, a tape at a time (bsr_stream_asm.h);
-  // 2: a wave's four tapes of a chunk in one block of assembly (bsr_stream_chunk_asm.h: K = 3, every tape on one basis)
+  // 2: a wave's four tapes of a chunk in one block of assembly (bsr_stream_chunk_asm.h: K = 3, every tape on one basis);
+  // 3: the loop over the slice's chunks inside that block too (the kernel's default where 2 applies)
   constexpr bool ASM = MODE == 1;
   static_assert(MODE != 1 || CB == 1, "the tape-at-a-time assembly interpreter takes one-block chunks");
-  static_assert(MODE != 2 || (KQ == 3 && QT == 4), "the chunk block is written for K = 3, four tapes per wave");
+  static_assert(MODE < 2 || (KQ == 3 && QT == 4), "the chunk block is written for K = 3, four tapes per wave");
+  static_assert(MODE != 3 || (CB == 1 && !STAMPS), "the pass block: one-block chunks, no per-chunk clock samples");
   constexpr int U = 2 * CB;
   constexpr int NUMAX = BSR_STREAM_UNITS_MAX / BSR_TILE_WAVES;   // DMA pieces per wave and chunk at most
   extern __shared__ __align__(16) unsigned char smem[];
@@ -332,6 +334,54 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     }
     if (issue_off == ring_bytes) issue_off = 0;
     uint32_t cur_off = 0;     // ... and where the chunk the waves compute on sits
+    if constexpr (MODE == 3) {
+      // the chunk loop itself in the block of assembly (bsr_stream_chunk_asm.h: BSR_STREAM_PASS_ASM_K3); what comes back
+      // here: sin / cos of huge arguments and tapes for the stack machine, with the loop's state in sv[5..9]
+      const Bases B = fetch_bases();
+      uint32_t resume = 0, st, sv[10], lc_out;
+      double z0, z1, s00, s01;
+      asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
+                        "=v"(sv[4]), "=v"(sv[5]), "=v"(sv[6]), "=v"(sv[7]), "=v"(sv[8]), "=v"(sv[9]));
+      const uint32_t yo = (uint32_t)y_slot << 10, lane16 = (uint32_t)lane * 16u;
+      const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
+      const uint32_t ring_u = (uint32_t)R, nch_u = (uint32_t)n_chunks, nmine_u = (uint32_t)n_mine, wave_u = (uint32_t)wave;
+      const uint32_t b0_u = (uint32_t)b0;
+      for (;;) {
+        asm volatile(BSR_STREAM_PASS_ASM_K3
+                     : [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [sa0] "+v"(A[0].a0),
+                       [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax),
+                       [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [sa1] "+v"(A[1].a0),
+                       [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax),
+                       [ca2] "+v"(A[2].c[0]), [cb2] "+v"(A[2].c[1]), [cc2] "+v"(A[2].c[2]), [sa2] "+v"(A[2].a0),
+                       [sb2] "+v"(A[2].a1), [am2] "+v"(A[2].amax),
+                       [ca3] "+v"(A[3].c[0]), [cb3] "+v"(A[3].c[1]), [cc3] "+v"(A[3].c[2]), [sa3] "+v"(A[3].a0),
+                       [sb3] "+v"(A[3].a1), [am3] "+v"(A[3].amax),
+                       [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]),
+                       [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [sv5] "+v"(sv[5]),
+                       [sv6] "+v"(sv[6]), [sv7] "+v"(sv[7]), [sv8] "+v"(sv[8]), [sv9] "+v"(sv[9]), [st] "=s"(st),
+                       [lc] "=&v"(lc_out)
+                     : [resume] "s"(resume), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds),
+                       [lane16] "v"(lane16), [ba0] "s"(B.p[0]), [ba1] "s"(B.p[1]), [ba2] "s"(B.p[2]), [ba3] "s"(B.p[3]),
+                       [nch] "s"(nch_u), [bufb] "s"(buf_bytes), [ring] "s"(ring_u), [lds0] "s"(lds0), [wave] "s"(wave_u),
+                       [nmine] "s"(nmine_u), [ioff] "s"(issue_off), [b0] "s"(b0_u)
+                     : BSR_STREAM_PASS_CLOBBERS);
+        if (st == 0) break;
+        const uint32_t what = st & 15u;
+        if (what == 1) {
+          const uint32_t cur_lds = __builtin_amdgcn_readfirstlane(sv[9]);   // LDS address of the chunk being computed on
+          const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), my + (st >> 4),
+                                           reinterpret_cast<const double*>(smem + (cur_lds - lds0)), 2 * lane, lane);
+          z0 = zb.x;
+          z1 = zb.y;
+        } else {
+          double zz[2] = {z0, z1};
+          sincos_vals<2>(zz, what == BSR_OP_COS + 1 ? 1 : 0);
+          z0 = zz[0];
+          z1 = zz[1];
+        }
+        resume = __builtin_amdgcn_readfirstlane(st);
+      }
+    } else
     for (int ci = 0; ci < n_chunks; ++ci) {
       const Bases B = fetch_bases();   // (for the request behind the barrier; the loads return while the wave waits there)
       {
@@ -540,7 +590,7 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   // BSR_STREAM_ASM=0: the C++ interpreter (tape_fast) on one-block chunks too -- the cross-check of the assembly ones;
   // 1: the assembly interpreter a tape at a time; default: the wave's four tapes in one block where it applies (K = 3,
   // one chain's basis behind y), else 1
-  static const int asm_mode = env_int("BSR_STREAM_ASM", 2);
+  static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
   const bool chunk_block = KQ == 3 && QT == 4 && asm_mode >= 2 && a.g.ncols_fixed == KQ;
   if (a.g.chunk_blocks == 2) {
     if constexpr (KQ == 3 && QT == 4) {
@@ -557,6 +607,7 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   if constexpr (KQ == 3 && QT == 4) {
     if (chunk_block) {
       if (a.stamps) launch_one<KQ, QT, 1, true, 2>(st, a, lds);   // (BSR_TILE_STAMPS=1: per-wave clock samples)
+      else if (asm_mode >= 3) launch_one<KQ, QT, 1, false, 3>(st, a, lds);
       else launch_one<KQ, QT, 1, false, 2>(st, a, lds);
       return;
     }
@@ -576,7 +627,7 @@ size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof
 // whether a batch of this shape takes the chunk block of assembly (K = 3, four sets of sums per wave, one chain's basis):
 // then two-block chunks cost nothing but LDS (bsr_stage.hip: stage_tile's geometry)
 bool stream_chunk_block(int K, int ncols_fixed) {
-  static const int asm_mode = env_int("BSR_STREAM_ASM", 2);
+  static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
   return K == 3 && stream_qmax(3) == 4 && asm_mode >= 2 && ncols_fixed == K;
 }
 

@@ -234,23 +234,16 @@
   "s_cbranch_scc1 .Lsc_acc" #q "_%=\n\t"                                         \
   "s_branch .Lsc_state%=\n\t"
 
-#define BSR_STREAM_CHUNK_ASM_K3_(SH, O1, O2, O3)                                 \
-  "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
+// -- shared pieces of the two blocks below --
+#define BSR_SC_TABLE_BASE                                                        \
   "s_getpc_b64 s[24:25]\n"                                                       \
   ".Lsc_pc%=:\n\t"                                                               \
   "s_add_u32 s24, s24, .Lsc_tab%=-.Lsc_pc%=\n\t"                                 \
   "s_addc_u32 s25, s25, 0\n\t"                                                   \
-  "s_mov_b32 s27, s25\n\t"                                                       \
-  "v_add_u32_e32 v20, %[yo], %[lc]\n\t"   /* y and the basis columns of the lane's rows, once for the four tapes */ \
-  "ds_read_b128 v[24:27], v20\n\t"                                               \
-  "ds_read_b128 v[28:31], v20 offset:" O1 "\n\t"                                 \
-  "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"                                 \
-  "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"                                 \
-  "s_cmp_lg_u32 %[resume], 0\n\t"                                                \
-  "s_cbranch_scc1 .Lsc_resume%=\n\t"                                             \
-  BSR_SC_TAPE(0, 1) BSR_SC_TAPE(1, 2) BSR_SC_TAPE(2, 3) BSR_SC_TAPE(3, 4)        \
-  "s_mov_b32 %[st], 0\n\t"                                                       \
-  "s_branch .Lsc_exit%=\n"                                                       \
+  "s_mov_b32 s27, s25\n\t"
+#define BSR_SC_TAPES BSR_SC_TAPE(0, 1) BSR_SC_TAPE(1, 2) BSR_SC_TAPE(2, 3) BSR_SC_TAPE(3, 4)
+// coming back (`resume` = what the block left with): which tape, then BSR_SC_RESUME of that tape
+#define BSR_SC_RESUME_PART                                                       \
   ".Lsc_resume%=:\n\t"                                                           \
   "s_lshr_b32 s10, %[resume], 4\n\t"                                             \
   "s_and_b32 s12, %[resume], 15\n\t"                                             \
@@ -270,7 +263,9 @@
   "v_readfirstlane_b32 s13, %[sv4]\n\t"                                          \
   "v_mov_b64_e32 v[4:5], %[s0]\n\t"                                              \
   "v_mov_b64_e32 v[6:7], %[s1]\n\t"                                              \
-  BSR_SC_DISPATCH                                                                \
+  BSR_SC_DISPATCH
+// the operator table (2 KB-aligned: the dispatch ORs a slot's offset into its address) and the operators too long for a slot
+#define BSR_SC_TABLE_PART(SH, O1, O2, O3)                                        \
   ".p2align 11\n"                                                                \
   ".Lsc_tab%=:\n\t"                                                              \
   "s_setpc_b64 s[28:29]\n\t"   /* 0: end of the tape */                          \
@@ -368,7 +363,9 @@
   BSR_SC_EXP("v[0:1]", "v0", "v1")                                               \
   BSR_SC_EXP("v[2:3]", "v2", "v3")                                               \
   BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
-  BSR_SC_DISPATCH                                                                \
+  BSR_SC_DISPATCH
+// leaving for the caller: sin / cos of huge arguments (the state out through the operands; which tape: by where `end` goes)
+#define BSR_SC_LEAVE_PART                                                        \
   ".Lsc_leave%=:\n\t"   /* sin, cos of huge arguments: out with the state; which tape: the offset of its add-up code */ \
   "s_sub_u32 s10, s28, s24\n\t"                                                  \
   "v_mov_b32_e32 %[sv0], s20\n\t"                                                \
@@ -390,9 +387,145 @@
   "s_add_u32 %[st], %[st], 16\n\t"                                               \
   "s_cmp_eq_u32 s10, .Lsc_acc2_%=-.Lsc_tab%=\n\t"                                \
   "s_cbranch_scc1 .Lsc_exit%=\n\t"                                               \
-  "s_add_u32 %[st], %[st], 16\n"                                                 \
+  "s_add_u32 %[st], %[st], 16\n"
+
+#define BSR_STREAM_CHUNK_ASM_K3_(SH, O1, O2, O3)                                 \
+  "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
+  BSR_SC_TABLE_BASE                                                              \
+  BSR_SC_RELOAD_YQ(O1, O2, O3)   /* y and the basis columns of the lane's rows, once for the four tapes */ \
+  "s_cmp_lg_u32 %[resume], 0\n\t"                                                \
+  "s_cbranch_scc1 .Lsc_resume%=\n\t"                                             \
+  BSR_SC_TAPES                                                                   \
+  "s_mov_b32 %[st], 0\n\t"                                                       \
+  "s_branch .Lsc_exit%=\n"                                                       \
+  BSR_SC_RESUME_PART                                                             \
+  BSR_SC_TABLE_PART(SH, O1, O2, O3)                                              \
+  BSR_SC_LEAVE_PART                                                              \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole pass of a wave over its slice in one block: for every chunk -- wait for its copies, barrier, request the
+// chunk R - 1 ahead, the four tapes (above).  Why: after the barrier all sixteen waves of the workgroup run this
+// hand-over at the same time on the CU's one scalar unit, and the compiler's version is 75 scalar instructions per
+// wave (column bases re-read and clamped per piece, a compare chain to pick s_waitcnt's immediate, a compare per piece,
+// spilled ring offsets): 0.6 us of every 3 us chunk.  Here: ~25.  One-block chunks only.
+//
+// More fixed registers: s[60:67] the column bases of the wave's (at most four) pieces, s68 chunk, s69 chunks of the
+// slice, s70 where in the ring the next request goes (byte offset), s71 LDS address of the next chunk to compute on,
+// s72 bytes of a buffer, s73 of the ring, s74 LDS address of the wave's first piece in buffer 0, s75 end of the ring,
+// s76 first chunk of the tail (fewer copies in flight than in steady state: wait for all), s77 chunks that still
+// request one, s78 next block to request, s79 LDS address of the chunk being computed on, s[80:81] the steady state's
+// s_waitcnt, s[82:83] entry into the request code for the wave's number of pieces, s84 LDS address of the ring.
+// A leave (st != 0) also puts s68, s70, s71, s78, s79 into sv5..sv9; the caller passes everything back as it got it.
+#define BSR_SP_PIECE(k, base)                                                    \
+  ".Lsp_is" #k "_%=:\n\t"                                                        \
+  "s_add_u32 m0, s10, " #k "*16384\n\t"                                          \
+  "s_nop 0\n\t"                                                                  \
+  "global_load_lds_dwordx4 v20, " base "\n\t"
+#define BSR_SP_WAIT(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch .Lsp_waited%=\n\t"
+
+#define BSR_STREAM_PASS_ASM_K3                                                   \
+  BSR_SC_TABLE_BASE                                                              \
+  "s_mov_b64 s[60:61], %[ba0]\n\t"                                               \
+  "s_mov_b64 s[62:63], %[ba1]\n\t"                                               \
+  "s_mov_b64 s[64:65], %[ba2]\n\t"                                               \
+  "s_mov_b64 s[66:67], %[ba3]\n\t"                                               \
+  "s_mov_b32 s69, %[nch]\n\t"                                                    \
+  "s_mov_b32 s72, %[bufb]\n\t"                                                   \
+  "s_mul_i32 s73, s72, %[ring]\n\t"                                              \
+  "s_mov_b32 s84, %[lds0]\n\t"                                                   \
+  "s_add_u32 s75, s84, s73\n\t"                                                  \
+  "s_lshl_b32 s10, %[wave], 10\n\t"                                              \
+  "s_add_u32 s74, s84, s10\n\t"                                                  \
+  "s_sub_u32 s10, %[ring], 2\n\t"                                                \
+  "s_sub_i32 s76, s69, s10\n\t"                                                  \
+  "s_sub_i32 s77, s76, 1\n\t"                                                    \
+  "s_mul_i32 s10, s10, %[nmine]\n\t"   /* copies of later chunks in flight, steady state */ \
+  "s_lshl_b32 s10, s10, 3\n\t"                                                   \
+  "s_add_u32 s80, s24, .Lsp_waits%=-.Lsc_tab%=\n\t"                              \
+  "s_addc_u32 s81, s25, 0\n\t"                                                   \
+  "s_add_u32 s80, s80, s10\n\t"                                                  \
+  "s_addc_u32 s81, s81, 0\n\t"                                                   \
+  "s_mov_b32 s10, .Lsp_is_none%=-.Lsc_tab%=\n\t"                                 \
+  "s_cmp_eq_u32 %[nmine], 1\n\t"                                                 \
+  "s_cselect_b32 s10, .Lsp_is0_%=-.Lsc_tab%=, s10\n\t"                           \
+  "s_cmp_eq_u32 %[nmine], 2\n\t"                                                 \
+  "s_cselect_b32 s10, .Lsp_is1_%=-.Lsc_tab%=, s10\n\t"                           \
+  "s_cmp_eq_u32 %[nmine], 3\n\t"                                                 \
+  "s_cselect_b32 s10, .Lsp_is2_%=-.Lsc_tab%=, s10\n\t"                           \
+  "s_cmp_eq_u32 %[nmine], 4\n\t"                                                 \
+  "s_cselect_b32 s10, .Lsp_is3_%=-.Lsc_tab%=, s10\n\t"                           \
+  "s_add_u32 s82, s24, s10\n\t"                                                  \
+  "s_addc_u32 s83, s25, 0\n\t"                                                   \
+  "s_cmp_lg_u32 %[resume], 0\n\t"                                                \
+  "s_cbranch_scc1 .Lsp_resume%=\n\t"                                             \
+  "s_mov_b32 s68, 0\n\t"                                                         \
+  "s_mov_b32 s70, %[ioff]\n\t"                                                   \
+  "s_mov_b32 s71, s84\n\t"                                                       \
+  "s_add_u32 s78, %[b0], %[ring]\n\t"                                            \
+  "s_sub_u32 s78, s78, 1\n"                                                      \
+  ".Lsp_loop%=:\n\t"                                                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  "s_cmp_ge_i32 s68, s76\n\t"                                                    \
+  "s_cbranch_scc1 .Lsp_wait0%=\n\t"                                              \
+  "s_setpc_b64 s[80:81]\n"                                                       \
+  ".Lsp_wait0%=:\n\t"                                                            \
+  "s_waitcnt vmcnt(0)\n"                                                         \
+  ".Lsp_waited%=:\n\t"                                                           \
+  "s_barrier\n\t"   /* chunk s68 has landed for everyone; everyone is done with the chunk before */ \
+  "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
+  "s_cmp_lt_i32 s68, s77\n\t"                                                    \
+  "s_cbranch_scc0 .Lsp_issued%=\n\t"                                             \
+  "v_lshl_add_u32 v20, s78, 10, %[lane16]\n\t"                                   \
+  "s_add_u32 s10, s74, s70\n\t"                                                  \
+  "s_setpc_b64 s[82:83]\n"                                                       \
+  ".Lsp_issued2%=:\n\t"                                                          \
+  "s_add_u32 s70, s70, s72\n\t"                                                  \
+  "s_cmp_eq_u32 s70, s73\n\t"                                                    \
+  "s_cselect_b32 s70, 0, s70\n\t"                                                \
+  "s_add_u32 s78, s78, 1\n"                                                      \
+  ".Lsp_issued%=:\n\t"                                                           \
+  "s_mov_b32 s79, s71\n\t"                                                       \
+  "v_add_u32_e32 %[lc], s71, %[lane16]\n\t"                                      \
+  "s_add_u32 s71, s71, s72\n\t"                                                  \
+  "s_cmp_eq_u32 s71, s75\n\t"                                                    \
+  "s_cselect_b32 s71, s84, s71\n\t"                                              \
+  BSR_SC_RELOAD_YQ("1024", "2048", "3072")                                       \
+  BSR_SC_TAPES                                                                   \
+  "s_add_u32 s68, s68, 1\n\t"                                                    \
+  "s_cmp_lt_u32 s68, s69\n\t"                                                    \
+  "s_cbranch_scc1 .Lsp_loop%=\n\t"                                               \
+  "s_mov_b32 %[st], 0\n\t"                                                       \
+  "s_branch .Lsc_exit%=\n"                                                       \
+  ".Lsp_resume%=:\n\t"   /* back into the chunk the block left */               \
+  "v_readfirstlane_b32 s68, %[sv5]\n\t"                                          \
+  "v_readfirstlane_b32 s70, %[sv6]\n\t"                                          \
+  "v_readfirstlane_b32 s71, %[sv7]\n\t"                                          \
+  "v_readfirstlane_b32 s78, %[sv8]\n\t"                                          \
+  "v_readfirstlane_b32 s79, %[sv9]\n\t"                                          \
+  "s_nop 3\n\t"                                                                  \
+  "v_add_u32_e32 %[lc], s79, %[lane16]\n\t"                                      \
+  BSR_SC_RELOAD_YQ("1024", "2048", "3072")                                       \
+  BSR_SC_RESUME_PART                                                             \
+  BSR_SC_TABLE_PART("10", "1024", "2048", "3072")                                \
+  ".Lsp_waits%=:\n\t"   /* the steady state's wait: entry 8 n for n copies of later chunks in flight */ \
+  BSR_SP_WAIT(0) BSR_SP_WAIT(1) BSR_SP_WAIT(2) BSR_SP_WAIT(3) BSR_SP_WAIT(4) BSR_SP_WAIT(5) BSR_SP_WAIT(6)     \
+  BSR_SP_WAIT(7) BSR_SP_WAIT(8)                                                  \
+  BSR_SP_PIECE(3, "s[66:67]") BSR_SP_PIECE(2, "s[64:65]") BSR_SP_PIECE(1, "s[62:63]") BSR_SP_PIECE(0, "s[60:61]") \
+  ".Lsp_is_none%=:\n\t"                                                          \
+  "s_branch .Lsp_issued2%=\n\t"                                                  \
+  BSR_SC_LEAVE_PART                                                              \
+  ".Lsc_exit%=:\n\t"                                                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  "v_mov_b32_e32 %[sv5], s68\n\t"                                                \
+  "v_mov_b32_e32 %[sv6], s70\n\t"                                                \
+  "v_mov_b32_e32 %[sv7], s71\n\t"                                                \
+  "v_mov_b32_e32 %[sv8], s78\n\t"                                                \
+  "v_mov_b32_e32 %[sv9], s79\n\t"
+
+#define BSR_STREAM_PASS_CLOBBERS BSR_STREAM_CHUNK_CLOBBERS, "m0", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+  "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84"
 
 // one-block chunks: a column of the buffer is 1024 bytes; two-block chunks: 2048 (the block's half picked by %[lc])
 #define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_K3_("10", "1024", "2048", "3072")

@@ -107,15 +107,16 @@ ctx.close()
 """
 
 
-def test_the_three_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path):
+def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path):
     """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
-    time (1) or a wave's four tapes in one block of assembly (2, the default at K = 3).  The assembly restates the
+    time (1), a wave's four tapes in one block of assembly (2) or the whole loop over the slice's chunks in it (3, the
+    default at K = 3).  The assembly restates the
     instruction sequences the compiler emits for the C++ -- division, cube, ln, the fused operands -- so every score of a
     batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
     sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran."""
     import subprocess
     out = {}
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "2", "3"):
         path = str(tmp_path / ("res%s.npy" % mode))
         env = dict(os.environ, BSR_STREAM_ASM=mode)
         p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path], env=env, capture_output=True, text=True,
@@ -125,3 +126,4 @@ def test_the_three_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path
     assert out["0"].size > 0
     assert (out["0"] == out["1"]).all(), np.nonzero(out["0"] != out["1"])[0][:20]
     assert (out["0"] == out["2"]).all(), np.nonzero(out["0"] != out["2"])[0][:20]
+    assert (out["0"] == out["3"]).all(), np.nonzero(out["0"] != out["3"])[0][:20]
