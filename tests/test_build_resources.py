@@ -122,6 +122,7 @@ def test_streaming_row_pass_keeps_compiler_memory_traffic_out_of_its_chunk_loop(
             n_scratch = sum("scratch_" in l for l in loop)
             n_vm = sum("vmcnt" in l for l in loop)
             n_call = sum("s_swappc" in l for l in loop)
-            assert n_scratch == 0 and n_vm == 0 and n_call <= 4, (name[0], n_scratch, n_vm, n_call)
+            # (mode 3 counts its own copies in the loop: the steady state's nine s_waitcnt vmcnt(n) and the tail's)
+            assert n_scratch == 0 and n_vm <= (10 if mode == 3 else 0) and n_call <= 4, (name[0], n_scratch, n_vm, n_call)
             seen += 1
     assert seen == 10
