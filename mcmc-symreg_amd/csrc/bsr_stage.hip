@@ -624,6 +624,8 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
         const int slot = s.wave_cnt[idx]++;
         const int pass = slot / tg.qmax, q = slot % tg.qmax;
         ri = (((size_t)grp * tg.n_pass + pass) * BSR_TILE_WAVES + best) * tg.qmax + q;
+        // (tried: less work for the younger waves of a SIMD -- it issues for its oldest wave first, the youngest runs the end
+        // of every chunk alone -- by 15 and 30 %: no difference, 84.6-85.7 us either way)
         s.wave_load[idx] += (double)D.cost;
       }
       left_idx[i] = (int32_t)ri;

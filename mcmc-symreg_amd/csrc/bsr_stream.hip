@@ -264,7 +264,15 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
 #define TSTAMP(i) do { if (STAMPS && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
   if (STAMPS && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
-  tables_to_lds();  // visible after the first barrier below
+  // the math tables into LDS by the same copies that bring the columns, requested first (copies complete in order: a
+  // wave that waits for its first chunk has its piece of the tables; everyone else's after the first barrier) -- read
+  // through registers they cost the kernel's start a round trip to memory before the first column was even requested
+  for (int t = wave; t < (int)(BSR_TAB_DOUBLES * sizeof(double) / 1024); t += BSR_TILE_WAVES) {
+    const char* src = (const char*)bsr_tables_src + t * 1024 + lane * 16;
+    const uint32_t la = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(size_t)(__attribute__((address_space(3))) void*)((char*)bsr_lds_tab + t * 1024));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(la) : "memory", "m0");
+  }
   unsigned long long busy = 0, t_busy = 0;
 
   // the wave's DMA pieces: piece k copies unit u = wave + 16 k of every chunk -- (column u / CB, block u % CB of the
@@ -315,15 +323,6 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     const uint32_t ln_lds = lds0 + ring_bytes + (uint32_t)wave * (QT * 48u);   // (its LDS address, for the assembly interpreter)
     if (pass != 0) __syncthreads();   // everyone is done with the last chunks (and the ln pairs) of the pass before
     const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-      const TapeRec CONSTANT_AS* rec = as_const(my + q);
-      A[q].clear();
-      if (lane == 0) {   // (scalar loads and LDS stores: no vector memory operation next to the copies' counter)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ln_mine[q * 3 + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
-      }
-    }
     uint32_t issue_off = 0;   // where in the ring the next chunk to be requested goes
     {
       const Bases B = fetch_bases();
@@ -333,6 +332,15 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       }
     }
     if (issue_off == ring_bytes) issue_off = 0;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {   // (under the first copies' flight)
+      const TapeRec CONSTANT_AS* rec = as_const(my + q);
+      A[q].clear();
+      if (lane == 0) {   // (scalar loads and LDS stores: no vector memory operation next to the copies' counter)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ln_mine[q * 3 + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
+      }
+    }
     uint32_t cur_off = 0;     // ... and where the chunk the waves compute on sits
     if constexpr (MODE == 3) {
       // the chunk loop itself in the block of assembly (bsr_stream_chunk_asm.h: BSR_STREAM_PASS_ASM_K3); what comes back
