@@ -202,6 +202,11 @@ struct TNode {
   double a = 0.0, b = 0.0;
 };
 
+// A scratch vector that keeps its capacity from call to call (one per call site and thread; never in a function that can
+// be entered again while it is in use): generating a proposal ran 40 heap allocations, a third of its time.
+#define BSR_SCRATCH(T, name) static thread_local std::vector<T> name; name.clear()
+typedef std::pair<int, int> BSR_PAIR_II;   // (a type without a comma, for the macro)
+
 struct Tree {
   std::vector<TNode> n;
   int root = 0;
@@ -214,7 +219,7 @@ struct Tree {
 
 void preorder(const Tree& t, int root, std::vector<int>& out) {
   out.clear();
-  std::vector<int> st;
+  BSR_SCRATCH(int, st);
   st.push_back(root);
   while (!st.empty()) {
     const int i = st.back();
@@ -227,11 +232,13 @@ void preorder(const Tree& t, int root, std::vector<int>& out) {
   }
 }
 
-Tree clone_tree(const Tree& src, int root) {  // compact copy of the subtree reachable from root
-  Tree d;
-  std::vector<int> order;
+// compact copy of the subtree reachable from root, into `d` (whose storage is reused)
+void clone_into(const Tree& src, int root, Tree& d) {
+  BSR_SCRATCH(int, order);
   preorder(src, root, order);
-  std::vector<int> map(src.n.size(), -1);
+  BSR_SCRATCH(int, map);
+  map.assign(src.n.size(), -1);
+  d.n.clear();
   d.n.reserve(order.size() + 8);
   for (int i : order) {
     map[i] = (int)d.n.size();
@@ -244,12 +251,17 @@ Tree clone_tree(const Tree& src, int root) {  // compact copy of the subtree rea
   }
   d.root = map[root];
   d.n[d.root].parent = -1;
+}
+Tree clone_tree(const Tree& src, int root) {
+  Tree d;
+  clone_into(src, root, d);
   return d;
 }
 
 int count_nodes(const Tree& t, int i) {
   int c = 0;
-  std::vector<int> st{i};
+  BSR_SCRATCH(int, st);
+  st.push_back(i);
   while (!st.empty()) {
     const int j = st.back();
     st.pop_back();
@@ -264,7 +276,8 @@ int count_nodes(const Tree& t, int i) {
 }
 int count_ln(const Tree& t, int i) {
   int c = 0;
-  std::vector<int> st{i};
+  BSR_SCRATCH(int, st);
+  st.push_back(i);
   while (!st.empty()) {
     const int j = st.back();
     st.pop_back();
@@ -280,7 +293,8 @@ int count_ln(const Tree& t, int i) {
 }
 void up_depth(Tree& t, int root) {
   t.n[root].depth = t.n[root].parent < 0 ? 0 : t.n[t.n[root].parent].depth + 1;
-  std::vector<int> st{root};
+  BSR_SCRATCH(int, st);
+  st.push_back(root);
   while (!st.empty()) {
     const int i = st.back();
     st.pop_back();
@@ -302,6 +316,20 @@ struct Params {
   int op_code[BSR_MAX_OPS];    // opcode of table entry k
   int op_type[BSR_MAX_OPS];    // arity of table entry k
   double w[BSR_MAX_OPS], cdf[BSR_MAX_OPS], logw[BSR_MAX_OPS];
+  // fstruc's per-node terms for the depths trees reach, computed once by the very calls fstruc made per node (the same
+  // libm results, bit for bit): the terminal's log(1 - 1 / (1 + depth)^-beta) - log(n_feature), the operator's
+  // log(1 + depth) beta
+  enum { DEPTH_TAB = 64 };
+  double fs_term[DEPTH_TAB], fs_op[DEPTH_TAB];
+  void fill_depth_tables() {
+    for (int dpt = 0; dpt < DEPTH_TAB; ++dpt) {
+      double ls = 0;
+      ls += flog(1 - 1 / std::pow(1 + dpt, -beta));
+      ls -= std::log((double)n_feature);
+      fs_term[dpt] = ls;
+      fs_op[dpt] = std::log((double)(1 + dpt)) * beta;
+    }
+  }
 
   static int arity_of(int code) {
     return (code == BSR_OP_ADD || code == BSR_OP_MUL || code == BSR_OP_SUB || code == BSR_OP_DIV) ? 2 : 1;
@@ -382,10 +410,15 @@ void fstruc(const Tree& t, int i, const Params& P, double sigma_a, double sigma_
   double ls = 0, lp = 0;
   const double logw = (nd.type != 0 && nd.op_ind >= 0) ? P.logw[nd.op_ind] : 0.0;
   if (nd.type == 0) {
-    ls += flog(1 - 1 / std::pow(1 + nd.depth, -P.beta));
-    ls -= std::log((double)P.n_feature);
+    if (nd.depth >= 0 && nd.depth < Params::DEPTH_TAB) {
+      ls += P.fs_term[nd.depth];   // (0 + a - b == (0 + a) - b: the table holds exactly what the two lines below add up to)
+    } else {
+      ls += flog(1 - 1 / std::pow(1 + nd.depth, -P.beta));
+      ls -= std::log((double)P.n_feature);
+    }
   } else {
     if (nd.depth == 0) ls += logw;
+    else if (nd.depth > 0 && nd.depth < Params::DEPTH_TAB) ls += P.fs_op[nd.depth] + logw;
     else ls += std::log((double)(1 + nd.depth)) * P.beta + logw;
     if (nd.type == 1 && nd.op == OP_LN) {
       lp -= std::pow(nd.a - 1, 2) / (2 * sigma_a);
@@ -449,7 +482,7 @@ struct Move {
 };
 
 int count_terms(const Tree& t, int root, int* total) {
-  std::vector<int> o;
+  BSR_SCRATCH(int, o);
   preorder(t, root, o);
   int nt = 0;
   for (int i : o) nt += t.n[i].type == 0;
@@ -460,12 +493,14 @@ int count_terms(const Tree& t, int root, int* total) {
 // One structural proposal on the private copy `t` (codes/funcs.py:406-923)
 void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, LegacyRng& r, Move& mv) {
   int Root = t.root;
-  std::vector<int> tree;
+  BSR_SCRATCH(int, tree);
   preorder(t, Root, tree);
   mv.ln_nodes.clear();
   mv.last_a.clear();
   mv.last_b.clear();
-  std::vector<int> term, nterm, detcd;
+  BSR_SCRATCH(int, term);
+  BSR_SCRATCH(int, nterm);
+  BSR_SCRATCH(int, detcd);
   for (int i : tree) {
     if (t.n[i].op == OP_LN && t.n[i].type == 1) {
       mv.ln_nodes.push_back(i);
@@ -687,7 +722,8 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
 // codes/funcs.py:935-1138
 void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, LegacyRng& r, double* sa2_out,
                  double* sb2_out, double* hratio, double* detjacob) {
-  std::vector<int> order, lns;
+  BSR_SCRATCH(int, order);
+  BSR_SCRATCH(int, lns);
   preorder(t, t.root, order);
   for (int i : order)
     if (t.n[i].op == OP_LN && t.n[i].type == 1) lns.push_back(i);
@@ -797,7 +833,10 @@ void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, Legacy
     new_sa2 = invgamma_rvs(r, 1);
     new_sb2 = invgamma_rvs(r, 1);
     const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
-    std::vector<double> va(lns.size()), vb(lns.size());
+    BSR_SCRATCH(double, va);
+    BSR_SCRATCH(double, vb);
+    va.resize(lns.size());
+    vb.resize(lns.size());
     for (size_t i = 0; i < lns.size(); ++i) {
       va[i] = r.normal(1, sa);
       vb[i] = r.normal(0, sb);
@@ -814,9 +853,11 @@ void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, Legacy
 // Postfix rows of the tree (heavier child of +/* first: Sethi-Ullman), as bsr/tape.py:flatten
 void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
   rows.clear();
-  std::vector<int> need(t.n.size(), 0);
+  rows.reserve(t.n.size());
+  BSR_SCRATCH(int, need);
+  need.assign(t.n.size(), 0);
   {
-    std::vector<std::pair<int, int>> st;
+    BSR_SCRATCH(BSR_PAIR_II, st);
     st.push_back({root, 0});
     while (!st.empty()) {
       auto [i, seen] = st.back();
@@ -839,8 +880,9 @@ void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
       }
     }
   }
-  std::vector<int> index(t.n.size(), -1);
-  std::vector<std::pair<int, int>> st;
+  BSR_SCRATCH(int, index);
+  index.assign(t.n.size(), -1);
+  BSR_SCRATCH(BSR_PAIR_II, st);
   st.push_back({root, 0});
   while (!st.empty()) {
     auto [i, seen] = st.back();
@@ -881,7 +923,7 @@ void flatten(const Tree& t, int root, std::vector<bsr_node>& rows) {
 }
 
 uint64_t tree_hash(const Tree& t, int root) {  // FNV-1a over the pre-order (type, operator, feature) sequence
-  std::vector<int> o;
+  BSR_SCRATCH(int, o);
   preorder(t, root, o);
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](uint64_t v) {
@@ -1200,6 +1242,7 @@ bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k, c
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
 void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
   c.cands.clear();
+  c.cands.reserve((size_t)std::max(0, max_n));   // (a candidate carries a copy of the random stream's state: 2.5 KB a move)
   int total = c.total + ahead, count = (c.count + ahead) % e->K;
   while ((int)c.cands.size() < max_n) {
     if (count == 0 && total >= e->val) break;  // `while total < val` is only tested between sweeps
@@ -1207,7 +1250,7 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     Cand& cd = c.cands.back();
     const int k = count;
     cd.k = k;
-    cd.tree = clone_tree(c.roots[k], c.roots[k].root);
+    clone_into(c.roots[k], c.roots[k].root, cd.tree);
     Move mv;
     prop_inplace(cd.tree, e->P, c.siga[k], c.sigb[k], c.rng, mv);
     cd.new_sigma = invgamma_rvs(c.rng, 4);
@@ -1435,6 +1478,7 @@ extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chain
   e->y_is_series = y_is_series;
   e->P.n_feature = n_feature;
   e->P.beta = beta;
+  e->P.fill_depth_tables();
   e->P.set_default_table();
   if (getenv("BSR_ENGINE_PREDICT")) e->predict_gate = atoi(getenv("BSR_ENGINE_PREDICT")) != 0;
   bsr_internal_feature_range(ctx, &e->x_lo, &e->x_hi);
