@@ -1624,7 +1624,9 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // when it arrives, and the chain generates afresh from the state behind the event: the sequence of consumed
   // proposals is the reference's whatever is thrown away (codes/funcs.py:1300-1303, :1226-1228).
   // On by default for K <= 4: at K = 5 and 8, where the tail kernels make the GPU the bound, it measured 2-7 % slower
-  // even when skipped adaptively (below).
+  // even when skipped adaptively (below).  (A THIRD batch per group, round 4: no gain -- an event every ~100 proposals
+  // voids two batches instead of one: discarded 6 711 -> 11 064 of 20 000 consumed, 0.56 M/s either way for one chain,
+  // 2.0-2.1 against 2.1-2.2 M/s for eight.)
   const bool lookahead = threaded && (getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) != 0 : e->K <= 4);
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
