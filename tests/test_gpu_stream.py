@@ -74,19 +74,20 @@ import stream_check as S
 from bsr.device import DeviceContext
 from bsr.tape import flatten
 leaf, un, bi = S.leaf, S.un, S.bi
-N, d, K, B = 200_077, 40, 3, 64
+d = int(sys.argv[3])
+N, K, B = (200_077 if d >= 20 else 1_000_077), 3, 64   # (few columns: a million rows before a slice no longer fits LDS)
 rs = np.random.RandomState(5)
 X = rs.uniform(-3, 3, size=(N, d))
-X[::977, 3] = 0.0                      # zeros for the protected divisions
-X[::1013, 4] = 1e200                   # overflow in the cube, huge arguments for sin / cos
+X[::977, 3 % d] = 0.0                  # zeros for the protected divisions
+X[::1013, 4 % d] = 1e200                   # overflow in the cube, huge arguments for sin / cos
 y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
 ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
 assert ctx.info()["row_pass"] == "k_stream", ctx.info()
-for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5))]):
+for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5 % d))]):
     ctx.set_current(0, k, flatten(t))
 ctx.refresh(0)
 trees = S.make_tapes(d, 40)
-x = leaf
+x = lambda f: leaf(f % d)
 trees += [bi('sub', x(1), x(2)), bi('div', x(1), x(3)), bi('div', bi('+', x(1), x(2)), un('neg', x(3))), un('inv', x(3)),
           un('cubic', x(4)), un('cubic', bi('*', x(4), x(4))), un('sin', x(4)), un('cos', bi('+', x(4), x(1))),
           un('log', x(3)), un('exp', un('log', bi('sub', x(6), x(7)))), bi('sub', un('exp', x(8)), un('sin', un('cos', x(9)))),
@@ -107,19 +108,22 @@ ctx.close()
 """
 
 
-def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("d", [40, 7])
+def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d):
     """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
     time (1), a wave's four tapes in one block of assembly (2) or the whole loop over the slice's chunks in it (3, the
     default at K = 3).  The assembly restates the
     instruction sequences the compiler emits for the C++ -- division, cube, ln, the fused operands -- so every score of a
     batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
-    sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran."""
+    sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran.
+    d = 7: few columns -- the assembly block then takes two-block chunks (half the barriers), the C++ interpreter
+    one-block chunks: a lane's rows reach its sums block by block either way, so the bytes are the same again."""
     import subprocess
     out = {}
     for mode in ("0", "1", "2", "3"):
         path = str(tmp_path / ("res%s.npy" % mode))
         env = dict(os.environ, BSR_STREAM_ASM=mode)
-        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path], env=env, capture_output=True, text=True,
+        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, (mode, p.stderr[-2000:])
         out[mode] = np.load(path)
