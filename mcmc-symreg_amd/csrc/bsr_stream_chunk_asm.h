@@ -168,13 +168,15 @@
   "s_nop 1\n\t"                                                         \
   "v_cndmask_b32_e32 " xlo ", v30, v14, vcc\n\t"   /* (v[30:31]: 1e10 -- a literal next to vcc is one scalar operand too many) */ \
   "v_cndmask_b32_e32 " xhi ", v31, v15, vcc\n\t"
-// y and the basis columns again (the operator above used their registers), then on with the tape
-#define BSR_SC_RELOAD_YQ(O1, O2, O3)                                    \
+// y and the K basis columns of the lane's two rows (v[24:27], v[28:31] ...): read once per chunk for the four tapes, and
+// again behind sin / cos / exp, which use their registers
+#define BSR_SC_YQ_HEAD                                                  \
   "v_add_u32_e32 v20, %[yo], %[lc]\n\t"                                 \
-  "ds_read_b128 v[24:27], v20\n\t"                                      \
-  "ds_read_b128 v[28:31], v20 offset:" O1 "\n\t"                        \
-  "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"                        \
-  "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"
+  "ds_read_b128 v[24:27], v20\n\t"
+#define BSR_SC_YQ1(O1) BSR_SC_YQ_HEAD "ds_read_b128 v[28:31], v20 offset:" O1 "\n\t"
+#define BSR_SC_YQ2(O1, O2) BSR_SC_YQ1(O1) "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"
+#define BSR_SC_YQ3(O1, O2, O3) BSR_SC_YQ2(O1, O2) "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"
+#define BSR_SC_YQ4(O1, O2, O3, O4) BSR_SC_YQ3(O1, O2, O3) "ds_read_b128 v[40:43], v20 offset:" O4 "\n\t"
 #define BSR_SC_QUAD(a, b, c, d, e, f, g, h)                             \
   ".p2align 6\n\t.quad " a ", " b ", " c ", " d ", " e ", " f ", " g ", " h "\n\t"
 
@@ -185,7 +187,16 @@
   "s_add_u32 s13, %[ln], " #q "*48\n\t"
 
 // Tape q of the wave: its program has been requested into s[16:23] (by the block's entry, or while tape q - 1 was added up)
-#define BSR_SC_TAPE(q, qnext)                                                    \
+// the sums' lines for basis columns 2..4 of row 0 / row 1 (K of them exist: BSR_SC_FNO where not)
+#define BSR_SC_FB0(q) "v_fmac_f64_e32 %[cb" #q "], v[32:33], v[12:13]\n\t"
+#define BSR_SC_FB1(q) "v_fmac_f64_e32 %[cb" #q "], v[34:35], v[16:17]\n\t"
+#define BSR_SC_FC0(q) "v_fmac_f64_e32 %[cc" #q "], v[36:37], v[12:13]\n\t"
+#define BSR_SC_FC1(q) "v_fmac_f64_e32 %[cc" #q "], v[38:39], v[16:17]\n\t"
+#define BSR_SC_FD0(q) "v_fmac_f64_e32 %[cd" #q "], v[40:41], v[12:13]\n\t"
+#define BSR_SC_FD1(q) "v_fmac_f64_e32 %[cd" #q "], v[42:43], v[16:17]\n\t"
+#define BSR_SC_FNO(q) ""
+
+#define BSR_SC_TAPE(q, qnext, B0, B1, C0, C1, D0, D1)                            \
   BSR_SC_TAPE_REGS(q)                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "s_cmp_lt_i32 s16, 0\n\t"                                                      \
@@ -211,14 +222,12 @@
   "v_fmac_f64_e32 %[sa" #q "], v[12:13], v[12:13]\n\t"                           \
   "v_fmac_f64_e32 %[sb" #q "], v[12:13], v[24:25]\n\t"                           \
   "v_fmac_f64_e32 %[ca" #q "], v[28:29], v[12:13]\n\t"                           \
-  "v_fmac_f64_e32 %[cb" #q "], v[32:33], v[12:13]\n\t"                           \
-  "v_fmac_f64_e32 %[cc" #q "], v[36:37], v[12:13]\n\t"                           \
+  B0(q) C0(q) D0(q)                                                              \
   "v_max_f64 %[am" #q "], v[14:15], |v[2:3]|\n\t"                                \
   "v_fmac_f64_e32 %[sa" #q "], v[16:17], v[16:17]\n\t"                           \
   "v_fmac_f64_e32 %[sb" #q "], v[16:17], v[26:27]\n\t"                           \
   "v_fmac_f64_e32 %[ca" #q "], v[30:31], v[16:17]\n\t"                           \
-  "v_fmac_f64_e32 %[cb" #q "], v[34:35], v[16:17]\n\t"                           \
-  "v_fmac_f64_e32 %[cc" #q "], v[38:39], v[16:17]\n"                             \
+  B1(q) C1(q) D1(q)                                                              \
   ".Lsc_next" #q "_%=:\n\t"
 
 // coming back into tape q: its program again (prescale, flags), then either the caller's values straight to the sums
@@ -241,7 +250,13 @@
   "s_add_u32 s24, s24, .Lsc_tab%=-.Lsc_pc%=\n\t"                                 \
   "s_addc_u32 s25, s25, 0\n\t"                                                   \
   "s_mov_b32 s27, s25\n\t"
-#define BSR_SC_TAPES BSR_SC_TAPE(0, 1) BSR_SC_TAPE(1, 2) BSR_SC_TAPE(2, 3) BSR_SC_TAPE(3, 4)
+#define BSR_SC_TAPES_K(B0, B1, C0, C1, D0, D1)                                                                        \
+  BSR_SC_TAPE(0, 1, B0, B1, C0, C1, D0, D1) BSR_SC_TAPE(1, 2, B0, B1, C0, C1, D0, D1)                                  \
+  BSR_SC_TAPE(2, 3, B0, B1, C0, C1, D0, D1) BSR_SC_TAPE(3, 4, B0, B1, C0, C1, D0, D1)
+#define BSR_SC_TAPES_1 BSR_SC_TAPES_K(BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO)
+#define BSR_SC_TAPES_2 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO)
+#define BSR_SC_TAPES_3 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FC0, BSR_SC_FC1, BSR_SC_FNO, BSR_SC_FNO)
+#define BSR_SC_TAPES_4 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FC0, BSR_SC_FC1, BSR_SC_FD0, BSR_SC_FD1)
 // coming back (`resume` = what the block left with): which tape, then BSR_SC_RESUME of that tape
 #define BSR_SC_RESUME_PART                                                       \
   ".Lsc_resume%=:\n\t"                                                           \
@@ -265,7 +280,7 @@
   "v_mov_b64_e32 v[6:7], %[s1]\n\t"                                              \
   BSR_SC_DISPATCH
 // the operator table (2 KB-aligned: the dispatch ORs a slot's offset into its address) and the operators too long for a slot
-#define BSR_SC_TABLE_PART(SH, O1, O2, O3)                                        \
+#define BSR_SC_TABLE_PART(SH, YQ)                                                \
   ".p2align 11\n"                                                                \
   ".Lsc_tab%=:\n\t"                                                              \
   "s_setpc_b64 s[28:29]\n\t"   /* 0: end of the tape */                          \
@@ -339,7 +354,7 @@
   "s_cbranch_vccnz .Lsc_leave%=\n\t"                                             \
   BSR_SC_SINCOS("v[0:1]", "v0", "v1", "", BSR_SC_SIN_TINY("v[0:1]", "v0", "v1")) \
   BSR_SC_SINCOS("v[2:3]", "v2", "v3", "", BSR_SC_SIN_TINY("v[2:3]", "v2", "v3")) \
-  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  YQ                                                                             \
   BSR_SC_DISPATCH                                                                \
   ".Lsc_cos%=:\n\t"                                                              \
   "s_movk_i32 s12, 5\n\t"                                                        \
@@ -352,7 +367,7 @@
   "s_cbranch_vccnz .Lsc_leave%=\n\t"                                             \
   BSR_SC_SINCOS("v[0:1]", "v0", "v1", "v_add_u32_e32 v20, 64, v20\n\t", BSR_SC_COS_MOVE("v[0:1]")) \
   BSR_SC_SINCOS("v[2:3]", "v2", "v3", "v_add_u32_e32 v20, 64, v20\n\t", BSR_SC_COS_MOVE("v[2:3]")) \
-  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  YQ                                                                             \
   BSR_SC_DISPATCH                                                                \
   ".Lsc_exp%=:\n\t"                                                              \
   "s_load_dwordx16 s[36:51], s[24:25], 832\n\t"                                  \
@@ -362,7 +377,7 @@
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   BSR_SC_EXP("v[0:1]", "v0", "v1")                                               \
   BSR_SC_EXP("v[2:3]", "v2", "v3")                                               \
-  BSR_SC_RELOAD_YQ(O1, O2, O3)                                                   \
+  YQ                                                                             \
   BSR_SC_DISPATCH
 // leaving for the caller: sin / cos of huge arguments (the state out through the operands; which tape: by where `end` goes)
 #define BSR_SC_LEAVE_PART                                                        \
@@ -389,17 +404,17 @@
   "s_cbranch_scc1 .Lsc_exit%=\n\t"                                               \
   "s_add_u32 %[st], %[st], 16\n"
 
-#define BSR_STREAM_CHUNK_ASM_K3_(SH, O1, O2, O3)                                 \
+#define BSR_STREAM_CHUNK_ASM_(SH, YQ, TP)                                        \
   "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
   BSR_SC_TABLE_BASE                                                              \
-  BSR_SC_RELOAD_YQ(O1, O2, O3)   /* y and the basis columns of the lane's rows, once for the four tapes */ \
+  YQ   /* y and the basis columns of the lane's rows, once for the four tapes */ \
   "s_cmp_lg_u32 %[resume], 0\n\t"                                                \
   "s_cbranch_scc1 .Lsc_resume%=\n\t"                                             \
-  BSR_SC_TAPES                                                                   \
+  TP                                                                             \
   "s_mov_b32 %[st], 0\n\t"                                                       \
   "s_branch .Lsc_exit%=\n"                                                       \
   BSR_SC_RESUME_PART                                                             \
-  BSR_SC_TABLE_PART(SH, O1, O2, O3)                                              \
+  BSR_SC_TABLE_PART(SH, YQ)                                              \
   BSR_SC_LEAVE_PART                                                              \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"
@@ -425,7 +440,7 @@
   "global_load_lds_dwordx4 v20, " base "\n\t"
 #define BSR_SP_WAIT(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch .Lsp_waited%=\n\t"
 
-#define BSR_STREAM_PASS_ASM_K3                                                   \
+#define BSR_STREAM_PASS_ASM_(YQ, TP)                                             \
   BSR_SC_TABLE_BASE                                                              \
   "s_mov_b64 s[60:61], %[ba0]\n\t"                                               \
   "s_mov_b64 s[62:63], %[ba1]\n\t"                                               \
@@ -491,8 +506,8 @@
   "s_add_u32 s71, s71, s72\n\t"                                                  \
   "s_cmp_eq_u32 s71, s75\n\t"                                                    \
   "s_cselect_b32 s71, s84, s71\n\t"                                              \
-  BSR_SC_RELOAD_YQ("1024", "2048", "3072")                                       \
-  BSR_SC_TAPES                                                                   \
+  YQ                                                                             \
+  TP                                                                             \
   "s_add_u32 s68, s68, 1\n\t"                                                    \
   "s_cmp_lt_u32 s68, s69\n\t"                                                    \
   "s_cbranch_scc1 .Lsp_loop%=\n\t"                                               \
@@ -506,9 +521,9 @@
   "v_readfirstlane_b32 s79, %[sv9]\n\t"                                          \
   "s_nop 3\n\t"                                                                  \
   "v_add_u32_e32 %[lc], s79, %[lane16]\n\t"                                      \
-  BSR_SC_RELOAD_YQ("1024", "2048", "3072")                                       \
+  YQ                                                                             \
   BSR_SC_RESUME_PART                                                             \
-  BSR_SC_TABLE_PART("10", "1024", "2048", "3072")                                \
+  BSR_SC_TABLE_PART("10", YQ)                                                    \
   ".Lsp_waits%=:\n\t"   /* the steady state's wait: entry 8 n for n copies of later chunks in flight */ \
   BSR_SP_WAIT(0) BSR_SP_WAIT(1) BSR_SP_WAIT(2) BSR_SP_WAIT(3) BSR_SP_WAIT(4) BSR_SP_WAIT(5) BSR_SP_WAIT(6)     \
   BSR_SP_WAIT(7) BSR_SP_WAIT(8)                                                  \
@@ -524,12 +539,23 @@
   "v_mov_b32_e32 %[sv8], s78\n\t"                                                \
   "v_mov_b32_e32 %[sv9], s79\n\t"
 
-#define BSR_STREAM_PASS_CLOBBERS BSR_STREAM_CHUNK_CLOBBERS, "m0", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+#define BSR_STREAM_PASS_CLOBBERS_(C) C, "m0", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
   "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84"
 
-// one-block chunks: a column of the buffer is 1024 bytes; two-block chunks: 2048 (the block's half picked by %[lc])
-#define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_K3_("10", "1024", "2048", "3072")
-#define BSR_STREAM_CHUNK2_ASM_K3 BSR_STREAM_CHUNK_ASM_K3_("11", "2048", "4096", "6144")
+// K = 1..4 basis columns; one-block chunks: a column of the buffer is 1024 bytes; two-block chunks: 2048 (the block's half
+// picked by %[lc])
+#define BSR_STREAM_CHUNK_ASM_K1 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ1("1024"), BSR_SC_TAPES_1)
+#define BSR_STREAM_CHUNK_ASM_K2 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2)
+#define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
+#define BSR_STREAM_CHUNK_ASM_K4 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
+#define BSR_STREAM_CHUNK2_ASM_K1 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ1("2048"), BSR_SC_TAPES_1)
+#define BSR_STREAM_CHUNK2_ASM_K2 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ2("2048", "4096"), BSR_SC_TAPES_2)
+#define BSR_STREAM_CHUNK2_ASM_K3 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ3("2048", "4096", "6144"), BSR_SC_TAPES_3)
+#define BSR_STREAM_CHUNK2_ASM_K4 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ4("2048", "4096", "6144", "8192"), BSR_SC_TAPES_4)
+#define BSR_STREAM_PASS_ASM_K1 BSR_STREAM_PASS_ASM_(BSR_SC_YQ1("1024"), BSR_SC_TAPES_1)
+#define BSR_STREAM_PASS_ASM_K2 BSR_STREAM_PASS_ASM_(BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2)
+#define BSR_STREAM_PASS_ASM_K3 BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
+#define BSR_STREAM_PASS_ASM_K4 BSR_STREAM_PASS_ASM_(BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
 
 #define BSR_STREAM_CHUNK_CLOBBERS                                                                                      \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17",   \
@@ -537,4 +563,8 @@
   "v38", "v39", "s8", "s9", "s10", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", \
   "s24", "s25", "s26", "s27", "s28", "s29", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", \
   "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc", "memory"
+// (K = 4: the fourth basis column's values)
+#define BSR_STREAM_CHUNK_CLOBBERS_K4 BSR_STREAM_CHUNK_CLOBBERS, "v40", "v41", "v42", "v43"
+#define BSR_STREAM_PASS_CLOBBERS BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS)
+#define BSR_STREAM_PASS_CLOBBERS_K4 BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS_K4)
 // clang-format on

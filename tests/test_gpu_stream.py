@@ -75,7 +75,7 @@ from bsr.device import DeviceContext
 from bsr.tape import flatten
 leaf, un, bi = S.leaf, S.un, S.bi
 d = int(sys.argv[3])
-N, K, B = (200_077 if d >= 20 else 1_000_077), 3, 64   # (few columns: a million rows before a slice no longer fits LDS)
+N, K, B = (200_077 if d >= 20 else 1_000_077), int(sys.argv[4]), 64   # (few columns: a million rows before a slice no longer fits LDS)
 rs = np.random.RandomState(5)
 X = rs.uniform(-3, 3, size=(N, d))
 X[::977, 3 % d] = 0.0                  # zeros for the protected divisions
@@ -83,7 +83,7 @@ X[::1013, 4 % d] = 1e200                   # overflow in the cube, huge argument
 y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
 ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
 assert ctx.info()["row_pass"] == "k_stream", ctx.info()
-for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5 % d))]):
+for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5 % d)), un('square', leaf(6 % d))][:K]):
     ctx.set_current(0, k, flatten(t))
 ctx.refresh(0)
 trees = S.make_tapes(d, 40)
@@ -108,11 +108,11 @@ ctx.close()
 """
 
 
-@pytest.mark.parametrize("d", [40, 7])
-def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d):
+@pytest.mark.parametrize("d,K", [(40, 3), (7, 3), (40, 1), (40, 2), (40, 4)])
+def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K):
     """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
     time (1), a wave's four tapes in one block of assembly (2) or the whole loop over the slice's chunks in it (3, the
-    default at K = 3).  The assembly restates the
+    default; 2 and 3 exist for K <= 4, four sets of sums per wave).  The assembly restates the
     instruction sequences the compiler emits for the C++ -- division, cube, ln, the fused operands -- so every score of a
     batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
     sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran.
@@ -123,7 +123,7 @@ def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d):
     for mode in ("0", "1", "2", "3"):
         path = str(tmp_path / ("res%s.npy" % mode))
         env = dict(os.environ, BSR_STREAM_ASM=mode)
-        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d)], env=env, capture_output=True, text=True,
+        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d), str(K)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, (mode, p.stderr[-2000:])
         out[mode] = np.load(path)
