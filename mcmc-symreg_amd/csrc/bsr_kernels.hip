@@ -96,6 +96,7 @@ struct SolveIn {
   MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
 };
 template <int K>
+#define BSR_JACOBI_DONE 1e-18   /* squared: a sweep that found nothing above 1e-9 relative was the last one needed */
 __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out);
 template <int K>
 __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out);
@@ -552,7 +553,11 @@ __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_scor
         }
       }
     }
-    if (off <= 1e-30) break;
+    // `off` is what the sweep FOUND in front of its rotations, the squared relative size of the largest off-diagonal
+    // term; cyclic Jacobi converges quadratically, so a sweep that found 1e-9 relative leaves 1e-18 behind -- below the
+    // 1e-17 at which a rotation is skipped anyway.  (Until round 4 the loop ran until a sweep FOUND <= 1e-15: one whole
+    // sweep more, only to look.)
+    if (off <= BSR_JACOBI_DONE) break;
   }
   double h[M];
 #pragma unroll
@@ -682,7 +687,7 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
     off = fmax(off, xor8(off, 1));
     off = fmax(off, xor8(off, 2));
     off = fmax(off, xor8(off, 4));
-    if (off <= 1e-30) break;  // wave-uniform: the lane groups are copies of each other
+    if (off <= BSR_JACOBI_DONE) break;  // wave-uniform: the lane groups are copies of each other (the threshold: solve_regs)
   }
   double h[M];
 #pragma unroll
