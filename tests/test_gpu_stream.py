@@ -75,7 +75,7 @@ from bsr.device import DeviceContext
 from bsr.tape import flatten
 leaf, un, bi = S.leaf, S.un, S.bi
 d = int(sys.argv[3])
-N, K, B = (200_077 if d >= 20 else 1_000_077), int(sys.argv[4]), 64   # (few columns: a million rows before a slice no longer fits LDS)
+N, K, B = (200_077 if d >= 20 else 1_000_077), int(sys.argv[4]), int(sys.argv[5])   # (few columns: a million rows before a slice no longer fits LDS)
 rs = np.random.RandomState(5)
 X = rs.uniform(-3, 3, size=(N, d))
 X[::977, 3 % d] = 0.0                  # zeros for the protected divisions
@@ -98,7 +98,7 @@ trees += [bi('sub', x(1), x(2)), bi('div', x(1), x(3)), bi('div', bi('+', x(1), 
           un('inv', un('inv', un('inv', x(23)))), bi('sub', un('square', x(24)), un('square', x(25))),
           bi('*', un('ln', x(26), 2.0, 0.0), x(27)), un('neg', un('neg', x(28))), un('cos', un('neg', x(29))),
           un('cubic', un('cubic', x(30)))]
-trees = trees[:B]
+trees = (trees * 2)[:B]   # (B = 100: more tapes than a launch's sixteen waves hold sets of sums for -- two passes)
 tapes = [flatten(t) for t in trees]
 n = len(tapes)
 with np.errstate(all="ignore"):
@@ -108,8 +108,8 @@ ctx.close()
 """
 
 
-@pytest.mark.parametrize("d,K", [(40, 3), (7, 3), (40, 1), (40, 2), (40, 4)])
-def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K):
+@pytest.mark.parametrize("d,K,B", [(40, 3, 64), (7, 3, 64), (3, 3, 64), (40, 3, 100), (40, 1, 64), (40, 2, 64), (40, 4, 64)])
+def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K, B):
     """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
     time (1), a wave's four tapes in one block of assembly (2) or the whole loop over the slice's chunks in it (3, the
     default; 2 and 3 exist for K <= 4, four sets of sums per wave).  The assembly restates the
@@ -117,13 +117,14 @@ def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K
     batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
     sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran.
     d = 7: few columns -- the assembly block then takes two-block chunks (half the barriers), the C++ interpreter
-    one-block chunks: a lane's rows reach its sums block by block either way, so the bytes are the same again."""
+    one-block chunks: a lane's rows reach its sums block by block either way, so the bytes are the same again.  d = 3:
+    fewer columns than waves (waves without a piece to copy).  B = 100: two passes over the slice."""
     import subprocess
     out = {}
     for mode in ("0", "1", "2", "3"):
         path = str(tmp_path / ("res%s.npy" % mode))
         env = dict(os.environ, BSR_STREAM_ASM=mode)
-        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d), str(K)], env=env, capture_output=True, text=True,
+        p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d), str(K), str(B)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, (mode, p.stderr[-2000:])
         out[mode] = np.load(path)
