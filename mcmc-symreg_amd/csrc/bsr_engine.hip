@@ -939,6 +939,32 @@ uint64_t tree_hash(const Tree& t, int root) {  // FNV-1a over the pre-order (typ
   return h;
 }
 
+// ... and over everything that decides the column: the ln nodes' parameters too (two trees with the same key compute
+// the same column, bit for bit)
+uint64_t tree_hash_full(const Tree& t, int root) {
+  BSR_SCRATCH(int, o);
+  preorder(t, root, o);
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    for (int k = 0; k < 8; ++k) {
+      h ^= (v >> (8 * k)) & 0xFF;
+      h *= 1099511628211ull;
+    }
+  };
+  for (int i : o) {
+    const TNode& nd = t.n[i];
+    mix(((uint64_t)(nd.type + 1) << 32) | (uint64_t)(uint32_t)(nd.type == 0 ? 100 + nd.feature : nd.op));
+    if (nd.type == 1 && nd.op == OP_LN) {
+      uint64_t a, b;
+      memcpy(&a, &nd.a, 8);
+      memcpy(&b, &nd.b, 8);
+      mix(a);
+      mix(b);
+    }
+  }
+  return h;
+}
+
 // Canonical key of the column a tree computes, as far as structure tells: equal keys = equal columns up to sign.
 // Children of + and * are combined order-free; a negation at the root is dropped (a column and its negative are
 // collinear).  Used to guess the rank gate: a candidate that repeats a sibling, or siblings that repeat each other.
@@ -975,6 +1001,7 @@ struct Cand {
   double Q, Qinv, hratio, detjacob, new_sigma, new_sa2, new_sb2, u;
   int action;
   bool pred_def = false;  // speculated as a rank-gate rejection: no accept-uniform was drawn behind it
+  uint64_t ghash = 0;     // tree_hash_full of the candidate, mixed with k (the gate's memory below)
   double sn_s = 0, sn_p = 0;  // fStruc of the proposed tree (structure / ln-parameter parts)
   double terms[8];            // what the device-side MH step needs (include/bsr_hip.h: bsr_score_submit_mh)
   int mhflags = 0;
@@ -1015,6 +1042,13 @@ struct ChainS {
   std::vector<double> colmax;      // max|.| of the chain's current columns (from the last refresh)
   std::vector<uint32_t> colflags;
   std::vector<Cand> cands;
+  // Candidates the rank gate has rejected in the chain's CURRENT state (emptied by every accepted move).  The gate's
+  // verdict is a function of the candidate and its siblings alone, and a chain proposes the same few mutations of its
+  // trees over and over (`inv(cub(x5))` for a current `cub(x5) * x0`: a column of range 1e16 next to siblings of range 1,
+  // rejected on scale, which the interval estimate below underrates): 93 % of the events that end a speculative run were
+  // rejections nobody predicted, most of them repeats.
+  std::vector<uint64_t> gate_memo;
+  int64_t n_evt_gate = 0, n_evt_pass = 0, n_pred_ok = 0;   // events by kind (BSR_ENGINE_PROF): a rejection nobody predicted, a predicted one that passed; predicted and right
   LegacyRng end_state;
 };
 
@@ -1238,6 +1272,19 @@ bool predict_gate_reject(bsr_engine* e, const ChainS& c, const Tree& t, int k, c
   return est > sib * (10.0 / tol) || est < sib * (tol / 10.0);
 }
 
+
+// diagnostics (BSR_ENGINE_DUMP_GATE=1): an expression as text
+std::string tree_text(const Tree& t, int i) {
+  static const char* nm[16] = {"inv", "ln", "neg", "sin", "cos", "exp", "sq", "cub", "+", "*", "x", "?", "?", "-", "/", "log"};
+  const TNode& nd = t.n[i];
+  if (nd.type == 0) return "x" + std::to_string(nd.feature);
+  if (nd.type == 1) {
+    if (nd.op == OP_LN) { char b[64]; snprintf(b, sizeof b, "ln[%.3g,%.3g](", nd.a, nd.b); return b + tree_text(t, nd.left) + ")"; }
+    return std::string(nm[nd.op & 15]) + "(" + tree_text(t, nd.left) + ")";
+  }
+  return "(" + tree_text(t, nd.left) + " " + nm[nd.op & 15] + " " + tree_text(t, nd.right) + ")";
+}
+
 // `ahead`: candidates of this chain generated before and not consumed yet (a batch in flight: they are assumed to
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
 void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
@@ -1261,7 +1308,9 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     cd.action = mv.action;
     flatten(cd.tree, cd.tree.root, cd.tape);
     cd.before_u = c.rng;
-    cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape);
+    cd.ghash = tree_hash_full(cd.tree, cd.tree.root) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
+    cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape) ||
+                  (e->predict_gate && std::find(c.gate_memo.begin(), c.gate_memo.end(), cd.ghash) != c.gate_memo.end());
     cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
     {  // the scalar terms of codes/funcs.py:1230-1296 that do not depend on the score
       fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &cd.sn_s, &cd.sn_p);
@@ -1365,11 +1414,19 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       ++c.n_rank_rej;
       c.def_ema[k] = 0.75 * c.def_ema[k] + 0.25;
       if (cd.pred_def) {  // speculated exactly that: the candidates behind it are on the right stream
+        ++c.n_pred_ok;
         if (e->verify_mh && ev && c.verify_expect_event != BSR_EV_NONE) return efail(e, BSR_E_STATE, "device MH scan: spurious event");
         continue;
       }
       if (e->verify_mh && ev && c.verify_expect_event != BSR_EV_GATE) return efail(e, BSR_E_STATE, "device MH scan missed a gate rejection");
       c.rng = cd.before_u;
+      ++c.n_evt_gate;
+      if (c.gate_memo.size() < 256) c.gate_memo.push_back(cd.ghash);
+      if (getenv("BSR_ENGINE_DUMP_GATE")) {
+        std::string l = "unpredicted gate rejection k=" + std::to_string(k) + ": " + tree_text(cd.tree, cd.tree.root) + "  | siblings:";
+        for (int j = 0; j < K; ++j) if (j != k) l += " [" + tree_text(c.roots[j], c.roots[j].root) + "]";
+        fprintf(stderr, "%s  smin/smax %.3g/%.3g\n", l.c_str(), sc.smin, sc.smax);
+      }
       broke = true;
       break;
     }
@@ -1378,6 +1435,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     if (cd.pred_def) {  // the gate passed a proposal speculated as rejected: its uniform is drawn now, from the state
       c.rng = cd.before_u;  // saved in front of it; whatever follows in the batch was generated on a shifted stream
       cd.u = c.rng.uniform();
+      ++c.n_evt_pass;
       tail_invalid = true;
     }
     const double yllstar = sc.loglik;
@@ -1412,6 +1470,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     }
     // ---- accepted: codes/bsr_class.py:200-243
     ++c.n_accept;
+    c.gate_memo.clear();   // (the siblings of every k change with this move)
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
     c.last_stale = true;
     c.roots[k] = cd.tree;
@@ -1822,9 +1881,17 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   }
   if (n_trace) *n_trace = e->n_trace;
   e->trace = nullptr;
-  if (getenv("BSR_ENGINE_PROF"))
+  if (getenv("BSR_ENGINE_PROF")) {
     fprintf(stderr, "bsr_engine_run (%s): generate %.3f s, submit %.3f s, wait %.3f s, consume %.3f s (thread-seconds)\n",
             threaded ? "worker threads" : "one thread", e->t_gen, e->t_submit, e->t_wait, e->t_consume);
+    int64_t a = 0, g = 0, ps = 0, ok = 0, rj = 0, np_ = 0;
+    for (const ChainS& c : e->chains) {
+      a += c.n_accept; g += c.n_evt_gate; ps += c.n_evt_pass; ok += c.n_pred_ok; rj += c.n_rank_rej; np_ += c.n_props;
+    }
+    fprintf(stderr, "  events in %lld consumed proposals: %lld accepts, %lld gate rejections nobody predicted, %lld predicted "
+            "rejections that passed the gate; %lld of %lld gate rejections predicted\n", (long long)np_, (long long)a,
+            (long long)g, (long long)ps, (long long)ok, (long long)rj);
+  }
   return rc;
 }
 
