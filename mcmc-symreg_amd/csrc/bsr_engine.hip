@@ -1048,6 +1048,7 @@ struct ChainS {
   // rejected on scale, which the interval estimate below underrates): 93 % of the events that end a speculative run were
   // rejections nobody predicted, most of them repeats.
   std::vector<uint64_t> gate_memo;
+  std::vector<uint64_t> gate_pass_memo;   // ... and the ones predicted rejected that passed (the estimates' false alarms)
   int64_t n_evt_gate = 0, n_evt_pass = 0, n_pred_ok = 0;   // events by kind (BSR_ENGINE_PROF): a rejection nobody predicted, a predicted one that passed; predicted and right
   LegacyRng end_state;
 };
@@ -1160,13 +1161,22 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
 // values spread over the interval.
 struct Iv {
   double lo, hi;
+  double mn;   // an estimate of the smallest |value| among the N rows (what 1/x blows up on); < 0: not tracked
 };
+// The range of a tree's values over the data, by interval arithmetic from the features' ranges; and, next to it, how close
+// to zero the values are likely to come: a feature that straddles zero comes within range / 2N of it, its cube within the
+// cube of that, and the interval alone (the cube's range / 2N) is ten orders of magnitude off -- `inv(cub(x5))`, a column
+// of range 1e16, used to be predicted harmless.
 Iv tree_range(const Tree& t, int i, const double* xlo, const double* xhi, double N) {
   const TNode& nd = t.n[i];
-  if (nd.type == 0) return {xlo[nd.feature], xhi[nd.feature]};
+  auto straddles = [](double lo, double hi) { return lo <= 0 && 0 <= hi; };
+  auto fresh = [&](double lo, double hi) {   // nothing known but the interval
+    return Iv{lo, hi, straddles(lo, hi) ? (hi - lo) / (2 * N) : std::min(std::fabs(lo), std::fabs(hi))};
+  };
+  if (nd.type == 0) return fresh(xlo[nd.feature], xhi[nd.feature]);
   const Iv a = tree_range(t, nd.left, xlo, xhi, N);
   auto mag = [](const Iv& v) { return std::max(std::fabs(v.lo), std::fabs(v.hi)); };
-  auto mul = [](const Iv& p, const Iv& q) {
+  auto mul = [&](const Iv& p, const Iv& q) {
     double c[4] = {p.lo * q.lo, p.lo * q.hi, p.hi * q.lo, p.hi * q.hi};
     double lo = kInf, hi = -kInf;
     for (double v : c) {
@@ -1174,47 +1184,46 @@ Iv tree_range(const Tree& t, int i, const double* xlo, const double* xhi, double
       lo = std::min(lo, v);
       hi = std::max(hi, v);
     }
-    return Iv{lo, hi};
+    return Iv{lo, hi, p.mn * q.mn};   // (the smallest values of both rarely share a row: an underestimate, the safe side)
   };
   auto inv = [&](const Iv& v) {
-    if (v.lo <= 0 && 0 <= v.hi) {
-      const double m = 2 * N / std::max(v.hi - v.lo, 1e-300);
-      return Iv{-m, m};
+    if (straddles(v.lo, v.hi)) {
+      const double m = 1 / std::max(v.mn, 1e-300);
+      return Iv{-m, m, 1 / std::max(mag(v), 1e-300)};
     }
-    return Iv{std::min(1 / v.lo, 1 / v.hi), std::max(1 / v.lo, 1 / v.hi)};
+    return Iv{std::min(1 / v.lo, 1 / v.hi), std::max(1 / v.lo, 1 / v.hi), 1 / std::max(mag(v), 1e-300)};
   };
   if (nd.type == 1) {
     switch (nd.op) {
       case BSR_OP_LN: {
         const double p = nd.a * a.lo + nd.b, q = nd.a * a.hi + nd.b;
-        return {std::min(p, q), std::max(p, q)};
+        return fresh(std::min(p, q), std::max(p, q));   // (the zero crossing moves with b)
       }
-      case BSR_OP_NEG: return {-a.hi, -a.lo};
+      case BSR_OP_NEG: return {-a.hi, -a.lo, a.mn};
       case BSR_OP_SIN:
-      case BSR_OP_COS: return {-1.0, 1.0};
+      case BSR_OP_COS: return fresh(-1.0, 1.0);
       case BSR_OP_EXP: {
         auto ex = [](double v) { return v > 200 ? 1e10 : std::exp(v); };
-        return {ex(a.lo), std::max(ex(a.hi), ex(std::min(a.hi, 200.0)))};
+        return fresh(ex(a.lo), std::max(ex(a.hi), ex(std::min(a.hi, 200.0))));
       }
       case BSR_OP_SQUARE: {
         const double m = std::max(a.lo * a.lo, a.hi * a.hi);
-        return {(a.lo <= 0 && 0 <= a.hi) ? 0.0 : std::min(a.lo * a.lo, a.hi * a.hi), m};
+        return {straddles(a.lo, a.hi) ? 0.0 : std::min(a.lo * a.lo, a.hi * a.hi), m, a.mn * a.mn};
       }
-      case BSR_OP_CUBIC: return {a.lo * a.lo * a.lo, a.hi * a.hi * a.hi};
+      case BSR_OP_CUBIC: return {a.lo * a.lo * a.lo, a.hi * a.hi * a.hi, a.mn * a.mn * a.mn};
       case BSR_OP_INV: return inv(a);
       case BSR_OP_LOG: {
         const double top = std::log(std::max(mag(a), 1e-300));
-        const double bot = (a.lo <= 0 && 0 <= a.hi) ? std::log(std::max((a.hi - a.lo) / (2 * N), 1e-300))
-                                                    : std::log(std::min(std::fabs(a.lo), std::fabs(a.hi)));
-        return {std::min(bot, top), top};
+        const double bot = std::log(std::max(a.mn, 1e-300));
+        return fresh(std::min(bot, top), top);
       }
       default: return a;
     }
   }
   const Iv b = tree_range(t, nd.right, xlo, xhi, N);
   switch (nd.op) {
-    case BSR_OP_ADD: return {a.lo + b.lo, a.hi + b.hi};
-    case BSR_OP_SUB: return {a.lo - b.hi, a.hi - b.lo};
+    case BSR_OP_ADD: return fresh(a.lo + b.lo, a.hi + b.hi);
+    case BSR_OP_SUB: return fresh(a.lo - b.hi, a.hi - b.lo);
     case BSR_OP_DIV: return mul(a, inv(b));
     default: return mul(a, b);
   }
@@ -1311,6 +1320,8 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     cd.ghash = tree_hash_full(cd.tree, cd.tree.root) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
     cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape) ||
                   (e->predict_gate && std::find(c.gate_memo.begin(), c.gate_memo.end(), cd.ghash) != c.gate_memo.end());
+    if (cd.pred_def && std::find(c.gate_pass_memo.begin(), c.gate_pass_memo.end(), cd.ghash) != c.gate_pass_memo.end())
+      cd.pred_def = false;
     cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
     {  // the scalar terms of codes/funcs.py:1230-1296 that do not depend on the score
       fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &cd.sn_s, &cd.sn_p);
@@ -1436,6 +1447,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       c.rng = cd.before_u;  // saved in front of it; whatever follows in the batch was generated on a shifted stream
       cd.u = c.rng.uniform();
       ++c.n_evt_pass;
+      if (c.gate_pass_memo.size() < 256) c.gate_pass_memo.push_back(cd.ghash);
       tail_invalid = true;
     }
     const double yllstar = sc.loglik;
@@ -1471,6 +1483,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     // ---- accepted: codes/bsr_class.py:200-243
     ++c.n_accept;
     c.gate_memo.clear();   // (the siblings of every k change with this move)
+    c.gate_pass_memo.clear();
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
     c.last_stale = true;
     c.roots[k] = cd.tree;
@@ -1646,7 +1659,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   };
   struct Group {
     std::vector<ChainS*> chains;
-    Lane lane[2];
+    Lane lane[3];   // the batch being consumed next and up to two generated ahead of it
+    int fifo[3] = {0, 0, 0}, n_fly = 0;   // lanes in flight, oldest first
     double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
     double evt_ema = 0.0;   // share of this group's chain batches that ended in an event lately (lookahead pays while it is low)
   };
@@ -1683,15 +1697,23 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // when it arrives, and the chain generates afresh from the state behind the event: the sequence of consumed
   // proposals is the reference's whatever is thrown away (codes/funcs.py:1300-1303, :1226-1228).
   // On by default for K <= 4: at K = 5 and 8, where the tail kernels make the GPU the bound, it measured 2-7 % slower
-  // even when skipped adaptively (below).  (A THIRD batch per group, round 4: no gain -- an event every ~100 proposals
-  // voids two batches instead of one: discarded 6 711 -> 11 064 of 20 000 consumed, 0.56 M/s either way for one chain,
-  // 2.0-2.1 against 2.1-2.2 M/s for eight.)
-  const bool lookahead = threaded && (getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) != 0 : e->K <= 4);
+  // even when skipped adaptively (below).
+  // BSR_ENGINE_LOOKAHEAD: batches generated ahead per group, 0..2 (two need a third batch slot per group: up to four
+  // groups).  Default: two for a single group -- a lone chain's thread still spent a quarter of its cycle waiting with
+  // one; 0.61-0.66 -> 0.72 M consumed proposals/s -- one otherwise (eight chains in four groups: 2.4-2.7 M either way).
+  // The second only pays since the gate's memory (ChainS::gate_memo) made events rare: with one every ~100 proposals it
+  // voided two batches instead of one and gained nothing (discarded 6 711 -> 11 064 of 20 000 consumed, 0.56 M/s either
+  // way).
+  const int la_env = getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) : -1;
+  const int la_max = n_groups <= 4 ? 2 : 1;
+  const int la_depth = !threaded ? 0 : (la_env >= 0 ? std::min(la_env, la_max) : (e->K <= 4 ? (n_groups == 1 ? 2 : 1) : 0));
+  const bool lookahead = la_depth > 0;
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
   for (int gi = 0; gi < n_groups; ++gi) {
     groups[gi].lane[0].slot = threaded ? gi : -1;
     groups[gi].lane[1].slot = threaded ? BSR_MAX_INFLIGHT + gi : -1;
+    groups[gi].lane[2].slot = threaded ? BSR_MAX_INFLIGHT + 4 + gi : -1;   // (only with up to four groups: la_max)
   }
   const int per_group_cap = std::max(1, max_batch / n_groups);
   const bool use_mh = e->device_mh && !trace && e->K > 1;
@@ -1699,7 +1721,6 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // generates and submits the batch of lane `li`; ahead: behind the candidates the group's other lane has in flight
   auto submit = [&](Group& g, int li, bool ahead) -> int {
     Lane& L = g.lane[li];
-    const Lane& O = g.lane[li ^ 1];
     L.rows.clear();
     L.off.assign(1, 0);
     L.chs.clear();
@@ -1725,7 +1746,12 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         continue;
       }
       // what this chain has in flight ahead of the new candidates (the other lane's share, unless an event voided it)
-      const int n_ahead = (ahead && O.inflight && ci < O.valid.size() && O.valid[ci]) ? O.span[ci].second : 0;
+      int n_ahead = 0;
+      if (ahead)
+        for (int ol = 0; ol < 3; ++ol) {
+          const Lane& O = g.lane[ol];
+          if (ol != li && O.inflight && ci < O.valid.size() && O.valid[ci]) n_ahead += O.span[ci].second;
+        }
       int room = per;
       // speculate only about as far as this chain's batches have recently been consumed
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
@@ -1775,7 +1801,6 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // waits for lane `li`'s batch and consumes it chain by chain
   auto collect = [&](Group& g, int li) -> int {
     Lane& L = g.lane[li];
-    Lane& O = g.lane[li ^ 1];
     if (!L.inflight) return BSR_OK;
     L.inflight = false;
     const double tw0 = now_s();
@@ -1802,11 +1827,19 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       }
       c.cands.swap(L.cands[i]);
       c.end_state = L.end_state[i];
-      const bool more_ahead = O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0;
+      bool more_ahead = false;
+      for (int ol = 0; ol < 3; ++ol) {
+        const Lane& O = g.lane[ol];
+        more_ahead = more_ahead || (ol != li && O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0);
+      }
       bool broke = false;
       r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke);
       g.evt_ema = 0.9 * g.evt_ema + (broke ? 0.1 : 0.0);
-      if (broke && O.inflight && i < O.valid.size()) O.valid[i] = 0;   // what was generated behind these is void
+      if (broke)   // what was generated behind these is void
+        for (int ol = 0; ol < 3; ++ol) {
+          Lane& O = g.lane[ol];
+          if (ol != li && O.inflight && i < O.valid.size()) O.valid[i] = 0;
+        }
       if (r != BSR_OK) return r;
     }
     g.t_consume += now_s() - tw1;
@@ -1817,21 +1850,36 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::atomic<int> first_rc{BSR_OK};
     auto worker = [&](Group& g, bool own_thread) {
       if (own_thread) bsr_internal_place_thread();   // (the caller's thread, which runs group 0, stays where it is)
-      int cur = 0;
+      auto free_lane = [&]() {
+        for (int l = 0; l < 3; ++l)
+          if (!g.lane[l].inflight) return l;
+        return -1;
+      };
       int r = submit(g, 0, false);
-      while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK && g.lane[cur].inflight) {
-        // a lookahead batch is consumed only if the batch in front of it ends as speculated: while more than half of
-        // the group's chain batches end in an event (K = 8: six in seven) it would mostly be scored for nothing
-        if (lookahead && g.evt_ema < 0.5) {
-          r = submit(g, cur ^ 1, true);
-          if (r != BSR_OK) break;
+      g.n_fly = 0;
+      if (g.lane[0].inflight) g.fifo[g.n_fly++] = 0;
+      while (r == BSR_OK && first_rc.load(std::memory_order_relaxed) == BSR_OK && g.n_fly > 0) {
+        // batches generated ahead are consumed only if the ones in front of them end as speculated: while more than half
+        // of the group's chain batches end in an event (K = 8: six in seven) they would mostly be scored for nothing
+        while (r == BSR_OK && lookahead && g.evt_ema < 0.5 && g.n_fly < 1 + la_depth) {
+          const int l = free_lane();
+          if (l < 0) break;
+          r = submit(g, l, true);
+          if (r != BSR_OK || !g.lane[l].inflight) break;   // (nothing left to generate ahead)
+          g.fifo[g.n_fly++] = l;
         }
+        if (r != BSR_OK) break;
+        const int cur = g.fifo[0];
+        for (int q = 1; q < g.n_fly; ++q) g.fifo[q - 1] = g.fifo[q];
+        --g.n_fly;
         r = collect(g, cur);
         if (r != BSR_OK) break;
-        if (g.lane[cur ^ 1].inflight) cur ^= 1;
-        else r = submit(g, cur, false);
+        if (g.n_fly == 0) {
+          r = submit(g, cur, false);
+          if (r == BSR_OK && g.lane[cur].inflight) g.fifo[g.n_fly++] = cur;
+        }
       }
-      for (int li = 0; li < 2; ++li) {
+      for (int li = 0; li < 3; ++li) {
         Lane& L = g.lane[li];
         if (!L.inflight) continue;   // left in flight by an error (here or elsewhere): drain so the context stays usable
         L.inflight = false;
