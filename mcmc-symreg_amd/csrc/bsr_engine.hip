@@ -46,6 +46,7 @@ struct LegacyRng {
   int pos = 624;
   int has_gauss = 0;
   double gauss = 0.0;
+  uint64_t draws = 0;   // 32-bit outputs taken so far (a position a copy of the state can be replayed to: RngMark)
 
   void seed(uint32_t s) {  // np.random.seed(int): mt19937_seed
     for (int i = 0; i < 624; ++i) {
@@ -75,6 +76,7 @@ struct LegacyRng {
   uint32_t next32() {
     if (pos == 624) refill();
     uint32_t yv = key[pos++];
+    ++draws;
     yv ^= (yv >> 11);
     yv ^= (yv << 7) & 0x9d2c5680u;
     yv ^= (yv << 15) & 0xefc60000u;
@@ -122,6 +124,22 @@ struct LegacyRng {
   }
   double normal(double loc, double scale) { return loc + scale * standard_normal(); }
 };
+
+// A position in a random stream, 24 bytes: a candidate used to carry a copy of the whole state (2.5 KB, copied for every
+// proposal generated); it now carries the position, and the one time in a thousand the stream has to go back there the
+// state at the start of the candidate's batch is replayed up to it.
+struct RngMark {
+  uint64_t draws = 0;
+  int has_gauss = 0;
+  double gauss = 0.0;
+};
+inline RngMark mark_of(const LegacyRng& r) { return RngMark{r.draws, r.has_gauss, r.gauss}; }
+inline void replay_to(LegacyRng& r, const LegacyRng& start, const RngMark& m) {
+  r = start;
+  while (r.draws < m.draws) (void)r.next32();
+  r.has_gauss = m.has_gauss;
+  r.gauss = m.gauss;
+}
 
 // Q(a,x) = p solved for x, a in {1,4} (scipy.special.gammainccinv; invgamma.rvs(a) = 1/gammainccinv(a, U))
 double gammainccinv_int(int a, double p) {
@@ -1005,7 +1023,7 @@ struct Cand {
   double sn_s = 0, sn_p = 0;  // fStruc of the proposed tree (structure / ln-parameter parts)
   double terms[8];            // what the device-side MH step needs (include/bsr_hip.h: bsr_score_submit_mh)
   int mhflags = 0;
-  LegacyRng before_u;
+  RngMark before_u;   // where the stream stood in front of the candidate's accept-uniform (replayed from ChainS::start_state)
   std::vector<bsr_node> tape;
 };
 
@@ -1051,6 +1069,8 @@ struct ChainS {
   std::vector<uint64_t> gate_pass_memo;   // ... and the ones predicted rejected that passed (the estimates' false alarms)
   int64_t n_evt_gate = 0, n_evt_pass = 0, n_pred_ok = 0;   // events by kind (BSR_ENGINE_PROF): a rejection nobody predicted, a predicted one that passed; predicted and right
   LegacyRng end_state;
+  LegacyRng gen_start;     // the stream in front of the batch generate() built last (travels with the batch: Lane::start_state)
+  LegacyRng start_state;   // the stream in front of the batch being consumed (what the candidates' marks are replayed from)
 };
 
 }  // namespace
@@ -1298,7 +1318,8 @@ std::string tree_text(const Tree& t, int i) {
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
 void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
   c.cands.clear();
-  c.cands.reserve((size_t)std::max(0, max_n));   // (a candidate carries a copy of the random stream's state: 2.5 KB a move)
+  c.cands.reserve((size_t)std::max(0, max_n));
+  c.gen_start = c.rng;   // (one copy of the stream's state per batch; the candidates carry positions in it)
   int total = c.total + ahead, count = (c.count + ahead) % e->K;
   while ((int)c.cands.size() < max_n) {
     if (count == 0 && total >= e->val) break;  // `while total < val` is only tested between sweeps
@@ -1316,7 +1337,7 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     cd.Qinv = mv.Qinv;
     cd.action = mv.action;
     flatten(cd.tree, cd.tree.root, cd.tape);
-    cd.before_u = c.rng;
+    cd.before_u = mark_of(c.rng);
     cd.ghash = tree_hash_full(cd.tree, cd.tree.root) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
     cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape) ||
                   (e->predict_gate && std::find(c.gate_memo.begin(), c.gate_memo.end(), cd.ghash) != c.gate_memo.end());
@@ -1416,7 +1437,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       tr->n_nodes = count_nodes(cd.tree, cd.tree.root);
     }
     if (sc.rank < 0 && !e->nan_reject) {
-      c.rng = cd.before_u;
+      replay_to(c.rng, c.start_state, cd.before_u);
       return efail(e, BSR_E_LINALG, "SVD did not converge");  // NaN in new_outputs, codes/funcs.py:1226
     }
     ++c.total;
@@ -1430,7 +1451,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
         continue;
       }
       if (e->verify_mh && ev && c.verify_expect_event != BSR_EV_GATE) return efail(e, BSR_E_STATE, "device MH scan missed a gate rejection");
-      c.rng = cd.before_u;
+      replay_to(c.rng, c.start_state, cd.before_u);
       ++c.n_evt_gate;
       if (c.gate_memo.size() < 256) c.gate_memo.push_back(cd.ghash);
       if (getenv("BSR_ENGINE_DUMP_GATE")) {
@@ -1444,7 +1465,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.def_ema[k] *= 0.75;
     bool tail_invalid = false;
     if (cd.pred_def) {  // the gate passed a proposal speculated as rejected: its uniform is drawn now, from the state
-      c.rng = cd.before_u;  // saved in front of it; whatever follows in the batch was generated on a shifted stream
+      replay_to(c.rng, c.start_state, cd.before_u);  // in front of it; whatever follows in the batch was generated on a shifted stream
       cd.u = c.rng.uniform();
       ++c.n_evt_pass;
       if (c.gate_pass_memo.size() < 256) c.gate_pass_memo.push_back(cd.ghash);
@@ -1510,7 +1531,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.total = 0;
     for (int j = 0; j < K; ++j)
       if (j != k) c.def_ema[j] = 0.0;  // their sibling set has changed
-    c.rng = cd.before_u;
+    replay_to(c.rng, c.start_state, cd.before_u);
     c.rng.uniform();
     if (tr) tr->rmse = rmse;
     const int m = std::min<int>(10, (int)c.errs.size());  // codes/bsr_class.py:248-252
@@ -1652,6 +1673,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::vector<std::pair<int, int>> span;       // per chain of the group: first proposal, count
     std::vector<std::vector<Cand>> cands;        // per chain: its candidates in this batch
     std::vector<LegacyRng> end_state;            // per chain: the random stream behind its last candidate
+    std::vector<LegacyRng> start_state;          // ... and in front of its first
     std::vector<char> valid;                     // per chain: 0 once an event in the batch before made them void
     int32_t ticket = -1;
     int slot = -1;  // >= 0: this group's worker thread owns that batch slot
@@ -1733,6 +1755,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     const size_t nc = g.chains.size();
     L.cands.resize(nc);
     L.end_state.resize(nc);
+    L.start_state.resize(nc);
     L.valid.assign(nc, 1);
     int n_live = 0;
     for (ChainS* c : g.chains) n_live += is_live(*c) ? 1 : 0;
@@ -1773,6 +1796,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       if (!c->cands.empty()) L.spans.push_back((int32_t)L.chs.size());
       if (c->cands.empty() && !ahead && room > 0) c->done = true;
       L.end_state[ci] = c->end_state;
+      L.start_state[ci] = c->gen_start;
       L.cands[ci].swap(c->cands);
     }
     if (L.chs.empty()) return BSR_OK;
@@ -1827,6 +1851,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       }
       c.cands.swap(L.cands[i]);
       c.end_state = L.end_state[i];
+      c.start_state = L.start_state[i];
       bool more_ahead = false;
       for (int ol = 0; ol < 3; ++ol) {
         const Lane& O = g.lane[ol];
