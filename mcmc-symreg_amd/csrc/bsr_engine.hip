@@ -1718,17 +1718,18 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   // (accept, gate verdict against the speculation) makes the chain's share of the second one void -- it is skipped
   // when it arrives, and the chain generates afresh from the state behind the event: the sequence of consumed
   // proposals is the reference's whatever is thrown away (codes/funcs.py:1300-1303, :1226-1228).
-  // On by default for K <= 4: at K = 5 and 8, where the tail kernels make the GPU the bound, it measured 2-7 % slower
-  // even when skipped adaptively (below).
+  // (Until round 4 it was off for K >= 5: there, before the gate's memory, six in seven batches ended in an event.)
   // BSR_ENGINE_LOOKAHEAD: batches generated ahead per group, 0..2 (two need a third batch slot per group: up to four
   // groups).  Default: two for a single group -- a lone chain's thread still spent a quarter of its cycle waiting with
-  // one; 0.61-0.66 -> 0.72 M consumed proposals/s -- one otherwise (eight chains in four groups: 2.4-2.7 M either way).
+  // one; 0.61-0.66 -> 0.72 M consumed proposals/s -- one otherwise (eight chains in four groups: 2.4-2.7 M either way;
+  // K = 8: one chain 0.31 -> 0.48 M with one ahead, the same with two; eight chains 1.0 M with none or one, 0.83 M with
+  // two -- until the gate's memory six in seven of its batches ended in an event and lookahead was off for K >= 5).
   // The second only pays since the gate's memory (ChainS::gate_memo) made events rare: with one every ~100 proposals it
   // voided two batches instead of one and gained nothing (discarded 6 711 -> 11 064 of 20 000 consumed, 0.56 M/s either
   // way).
   const int la_env = getenv("BSR_ENGINE_LOOKAHEAD") ? atoi(getenv("BSR_ENGINE_LOOKAHEAD")) : -1;
   const int la_max = n_groups <= 4 ? 2 : 1;
-  const int la_depth = !threaded ? 0 : (la_env >= 0 ? std::min(la_env, la_max) : (e->K <= 4 ? (n_groups == 1 ? 2 : 1) : 0));
+  const int la_depth = !threaded ? 0 : (la_env >= 0 ? std::min(la_env, la_max) : ((e->K <= 4 && n_groups == 1) ? 2 : 1));
   const bool lookahead = la_depth > 0;
   std::vector<Group> groups(n_groups);
   for (size_t i = 0; i < live.size(); ++i) groups[i % n_groups].chains.push_back(live[i]);
