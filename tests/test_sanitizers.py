@@ -64,3 +64,32 @@ def test_golden_traces_through_the_address_sanitized_sampler(tmp_path):
     assert r.returncode == 0, tail
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[:4000]
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_the_sampler_predicts_most_rank_gate_rejections(tmp_path):
+    """What ends a speculative run of the native sampler is, nine times in ten, a rank-gate rejection nobody predicted
+    (codes/funcs.py:1226-1228 draws no accept-uniform behind one: everything generated behind it is void).  The
+    sampler predicts them from structure (repeats, linear spans), from an interval estimate of a candidate's scale that
+    tracks how close to zero its values come, and from its memory of what the gate has already rejected in the chain's
+    current state.  Pinned on the CPU stand-in of the data side (which computes the true ranks): of the gate's
+    rejections in 8 chains x 2 000 proposals at least 85 % are predicted, and false alarms stay below the hits' tenth
+    (before round 4: 38 % predicted on the GPU box's mix)."""
+    exe = str(tmp_path / "engine_host")
+    src = [os.path.join(ROOT, "mcmc-symreg_amd", "csrc", "bsr_engine.hip"), os.path.join(ROOT, "tests", "native", "stub_scorer.cpp"),
+           os.path.join(ROOT, "tests", "native", "engine_tsan_main.cpp")]
+    cmd = ["g++", "-std=c++17", "-O2", "-DBSR_HOST_ONLY", "-pthread", "-I" + os.path.join(ROOT, "include")]
+    for f in src:
+        cmd += ["-x", "c++", f]
+    b = subprocess.run(cmd + ["-o", exe], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-4000:]
+    r = subprocess.run([exe, "8", "2000"], env=dict(os.environ, BSR_ENGINE_PROF="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import re
+    m = re.search(r"events in (\d+) consumed proposals: (\d+) accepts, (\d+) gate rejections nobody predicted, (\d+) predicted "
+                  r"rejections that passed the gate; (\d+) of (\d+) gate rejections predicted", r.stderr)
+    assert m, r.stderr[-2000:]
+    n, acc, missed, false_alarm, hit, rej = (int(v) for v in m.groups())
+    assert n == 16000 and rej > 100, m.group(0)
+    assert hit >= 0.85 * rej, m.group(0)
+    assert false_alarm <= 0.1 * hit, m.group(0)
