@@ -132,3 +132,15 @@ def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K
     assert (out["0"] == out["1"]).all(), np.nonzero(out["0"] != out["1"])[0][:20]
     assert (out["0"] == out["2"]).all(), np.nonzero(out["0"] != out["2"])[0][:20]
     assert (out["0"] == out["3"]).all(), np.nonzero(out["0"] != out["3"])[0][:20]
+
+
+@pytest.mark.parametrize("K,chains,d", [(3, 3, 50), (8, 2, 30)])
+def test_a_streaming_context_of_several_chains_scores_each_proposal_as_its_chain_alone_would(K, chains, d):
+    """Several chains in one streaming context: their bases sit side by side in the chunk buffer and every tape reads its
+    own chain's (the assembly interpreter a tape at a time: the chunk block wants ONE basis behind y).  Rank and
+    log-likelihood of every proposal must be the bytes a context holding that chain alone gives."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "stream_multichain_check.py"), "--K", str(K),
+                        "--chains", str(chains), "--d", str(d)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "MULTI-CHAIN STREAM CHECK OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "multi-chain context: k_stream" in p.stdout
