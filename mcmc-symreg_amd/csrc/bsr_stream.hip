@@ -466,48 +466,44 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
         // (two-block chunks: the same block of assembly on either half -- a lane's rows reach its sums in the order of
         // one-block chunks, block by block: the same sums bit for bit, with half the barriers)
+#define BSR_SC_OPERANDS(SUMS)                                                                                          \
+  : SUMS, [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]), [sv1] "+v"(sv[1]),            \
+    [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)                                              \
+  : [resume] "s"(resume), [lc] "v"(lcb), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds)                \
+  :
+#define BSR_SC_EMIT(T1, T2, T3, T4)                                                                                    \
+  if constexpr (KQ == 1) asm volatile(T1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);                     \
+  else if constexpr (KQ == 2) asm volatile(T2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);                \
+  else if constexpr (KQ == 3) asm volatile(T3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);                \
+  else asm volatile(T4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4)
 #pragma unroll 1
         for (int jb = 0; jb < nbc; ++jb) {
-        const uint32_t lcb = lc + (uint32_t)jb * 1024u;
-        resume = 0;
-        for (;;) {
-#define BSR_SC_OPERANDS(SUMS) \
-                       : SUMS, \
-                         [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]), \
-                         [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st) \
-                       : [resume] "s"(resume), [lc] "v"(lcb), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds) \
-                       :
-#define BSR_SC_EMIT(T1, T2, T3, T4)                                                                         \
-  if constexpr (KQ == 1) asm volatile(T1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);                          \
-  else if constexpr (KQ == 2) asm volatile(T2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);                     \
-  else if constexpr (KQ == 3) asm volatile(T3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);                     \
-  else asm volatile(T4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4)
-          if constexpr (CB == 2) {
-            BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K1, BSR_STREAM_CHUNK2_ASM_K2, BSR_STREAM_CHUNK2_ASM_K3, BSR_STREAM_CHUNK2_ASM_K4);
-          } else {
-            BSR_SC_EMIT(BSR_STREAM_CHUNK_ASM_K1, BSR_STREAM_CHUNK_ASM_K2, BSR_STREAM_CHUNK_ASM_K3, BSR_STREAM_CHUNK_ASM_K4);
+          const uint32_t lcb = lc + (uint32_t)jb * 1024u;
+          resume = 0;
+          for (;;) {
+            if constexpr (CB == 2) {
+              BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K1, BSR_STREAM_CHUNK2_ASM_K2, BSR_STREAM_CHUNK2_ASM_K3, BSR_STREAM_CHUNK2_ASM_K4);
+            } else {
+              BSR_SC_EMIT(BSR_STREAM_CHUNK_ASM_K1, BSR_STREAM_CHUNK_ASM_K2, BSR_STREAM_CHUNK_ASM_K3, BSR_STREAM_CHUNK_ASM_K4);
+            }
+            if (st == 0) break;
+            const uint32_t what = st & 15u;
+            if (what == 1) {
+              const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
+                                               my + (st >> 4), cur, jb * BSR_TILE_BLOCK + 2 * lane, lane);
+              z0 = zb.x;
+              z1 = zb.y;
+            } else {   // sin / cos of huge arguments (exp never leaves the block)
+              double zz[2] = {z0, z1};
+              sincos_vals<2>(zz, what == BSR_OP_COS + 1 ? 1 : 0);
+              z0 = zz[0];
+              z1 = zz[1];
+            }
+            resume = __builtin_amdgcn_readfirstlane(st);
           }
+        }
 #undef BSR_SC_EMIT
 #undef BSR_SC_OPERANDS
-          if (st == 0) break;
-          const uint32_t what = st & 15u;
-          if (what == 1) {
-            const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
-                                             my + (st >> 4), cur, jb * BSR_TILE_BLOCK + 2 * lane, lane);
-            z0 = zb.x;
-            z1 = zb.y;
-          } else if (what == BSR_OP_EXP + 1) {
-            z0 = op_exp<double>(z0);
-            z1 = op_exp<double>(z1);
-          } else {
-            double zz[2] = {z0, z1};
-            sincos_vals<2>(zz, what == BSR_OP_COS + 1 ? 1 : 0);
-            z0 = zz[0];
-            z1 = zz[1];
-          }
-          resume = __builtin_amdgcn_readfirstlane(st);
-        }
-        }
         if (STAMPS) busy += __builtin_amdgcn_s_memtime() - t_busy;
         if (ci == 0 && pass == 0) TSTAMP(2);
         continue;
