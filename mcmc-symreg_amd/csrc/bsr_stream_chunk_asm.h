@@ -186,7 +186,11 @@
   "s_subb_u32 s29, s25, 0\n\t"                                                   \
   "s_add_u32 s13, %[ln], " #q "*48\n\t"
 
-// Tape q of the wave: its program has been requested into s[16:23] (by the block's entry, or while tape q - 1 was added up)
+// Tape q of the wave: its program has been requested into s[16:23] (by the block's entry, or while tape q - 1 was added up).
+// Its priority is 3 - q: a SIMD issues for its oldest wave first, so left alone its four waves finish a chunk one after
+// the other and the youngest runs the end by itself, with nothing to hide its latencies behind; a wave that has moved on
+// to its next tape now yields to the ones still on an earlier tape, and they reach the barrier together (C5: +4 %,
+// interleaved A/B of two builds in one box).
 // the sums' lines for basis columns 2..4 of row 0 / row 1 (K of them exist: BSR_SC_FNO where not)
 #define BSR_SC_FB0(q) "v_fmac_f64_e32 %[cb" #q "], v[32:33], v[12:13]\n\t"
 #define BSR_SC_FB1(q) "v_fmac_f64_e32 %[cb" #q "], v[34:35], v[16:17]\n\t"
@@ -197,6 +201,7 @@
 #define BSR_SC_FNO(q) ""
 
 #define BSR_SC_TAPE(q, qnext, B0, B1, C0, C1, D0, D1)                            \
+  "s_setprio 3-" #q "\n\t"   /* the waves that are behind go first (below) */   \
   BSR_SC_TAPE_REGS(q)                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "s_cmp_lt_i32 s16, 0\n\t"                                                      \
