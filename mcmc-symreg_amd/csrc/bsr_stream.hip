@@ -205,7 +205,7 @@ __device__ __attribute__((noinline)) void leftover_call(const TileArgs<double>* 
   leftover_unit<double, KQ, AT, TileGeom CONSTANT_AS>(a, a.g, lane, tk);
 }
 
-// the four sets of sums of a wave as operands of the assembly blocks, for K = 1..4 basis columns
+// the sets of sums of a wave (four at K <= 4, two at K >= 5) as operands of the assembly blocks, for K = 1..8 basis columns
 #define BSR_SC_SUMS_1 \
   [ca0] "+v"(A[0].c[0]), [sa0] "+v"(A[0].a0), [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
   [ca1] "+v"(A[1].c[0]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax), \
@@ -226,6 +226,18 @@ __device__ __attribute__((noinline)) void leftover_call(const TileArgs<double>* 
   [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [cd1] "+v"(A[1].c[3]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax), \
   [ca2] "+v"(A[2].c[0]), [cb2] "+v"(A[2].c[1]), [cc2] "+v"(A[2].c[2]), [cd2] "+v"(A[2].c[3]), [sa2] "+v"(A[2].a0), [sb2] "+v"(A[2].a1), [am2] "+v"(A[2].amax), \
   [ca3] "+v"(A[3].c[0]), [cb3] "+v"(A[3].c[1]), [cc3] "+v"(A[3].c[2]), [cd3] "+v"(A[3].c[3]), [sa3] "+v"(A[3].a0), [sb3] "+v"(A[3].a1), [am3] "+v"(A[3].amax)
+#define BSR_SC_SUMS_5 \
+  [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [cd0] "+v"(A[0].c[3]), [ce0] "+v"(A[0].c[4]), [sa0] "+v"(A[0].a0), [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
+  [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [cd1] "+v"(A[1].c[3]), [ce1] "+v"(A[1].c[4]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax)
+#define BSR_SC_SUMS_6 \
+  [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [cd0] "+v"(A[0].c[3]), [ce0] "+v"(A[0].c[4]), [cf0] "+v"(A[0].c[5]), [sa0] "+v"(A[0].a0), [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
+  [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [cd1] "+v"(A[1].c[3]), [ce1] "+v"(A[1].c[4]), [cf1] "+v"(A[1].c[5]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax)
+#define BSR_SC_SUMS_7 \
+  [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [cd0] "+v"(A[0].c[3]), [ce0] "+v"(A[0].c[4]), [cf0] "+v"(A[0].c[5]), [cg0] "+v"(A[0].c[6]), [sa0] "+v"(A[0].a0), [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
+  [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [cd1] "+v"(A[1].c[3]), [ce1] "+v"(A[1].c[4]), [cf1] "+v"(A[1].c[5]), [cg1] "+v"(A[1].c[6]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax)
+#define BSR_SC_SUMS_8 \
+  [ca0] "+v"(A[0].c[0]), [cb0] "+v"(A[0].c[1]), [cc0] "+v"(A[0].c[2]), [cd0] "+v"(A[0].c[3]), [ce0] "+v"(A[0].c[4]), [cf0] "+v"(A[0].c[5]), [cg0] "+v"(A[0].c[6]), [ch0] "+v"(A[0].c[7]), [sa0] "+v"(A[0].a0), [sb0] "+v"(A[0].a1), [am0] "+v"(A[0].amax), \
+  [ca1] "+v"(A[1].c[0]), [cb1] "+v"(A[1].c[1]), [cc1] "+v"(A[1].c[2]), [cd1] "+v"(A[1].c[3]), [ce1] "+v"(A[1].c[4]), [cf1] "+v"(A[1].c[5]), [cg1] "+v"(A[1].c[6]), [ch1] "+v"(A[1].c[7]), [sa1] "+v"(A[1].a0), [sb1] "+v"(A[1].a1), [am1] "+v"(A[1].amax)
 
 // A tape the fast interpreters do not take, on the lane's two rows of one block of the staged chunk.  Out of line on
 // purpose: the stack machine keeps its deeper values in scratch memory, and with scratch accesses anywhere in the chunk
@@ -262,7 +274,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   // 3: the loop over the slice's chunks inside that block too (the kernel's default where 2 applies)
   constexpr bool ASM = MODE == 1;
   static_assert(MODE != 1 || CB == 1, "the tape-at-a-time assembly interpreter takes one-block chunks");
-  static_assert(MODE < 2 || (KQ <= 4 && QT == 4), "the chunk block is written for four tapes per wave (K <= 4)");
+  static_assert(MODE < 2 || (KQ <= 4 && QT == 4) || (KQ >= 5 && QT == 2),
+                "the chunk block is written for four tapes per wave at K <= 4, two at K >= 5");
   static_assert(MODE != 3 || (CB == 1 && !STAMPS), "the pass block: one-block chunks, no per-chunk clock samples");
   constexpr int U = 2 * CB;
   constexpr int NUMAX = BSR_STREAM_UNITS_MAX / BSR_TILE_WAVES;   // DMA pieces per wave and chunk at most
@@ -390,7 +403,11 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         if constexpr (KQ == 1) asm volatile(BSR_STREAM_PASS_ASM_K1 BSR_SP_OPERANDS(BSR_SC_SUMS_1) : BSR_STREAM_PASS_CLOBBERS);
         else if constexpr (KQ == 2) asm volatile(BSR_STREAM_PASS_ASM_K2 BSR_SP_OPERANDS(BSR_SC_SUMS_2) : BSR_STREAM_PASS_CLOBBERS);
         else if constexpr (KQ == 3) asm volatile(BSR_STREAM_PASS_ASM_K3 BSR_SP_OPERANDS(BSR_SC_SUMS_3) : BSR_STREAM_PASS_CLOBBERS);
-        else asm volatile(BSR_STREAM_PASS_ASM_K4 BSR_SP_OPERANDS(BSR_SC_SUMS_4) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (KQ == 4) asm volatile(BSR_STREAM_PASS_ASM_K4 BSR_SP_OPERANDS(BSR_SC_SUMS_4) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (KQ == 5) asm volatile(BSR_STREAM_PASS_ASM_K5 BSR_SP_OPERANDS(BSR_SC_SUMS_5) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else if constexpr (KQ == 6) asm volatile(BSR_STREAM_PASS_ASM_K6 BSR_SP_OPERANDS(BSR_SC_SUMS_6) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else if constexpr (KQ == 7) asm volatile(BSR_STREAM_PASS_ASM_K7 BSR_SP_OPERANDS(BSR_SC_SUMS_7) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else asm volatile(BSR_STREAM_PASS_ASM_K8 BSR_SP_OPERANDS(BSR_SC_SUMS_8) : BSR_STREAM_PASS_CLOBBERS_K8);
 #undef BSR_SP_OPERANDS
         if (st == 0) break;
         const uint32_t what = st & 15u;
@@ -471,20 +488,24 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)                                              \
   : [resume] "s"(resume), [lc] "v"(lcb), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds)                \
   :
-#define BSR_SC_EMIT(T1, T2, T3, T4)                                                                                    \
-  if constexpr (KQ == 1) asm volatile(T1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);                     \
-  else if constexpr (KQ == 2) asm volatile(T2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);                \
-  else if constexpr (KQ == 3) asm volatile(T3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);                \
-  else asm volatile(T4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4)
+#define BSR_SC_EMIT(P)                                                                                                 \
+  if constexpr (KQ == 1) asm volatile(P##1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);                   \
+  else if constexpr (KQ == 2) asm volatile(P##2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);              \
+  else if constexpr (KQ == 3) asm volatile(P##3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);              \
+  else if constexpr (KQ == 4) asm volatile(P##4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4);           \
+  else if constexpr (KQ == 5) asm volatile(P##5 BSR_SC_OPERANDS(BSR_SC_SUMS_5) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else if constexpr (KQ == 6) asm volatile(P##6 BSR_SC_OPERANDS(BSR_SC_SUMS_6) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else if constexpr (KQ == 7) asm volatile(P##7 BSR_SC_OPERANDS(BSR_SC_SUMS_7) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else asm volatile(P##8 BSR_SC_OPERANDS(BSR_SC_SUMS_8) BSR_STREAM_CHUNK_CLOBBERS_K8)
 #pragma unroll 1
         for (int jb = 0; jb < nbc; ++jb) {
           const uint32_t lcb = lc + (uint32_t)jb * 1024u;
           resume = 0;
           for (;;) {
             if constexpr (CB == 2) {
-              BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K1, BSR_STREAM_CHUNK2_ASM_K2, BSR_STREAM_CHUNK2_ASM_K3, BSR_STREAM_CHUNK2_ASM_K4);
+              BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K);
             } else {
-              BSR_SC_EMIT(BSR_STREAM_CHUNK_ASM_K1, BSR_STREAM_CHUNK_ASM_K2, BSR_STREAM_CHUNK_ASM_K3, BSR_STREAM_CHUNK_ASM_K4);
+              BSR_SC_EMIT(BSR_STREAM_CHUNK_ASM_K);
             }
             if (st == 0) break;
             const uint32_t what = st & 15u;
@@ -613,9 +634,10 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   // 1: the assembly interpreter a tape at a time; default: the wave's four tapes in one block where it applies (K = 3,
   // one chain's basis behind y), else 1
   static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
-  const bool chunk_block = KQ <= 4 && QT == 4 && asm_mode >= 2 && a.g.ncols_fixed == KQ;
+  constexpr bool BLOCK_SHAPE = (KQ <= 4 && QT == 4) || (KQ >= 5 && QT == 2);
+  const bool chunk_block = BLOCK_SHAPE && asm_mode >= 2 && a.g.ncols_fixed == KQ;
   if (a.g.chunk_blocks == 2) {
-    if constexpr (KQ <= 4 && QT == 4) {
+    if constexpr (BLOCK_SHAPE) {
       if (chunk_block) {
         if (a.stamps) launch_one<KQ, QT, 2, true, 2>(st, a, lds);
         else launch_one<KQ, QT, 2, false, 2>(st, a, lds);
@@ -626,7 +648,7 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
     else launch_one<KQ, QT, 2, false, 0>(st, a, lds);
     return;
   }
-  if constexpr (KQ <= 4 && QT == 4) {
+  if constexpr (BLOCK_SHAPE) {
     if (chunk_block) {
       if (a.stamps) launch_one<KQ, QT, 1, true, 2>(st, a, lds);   // (BSR_TILE_STAMPS=1: per-wave clock samples)
       else if (asm_mode >= 3) launch_one<KQ, QT, 1, false, 3>(st, a, lds);
@@ -650,7 +672,7 @@ size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof
 // then two-block chunks cost nothing but LDS (bsr_stage.hip: stage_tile's geometry)
 bool stream_chunk_block(int K, int ncols_fixed) {
   static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
-  return K <= 4 && stream_qmax(K) == 4 && asm_mode >= 2 && ncols_fixed == K;
+  return stream_qmax(K) == (K <= 4 ? 4 : 2) && asm_mode >= 2 && ncols_fixed == K;
 }
 
 int stream_qmax(int K) {

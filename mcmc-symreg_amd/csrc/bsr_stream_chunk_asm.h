@@ -177,6 +177,10 @@
 #define BSR_SC_YQ2(O1, O2) BSR_SC_YQ1(O1) "ds_read_b128 v[32:35], v20 offset:" O2 "\n\t"
 #define BSR_SC_YQ3(O1, O2, O3) BSR_SC_YQ2(O1, O2) "ds_read_b128 v[36:39], v20 offset:" O3 "\n\t"
 #define BSR_SC_YQ4(O1, O2, O3, O4) BSR_SC_YQ3(O1, O2, O3) "ds_read_b128 v[40:43], v20 offset:" O4 "\n\t"
+#define BSR_SC_YQ5(O1, O2, O3, O4, O5) BSR_SC_YQ4(O1, O2, O3, O4) "ds_read_b128 v[44:47], v20 offset:" O5 "\n\t"
+#define BSR_SC_YQ6(O1, O2, O3, O4, O5, O6) BSR_SC_YQ5(O1, O2, O3, O4, O5) "ds_read_b128 v[48:51], v20 offset:" O6 "\n\t"
+#define BSR_SC_YQ7(O1, O2, O3, O4, O5, O6, O7) BSR_SC_YQ6(O1, O2, O3, O4, O5, O6) "ds_read_b128 v[52:55], v20 offset:" O7 "\n\t"
+#define BSR_SC_YQ8(O1, O2, O3, O4, O5, O6, O7, O8) BSR_SC_YQ7(O1, O2, O3, O4, O5, O6, O7) "ds_read_b128 v[56:59], v20 offset:" O8 "\n\t"
 #define BSR_SC_QUAD(a, b, c, d, e, f, g, h)                             \
   ".p2align 6\n\t.quad " a ", " b ", " c ", " d ", " e ", " f ", " g ", " h "\n\t"
 
@@ -198,9 +202,33 @@
 #define BSR_SC_FC1(q) "v_fmac_f64_e32 %[cc" #q "], v[38:39], v[16:17]\n\t"
 #define BSR_SC_FD0(q) "v_fmac_f64_e32 %[cd" #q "], v[40:41], v[12:13]\n\t"
 #define BSR_SC_FD1(q) "v_fmac_f64_e32 %[cd" #q "], v[42:43], v[16:17]\n\t"
-#define BSR_SC_FNO(q) ""
+#define BSR_SC_FE0(q) "v_fmac_f64_e32 %[ce" #q "], v[44:45], v[12:13]\n\t"
+#define BSR_SC_FE1(q) "v_fmac_f64_e32 %[ce" #q "], v[46:47], v[16:17]\n\t"
+#define BSR_SC_FF0(q) "v_fmac_f64_e32 %[cf" #q "], v[48:49], v[12:13]\n\t"
+#define BSR_SC_FF1(q) "v_fmac_f64_e32 %[cf" #q "], v[50:51], v[16:17]\n\t"
+#define BSR_SC_FG0(q) "v_fmac_f64_e32 %[cg" #q "], v[52:53], v[12:13]\n\t"
+#define BSR_SC_FG1(q) "v_fmac_f64_e32 %[cg" #q "], v[54:55], v[16:17]\n\t"
+#define BSR_SC_FH0(q) "v_fmac_f64_e32 %[ch" #q "], v[56:57], v[12:13]\n\t"
+#define BSR_SC_FH1(q) "v_fmac_f64_e32 %[ch" #q "], v[58:59], v[16:17]\n\t"
+// rows 0 and 1 of basis columns 2..K of tape q
+#define BSR_SC_R0_1(q) ""
+#define BSR_SC_R1_1(q) ""
+#define BSR_SC_R0_2(q) BSR_SC_FB0(q)
+#define BSR_SC_R1_2(q) BSR_SC_FB1(q)
+#define BSR_SC_R0_3(q) BSR_SC_R0_2(q) BSR_SC_FC0(q)
+#define BSR_SC_R1_3(q) BSR_SC_R1_2(q) BSR_SC_FC1(q)
+#define BSR_SC_R0_4(q) BSR_SC_R0_3(q) BSR_SC_FD0(q)
+#define BSR_SC_R1_4(q) BSR_SC_R1_3(q) BSR_SC_FD1(q)
+#define BSR_SC_R0_5(q) BSR_SC_R0_4(q) BSR_SC_FE0(q)
+#define BSR_SC_R1_5(q) BSR_SC_R1_4(q) BSR_SC_FE1(q)
+#define BSR_SC_R0_6(q) BSR_SC_R0_5(q) BSR_SC_FF0(q)
+#define BSR_SC_R1_6(q) BSR_SC_R1_5(q) BSR_SC_FF1(q)
+#define BSR_SC_R0_7(q) BSR_SC_R0_6(q) BSR_SC_FG0(q)
+#define BSR_SC_R1_7(q) BSR_SC_R1_6(q) BSR_SC_FG1(q)
+#define BSR_SC_R0_8(q) BSR_SC_R0_7(q) BSR_SC_FH0(q)
+#define BSR_SC_R1_8(q) BSR_SC_R1_7(q) BSR_SC_FH1(q)
 
-#define BSR_SC_TAPE(q, qnext, B0, B1, C0, C1, D0, D1)                            \
+#define BSR_SC_TAPE(q, qnext, R0, R1)                                            \
   "s_setprio 3-" #q "\n\t"   /* the waves that are behind go first (below) */   \
   BSR_SC_TAPE_REGS(q)                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
@@ -227,12 +255,12 @@
   "v_fmac_f64_e32 %[sa" #q "], v[12:13], v[12:13]\n\t"                           \
   "v_fmac_f64_e32 %[sb" #q "], v[12:13], v[24:25]\n\t"                           \
   "v_fmac_f64_e32 %[ca" #q "], v[28:29], v[12:13]\n\t"                           \
-  B0(q) C0(q) D0(q)                                                              \
+  R0(q)                                                                          \
   "v_max_f64 %[am" #q "], v[14:15], |v[2:3]|\n\t"                                \
   "v_fmac_f64_e32 %[sa" #q "], v[16:17], v[16:17]\n\t"                           \
   "v_fmac_f64_e32 %[sb" #q "], v[16:17], v[26:27]\n\t"                           \
   "v_fmac_f64_e32 %[ca" #q "], v[30:31], v[16:17]\n\t"                           \
-  B1(q) C1(q) D1(q)                                                              \
+  R1(q)                                                                          \
   ".Lsc_next" #q "_%=:\n\t"
 
 // coming back into tape q: its program again (prescale, flags), then either the caller's values straight to the sums
@@ -255,14 +283,18 @@
   "s_add_u32 s24, s24, .Lsc_tab%=-.Lsc_pc%=\n\t"                                 \
   "s_addc_u32 s25, s25, 0\n\t"                                                   \
   "s_mov_b32 s27, s25\n\t"
-#define BSR_SC_TAPES_K(B0, B1, C0, C1, D0, D1)                                                                        \
-  BSR_SC_TAPE(0, 1, B0, B1, C0, C1, D0, D1) BSR_SC_TAPE(1, 2, B0, B1, C0, C1, D0, D1)                                  \
-  BSR_SC_TAPE(2, 3, B0, B1, C0, C1, D0, D1) BSR_SC_TAPE(3, 4, B0, B1, C0, C1, D0, D1)
-#define BSR_SC_TAPES_1 BSR_SC_TAPES_K(BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO)
-#define BSR_SC_TAPES_2 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO, BSR_SC_FNO)
-#define BSR_SC_TAPES_3 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FC0, BSR_SC_FC1, BSR_SC_FNO, BSR_SC_FNO)
-#define BSR_SC_TAPES_4 BSR_SC_TAPES_K(BSR_SC_FB0, BSR_SC_FB1, BSR_SC_FC0, BSR_SC_FC1, BSR_SC_FD0, BSR_SC_FD1)
-// coming back (`resume` = what the block left with): which tape, then BSR_SC_RESUME of that tape
+// four tapes per wave (K <= 4), or two (K >= 5: a set of sums is 8 + 3 registers pairs; the labels of tapes 2 and 3 that
+// the shared resume / leave code names then stand behind the last tape and are never reached)
+#define BSR_SC_TAPES4(R0, R1) BSR_SC_TAPE(0, 1, R0, R1) BSR_SC_TAPE(1, 2, R0, R1) BSR_SC_TAPE(2, 3, R0, R1) BSR_SC_TAPE(3, 4, R0, R1)
+#define BSR_SC_TAPES2(R0, R1) BSR_SC_TAPE(0, 1, R0, R1) BSR_SC_TAPE(1, 2, R0, R1) ".Lsc_acc2_%=:\n.Lsc_acc3_%=:\n\t"
+#define BSR_SC_TAPES_1 BSR_SC_TAPES4(BSR_SC_R0_1, BSR_SC_R1_1)
+#define BSR_SC_TAPES_2 BSR_SC_TAPES4(BSR_SC_R0_2, BSR_SC_R1_2)
+#define BSR_SC_TAPES_3 BSR_SC_TAPES4(BSR_SC_R0_3, BSR_SC_R1_3)
+#define BSR_SC_TAPES_4 BSR_SC_TAPES4(BSR_SC_R0_4, BSR_SC_R1_4)
+#define BSR_SC_TAPES_5 BSR_SC_TAPES2(BSR_SC_R0_5, BSR_SC_R1_5)
+#define BSR_SC_TAPES_6 BSR_SC_TAPES2(BSR_SC_R0_6, BSR_SC_R1_6)
+#define BSR_SC_TAPES_7 BSR_SC_TAPES2(BSR_SC_R0_7, BSR_SC_R1_7)
+#define BSR_SC_TAPES_8 BSR_SC_TAPES2(BSR_SC_R0_8, BSR_SC_R1_8)
 #define BSR_SC_RESUME_PART                                                       \
   ".Lsc_resume%=:\n\t"                                                           \
   "s_lshr_b32 s10, %[resume], 4\n\t"                                             \
@@ -562,6 +594,27 @@
 #define BSR_STREAM_PASS_ASM_K3 BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
 #define BSR_STREAM_PASS_ASM_K4 BSR_STREAM_PASS_ASM_(BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
 
+#define BSR_SC_YQ_A5 BSR_SC_YQ5("1024", "2048", "3072", "4096", "5120")
+#define BSR_SC_YQ_A6 BSR_SC_YQ6("1024", "2048", "3072", "4096", "5120", "6144")
+#define BSR_SC_YQ_A7 BSR_SC_YQ7("1024", "2048", "3072", "4096", "5120", "6144", "7168")
+#define BSR_SC_YQ_A8 BSR_SC_YQ8("1024", "2048", "3072", "4096", "5120", "6144", "7168", "8192")
+#define BSR_SC_YQ_B5 BSR_SC_YQ5("2048", "4096", "6144", "8192", "10240")
+#define BSR_SC_YQ_B6 BSR_SC_YQ6("2048", "4096", "6144", "8192", "10240", "12288")
+#define BSR_SC_YQ_B7 BSR_SC_YQ7("2048", "4096", "6144", "8192", "10240", "12288", "14336")
+#define BSR_SC_YQ_B8 BSR_SC_YQ8("2048", "4096", "6144", "8192", "10240", "12288", "14336", "16384")
+#define BSR_STREAM_CHUNK_ASM_K5 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A5, BSR_SC_TAPES_5)
+#define BSR_STREAM_CHUNK_ASM_K6 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A6, BSR_SC_TAPES_6)
+#define BSR_STREAM_CHUNK_ASM_K7 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A7, BSR_SC_TAPES_7)
+#define BSR_STREAM_CHUNK_ASM_K8 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A8, BSR_SC_TAPES_8)
+#define BSR_STREAM_CHUNK2_ASM_K5 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B5, BSR_SC_TAPES_5)
+#define BSR_STREAM_CHUNK2_ASM_K6 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B6, BSR_SC_TAPES_6)
+#define BSR_STREAM_CHUNK2_ASM_K7 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B7, BSR_SC_TAPES_7)
+#define BSR_STREAM_CHUNK2_ASM_K8 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B8, BSR_SC_TAPES_8)
+#define BSR_STREAM_PASS_ASM_K5 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A5, BSR_SC_TAPES_5)
+#define BSR_STREAM_PASS_ASM_K6 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A6, BSR_SC_TAPES_6)
+#define BSR_STREAM_PASS_ASM_K7 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A7, BSR_SC_TAPES_7)
+#define BSR_STREAM_PASS_ASM_K8 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A8, BSR_SC_TAPES_8)
+
 #define BSR_STREAM_CHUNK_CLOBBERS                                                                                      \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17",   \
   "v18", "v19", "v20", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", \
@@ -572,4 +625,8 @@
 #define BSR_STREAM_CHUNK_CLOBBERS_K4 BSR_STREAM_CHUNK_CLOBBERS, "v40", "v41", "v42", "v43"
 #define BSR_STREAM_PASS_CLOBBERS BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS)
 #define BSR_STREAM_PASS_CLOBBERS_K4 BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS_K4)
+// (K = 5..8: up to eight basis columns)
+#define BSR_STREAM_CHUNK_CLOBBERS_K8 BSR_STREAM_CHUNK_CLOBBERS_K4, "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", \
+  "v54", "v55", "v56", "v57", "v58", "v59"
+#define BSR_STREAM_PASS_CLOBBERS_K8 BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS_K8)
 // clang-format on

@@ -83,7 +83,9 @@ X[::1013, 4 % d] = 1e200                   # overflow in the cube, huge argument
 y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
 ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
 assert ctx.info()["row_pass"] == "k_stream", ctx.info()
-for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5 % d)), un('square', leaf(6 % d))][:K]):
+for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(5 % d)), un('square', leaf(6 % d)),
+                       un('cubic', leaf(7 % d)), bi('+', leaf(8 % d), leaf(9 % d)), un('exp', leaf(10 % d)),
+                       un('inv', un('ln', un('square', leaf(11 % d)), 1.0, 1.0))][:K]):
     ctx.set_current(0, k, flatten(t))
 ctx.refresh(0)
 trees = S.make_tapes(d, 40)
@@ -108,11 +110,12 @@ ctx.close()
 """
 
 
-@pytest.mark.parametrize("d,K,B", [(40, 3, 64), (7, 3, 64), (3, 3, 64), (40, 3, 100), (40, 1, 64), (40, 2, 64), (40, 4, 64)])
+@pytest.mark.parametrize("d,K,B", [(40, 3, 64), (7, 3, 64), (3, 3, 64), (40, 3, 100), (40, 1, 64), (40, 2, 64), (40, 4, 64),
+                                   (40, 5, 64), (40, 8, 64), (7, 8, 64)])
 def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K, B):
     """bsr_stream.hip evaluates fast tapes by the C++ interpreter (BSR_STREAM_ASM=0), the assembly interpreter a tape at a
     time (1), a wave's four tapes in one block of assembly (2) or the whole loop over the slice's chunks in it (3, the
-    default; 2 and 3 exist for K <= 4, four sets of sums per wave).  The assembly restates the
+    default: four sets of sums per wave at K <= 4, two at K >= 5).  The assembly restates the
     instruction sequences the compiler emits for the C++ -- division, cube, ln, the fused operands -- so every score of a
     batch that reaches every operator (zeros under the protected divisions, overflow in the cube, huge arguments of
     sin / cos, `log` and deep tapes that go to the stack machine) must be the same BYTES whichever interpreter ran.
