@@ -16,13 +16,18 @@
 // Chunks are one or two 128-row blocks.  With all 64 tapes in ONE group (four per wave at K <= 4) every column is
 // streamed once per launch (k_tile's two groups both streamed the columns they shared: 1.38x the algorithmic bytes).
 //
-// Tapes the fast interpreter does not take (not a chain, more than 16 entries, 8 terminals or 3 ln nodes) run through
-// the stack machine of bsr_device.h on the same staged rows -- one copy of it behind the unrolled tapes.  Nothing in the
-// loop is a call (sin, cos, exp inline; only their huge-argument lanes and the extension operator `log` go out of line):
-// every device function starts with s_waitcnt vmcnt(0), which would wait for the wave's copies in flight.  Either way the values of a row and the order
-// of every sum are those of the other row passes: per lane the blocks of the slice in order, the lane's two rows of a
-// block in order; one lane reduction per (tape, slice) in the fixed network of reduce_store.  What is summed in which
-// order depends on the context's slices only, never on the batch.
+// The fast interpreter exists three times over (template parameter MODE; BSR_STREAM_ASM): in C++ (tape_fast below), in
+// gfx950 assembly a tape at a time (bsr_stream_asm.h), and as one block of assembly that runs a wave's tapes of a chunk --
+// and, in mode 3, the loop over the slice's chunks -- (bsr_stream_chunk_asm.h: the default; a CU has one scalar unit for
+// its sixteen waves, and the compiler's interpreter is a scalar program).  All three give a row's value the same bits.
+//
+// Tapes the fast interpreter does not take (more than 16 entries, 8 terminals or 3 ln nodes, more than one value below
+// the accumulator, a `log`) go to the stack machine of bsr_device.h on the same staged rows, out of line (generic_block).
+// Nothing else in the loop is a call (sin, cos, exp inline; only sin / cos of huge arguments go out of line): every device
+// function starts with s_waitcnt vmcnt(0), which waits for the wave's copies in flight.  Either way the values of a row
+// and the order of every sum are those of the other row passes: per lane the blocks of the slice in order, the lane's two
+// rows of a block in order; one lane reduction per (tape, slice) in the fixed network of reduce_store.  What is summed in
+// which order depends on the context's slices only, never on the batch.
 #include "bsr_tile_common.h"
 #include "bsr_stream_asm.h"
 #include "bsr_stream_chunk_asm.h"
