@@ -406,13 +406,12 @@ def attach_valu(out, name, B, C, dtype, n_cu_used=None):
 def gather_trees(wl, ranks):
     """The one exchange of the path: every chain's current (accepted) trees, all-gathered over RCCL."""
     import numpy as np
-    from bsr.dist import pack_chain_record, RECORD_BYTES
+    from bsr.dist import pack_chain_record, gather_raw
     if ranks.world <= 1:
         return None
-    rec = np.concatenate([pack_chain_record(ch) for ch in wl["chains"]])
-    got = ranks.gather.allgather(rec)
-    assert got.shape == (ranks.world, RECORD_BYTES * wl["C"]), got.shape
-    return int(got.shape[0] * wl["C"])
+    got = gather_raw(ranks.gather, [pack_chain_record(ch) for ch in wl["chains"]])
+    assert len(got) == ranks.world * wl["C"], len(got)
+    return len(got)
 
 
 def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
@@ -451,7 +450,7 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
         n_gathered = None
         total = done
         if ranks.world > 1:
-            n_gathered = int(D.gather_raw(ranks.gather, recs, chains).shape[0])
+            n_gathered = len(D.gather_raw(ranks.gather, recs))
             total = float(np.sum(ranks.gather.allgather(np.array([done], dtype=np.float64).view(np.uint8))
                                  .reshape(-1).view(np.float64)))
         return {"metric": "consumed MH proposals/s, native sampler, %d chains x batch %d per GPU" % (chains, batch),

@@ -174,8 +174,8 @@ class DeviceContext:
         _lib.check(self._L.bsr_place_info(_lib.ptr(pl)), self._h)
         return {"gpu_numa_node": int(pl[2]),"submit_threads": int(v[0]), "lib_cpus": int(v[1]), "caller_pinned": bool(v[2]),
                 "cpu_budget": v[3] / 100.0, "tape_groups": int(v[4]), "row_slices": int(v[5]),
-                "blocks_per_slice": int(v[6]), "slices_whole": int(v[7]) == 1, "streaming": int(v[7]) == 2,
-                "row_pass": {1: "k_tile1", 2: "k_stream"}.get(int(v[7]), "k_tile/k_rows")}
+                "blocks_per_slice": int(v[6]), "slices_whole": int(v[7]) in (1, 3), "streaming": int(v[7]) == 2,
+                "row_pass": {1: "k_tile1", 2: "k_stream", 3: "k_tile1a"}.get(int(v[7]), "k_tile/k_rows")}
 
     def last_timing(self):
         us = np.zeros(5, dtype=np.float64)

@@ -4,7 +4,8 @@ chains' accepted trees.
 A "chain" is one pass of the reference's restart loop (codes/bsr_class.py:99): fresh sigma, fresh K trees, no data
 flowing between chains except the final append to ROOTS/BETAS/trainERRS (codes/bsr_class.py:270-273).  Chain c runs
 on rank c % world with its own RNG stream (np.random.seed(seed_base + c)), so results do not depend on the world
-size.  The gather moves fixed-size records (K padded tapes + Beta + counters), tens of KB per rank: latency-bound.
+size.  The gather moves the chains' records -- K tapes at full length, Beta, counters, the whole RMSE history --
+in two collectives (sizes, then payloads): a few KB per rank for the trees the sampler visits, latency-bound.
 """
 import os
 
@@ -13,12 +14,10 @@ import numpy as np
 from .tape import NODE_DTYPE, flatten, unflatten
 
 MAX_K = 8
-RECORD_NODES = 255            # nodes kept per tree in a record (longer tapes are flagged, not sent)
-HEADER_I32 = 16 + MAX_K       # chain id, K, n_props, n_accept, n_errs, truncated, ... , tape lengths
+HEADER_I32 = 16 + MAX_K       # chain id, K, n_props, n_accept, n_errs, 0, rank rejects, discarded, 0, record bytes, ..., tape lengths
 HEADER_F64 = 4 + (MAX_K + 1)  # sigma, last rmse, best rmse, spare, Beta[K+1]
-ERRS_CAP = 1024               # per-accept RMSE history kept in a record (train_err_, codes/bsr_class.py:233, 270)
-RECORD_BYTES = HEADER_I32 * 4 + HEADER_F64 * 8 + ERRS_CAP * 8 + MAX_K * RECORD_NODES * NODE_DTYPE.itemsize
-assert RECORD_BYTES % 8 == 0
+HEADER_BYTES = HEADER_I32 * 4 + HEADER_F64 * 8
+assert HEADER_BYTES % 8 == 0
 
 
 def shard(n_chains, world, rank):
@@ -28,31 +27,32 @@ def shard(n_chains, world, rank):
 
 def pack_record(chain_id, roots, beta, sigma, errs, n_props, n_accept, n_rank_rejects=0, n_discarded=0,
                 tapes_in=None):
-    """One chain's outcome as RECORD_BYTES bytes (roots: Node trees, or tapes_in: their postfix tapes)."""
+    """One chain's outcome as bytes: a fixed header, then the WHOLE per-accept RMSE history (train_err_,
+    codes/bsr_class.py:233, 270) and the K trees' postfix tapes at their full length -- what ROOTS.append(Roots) keeps
+    (codes/bsr_class.py:270-273), whatever its size (roots: Node trees, or tapes_in: their tapes)."""
     K = len(roots) if tapes_in is None else len(tapes_in)
+    if K > MAX_K:
+        raise ValueError("a record holds at most %d trees" % MAX_K)
     hi = np.zeros(HEADER_I32, dtype=np.int32)
     hf = np.zeros(HEADER_F64, dtype=np.float64)
-    he = np.zeros(ERRS_CAP, dtype=np.float64)
-    tapes = np.zeros((MAX_K, RECORD_NODES), dtype=NODE_DTYPE)
-    hi[0], hi[1], hi[2], hi[3], hi[4] = chain_id, K, n_props, n_accept, len(errs)
+    he = np.ascontiguousarray(errs, dtype=np.float64).reshape(-1)
+    tapes = [np.ascontiguousarray(flatten(roots[k]) if tapes_in is None else tapes_in[k], dtype=NODE_DTYPE).reshape(-1)
+             for k in range(K)]
+    hi[0], hi[1], hi[2], hi[3], hi[4] = chain_id, K, n_props, n_accept, he.size
     hi[6], hi[7] = n_rank_rejects, n_discarded
-    hi[8] = 1 if len(errs) > ERRS_CAP else 0     # the RMSE history below is the LAST ERRS_CAP entries of a longer one
-    he[:min(len(errs), ERRS_CAP)] = np.asarray(errs, dtype=np.float64)[-ERRS_CAP:] if len(errs) else []
     for k in range(K):
-        t = flatten(roots[k]) if tapes_in is None else tapes_in[k]
-        if len(t) > RECORD_NODES:
-            hi[5] |= (1 << k)
-            hi[16 + k] = -len(t)
-        else:
-            hi[16 + k] = len(t)
-            tapes[k, :len(t)] = t
+        hi[16 + k] = len(tapes[k])
     hf[0] = sigma
-    hf[1] = errs[-1] if len(errs) else np.nan
-    hf[2] = min(errs) if len(errs) else np.nan
+    hf[1] = he[-1] if he.size else np.nan
+    hf[2] = he.min() if he.size else np.nan
     b = np.asarray(beta, dtype=np.float64).reshape(-1)
     hf[4:4 + len(b)] = b
-    out = np.concatenate([hi.view(np.uint8), hf.view(np.uint8), he.view(np.uint8), tapes.reshape(-1).view(np.uint8)])
-    assert out.size == RECORD_BYTES
+    total = HEADER_BYTES + he.size * 8 + sum(len(t) for t in tapes) * NODE_DTYPE.itemsize
+    if total >= 2 ** 31:
+        raise ValueError("chain record of %d bytes" % total)
+    hi[9] = total
+    out = np.concatenate([hi.view(np.uint8), hf.view(np.uint8), he.view(np.uint8)] + [t.view(np.uint8) for t in tapes])
+    assert out.size == total and total % 8 == 0
     return out
 
 
@@ -61,28 +61,69 @@ def pack_chain_record(chain):
     return pack_record(chain.index, chain.roots, chain.Beta, chain.sigma, chain.errs, chain.n_props, chain.n_accept)
 
 
+def record_bytes(buf):
+    """Length of the record that starts at buf[0] (from its header)."""
+    return int(np.ascontiguousarray(buf[:HEADER_I32 * 4], dtype=np.uint8).view(np.int32)[9])
+
+
 def unpack_record(buf):
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
-    assert buf.size == RECORD_BYTES
     ni = HEADER_I32 * 4
-    nf = HEADER_F64 * 8
-    ne = ERRS_CAP * 8
     hi = buf[:ni].view(np.int32)
-    hf = buf[ni:ni + nf].view(np.float64)
-    he = buf[ni + nf:ni + nf + ne].view(np.float64)
-    tapes = buf[ni + nf + ne:].view(NODE_DTYPE).reshape(MAX_K, RECORD_NODES)
-    K = int(hi[1])
-    roots, lens = [], []
+    hf = buf[ni:HEADER_BYTES].view(np.float64)
+    K, n_errs = int(hi[1]), int(hi[4])
+    assert buf.size >= int(hi[9]) >= HEADER_BYTES
+    at = HEADER_BYTES
+    he = buf[at:at + n_errs * 8].view(np.float64)
+    at += n_errs * 8
+    roots, lens, tapes = [], [], []
     for k in range(K):
         n = int(hi[16 + k])
+        t = buf[at:at + n * NODE_DTYPE.itemsize].view(NODE_DTYPE).copy()
+        at += n * NODE_DTYPE.itemsize
         lens.append(n)
-        roots.append(unflatten(tapes[k, :n]) if n > 0 else None)
-    return {"chain": int(hi[0]), "K": K, "n_props": int(hi[2]), "n_accept": int(hi[3]), "n_errs": int(hi[4]),
+        tapes.append(t)
+        roots.append(unflatten(t) if n > 0 else None)
+    assert at == int(hi[9])
+    return {"chain": int(hi[0]), "K": K, "n_props": int(hi[2]), "n_accept": int(hi[3]), "n_errs": n_errs,
             "n_rank_rejects": int(hi[6]), "n_discarded": int(hi[7]),
-            "errs": [float(v) for v in he[:min(int(hi[4]), ERRS_CAP)]], "errs_truncated": bool(hi[8]),
-            "truncated": int(hi[5]), "tape_len": lens, "sigma": float(hf[0]), "last_rmse": float(hf[1]),
-            "best_rmse": float(hf[2]), "beta": hf[4:4 + K + 1].copy().reshape(-1, 1), "roots": roots,
-            "tapes": [tapes[k, :max(0, lens[k])].copy() for k in range(K)]}
+            "errs": [float(v) for v in he], "errs_truncated": False,      # (both kept for callers of the fixed-size
+            "truncated": 0, "tape_len": lens, "sigma": float(hf[0]),      #  records of rounds 1-4: nothing is cut now)
+            "last_rmse": float(hf[1]), "best_rmse": float(hf[2]), "beta": hf[4:4 + K + 1].copy().reshape(-1, 1),
+            "roots": roots, "tapes": tapes}
+
+
+def split_records(payload):
+    """The records packed back to back in `payload` (uint8), in order."""
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    out, at = [], 0
+    while at + HEADER_BYTES <= payload.size:
+        n = record_bytes(payload[at:])
+        if n < HEADER_BYTES or at + n > payload.size:
+            raise ValueError("corrupt chain record at byte %d" % at)
+        out.append(payload[at:at + n])
+        at += n
+    if at != payload.size:
+        raise ValueError("%d stray bytes behind the last chain record" % (payload.size - at))
+    return out
+
+
+def save_records(path, recs):
+    """Records of any size in one .npz: the bytes back to back and where each one starts."""
+    sizes = np.array([r.size for r in recs], dtype=np.int64)
+    flat = np.concatenate(recs) if len(recs) else np.zeros(0, dtype=np.uint8)
+    with open(path, "wb") as f:
+        np.savez(f, bytes=flat, sizes=sizes)
+
+
+def load_records(path):
+    with np.load(path) as z:
+        flat, sizes = z["bytes"], z["sizes"]
+    out, at = [], 0
+    for n in sizes:
+        out.append(flat[at:at + int(n)])
+        at += int(n)
+    return out
 
 
 class RcclGather:
@@ -176,29 +217,33 @@ def allreduce_max(gather, value):
     return float(np.max(got.reshape(-1).view(np.float64)))
 
 
-def gather_raw(gather, local_records, chains_per_rank):
-    """local_records: list of packed records (padded to chains_per_rank with empty records).
-    Returns every rank's records as a uint8 array (n_chains, RECORD_BYTES) ordered by chain id."""
-    recs = list(local_records)
-    empty = np.zeros(RECORD_BYTES, dtype=np.uint8)
-    empty[:4] = np.array([-1], dtype=np.int32).view(np.uint8)
-    while len(recs) < chains_per_rank:
-        recs.append(empty)
-    got = gather.allgather(np.concatenate(recs))
+def gather_raw(gather, local_records, chains_per_rank=None):
+    """Every rank's records, ordered by chain id: a list of uint8 arrays (decode with unpack_record).
+
+    Two collectives, because a record is as long as its trees and its RMSE history are (a depth-12 tree has up to
+    8 191 nodes, BASELINE configs[4]): first every rank's payload size, then the payloads padded to the largest of
+    them -- what travels is proportional to what the chains hold, and nothing is cut (codes/bsr_class.py:270-276 keeps
+    whatever ROOTS.append(Roots) holds).  `chains_per_rank` is accepted for the callers of the fixed-size gather of
+    rounds 1-4 and not needed."""
+    recs = [np.ascontiguousarray(r, dtype=np.uint8) for r in local_records]
+    mine = np.concatenate(recs) if recs else np.zeros(0, dtype=np.uint8)
+    sizes = gather.allgather(np.array([mine.size], dtype=np.int64).view(np.uint8)).reshape(-1).view(np.int64)
+    widest = int(sizes.max()) if sizes.size else 0
+    if widest == 0:
+        return []
+    send = np.zeros((widest + 7) // 8 * 8, dtype=np.uint8)
+    send[:mine.size] = mine
+    got = gather.allgather(send)
     out = []
     for r in range(got.shape[0]):
-        for i in range(chains_per_rank):
-            rec = got[r, i * RECORD_BYTES:(i + 1) * RECORD_BYTES]
+        for rec in split_records(got[r, :int(sizes[r])]):
             cid = int(rec[:4].view(np.int32)[0])
             if cid >= 0:
-                out.append((cid, rec))
+                out.append((cid, rec.copy()))
     out.sort(key=lambda t: t[0])
-    return np.stack([rec for _, rec in out]) if out else np.zeros((0, RECORD_BYTES), dtype=np.uint8)
+    return [rec for _, rec in out]
 
 
-def gather_chains(gather, local_records, chains_per_rank):
+def gather_chains(gather, local_records, chains_per_rank=None):
     """gather_raw, unpacked: list of dicts ordered by chain id."""
-    raw = gather_raw(gather, local_records, chains_per_rank)
-    return [unpack_record(raw[i]) for i in range(raw.shape[0])]
-
-
+    return [unpack_record(r) for r in gather_raw(gather, local_records, chains_per_rank)]

@@ -21,8 +21,11 @@ from . import dist as D
 def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=-1, chains_per_launch=8,
              dtype="f64", y_is_series=True, max_props=-1, scorer=None, ops=None, op_weights=None):
     """Runs this rank's share of len(seeds) chains on `device` with the native sampler and gathers every rank's
-    records.  Returns (raw records of ALL chains ordered by chain id: uint8 (n_chains, RECORD_BYTES), decode with
-    bsr.dist.unpack_record; this rank's counters)."""
+    records.  Returns (raw records of ALL chains ordered by chain id: a list of uint8 arrays, decode with
+    bsr.dist.unpack_record; this rank's counters).
+
+    The rendezvous and the communicator come FIRST: a rank is "up" (bsr.launch.spawn's init_timeout) once it has
+    joined the node's gather, not once its chains are done -- a fit may take hours, joining may not."""
     from .chain import DeviceScorer
     from .native import NativeEngine
     X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
@@ -36,6 +39,7 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
     recs = []
     stats = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0, "chains": len(mine)}
     try:
+        gather, rdv = D.connect(scorer.ctx, rank, world)
         eng = NativeEngine(scorer.ctx, n_slots, X.shape[1], beta=beta, val=val, y_is_series=y_is_series)
         if ops is not None:
             eng.set_ops(ops, op_weights if op_weights is not None else [1.0 / len(ops)] * len(ops))
@@ -57,9 +61,7 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
                     stats["discarded"] += r["n_discarded"]
         finally:
             eng.close()
-        gather, rdv = D.connect(scorer.ctx, rank, world)
-        per_rank = (n_chains + world - 1) // world
-        allrecs = D.gather_raw(gather, recs, per_rank)
+        allrecs = D.gather_raw(gather, recs)
     finally:
         if own:
             scorer.close()
@@ -79,7 +81,7 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
         np.save(os.path.join(work, "X.npy"), np.ascontiguousarray(np.asarray(X, dtype=np.float64)))
         np.save(os.path.join(work, "y.npy"), np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1)))
         np.save(os.path.join(work, "seeds.npy"), np.asarray(seeds, dtype=np.int64))
-        out = os.path.join(work, "gathered.npy")
+        out = os.path.join(work, "gathered.npz")
         pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = {"PYTHONPATH": pkg_parent + os.pathsep + os.environ.get("PYTHONPATH", ""),
                "BSR_DEVICES": ",".join(str(int(d)) for d in devices)}
@@ -99,8 +101,7 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
             raise TimeoutError("bsr.sharded: %s (rank exit codes %r)" % (codes.reason, list(codes)))
         if any(c != 0 for c in codes):
             raise RuntimeError("bsr.sharded: rank exit codes %r" % (list(codes),))
-        raw = np.load(out)
-        return [D.unpack_record(raw[i]) for i in range(raw.shape[0])]
+        return [D.unpack_record(r) for r in D.load_records(out)]
     finally:
         for name in os.listdir(work):
             try:
@@ -116,7 +117,7 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
 def main(argv=None):
     ap = argparse.ArgumentParser(description="one rank of a sharded BSR fit (see fit_sharded)")
     ap.add_argument("--data", required=True, help="directory holding X.npy, y.npy, seeds.npy")
-    ap.add_argument("--out", required=True, help="rank 0 writes the gathered records here (.npy, uint8 [chains, bytes])")
+    ap.add_argument("--out", required=True, help="rank 0 writes the gathered records here (.npz: bsr.dist.load_records)")
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--val", type=int, default=100)
@@ -140,8 +141,8 @@ def main(argv=None):
                               ops=args.ops.split(",") if args.ops else None,
                               op_weights=[float(v) for v in args.op_weights.split(",")] if args.op_weights else None)
     if rank == 0:
-        tmp = args.out + ".tmp.npy"
-        np.save(tmp, allrecs)
+        tmp = args.out + ".tmp"
+        D.save_records(tmp, allrecs)
         os.replace(tmp, args.out)
     sys.stderr.write("bsr.sharded rank %d/%d on device %d: %d chains, %d proposals, %d accepts\n"
                      % (rank, world, device, stats["chains"], stats["proposals"], stats["accepts"]))

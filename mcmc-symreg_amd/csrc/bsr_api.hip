@@ -25,6 +25,7 @@
 thread_local std::string g_create_error;
 std::atomic<long long> g_ns_stage{0}, g_ns_desc{0}, g_ns_enq{0}, g_n_sub{0};
 std::atomic<long long> g_ns_issue{0}, g_n_issue{0}, g_ns_wait{0}, g_n_wait{0};
+std::atomic<long long> g_ns_part[12];   // issue_batch, piece by piece: host staging, upload, row pass, solve, residual pass, finalize + events, done event
 const bool g_host_prof = getenv("BSR_HOST_PROF") != nullptr;
 const bool g_stream_stats = getenv("BSR_STREAM_STATS") != nullptr;
 std::atomic<long long> g_ss_entries[2][16], g_ss_tapes[2], g_ss_batches{0}, g_ss_derived{0}, g_ss_cols{0};
@@ -84,6 +85,14 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
             g_ns_stage.load() / n * 1e-3, g_ns_desc.load() / n * 1e-3, g_ns_enq.load() / n * 1e-3, n,
             g_ns_issue.load() / std::max(1.0, (double)g_n_issue.load()) * 1e-3, (double)g_n_issue.load(),
             g_ns_wait.load() / std::max(1.0, (double)g_n_wait.load()) * 1e-3, (double)g_n_wait.load());
+    const double ni = std::max(1.0, (double)g_n_issue.load());
+    fprintf(stderr, "  issuing, piece by piece (us): staging on this thread %.2f, upload %.2f, row pass launch %.2f, k_solve launch %.2f, "
+            "residual pass launch %.2f, finalize / events launches %.2f, done event %.2f\n",
+            g_ns_part[0].load() / ni * 1e-3, g_ns_part[1].load() / ni * 1e-3, g_ns_part[2].load() / ni * 1e-3,
+            g_ns_part[3].load() / ni * 1e-3, g_ns_part[4].load() / ni * 1e-3, g_ns_part[5].load() / ni * 1e-3,
+            g_ns_part[6].load() / ni * 1e-3);
+    fprintf(stderr, "  staging on the issuing thread (us): mark_in_span %.2f, stage_tile %.2f, build_tile_launch %.2f\n",
+            g_ns_part[7].load() / ni * 1e-3, g_ns_part[8].load() / ni * 1e-3, g_ns_part[9].load() / ni * 1e-3);
   }
   if (g_stream_stats && g_ss_batches.load() > 0) {
     static const char* names[16] = {"inv", "ln", "neg", "sin", "cos", "exp", "square", "cubic", "add", "mul", "T", "add_T",
@@ -264,13 +273,18 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // 3 900 CU-us per batch: 11.7-11.9 instead of 12.7-13.3 us per pipelined step).  A launch narrower than the
       // machine leaves the other CUs to the batches behind it.
       const int long_bps = 8;   // (6, 5, 4 and 10 blocks per slice measured 1.2-2.4 us per step slower, interleaved in one box)
-      const int long_slices = c->tile_blocks / long_bps;
+      // slices of WHOLE blocks only (the block that holds row N, N not a multiple of 128, is a leftover unit -- the one place
+      // that masks rows): `whole` blocks dealt over the slices, the first `long` of them one block longer -- so a
+      // slice count that leaves no slice above long_bps blocks
+      const int whole = (int)(N / BSR_TILE_BLOCK);
+      const int long_slices = (whole + long_bps - 1) / long_bps;
       // (from 32 slices on: a short data set keeps the many short slices -- one batch at a time is what it is scored in)
       const bool long_ok = max_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
                            worst_cols * (size_t)long_bps * BSR_TILE_BLOCK * c->esz <= budget && !getenv("BSR_TILE_T") &&
                            env_int("BSR_TILE_LONG", 1);
       if (long_ok) c->tile_cus = long_slices;
-      auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, c->tile_blocks / sl); };
+      // blocks of the longest slice when `whole` blocks are dealt over tile_cus / t slices
+      auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, (whole + sl - 1) / sl); };
       auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
       // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):
       // the largest T in {4, 2, 1} with a tape per wave at most -- fewer tapes per wave and longer slices (fewer lane
@@ -303,22 +317,18 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       if (c->tile_whole && !fits_whole(T)) c->tile_whole = false;
       c->tile_T = T;
       c->tile_slices = std::max(1, c->tile_cus / T);
-      // every slice holds the same number of blocks; what is left behind the last slice (n_blocks mod n_slices blocks)
-      // goes out as single (tape, block) units dealt to the waves of the launch (bsr_tile.hip: leftover_units)
-      // ... of WHOLE blocks: the block that holds row N (N not a multiple of 128) is always a leftover unit, the only place
-      // that masks rows
-      c->tile_bps = (int)(N / BSR_TILE_BLOCK) / c->tile_slices;
-      c->tile_left = c->tile_blocks - c->tile_bps * c->tile_slices;
-      if (c->tile_stream) {
-        // every WHOLE block in a slice, the first tile_long slices one block longer; the block that holds row N (N not a
-        // multiple of 128) goes out as (tape, block) units behind the loop: nothing in the loop masks rows
-        const int whole = (int)(N / BSR_TILE_BLOCK);
-        c->tile_bps = whole / c->tile_slices;
-        c->tile_long = whole - c->tile_bps * c->tile_slices;
-        c->tile_left = c->tile_blocks - whole;
-      }
+      // every WHOLE block in a slice, the first tile_long slices one block longer (round 5: whole-slice contexts too --
+      // before, what n_blocks mod n_slices left behind the last slice went out as (tape, block) units through L2, 6 x 64
+      // of them at C2, and a data set whose block count was a multiple of the slice count while N was not a multiple of
+      // 128 lost a block per slice to them); the block that holds row N (N not a multiple of 128) goes out as (tape,
+      // block) units behind the loop: nothing in the loop masks rows
+      c->tile_bps = whole / c->tile_slices;
+      c->tile_long = whole - c->tile_bps * c->tile_slices;
+      c->tile_left = c->tile_blocks - whole;
       break;
     }
+    c->tile_asm = c->tile_whole && c->dtype == BSR_DTYPE_F64 && tile_asm_takes(K) && env_int("BSR_TILE_ASM", 1) != 0;
+    c->tile_split = env_int("BSR_TILE_SPLIT", 1) != 0;
     c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
                         (size_t)((max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax) + 1) + 64;
     if (!c->tile_whole && !getenv("BSR_DERIVED_MAX")) c->derived_max = 16;   // chunked: the transcendentals saved are worth more columns
@@ -595,6 +605,7 @@ struct TailJob {
   LaunchGeom g;
   bool scoring, maybe_tile;
   bool restage;   // false: a rescoring run over descriptors of the batch already staged (groups and streams stand)
+  bool deferred;  // the batch's staging itself (stage_submitted) still to be done, from the slot's copies of the inputs
   double rank_floor;
 };
 static void launcher_push(bsr_ctx* c, const TailJob& job);
@@ -618,8 +629,22 @@ static void mark_in_span(bsr_ctx* c, BatchSlot& s, int P) {
   }
 }
 
-static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
+static int stage_submitted(bsr_ctx* c, BatchSlot& s, int B, TailJob* job);
+static hipError_t use_device_fwd(const bsr_ctx* c);
+
+static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
   const long long t_issue0 = host_now();
+  TailJob j = j_in;
+  if (j.deferred) {
+    // the caller only validated and copied its inputs (bsr_internal_submit_mh): streams, descriptors and launch geometry
+    // here, in front of the launches, on this thread
+    const int rc0 = stage_submitted(c, s, j.P, &j);
+    if (rc0 != BSR_OK) {   // nothing was launched: the waiter sees the error
+      s.tail_rc = rc0;
+      s.tail_gen.store(s.tail_wanted, std::memory_order_release);
+      return rc0;
+    }
+  }
   hipStream_t st = s.stream;
   int rc = BSR_OK;
   auto step = [&](hipError_t e, const char* what) {
@@ -633,13 +658,22 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   bool tile = false;
   TileGeom tg;
   memset(&tg, 0, sizeof tg);
+  const long long tq0 = g_host_prof ? host_now() : 0;
   if (j.scoring && j.restage && c->selfdup) mark_in_span(c, s, j.P);
+  const long long tq1 = g_host_prof ? host_now() : 0;
+  long long tq2 = tq1;
   if (j.maybe_tile) {
     if (j.restage) stage_tile(c, s, j.P);
+    tq2 = g_host_prof ? host_now() : 0;
     if (s.tile) {
       rc = build_tile_launch(c, s, j.P, &tg);
       tile = rc == BSR_OK;
     }
+  }
+  if (g_host_prof) {
+    g_ns_part[7].fetch_add(tq1 - tq0, std::memory_order_relaxed);
+    g_ns_part[8].fetch_add(tq2 - tq1, std::memory_order_relaxed);
+    g_ns_part[9].fetch_add(host_now() - tq2, std::memory_order_relaxed);
   }
   const int n_part = tile ? tg.n_part : j.g.n_rb;   // partial records per proposal that k_solve reduces
   if (j.maybe_tile && !tile) {   // the work-queue pass after all: its order of the tapes
@@ -647,6 +681,14 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     cost_order(s.order_tmp, s.order_keys, j.P, [&](int i) { return hd[i].cost; });
     for (int i = 0; i < j.P; ++i) hd[i].order = s.order_tmp[i];
   }
+  long long t_part = g_host_prof ? host_now() : 0;
+  auto part = [&](int i) {
+    if (!g_host_prof) return;
+    const long long t = host_now();
+    g_ns_part[i].fetch_add(t - t_part, std::memory_order_relaxed);
+    t_part = t;
+  };
+  if (g_host_prof) g_ns_part[0].fetch_add(t_part - t_issue0, std::memory_order_relaxed);
   const size_t in_bytes = tile ? s.off_recs + s.recs_bytes : s.off_streams + (s.code_words + s.feat_words + s.ln_words) * 8;
   if (rc != BSR_OK) {   // nothing was launched: the waiter sees the error
     s.tail_rc = rc;
@@ -677,6 +719,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       step(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, s0), "hipMemcpyAsync");
     }
     s.stream_dirty = false;   // this batch's completion covers everything before it on the stream
+    part(1);
     if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
     if (tile) {
       const uint64_t* codes = s.d_streams();
@@ -691,6 +734,8 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         a.N = c->N; a.codes = codes; a.feats = feats_lds; a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched();
         a.part = s.part1; a.P = j.P; a.K = c->K; a.stamps = c->d_stamps;
         a.srec = s.tile_stream ? reinterpret_cast<const StreamRec*>(s.d_in + s.off_recs + s.srec_off) : nullptr;
+        a.tprog = (s.tprog_off != 0 && tg.per_group > 0) ? reinterpret_cast<const TileProg*>(s.d_in + s.off_recs + s.tprog_off) : nullptr;
+        a.split_stage = c->tile_split;
         for (int i = 0; i < 8; ++i) a.grp_nF[i] = s.grp_nF[i];
         // the groups' column tables inside the argument block: 128 pointers dealt to 1, 2 or 4 groups
         constexpr int n_arg = BSR_TILE_ARG_GROUPS * BSR_TILE_ARG_COLS;
@@ -707,6 +752,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
         TileArgs<double> a;
         fill(a);
         if (s.tile_stream) launch_stream(s0, a);
+        else if (a.tprog) launch_tile_asm(s0, a);
         else launch_tile<double>(s0, a);
       } else {
         TileArgs<float> a;
@@ -717,10 +763,12 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
       launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 0);
     }
     if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
+    part(2);
   }
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
   launch_solve(st, s.d_desc(), c->d_ck, j.P, n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
+  part(3);
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
   // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
   // registers for the solver (K <= 3) and the hand-over memory is uncached (ensure_partials): one launch fewer
@@ -734,6 +782,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
     }
     launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st, fuse_fin ? &fin : nullptr);
   }
+  part(4);
   if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
   if (j.scoring && !fuse_fin)
     launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
@@ -741,7 +790,9 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j) {
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
+  part(5);
   step(hipEventRecord(s.done, st), "hipEventRecord");
+  part(6);
   s.tail_rc = rc;
   if (g_host_prof) {
     g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
@@ -873,8 +924,8 @@ static void launcher_stop(bsr_ctx* c) {
   c->launcher = nullptr;
 }
 
-// Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
-static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage = true) {
+// The launch geometry, partial-record buffers and tape order of the P descriptors staged in slot `s`: what issue_batch needs.
+static int prepare_job(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage, TailJob* jobp) {
   PropDesc* hd = s.h_desc();
   int spill_slots = 0;
   for (int i = 0; i < P; ++i) spill_slots = std::max(spill_slots, hd[i].spill_need);
@@ -887,7 +938,6 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage =
     int rc0 = ensure_partials(c, s, gp, P, spill_slots);
     if (rc0 != BSR_OK) return rc0;
   }
-  int rc = BSR_OK;
   // work-queue order: heaviest tapes first (stable, so equal costs keep batch order); a batch that may take the tile
   // pass gets its order where that is decided (issue_batch)
   s.order_n = -1;
@@ -897,14 +947,23 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage =
   }
   const int nq = (hd[0].mode == BSR_MODE_SCORE) ? hd[0].nq : 0;
   s.timed = c->prof;  // the level in force when the batch was enqueued decides which events exist at wait time
-  TailJob job;
+  TailJob& job = *jobp;
   job.slot = (int)(&s - c->slot);
   job.P = P; job.g = g; job.spill_slots = spill_slots; job.nq = nq; job.scoring = scoring;
   job.maybe_tile = maybe_tile;
   job.restage = restage;
+  job.deferred = false;
   // f32 columns: an exact duplicate leaves a residual of a few eps_f32; keep the gate's verdict on those
   job.rank_floor = (c->dtype == BSR_DTYPE_F32) ? 32.0 * 1.1920929e-7 : 0.0;
   s.flag_par ^= 1;   // this batch's list of flagged proposals; its k_solve empties the other one
+  return BSR_OK;
+}
+
+// Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
+static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage = true) {
+  TailJob job;
+  int rc = prepare_job(c, s, P, scoring, restage, &job);
+  if (rc != BSR_OK) return rc;
   s.tail_rc = BSR_OK;
   s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
   // Seven HIP calls per batch cost the host more than staging the batch does.  A scoring batch is handed to the
@@ -1225,22 +1284,16 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
 // worker threads each own one).
 int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                         const int32_t* which_k, const double* sigma, int32_t B) {
-  return bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0);
+  return bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0, false);
 }
 
-int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
-                           const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
-                           const int32_t* mhflags, const int32_t* span_off, int32_t n_spans) {
-  if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
-  HIPCHK(c, hipSetDevice(c->device));
+// The staging of a submitted batch from the slot's copies of its inputs (rows_copy / off_copy / sub_*): streams and tape
+// groups (stage_tapes), descriptors, launch geometry.  On the caller's thread, or -- deferred -- on a submission thread in
+// front of the batch's launches (issue_batch).
+static int stage_submitted(bsr_ctx* c, BatchSlot& s, int B, TailJob* job) {
   const int K = c->K;
-  for (int i = 0; i < B; ++i) {
-    int rc = chain_ok(c, chain[i], which_k[i]);
-    if (rc != BSR_OK) return rc;
-    if (!c->ready[chain[i]]) return fail(c, BSR_E_STATE, "bsr_score_submit: chain not refreshed");
-  }
-  BatchSlot& s = c->slot[si];
-  if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
+  const int32_t* chain = s.sub_chain.data();
+  const int32_t* which_k = s.sub_k.data();
   std::vector<TapeLoc>& loc = s.loc_tmp;   // (kept with the slot: a fresh vector is an allocation per batch)
   const long long th0 = host_now();
   for (int32_t ch : s.batch_chains) s.chain_slot[ch] = -1;
@@ -1250,7 +1303,7 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
       s.chain_slot[chain[i]] = (int32_t)s.batch_chains.size();
       s.batch_chains.push_back(chain[i]);
     }
-  int rc = stage_tapes(c, s, rows, tape_off, B, &loc, (int)s.batch_chains.size());
+  int rc = stage_tapes(c, s, s.rows_copy.data(), s.off_copy.data(), B, &loc, (int)s.batch_chains.size());
   if (rc != BSR_OK) return rc;
   const long long th1 = host_now();
   PropDesc* hd = s.h_desc();
@@ -1265,36 +1318,11 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
     D->qbase = col_ptr(c, c->Q, (int64_t)chain[i] * K);
     D->zout = nullptr;
     D->qslot = 0;   // (tile pass: set with the tape's group by stage_tile)
-    D->s = c->h_ck[chain[i]].s_k[which_k[i]];
-    D->sigma = sigma[i];
-    // (whether the candidate lies in the span of its chain's current columns by construction -- D->self_dup -- is worked
-    // out where the batch's launches are issued, against the bases snapshotted here: mark_in_span)
-    if (c->selfdup) {
-      if (s.span_snap.size() != c->span.size()) s.span_snap.resize(c->span.size());
-      if (s.span_snap[chain[i]].get() != c->span[chain[i]].get()) s.span_snap[chain[i]] = c->span[chain[i]];
-    }
+    D->s = s.sub_s[i];   // the chain's prescale for tree k as it stood when the batch was submitted
+    D->sigma = s.sub_sigma[i];
   }
-  // keep the batch's tapes: bsr_commit makes one of them a current tree (its canonical form is needed then)
-  s.rows_copy.assign(rows, rows + tape_off[B]);
-  s.off_copy.assign(tape_off, tape_off + B + 1);
-  s.n_spans = 0;
-  if (n_spans > 0) {
-    if (!terms8 || !mhflags || !span_off || n_spans > B || span_off[0] != 0 || span_off[n_spans] != B)
-      return fail(c, BSR_E_ARG, "bsr_score_submit_mh: bad terms / flags / spans");
-    for (int j = 0; j < n_spans; ++j) {
-      if (span_off[j + 1] <= span_off[j]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: empty or unordered span");
-      for (int i = span_off[j]; i < span_off[j + 1]; ++i)
-        if (chain[i] != chain[span_off[j]]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: a span mixes chains");
-    }
-    memcpy(s.h_terms(), terms8, sizeof(double) * 8 * (size_t)B);
-    memcpy(s.h_mhflags(), mhflags, sizeof(int32_t) * (size_t)B);
-    memcpy(s.h_spans(), span_off, sizeof(int32_t) * ((size_t)n_spans + 1));
-    s.n_spans = n_spans;
-  }
-  s.scored = true;
-  ++s.gen;
   const long long th2 = host_now();
-  rc = enqueue(c, s, B, true);
+  rc = prepare_job(c, s, B, true, true, job);
   if (g_host_prof) {
     g_ns_stage.fetch_add(th1 - th0, std::memory_order_relaxed);
     g_ns_desc.fetch_add(th2 - th1, std::memory_order_relaxed);
@@ -1304,11 +1332,107 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
   return rc;
 }
 
+// `defer`: leave the staging to the submission thread that issues the batch's launches (a plain caller's thread is the
+// pipeline's bottleneck: 4.4 of its 9.5 us per batch were staging); the caller still validates every tape, so
+// an argument error comes back from the submit call itself.  What the deferred staging can still fail on (buffer
+// growth, a schedule beyond its capacity) surfaces at the wait, like a failed launch.
+int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
+                           const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
+                           const int32_t* mhflags, const int32_t* span_off, int32_t n_spans, bool defer) {
+  if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
+  HIPCHK(c, use_device_fwd(c));
+  for (int i = 0; i < B; ++i) {
+    int rc = chain_ok(c, chain[i], which_k[i]);
+    if (rc != BSR_OK) return rc;
+    if (!c->ready[chain[i]]) return fail(c, BSR_E_STATE, "bsr_score_submit: chain not refreshed");
+  }
+  BatchSlot& s = c->slot[si];
+  if (s.pending) return fail(c, BSR_E_STATE, "bsr_score_submit: every batch slot is in flight (wait first)");
+  if (!rows || !tape_off || B <= 0) return fail(c, BSR_E_ARG, "null tapes / empty batch");
+  if (B > c->max_batch) return fail(c, BSR_E_TOOBIG, "batch larger than max_batch");
+  if (tape_off[0] != 0) return fail(c, BSR_E_ARG, "tape_off[0] must be 0");
+  if (n_spans > 0) {
+    if (!terms8 || !mhflags || !span_off || n_spans > B || span_off[0] != 0 || span_off[n_spans] != B)
+      return fail(c, BSR_E_ARG, "bsr_score_submit_mh: bad terms / flags / spans");
+    for (int j = 0; j < n_spans; ++j) {
+      if (span_off[j + 1] <= span_off[j]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: empty or unordered span");
+      for (int i = span_off[j]; i < span_off[j + 1]; ++i)
+        if (chain[i] != chain[span_off[j]]) return fail(c, BSR_E_ARG, "bsr_score_submit_mh: a span mixes chains");
+    }
+  }
+  defer = defer && c->launcher != nullptr && n_spans <= 0;
+  if (defer) {   // (the staging validates as it goes; deferred, the caller still must)
+    for (int i = 0; i < B; ++i) {
+      int mx = 0;
+      int rc = check_tape(c, rows + tape_off[i], tape_off[i + 1] - tape_off[i], &mx);
+      if (rc != BSR_OK) return rc;
+    }
+  }
+  // keep the batch's inputs: the staging reads them (perhaps on another thread, when the caller's arrays may be gone),
+  // and bsr_commit makes one of the tapes a current tree (its canonical form is needed then)
+  s.rows_copy.assign(rows, rows + tape_off[B]);
+  s.off_copy.assign(tape_off, tape_off + B + 1);
+  s.sub_chain.assign(chain, chain + B);
+  s.sub_k.assign(which_k, which_k + B);
+  s.sub_sigma.assign(sigma, sigma + B);
+  s.sub_s.resize((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    s.sub_s[i] = c->h_ck[chain[i]].s_k[which_k[i]];
+    // (whether the candidate lies in the span of its chain's current columns by construction -- D->self_dup -- is worked
+    // out where the batch's launches are issued, against the bases snapshotted here: mark_in_span)
+    if (c->selfdup) {
+      if (s.span_snap.size() != c->span.size()) s.span_snap.resize(c->span.size());
+      if (s.span_snap[chain[i]].get() != c->span[chain[i]].get()) s.span_snap[chain[i]] = c->span[chain[i]];
+    }
+  }
+  s.n_spans = 0;
+  if (defer) {
+    s.scored = true;
+    ++s.gen;
+    TailJob job;
+    memset(&job, 0, sizeof job);
+    job.slot = si;
+    job.P = B;
+    job.scoring = true;
+    job.restage = true;
+    job.deferred = true;
+    s.tail_rc = BSR_OK;
+    s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
+    launcher_push(c, job);
+    s.P = B;
+    s.pending = true;
+    return BSR_OK;
+  }
+  TailJob job;
+  int rc = stage_submitted(c, s, B, &job);
+  if (rc != BSR_OK) return rc;
+  if (n_spans > 0) {
+    memcpy(s.h_terms(), terms8, sizeof(double) * 8 * (size_t)B);
+    memcpy(s.h_mhflags(), mhflags, sizeof(int32_t) * (size_t)B);
+    memcpy(s.h_spans(), span_off, sizeof(int32_t) * ((size_t)n_spans + 1));
+    s.n_spans = n_spans;
+  }
+  s.scored = true;
+  ++s.gen;
+  s.tail_rc = BSR_OK;
+  s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
+  if (c->launcher) {
+    launcher_push(c, job);
+  } else {
+    rc = issue_batch(c, s, job);
+    if (rc != BSR_OK) return rc;
+  }
+  s.P = B;
+  s.pending = true;
+  return BSR_OK;
+}
+
 extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                                 const int32_t* which_k, const double* sigma, int32_t B, int32_t* ticket) {
   if (!c || !chain || !which_k || !sigma || !ticket) return BSR_E_ARG;
   const int si = c->next_slot;
-  int rc = bsr_internal_submit(c, si, rows, tape_off, chain, which_k, sigma, B);
+  static const bool defer = env_int("BSR_DEFER_STAGE", 0) != 0;
+  int rc = bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0, defer);
   if (rc != BSR_OK) return rc;
   *ticket = si;
   c->next_slot = (si + 1) % BSR_MAX_INFLIGHT;
@@ -1316,8 +1440,16 @@ extern "C" int bsr_score_submit(bsr_ctx* c, const bsr_node* rows, const int32_t*
 }
 
 // Waits for slot `ticket` only and copies its scores out; touches no other slot and no context-wide state (K > 1).
+// the context's device for the calling thread: asked for only when another one is current (hipGetDevice reads a
+// thread-local; hipSetDevice takes the runtime's locks -- twice per batch on a caller whose thread is the pipeline's bound)
+static inline hipError_t use_device(const bsr_ctx* c) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == c->device) return hipSuccess;
+  return hipSetDevice(c->device);
+}
+
 int bsr_internal_wait(bsr_ctx* c, int ticket, bsr_score* out) {
-  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, use_device(c));
   BatchSlot& s = c->slot[ticket];
   if (!s.scored) return fail(c, BSR_E_STATE, "bsr_score_wait: nothing submitted under this ticket");
   int rc = wait_slot(c, s);
@@ -1333,15 +1465,17 @@ extern "C" int bsr_score_submit_mh(bsr_ctx* c, const bsr_node* rows, const int32
   if (!c || !chain || !which_k || !sigma || !ticket || n_spans <= 0) return BSR_E_ARG;
   if (c->K == 1) return fail(c, BSR_E_STATE, "bsr_score_submit_mh: treeNum = 1 rescoring needs the plain submit/wait pair");
   const int si = c->next_slot;
-  int rc = bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, terms8, flags, span_off, n_spans);
+  int rc = bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, terms8, flags, span_off, n_spans, false);
   if (rc != BSR_OK) return rc;
   *ticket = si;
   c->next_slot = (si + 1) % BSR_MAX_INFLIGHT;
   return BSR_OK;
 }
 
+static hipError_t use_device_fwd(const bsr_ctx* c) { return use_device(c); }
+
 int bsr_internal_wait_mh(bsr_ctx* c, int ticket, bsr_score* out, bsr_event* events) {
-  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, use_device(c));
   BatchSlot& s = c->slot[ticket];
   if (!s.scored || s.n_spans <= 0) return fail(c, BSR_E_STATE, "bsr_score_wait_mh: no MH batch under this ticket");
   int rc = wait_slot(c, s);
@@ -1526,7 +1660,7 @@ extern "C" int bsr_ctx_info(const bsr_ctx* c, int32_t* info8) {
   info8[4] = c->tile_T;
   info8[5] = c->tile_slices;
   info8[6] = c->tile_bps;
-  info8[7] = c->tile_whole ? 1 : (c->tile_stream ? 2 : 0);   // 1: whole slices in LDS (k_tile1), 2: streaming kernel, 0: chunked k_tile / k_rows
+  info8[7] = c->tile_whole ? (c->tile_asm ? 3 : 1) : (c->tile_stream ? 2 : 0);   // 1: whole slices in LDS (k_tile1), 3: the same with the tape loop in assembly (k_tile1a), 2: streaming kernel, 0: chunked k_tile / k_rows
   return BSR_OK;
 }
 

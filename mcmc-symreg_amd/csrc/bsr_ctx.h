@@ -51,6 +51,7 @@ struct BatchSlot {
   size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
   size_t recs_bytes = 0; // ... of which this batch uses so many bytes
   size_t srec_off = 0;   // streaming kernel: its StreamRecs, so many bytes behind off_recs
+  size_t tprog_off = 0;  // whole-slice kernel with the assembly tape loop: its TileProgs, so many bytes behind off_recs (0: none)
   // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
   MhRes* d_mh = nullptr;
   bsr_event* h_ev = nullptr;   // pinned, written by k_events
@@ -116,6 +117,8 @@ struct BatchSlot {
   uint64_t bar_readback = 0;         // (sink of the read that closes a BAR upload)
   std::vector<bsr_node> rows_copy;   // the scored batch's tapes (a commit makes one of them a current tree)
   std::vector<int32_t> off_copy;
+  std::vector<int32_t> sub_chain, sub_k;   // the submitted batch's chain / tree index / sigma per proposal, and the chain's
+  std::vector<double> sub_sigma, sub_s;    // prescale for that tree as it stood at the submit (the staging may run later)
   std::vector<int> order_tmp;    // the staged batch's tapes by cost, heaviest first (cost_order)
   std::vector<TapeLoc> loc_tmp;   // scratch of a submission
   std::vector<uint32_t> order_keys;
@@ -204,6 +207,8 @@ struct bsr_ctx {
   int tile_on = 1;
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
+  int tile_asm = 0;         // whole-slice fp64 contexts of K <= 4: the tape loop in assembly (bsr_tile_asm.hip; BSR_TILE_ASM=0: k_tile1)
+  int tile_split = 1;       // ... its staging in two halves (BSR_TILE_SPLIT=0: everything at the first barrier)
   bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
   bool tile_stream = false; // chunked fp64 context: the streaming kernel (bsr_stream.hip) with its own geometry -- every
   int tile_long = 0;        // block in a slice, the first tile_long slices one block longer, no leftover units

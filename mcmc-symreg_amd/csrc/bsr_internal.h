@@ -182,6 +182,19 @@ struct StreamRec {
 };
 static_assert(sizeof(StreamRec) == 32, "one scalar load per tape");
 
+// The whole-slice kernel's assembly tape loop (bsr_tile_asm.hip: k_tile1a) reads a tape as ONE 64-byte program, in the
+// group's cost order (entry i of a group's array = entry i of its list; one record of padding, p = -1, behind the last).
+struct TileProg {
+  int32_t meta;         // bit 31: the block of assembly takes the tape (a chain of at most 17 entries, 8 terminals in LDS
+                        // slots below 256, 2 ln nodes, no `log`); bits 0..7: LDS slot of the chain's first basis column
+  int32_t p;            // tape (proposal) index, -1: padding
+  double s;             // prescale of the candidate column
+  uint64_t code;        // the entries behind the leading terminal, 4 bits each: operator + 1, 0 behind the last
+  uint64_t slots;       // LDS slots of the terminals in stream order, 8 bits each (the leading terminal first)
+  double ln[4];         // the (a, b) pairs of the first two ln nodes
+};
+static_assert(sizeof(TileProg) == 64, "one scalar load per tape");
+
 template <typename T>
 struct TileArgs {
   TileGeom g;
@@ -199,6 +212,8 @@ struct TileArgs {
   const PropDesc* desc;
   const TapeRec* sched;       // [T][n_pass][BSR_TILE_WAVES][qmax] the waves' tapes (host: cost-balanced)
   const StreamRec* srec;      // the same schedule as StreamRecs (streaming kernel), else null
+  const TileProg* tprog;      // whole-slice kernel with the assembly tape loop: [T][per_group + 1] programs, else null
+  int split_stage;            // ... its staging in two halves (0: everything at the first barrier, as k_tile1 stages)
   double* part;               // [P][n_part][BSR_P1_WORDS]
   int P;
   int K;
@@ -210,8 +225,10 @@ struct TileArgs {
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
 void launch_stream(hipStream_t st, const TileArgs<double>& a);   // bsr_stream.hip: fp64 slices that stream through LDS
+void launch_tile_asm(hipStream_t st, const TileArgs<double>& a); // bsr_tile_asm.hip: whole slices, tape loop in assembly (a.tprog)
 #endif
 size_t tile_lds_bytes_max();
+bool tile_asm_takes(int K);       // the assembly tape loop is written for these K (fp64, whole-slice contexts)
 int tile_qmax(int K);
 size_t stream_ln_bytes(int qt);   // LDS the streaming kernel needs behind its ring
 int stream_qmax(int K);
@@ -233,7 +250,8 @@ __attribute__((visibility("hidden"))) int bsr_internal_submit(bsr_ctx* c, int sl
 __attribute__((visibility("hidden"))) int bsr_internal_wait(bsr_ctx* c, int slot, bsr_score* out);
 __attribute__((visibility("hidden"))) int bsr_internal_submit_mh(bsr_ctx* c, int slot, const bsr_node* rows, const int32_t* tape_off,
                            const int32_t* chain, const int32_t* which_k, const double* sigma, int32_t B,
-                           const double* terms8, const int32_t* flags, const int32_t* span_off, int32_t n_spans);
+                           const double* terms8, const int32_t* flags, const int32_t* span_off, int32_t n_spans,
+                           bool defer = false);
 __attribute__((visibility("hidden"))) int bsr_internal_wait_mh(bsr_ctx* c, int slot, bsr_score* out, bsr_event* events);
 __attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int slot, int32_t chain, int32_t k, int32_t idx);
 __attribute__((visibility("hidden"))) void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi);

@@ -143,7 +143,7 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
       std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
     }
     const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
-    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps) * BSR_TILE_BLOCK * c->esz);
+    size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps + (c->tile_long > 0 ? 1 : 0)) * BSR_TILE_BLOCK * c->esz);
     long room = (long)fit - fixed;
     if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
     // (streaming contexts too: trading derived columns for a deeper LDS ring -- 3 buffers instead of 2 in the batches
@@ -261,7 +261,8 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     lw += (size_t)nl + 1;
   }
   const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t) +
-                            (c->tile_stream ? (c->tile_sched_cap + 2) * sizeof(StreamRec) : 0)) / 8 + 32;
+                            (c->tile_stream ? (c->tile_sched_cap + 2) * sizeof(StreamRec) : 0) +
+                            (c->tile_asm ? ((size_t)c->tile_T * (c->max_batch + 1) + 2) * sizeof(TileProg) : 0)) / 8 + 32;
   int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw + rec_words);
   if (rc != BSR_OK) return rc;
   s.off_recs = (s.off_streams + (cw + 2 * fw + 2 * lw) * 8 + 127) / 128 * 128;
@@ -514,8 +515,9 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       if (!s.tile_stream) { chunk = 0; ring = 1; }
     }
     if (s.tile_stream) {
-    } else if (per_block * (size_t)(c->tile_bps + (c->tile_long > 0 ? 1 : 0)) <= budget && (force_chunk <= 0 || force_chunk >= c->tile_bps)) {
-      chunk = c->tile_bps;
+    } else if (per_block * (size_t)(c->tile_bps + (c->tile_long > 0 ? 1 : 0)) <= budget &&
+               (force_chunk <= 0 || force_chunk >= c->tile_bps + (c->tile_long > 0 ? 1 : 0))) {
+      chunk = c->tile_bps + (c->tile_long > 0 ? 1 : 0);   // the whole slice, the longest one's blocks per column
     } else if (c->esz == 4) {   // f32: one buffer, staged through registers
       chunk = (int)std::min<size_t>((size_t)c->tile_bps, budget / per_block);
       if (chunk >= BSR_TILE_NB) chunk = chunk / BSR_TILE_NB * BSR_TILE_NB;
@@ -593,7 +595,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
     const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
     if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
     TapeRec* sc = s.h_sched();
-    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps ? most : 0;   // whole slice: the waves pull from the group's list
+    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps + (tg.n_long > 0 ? 1 : 0) ? most : 0;   // whole slice: the waves pull from the group's list
     s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
     for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
     int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)
@@ -717,6 +719,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       }
       s.recs_bytes = s.srec_off + (n_sched + 1) * sizeof(StreamRec);
     }
+    s.tprog_off = 0;
     if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded
       int32_t* glist = left_idx + P;
       for (size_t i = 0; i < (size_t)tg.T * tg.per_group; ++i) glist[i] = -1;
@@ -724,6 +727,54 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       for (int i = 0; i < P; ++i) {
         const int grp = hd[s.order_tmp[i]].grp;
         glist[(size_t)grp * tg.per_group + fill[grp]++] = left_idx[i];
+      }
+      if (c->tile_asm) {
+        // the assembly tape loop's 64-byte programs (bsr_tile_asm.h), entry i of a group's array = entry i of its list,
+        // one record of padding behind the last: what the block takes is a tape that holds at most one value below the
+        // accumulator and whose entries behind the leading terminal fit one 64-bit word as operator + 1 (0 ends the tape; `log` would need 16), with its terminals'
+        // slots in one word of bytes and at most two ln nodes
+        s.tprog_off = (s.recs_bytes + 63) / 64 * 64;
+        TileProg* tp = reinterpret_cast<TileProg*>(reinterpret_cast<char*>(sc) + s.tprog_off);
+        const size_t n_prog = (size_t)tg.T * (tg.per_group + 1);
+        for (size_t gi = 0; gi < (size_t)tg.T; ++gi) {
+          for (int i = 0; i <= tg.per_group; ++i) {
+            TileProg& Q = tp[gi * (tg.per_group + 1) + i];
+            memset(&Q, 0, sizeof Q);
+            Q.p = -1;
+            const int32_t ri = i < tg.per_group ? glist[gi * tg.per_group + i] : -1;
+            if (ri < 0) continue;
+            const TapeRec& R = sc[ri];
+            bool fast = ((R.chain & 1) != 0 || hd[R.p].max_sp <= 2) && R.n_nodes <= 17 && R.n_term <= 8 && R.n_ln <= 2 &&
+                        tg.ncols < 256 && R.qslot < 256;
+            static const int asm_mode = env_int("BSR_TILE_ASM", 1);   // (2: test hook -- every tape back to the C++ interpreter)
+            if (asm_mode == 2) fast = false;
+            uint64_t enc = 0;
+            for (int e = 1; fast && e < R.n_nodes; ++e) {
+              const uint64_t w = e < 16 ? R.code0 : R.code1;
+              const int op = (int)((w >> (4 * (e & 15))) & 15u);
+              if (op == BSR_OP_LOG) fast = false;
+              enc |= (uint64_t)((op + 1) & 15) << (4 * (e - 1));
+            }
+            uint64_t slots = 0;
+            for (int t = 0; t < 8 && t < R.n_term; ++t) {
+              const uint64_t w = (t < 4) ? R.f0 : R.f1;
+              slots |= ((w >> (16 * (t & 3))) & 0xFFu) << (8 * t);
+            }
+            static const int astats = env_int("BSR_ASM_STATS", 0);   // diagnostics: what the block of assembly does not take
+            if (astats) {
+              static std::atomic<long> n_all{0}, n_fast{0}, n_stack{0};
+              const long a = ++n_all, f = n_fast += fast ? 1 : 0, st = n_stack += (R.chain & 1) ? 0 : 1;
+              if (a % 6400 == 0) fprintf(stderr, "tile asm: %ld tapes, %ld for the block, %ld not chains\n", a, f, st);
+            }
+            Q.meta = (fast ? (int32_t)0x80000000 : 0) | (R.qslot & 0xFF);
+            Q.p = R.p;
+            Q.s = R.s;
+            Q.code = fast ? enc : 0;
+            Q.slots = slots;
+            for (int t = 0; t < 4; ++t) Q.ln[t] = R.ln[t];
+          }
+        }
+        s.recs_bytes = s.tprog_off + n_prog * sizeof(TileProg);
       }
     }
   }

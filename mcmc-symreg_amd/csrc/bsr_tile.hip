@@ -264,8 +264,9 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1(TileArgs<T> 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tg = blockIdx.x / g.n_slices, slice = blockIdx.x - tg * g.n_slices;
-  const int b0 = slice * g.bps;
-  const int nb = g.bps;
+  // slices of bps whole blocks, the first n_long of them one more (LDS holds the longest: chunk_blocks per column)
+  const int b0 = slice * g.bps + min(slice, g.n_long);
+  const int nb = g.bps + (slice < g.n_long ? 1 : 0);
   const int chunk_rows = g.chunk_blocks * BSR_TILE_BLOCK;
   const T* const CONSTANT_AS* colsrc = group_cols<T>(a, tg);
   const int y_slot = a.grp_nF[tg & 7];

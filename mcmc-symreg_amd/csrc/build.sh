@@ -9,7 +9,7 @@ obj="$here/build"
 mkdir -p "$obj"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -structurizecfg-skip-uniform-regions=true
        -Wall -Wno-unused-function -Wno-inline-asm ${BSR_EXTRA_FLAGS:-})
-srcs=(bsr_tile bsr_stream bsr_kernels bsr_api bsr_stage bsr_place bsr_comm bsr_engine bsr_refresh)
+srcs=(bsr_tile bsr_tile_asm bsr_stream bsr_kernels bsr_api bsr_stage bsr_place bsr_comm bsr_engine bsr_refresh)
 pids=()
 for s in "${srcs[@]}"; do
   [ -f "$here/$s.hip" ] || continue

@@ -90,7 +90,7 @@ def test_record_roundtrip():
     g = load_golden("g2_grow.json")
     roots = [node_from_spec(c["tree"]) for c in g["cases"][:3]]
     rec = D.pack_record(7, roots, np.arange(4.0), 0.5, [1.0, 0.7], 123, 2)
-    assert rec.size == D.RECORD_BYTES
+    assert rec.size == D.record_bytes(rec)
     u = D.unpack_record(rec)
     assert u["chain"] == 7 and u["K"] == 3 and u["n_props"] == 123 and u["n_accept"] == 2
     assert [Express(t) for t in u["roots"]] == [Express(t) for t in roots]

@@ -42,7 +42,7 @@ def test_config4_share_equals_single_chain_runs_and_the_oracle():
     K, val = 3, 40
     seeds = [1000 + c for c in range(8)]
     raw, stats = run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=val, chains_per_launch=8)
-    together = [D.unpack_record(raw[i]) for i in range(raw.shape[0])]
+    together = [D.unpack_record(r) for r in raw]
     assert [r["chain"] for r in together] == list(range(8))
     assert stats["proposals"] == sum(r["n_props"] for r in together) and stats["chains"] == 8
     for c in range(8):

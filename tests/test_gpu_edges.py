@@ -359,7 +359,7 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
 
     def run(env):
         for k in ("BSR_TILE", "BSR_TILE_CHUNK", "BSR_TILE_RING", "BSR_TILE_T", "BSR_DERIVED", "BSR_SUBMIT_THREAD",
-                  "BSR_SELFDUP", "BSR_AUX_CUS", "BSR_BAR_WRITE", "BSR_CHAIN_EVAL", "BSR_REORDER"):
+                  "BSR_SELFDUP", "BSR_AUX_CUS", "BSR_BAR_WRITE", "BSR_CHAIN_EVAL", "BSR_REORDER", "BSR_TILE_ASM", "BSR_TILE_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -371,6 +371,10 @@ def test_tile_pass_variants_and_derived_columns_agree_to_the_bit(N, d, K, monkey
         c.close()
         return out
     base = run({})
+    # the tape loop in assembly (k_tile1a: the default for whole slices at K <= 4) against the compiler's k_tile1, and its
+    # staging in two halves against everything at the first barrier
+    assert run({"BSR_TILE_ASM": "0"}).tobytes() == base.tobytes()
+    assert run({"BSR_TILE_SPLIT": "0"}).tobytes() == base.tobytes()
     # chain tapes through the stack machine (two blocks per pass) instead of the register-resident pass; operands of
     # + and * in tape order instead of fusing order: the same value for every row, the same sums
     assert run({"BSR_CHAIN_EVAL": "0"}).tobytes() == base.tobytes()

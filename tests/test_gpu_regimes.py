@@ -36,9 +36,9 @@ def bi(op, l, r):
 
 # (name, N, d, K, chains, max_batch, dtype) -> expected (row_pass, tape_groups, row_slices, blocks_per_slice)
 CASES = [
-    ("C2", 100_000, 10, 3, 1, 64, "f64", ("k_tile1", 1, 97, 8)),
+    ("C2", 100_000, 10, 3, 1, 64, "f64", ("k_tile1a", 1, 98, 7)),
     ("C3", 100_000, 10, 8, 1, 64, "f64", ("k_tile1", 1, 192, 4)),
-    ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1", None, None, None)),
+    ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1a", None, None, None)),
     ("C5", 1_000_000, 50, 3, 1, 64, "f64", ("k_stream", 1, 256, 30)),
     ("C5 f32", 1_000_000, 50, 3, 1, 64, "f32", ("k_tile/k_rows", None, None, None)),
 ]
@@ -56,7 +56,7 @@ def test_the_regime_each_baseline_config_selects(name, N, d, K, chains, max_batc
         for key, w in zip(("tape_groups", "row_slices", "blocks_per_slice"), want[1:]):
             if w is not None:
                 assert info[key] == w, (name, key, info)
-        assert info["streaming"] == (want[0] == "k_stream") and info["slices_whole"] == (want[0] == "k_tile1")
+        assert info["streaming"] == (want[0] == "k_stream") and info["slices_whole"] == (want[0] in ("k_tile1", "k_tile1a"))
         # ... and the kernel runs: one batch through it
         pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cos', leaf(4)),
                 un('cubic', leaf(5)), bi('+', leaf(6), leaf(7)), un('inv', un('ln', un('square', leaf(8)), 1.0, 1.0)),

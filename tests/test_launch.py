@@ -37,16 +37,40 @@ WORKER = textwrap.dedent('''
         tape[0] = (10, -1, -1, c %% 3, 0.0, 0.0)
         recs.append(D.pack_record(c, None, np.arange(3.0) + c, 0.5 + c, [1.0 / (c + 1)] * c, 100 + c, c, 7, 9,
                                   tapes_in=[tape, tape]))
-    raw = D.gather_raw(g, recs, (n_chains + world - 1) // world)
-    out = [D.unpack_record(raw[i]) for i in range(raw.shape[0])]
+    # ... one of them as large as the reference's restart loop can make it: a depth-12 comb of 8 191 nodes and a
+    # 2 000-entry RMSE history (codes/bsr_class.py:270-276 keeps whatever ROOTS.append(Roots) holds)
+    big_tape = None
+    if 3 in D.shard(n_chains, world, rank):
+        from bsr.node import Node
+        from bsr.tape import flatten
+        def full(depth):
+            if depth == 12:
+                n = Node(depth); n.type = 0; n.feature = np.array([depth %% 3]); return n
+            n = Node(depth); n.type, n.operator = 2, '+' if depth %% 2 else '*'
+            n.left, n.right = full(depth + 1), full(depth + 1)
+            n.left.parent = n.right.parent = n
+            return n
+        big_tape = flatten(full(0))
+        assert len(big_tape) == 8191
+        recs[[int(r[:4].view(np.int32)[0]) for r in recs].index(3)] = D.pack_record(
+            3, None, np.arange(3.0) + 3, 3.5, list(np.linspace(9.0, 1.0, 2000)), 103, 3, 7, 9, tapes_in=[big_tape, big_tape[:1]])
+    raw = D.gather_raw(g, recs)
+    out = [D.unpack_record(r) for r in raw]
     assert [r["chain"] for r in out] == list(range(n_chains))
+    assert out[3]["tape_len"] == [8191, 1] and out[3]["n_errs"] == 2000 and len(out[3]["errs"]) == 2000
+    assert out[3]["errs"] == [float(v) for v in np.linspace(9.0, 1.0, 2000)] and not out[3]["errs_truncated"]
+    if big_tape is not None:
+        assert out[3]["tapes"][0].tobytes() == big_tape.tobytes()
+    from bsr.node import Express
+    assert Express(out[3]["roots"][0]).count("x[") == 4096
+    out[3]["errs"] = [1.0 / 4] * 3       # (the checks below: the small record's values)
     for c, r in enumerate(out):
         assert r["n_props"] == 100 + c and r["n_accept"] == c and r["n_rank_rejects"] == 7 and r["n_discarded"] == 9
         assert r["errs"] == [1.0 / (c + 1)] * c and r["sigma"] == 0.5 + c
         assert np.array_equal(r["beta"].reshape(-1), np.arange(3.0) + c)
         assert int(r["tapes"][0]["feature"][0]) == c %% 3
     if rank == 0:
-        print("DIGEST", hashlib.sha1(raw.tobytes()).hexdigest())
+        print("DIGEST", hashlib.sha1(b"".join(r.tobytes() for r in raw)).hexdigest())
 ''')
 
 
@@ -83,11 +107,12 @@ def test_record_keeps_the_rmse_history_and_counters():
     tape[0] = (10, -1, -1, 1, 0.0, 0.0)
     tape[1] = (10, -1, -1, 0, 0.0, 0.0)
     tape[2] = (9, 0, 1, 0, 0.0, 0.0)
-    errs = list(np.linspace(2.0, 1.0, 1500))                 # longer than the record keeps: the tail survives
+    errs = list(np.linspace(2.0, 1.0, 1500))                 # the whole history travels, whatever its length
     rec = D.pack_record(3, None, [0.1, 0.2], 0.7, errs, 5000, 1500, 11, 22, tapes_in=[tape])
+    assert rec.size == D.record_bytes(rec) == D.HEADER_BYTES + 1500 * 8 + 3 * D.NODE_DTYPE.itemsize
     u = D.unpack_record(rec)
-    assert u["n_errs"] == 1500 and len(u["errs"]) == D.ERRS_CAP and u["errs"][-1] == 1.0
-    assert u["errs"] == [float(v) for v in errs[-D.ERRS_CAP:]]
+    assert u["n_errs"] == 1500 and len(u["errs"]) == 1500 and u["errs"][-1] == 1.0
+    assert u["errs"] == [float(v) for v in errs]
     assert (u["n_rank_rejects"], u["n_discarded"], u["K"]) == (11, 22, 1)
     from bsr.node import Express
     assert Express(u["roots"][0]) == "(x[1])*(x[0])"
@@ -203,14 +228,35 @@ def test_comm_entry_points_reject_bad_arguments_without_a_device():
     assert L.bsr_comm_unique_id(None) == -1
 
 
-def test_record_flags_a_truncated_rmse_history():
+def test_records_of_any_size_survive_the_gather_and_the_file(tmp_path):
+    """Nothing is cut: a long RMSE history and a long tape come back whole through split_records (what a rank's payload
+    is parsed with), through a world-of-one gather, and through the .npz a sharded fit hands its parent."""
     sys.path.insert(0, PKG)
     from bsr import dist as D
     tape = np.zeros(1, dtype=D.NODE_DTYPE)
     tape[0] = (10, -1, -1, 0, 0.0, 0.0)
-    long = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, list(range(D.ERRS_CAP + 5)), 10, 5, tapes_in=[tape]))
-    short = D.unpack_record(D.pack_record(0, None, [0.1, 0.2], 0.7, [1.0, 2.0], 10, 2, tapes_in=[tape]))
-    assert long["errs_truncated"] and not short["errs_truncated"]
+    long_tape = np.zeros(5001, dtype=D.NODE_DTYPE)
+    long_tape[0] = (10, -1, -1, 1, 0.0, 0.0)
+    for i in range(1, 5001, 2):                          # x1, then 2 500 times `x0 +`: a comb 2 501 deep
+        long_tape[i] = (10, -1, -1, 0, 0.0, 0.0)
+        long_tape[i + 1] = (8, i - 1, i, 0, 0.0, 0.0)
+    recs = [D.pack_record(0, None, [0.1, 0.2], 0.7, list(range(5000)), 10, 5, tapes_in=[tape]),
+            D.pack_record(1, None, [0.1, 0.2], 0.7, [1.0, 2.0], 10, 2, tapes_in=[long_tape]),
+            D.pack_record(2, None, [0.3, 0.4], 0.9, [], 0, 0, tapes_in=[tape])]
+    got = D.split_records(np.concatenate(recs))
+    assert [g.tobytes() for g in got] == [r.tobytes() for r in recs]
+    with pytest.raises(ValueError):
+        D.split_records(np.concatenate(recs)[:-8])
+    out = D.gather_chains(D.SoloGather(), recs[::-1])
+    assert [o["chain"] for o in out] == [0, 1, 2]
+    assert out[0]["errs"] == [float(v) for v in range(5000)] and not out[0]["errs_truncated"] and out[0]["truncated"] == 0
+    assert out[1]["tape_len"] == [5001] and out[1]["tapes"][0].tobytes() == long_tape.tobytes()
+    assert out[2]["errs"] == [] and np.isnan(out[2]["last_rmse"])
+    path = str(tmp_path / "g.npz")
+    D.save_records(path, recs)
+    assert [r.tobytes() for r in D.load_records(path)] == [r.tobytes() for r in recs]
+    D.save_records(path, [])
+    assert D.load_records(path) == []
 
 
 def test_a_rank_whose_communicator_fails_ends_the_job_with_its_error_text(tmp_path):

@@ -20,7 +20,7 @@ for i in range(1, 5):
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
         if "k_tile" not in k and "k_stream" not in k: continue
-        import re as _re; k = (_re.search(r"k_(tile1?|stream)<[^>]*>", k) or _re.search(r".{0,60}$", k)).group(0)
+        import re as _re; k = (_re.search(r"k_(tile1a|tile1|tile|stream)<[^>]*>", k) or _re.search(r".{0,60}$", k)).group(0)
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (k, r["Dispatch_Id"])
         if key not in seen: seen.add(key); n[k] += 1

@@ -3,7 +3,7 @@
 # usage: bash tools/timeline.sh [bench args...]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/tl
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 200 --warmup 20 --cpu-sample 0 --extras 0 --min-time 0 "$@" > gpurun_out/tl_bench.json 2> gpurun_out/tl.err
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 400 --warmup 20 --cpu-sample 0 --extras 0 --min-time 0 "$@" > gpurun_out/tl_bench.json 2> gpurun_out/tl.err
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/tl/*/*kernel_trace.csv")[0]
@@ -45,7 +45,25 @@ for t, d, k in pts:
 tot = (t1 - t0)
 print("share of the window: idle %.1f%%, only small kernels %.1f%%, one row pass alone %.1f%%, row pass + small kernels %.1f%%, two or more row passes %.1f%%"
       % (100 * idle / tot, 100 * only_small / tot, 100 * tile_alone / tot, 100 * tile_plus_small / tot, 100 * tile_multi / tot))
-print("sample (us from window start):")
+# how much of the machine the row passes hold: their workgroups take a whole CU each (grid size from the trace)
+wg = {}
+for r in rows:
+    n = r["Kernel_Name"]
+    if "k_tile" in n or "k_stream" in n:
+        try:
+            wg[int(r["Start_Timestamp"])] = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+        except Exception:
+            pass
+cu_us = sum(((e - s) / 1e3) * wg.get(s, 97) for s, e, k, q in sel if k == "tile")
+print("row passes: %.0f CU-us per batch (launch duration x workgroups), %.1f%% of 256 CUs x window" % (cu_us / n_tile, 100 * cu_us / (256 * span)))
+# row passes in flight, launch by launch: start, end, how many other row passes overlap it
+tl = [(s, e) for s, e, k, q in sel if k == "tile"]
+print("consecutive row passes (us from window start): start -> end, others in flight at its start / overlapping it at all")
+for i, (s, e) in enumerate(tl[:220]):
+    at_start = sum(1 for s2, e2 in tl if s2 < s < e2)
+    overl = sum(1 for s2, e2 in tl if (s2, e2) != (s, e) and s2 < e and e2 > s)
+    print("   %4d  %9.2f -> %9.2f   %d / %d" % (i, (s - t0) / 1e3, (e - t0) / 1e3, at_start, overl))
+print("sample of all kernels (us from window start):")
 for s, e, k, q in sel[:24]:
     print("   %8.2f -> %8.2f  %-9s queue %s" % ((s - t0) / 1e3, (e - t0) / 1e3, k, q))
 PY
