@@ -90,7 +90,10 @@ inline bool pick_cpus(const std::string& root, const char* bdf, const cpu_set_t&
   }
   if (doms.empty()) return false;
   size_t pickd;
-  if (lw > 1 && lr >= 0) pickd = (size_t)lr % doms.size();
+  // GPU's node known: the node's domains in order, one per rank whose GPU sits there.  Unknown (sysfs says -1: common in
+  // VMs and containers): the pool is every allowed CPU, and the ranks are dealt evenly over ALL its domains -- rank lr
+  // mod their number would pack a node's ranks onto the first domains of socket 0.
+  if (lw > 1 && lr >= 0) pickd = numa >= 0 ? (size_t)lr % doms.size() : ((size_t)lr * doms.size()) / (size_t)lw % doms.size();
   else pickd = cur_dom >= 0 ? (size_t)cur_dom : 0;
   *out = doms[pickd];
   return CPU_COUNT(out) >= 4;   // fewer is not worth it (and a submission thread needs a core of its own)

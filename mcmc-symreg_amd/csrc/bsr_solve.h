@@ -1,0 +1,509 @@
+// The per-proposal small algebra shared by k_solve / k_finalize / the fused finalise step (bsr_kernels.hip) and the row
+// pass that solves a proposal itself when its last partial record has landed (bsr_tile_asm.hip): rank gate, ridge OLS,
+// SSE and log-likelihood of codes/funcs.py:1147-1174, 1226 from the O(N) sums of the row pass.
+#pragma once
+#include "bsr_device.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-proposal small algebra.  One wave per proposal.
+//
+// The chain keeps ONE orthonormal basis of its K current columns, O_j d_j = sum_i Q_i R_ij (d_j: power-of-two column
+// prescales).  A proposal replaces tree k by the candidate z.  With s the candidate's prescale, c = Q^T (s z),
+// w = s z - Q c (orthogonal to Q, |w| = rho):
+//   s * new_outputs = [Q, w/rho] S,   S = [[R_{-k} (s/d), c], [0, rho]]      ((K+1) x K: R without column k)
+// (columns: siblings ascending, then the candidate).  [Q, w/rho] has orthonormal columns, so the singular values of S
+// are those of s*new_outputs (rank gate, codes/funcs.py:1226), and with XX = new_outputs/scale = [Q, w/rho] (tau S),
+// tau = 1/(s*scale), h = [Q^T y, w.y/rho], S = U Sigma V^T (one-sided Jacobi on the K columns of length K+1):
+//   Beta = V (tau Sigma)/(tau^2 Sigma^2 + 1e-6) U^T h                  (ridge OLS, codes/funcs.py:1151-1155)
+//   SSE  = (|y_perp|^2 - (w.y/rho)^2) + | h - U diag(d_m/(d_m + 1e-6)) U^T h |^2,  d_m = tau^2 sigma_m^2
+// (codes/funcs.py:1162): the first term is what lies outside the (K+1)-dimensional frame, the second the misfit
+// inside it -- the ridge shrinkage plus the one frame direction the new columns do not span (the old column k's own
+// contribution), measured as a residual vector, never as a difference of squares.  The only O(N) inputs are c,
+// |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2 would
+// cancel (candidate nearly inside the span of the current columns).
+struct SolveIn {
+  const ChainB* ck;
+  const double* c;   // LDS: projections of s*z on the basis (K values)
+  double rho2;       // |w|^2
+  double wy;         // w . y
+  double zz;         // |s z|^2
+  double tau, s, sigma, scale, maxabs;
+  int K, k;
+  int64_t N;
+  uint32_t flags;
+  double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
+  MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
+};
+template <int K>
+__device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out);
+template <int K>
+__device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out);
+
+// 1/x and 1/sqrt(x) for the Jacobi rotations: the hardware estimate and two Newton steps (a few roundings, not correctly
+// rounded -- a rotation only has to be orthogonal to rounding, which cs^2 + sn^2 = 1 +- a few ulp is; the singular values
+// themselves are measured with IEEE sqrt afterwards).  The IEEE division and square root are ~14 and ~20 dependent
+// instructions each, five of them per rotation: two thirds of what a rotation costs a wave that runs alone.
+__device__ __forceinline__ double rot_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rot_rsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  return r;
+}
+// (cs, sn) of the rotation that annihilates gamma between columns of squared norms alpha and beta.
+// The estimates' Newton steps turn the IEEE limits into NaN (rsq(inf) = 0, then -0.5 inf 0; rcp of a denormal is inf, then
+// inf - inf): where zeta^2 overflows, or 2 gamma is too small to invert, the IEEE forms gave tt = 0 -- the identity
+// rotation, which is also the right answer (the off-diagonal is negligible next to the diagonal's gap) -- so anything
+// that is not finite falls back to exactly that.  Reachable only with column norms ~1e270 apart; a NaN here would
+// spread into W and every score of the proposal.
+__device__ __forceinline__ void rot_coeffs(double alpha, double beta, double gamma, double* cs, double* sn) {
+  const double zeta = (beta - alpha) * rot_rcp(2.0 * gamma);
+  const double s1 = fma(zeta, zeta, 1.0);
+  const double tt = copysign(1.0, zeta) * rot_rcp(fabs(zeta) + s1 * rot_rsq(s1));
+  const double c0 = rot_rsq(fma(tt, tt, 1.0));
+  const double s0 = c0 * tt;
+  const bool ok = isfinite(c0) && isfinite(s0);
+  *cs = ok ? c0 : 1.0;
+  *sn = ok ? s0 : 0.0;
+}
+
+// entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
+__device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
+  if (m == K - 1) return (i < K) ? in.c[i < K ? i : 0] : rho;
+  const int j = (m < in.k) ? m : m + 1;            // sibling tree
+  if (i > j || i >= K) return 0.0;
+  const double dj = in.ck->d[j];
+  return (dj != 0.0) ? in.ck->R[i * BSR_NQ_MAX + j] * (in.s / dj) : 0.0;
+}
+
+__device__ __forceinline__ void store_score(const SolveIn& in, int K, bsr_score* out, double ll, double sse, double smin,
+                                            double smax, int rank, const double* bt) {
+  out->loglik = ll;
+  out->sse = sse;
+  out->scale = in.scale;
+  out->maxabs = in.maxabs;
+  out->smin = smin / in.s;
+  out->smax = smax / in.s;
+  out->rank = rank;
+  out->flags = in.flags | ((rank < K) ? BSR_F_RANKDEF : 0u);
+  in.mh->loglik = ll;
+  in.mh->rank = rank;
+}
+
+// K <= 4: the factor, its one-sided Jacobi SVD (W = S V ends with mutually orthogonal columns W[:,m] = sigma_m u_m)
+// and the ridge formulas held entirely in registers (K is a template parameter: every index is static).  All lanes
+// compute the same values, so there is no cross-lane traffic at all.
+template <int K>
+__device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out) {
+  constexpr int M = K + 1;
+  const int k = in.k;
+  const ChainB* ck = in.ck;
+  // a residual at the rounding level of s z (a candidate that reproduces a vector of the span, e.g. the old column
+  // itself) carries no direction: w = 0.  The cut is half of numpy's rank tolerance relative to |s z|, so it moves
+  // every singular value of the factor by less than half that tolerance.
+  const double rel_w = 0.5 * (double)((in.N > (int64_t)K) ? in.N : (int64_t)K) * 2.220446049250313e-16;
+  const double rho = (in.rho2 > fmax(1e-30, rel_w * rel_w) * in.zz) ? sqrt(in.rho2) : 0.0;
+  double W[M][K], V[K][K];
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) W[i][j] = factor_entry(in, K, i, j, rho);
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int a = 0; a < K - 1; ++a) {
+#pragma unroll
+      for (int b = a + 1; b < K; ++b) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          alpha = fma(W[i][a], W[i][a], alpha);
+          beta = fma(W[i][b], W[i][b], beta);
+          gamma = fma(W[i][a], W[i][b], gamma);
+        }
+        // the rotation is skipped when |gamma| <= 1e-17 sqrt(alpha beta) and the sweep's measure is max |gamma| /
+        // sqrt(alpha beta): both compared in squares (two dependent square roots fewer per rotation)
+        const double ab = alpha * beta, g2 = gamma * gamma;
+        if (ab > 0.0 && g2 > 1e-34 * ab) {
+          off = fmax(off, g2 * rot_rcp(ab));
+          double cs, sn;
+          rot_coeffs(alpha, beta, gamma, &cs, &sn);
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            const double wa = W[i][a], wb = W[i][b];
+            W[i][a] = cs * wa - sn * wb;
+            W[i][b] = sn * wa + cs * wb;
+          }
+#pragma unroll
+          for (int i = 0; i < K; ++i) {
+            const double va = V[i][a], vb = V[i][b];
+            V[i][a] = cs * va - sn * vb;
+            V[i][b] = sn * va + cs * vb;
+          }
+        }
+      }
+    }
+    // (`off` is what the sweep FOUND in front of its rotations, so the last sweep only looks.  Stopping at 1e-18 --
+    // quadratic convergence: a sweep that found 1e-9 relative leaves 1e-18 -- was tried in round 4: no measurable
+    // difference, 8.85 against 8.82 us at K = 3, 22.6 against 23.1 at K = 8.  The kernel's 8.8 us are 4.6 us of launch,
+    // partial-record loads and lane reductions and 4.2 us of solve, most of it the divisions, square roots and the
+    // logarithm behind the sweeps.)
+    if (off <= 1e-30) break;
+  }
+  double h[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) h[i] = (i < K) ? ck->qy[i < K ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  const double eps = 1e-6;
+  double sv[K], coefj[K], r[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) r[i] = h[i];
+  double smax = 0.0, smin = INFINITY;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    double n2 = 0.0, tj = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      n2 = fma(W[i][j], W[i][j], n2);
+      tj = fma(W[i][j], h[i], tj);
+    }
+    sv[j] = sqrt(n2);
+    const double aj = (sv[j] > 0.0) ? tj / sv[j] : 0.0;                // u_j . h
+    const double dj = (in.tau * sv[j]) * (in.tau * sv[j]);
+    coefj[j] = (in.tau * sv[j]) / (dj + eps) * aj;
+    const double gj = (sv[j] > 0.0) ? dj / (dj + eps) * aj / sv[j] : 0.0;  // fitted share along u_j, per unit of W[:,j]
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(-gj, W[i][j], r[i]);
+    smax = fmax(smax, sv[j]);
+    smin = fmin(smin, sv[j]);
+  }
+  double misfit = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) misfit = fma(r[i], r[i], misfit);
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);
+  int rank = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) rank += (sv[j] > tol) ? 1 : 0;
+  const double sse = fmax(0.0, ck->yperp2 - h[K] * h[K]) + misfit;
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  double bt[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double bi = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) bi = fma(V[i][j], coefj[j], bi);
+    bt[i] = bi;
+  }
+  if (lane == 0) {
+    store_score(in, K, out, ll, sse, smin, smax, rank, bt);
+#pragma unroll
+    for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bt[i];
+    }
+  }
+}
+
+// K = 5..8: eight lanes per proposal, lane j = lane & 7 owns column j of the (K+1) x K factor W and of V in registers
+// (the 8 lane groups of the wave hold identical copies).  One-sided Jacobi with the XOR tournament ordering: in round
+// r = 1..7 column j pairs with column j ^ r, so the four rotations of a round run side by side and a sweep is 7
+// dependent steps instead of 28; the only cross-lane traffic is the partner's column (2K+1 shuffles per round), every
+// dot product is lane-local.  Both lanes of a pair evaluate the same expressions on the same operands, so they apply
+// bit-identical rotation coefficients.
+// v of lane (l ^ r), r in 1..7, inside groups of eight lanes -- with DPP moves (a couple of cycles) instead of
+// __shfl_xor, which lowers to ds_bpermute (an LDS round trip per 32 bits; the K >= 5 solver issues 17 of them per
+// rotation).  quad_perm covers r = 1, 2, 3; row_half_mirror is l -> 7 - l = l ^ 7; the rest are two steps.
+__device__ __forceinline__ double xor8(double v, int r) {
+  switch (r) {
+    case 1: return dpp_f64<0xB1, 0xF>(v);
+    case 2: return dpp_f64<0x4E, 0xF>(v);
+    case 3: return dpp_f64<0x1B, 0xF>(v);
+    case 4: return dpp_f64<0x1B, 0xF>(dpp_f64<0x141, 0xF>(v));
+    case 5: return dpp_f64<0x4E, 0xF>(dpp_f64<0x141, 0xF>(v));
+    case 6: return dpp_f64<0xB1, 0xF>(dpp_f64<0x141, 0xF>(v));
+    default: return dpp_f64<0x141, 0xF>(v);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_score* out) {
+  constexpr int M = K + 1;
+  const int j = lane & 7;
+  const int k = in.k;
+  const ChainB* ck = in.ck;
+  // a residual at the rounding level of s z (a candidate that reproduces a vector of the span, e.g. the old column
+  // itself) carries no direction: w = 0.  The cut is half of numpy's rank tolerance relative to |s z|, so it moves
+  // every singular value of the factor by less than half that tolerance.
+  const double rel_w = 0.5 * (double)((in.N > (int64_t)K) ? in.N : (int64_t)K) * 2.220446049250313e-16;
+  const double rho = (in.rho2 > fmax(1e-30, rel_w * rel_w) * in.zz) ? sqrt(in.rho2) : 0.0;
+  double W[M], V[K];
+#pragma unroll
+  for (int i = 0; i < M; ++i) W[i] = (j < K) ? factor_entry(in, K, i, (j < K) ? j : 0, rho) : 0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) V[i] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const int hb = (r >= 4) ? 4 : ((r >= 2) ? 2 : 1);
+      const bool low = (j & hb) == 0;  // j < (j ^ r)
+      double Wp[M], Vp[K];
+      double mine = 0.0, theirs = 0.0, gamma = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) Wp[i] = xor8(W[i], r);
+#pragma unroll
+      for (int i = 0; i < K; ++i) Vp[i] = xor8(V[i], r);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        mine = fma(W[i], W[i], mine);
+        theirs = fma(Wp[i], Wp[i], theirs);
+        gamma = fma(W[i], Wp[i], gamma);
+      }
+      const double alpha = low ? mine : theirs, beta = low ? theirs : mine;
+      const double ab = alpha * beta, g2 = gamma * gamma;   // squared criteria: see solve_regs
+      if (ab > 0.0 && g2 > 1e-34 * ab) {
+        off = fmax(off, g2 * rot_rcp(ab));
+        double cs, sn;
+        rot_coeffs(alpha, beta, gamma, &cs, &sn);
+        const double sp = low ? -sn : sn;  // low column: cs*W - sn*Wp ; high column: sn*Wp + cs*W
+#pragma unroll
+        for (int i = 0; i < M; ++i) W[i] = cs * W[i] + sp * Wp[i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) V[i] = cs * V[i] + sp * Vp[i];
+      }
+    }
+    off = fmax(off, xor8(off, 1));
+    off = fmax(off, xor8(off, 2));
+    off = fmax(off, xor8(off, 4));
+    if (off <= 1e-30) break;  // wave-uniform: the lane groups are copies of each other
+  }
+  double h[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) h[i] = (i < K) ? ck->qy[i < K ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  double n2 = 0.0, tj = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    n2 = fma(W[i], W[i], n2);
+    tj = fma(W[i], h[i], tj);
+  }
+  const double eps = 1e-6;
+  const double sv = sqrt(n2);                                   // sigma_j
+  const double aj = (sv > 0.0 && j < K) ? tj / sv : 0.0;        // u_j . h
+  const double dj = (in.tau * sv) * (in.tau * sv);
+  const double coef = (j < K) ? (in.tau * sv) / (dj + eps) * aj : 0.0;
+  const double gj = (sv > 0.0 && j < K) ? dj / (dj + eps) * aj / sv : 0.0;
+  // residual inside the frame: r = h - sum_j u_j (d_j/(d_j+eps)) (u_j . h), summed over the 8 column lanes
+  double misfit = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double t = gj * W[i];
+    t += xor8(t, 1);
+    t += xor8(t, 2);
+    t += xor8(t, 4);
+    const double ri = h[i] - t;
+    misfit = fma(ri, ri, misfit);
+  }
+  double smax = 0.0, smin = INFINITY;
+#pragma unroll
+  for (int a = 0; a < K; ++a) smax = fmax(smax, __shfl(sv, a, 8));
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tol = smax * fmax(dimmax * 2.220446049250313e-16, in.rank_floor);  // numpy matrix_rank default
+  int rank = 0;
+#pragma unroll
+  for (int a = 0; a < K; ++a) {
+    const double sva = __shfl(sv, a, 8);
+    smin = fmin(smin, sva);
+    rank += (sva > tol) ? 1 : 0;
+  }
+  const double sse = fmax(0.0, ck->yperp2 - h[K] * h[K]) + misfit;
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  double bt[K];                                                 // Beta'_i = sum_j V[i][j] coef_j
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double b = V[i] * coef;
+    b += xor8(b, 1);
+    b += xor8(b, 2);
+    b += xor8(b, 4);
+    bt[i] = b;
+  }
+  if (lane == 0) {
+    store_score(in, K, out, ll, sse, smin, smax, rank, bt);
+#pragma unroll
+    for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bt[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score* out) {
+  switch (in.K) {
+    case 1: solve_regs<1>(in, lane, out); break;
+    case 2: solve_regs<2>(in, lane, out); break;
+    case 3: solve_regs<3>(in, lane, out); break;
+    case 4: solve_regs<4>(in, lane, out); break;
+    case 5: solve_cols<5>(in, lane, out); break;
+    case 6: solve_cols<6>(in, lane, out); break;
+    case 7: solve_cols<7>(in, lane, out); break;
+    default: solve_cols<8>(in, lane, out); break;
+  }
+}
+
+
+// One proposal, one wave: reduces its n_rb partial records of the row pass (fixed order: lane-strided, then the wave
+// reduction), then rank gate / OLS / log-likelihood, or -- a candidate (nearly) inside the span of the current columns --
+// hands it to the residual pass through the flagged list.  sh_c: BSR_NQ_MAX doubles of LDS of the wave's own.
+// UNCACHED: the records sit in uncached memory and were written by other waves of THIS launch (read around the caches).
+template <bool UNCACHED>
+__device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, const ChainB* __restrict__ cks, int p, int n_rb,
+                                               const double* __restrict__ part1, int64_t N, PropCoef* __restrict__ coef,
+                                               bsr_score* __restrict__ outv, double rank_floor, int32_t* __restrict__ flagged,
+                                               MhRes* __restrict__ mhv, int lane, double* sh_c) {
+  double sum[BSR_NQ_MAX + 2];
+#pragma unroll
+  for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = 0.0;
+  double amax = 0.0;
+  uint32_t fl = 0;
+  for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
+    const double* qp = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
+    double q[BSR_P1_WORDS];
+#pragma unroll
+    for (int i = 0; i < BSR_P1_WORDS; ++i) q[i] = UNCACHED ? __builtin_nontemporal_load(qp + i) : qp[i];
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += q[i];
+    amax = fmax(amax, q[10]);
+    // the census of a partial record: inf in a row <=> its max|z| is inf; NaN in a row <=> its |s z|^2 is NaN (the tile
+    // pass leaves word 11 zero and the census to these two tests; the work-queue pass also sets the bits itself)
+    fl |= (uint32_t)q[11] | ((q[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q[8]) ? BSR_F_NAN : 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = wave_sum(sum[i]);
+  amax = wave_max(amax);
+  fl = wave_or(fl);
+  if (fl & BSR_F_INF) amax = INFINITY;
+
+  PropCoef* cf = coef + p;
+  bsr_score* out = outv + p;
+  if (dsc[p].mode == BSR_MODE_EVAL) {
+    if (lane == 0) {
+      cf->skip = 1;
+      out->maxabs = amax;
+      out->flags = fl;
+      out->rank = 0;
+      out->loglik = out->sse = out->scale = out->smin = out->smax = 0.0;
+      mhv[p].loglik = 0.0;
+      mhv[p].rank = 0;
+    }
+    return;
+  }
+  const int K = dsc[p].K, k = dsc[p].k, nq = dsc[p].nq;
+  const double s = dsc[p].s;
+  const ChainB* ck = cks + dsc[p].ck;
+  const uint32_t flags = fl | ck->flags_k[k];
+  const double scale_ref = fmax(ck->m_other[k], amax);
+  if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
+    if (lane == 0) {
+      cf->skip = 1;
+      out->loglik = NAN;
+      out->sse = NAN;
+      out->scale = (flags & BSR_F_NAN) ? NAN : INFINITY;
+      out->maxabs = amax;
+      out->smin = out->smax = NAN;
+      out->rank = (flags & BSR_F_NAN) ? -1 : 0;
+      out->flags = flags | BSR_F_RANKDEF;
+      mhv[p].loglik = NAN;
+      mhv[p].rank = out->rank;
+    }
+    if (lane < BSR_MAX_K) out->beta[lane] = NAN;
+    return;
+  }
+  const double zz = sum[BSR_NQ_MAX], zy = sum[BSR_NQ_MAX + 1];
+  if (K == 1) {
+    // no sibling fixes the accumulation scale; ask the host to rescore with a matched prescale
+    const double as = amax * s;
+    if (as > 0.0 && (as > 0x1p400 || as < 0x1p-400)) {
+      if (lane == 0) {
+        cf->skip = 1;
+        out->maxabs = amax;
+        out->flags = flags | BSR_F_SCALE_RETRY;
+        out->rank = 0;
+        out->loglik = out->sse = NAN;
+        mhv[p].loglik = NAN;
+        mhv[p].rank = 0;
+      }
+      return;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX; ++i) sh_c[i] = sum[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (waves do not share sh_c)
+  double cc = 0.0, cqy = 0.0;
+#pragma unroll
+  for (int i = 0; i < BSR_NQ_MAX; ++i) {
+    if (i < nq) {
+      cc = fma(sum[i], sum[i], cc);
+      cqy = fma(sum[i], ck->qy[i], cqy);
+    }
+  }
+  const double rho2 = zz - cc;
+  // the candidate is (nearly) inside the span of the current columns: |w|^2 and w.y come from the direct residual pass
+  const bool ambiguous = (nq > 0) && !(rho2 > 1e-6 * zz);
+  // ... unless the host recognised the candidate as the current tree k itself (4-7 % of the real mix, three quarters of
+  // what used to be flagged): then w = 0 exactly, which is what the residual pass would measure (|w|^2 ~ 1e-32 |s z|^2,
+  // below the cut) -- the same arithmetic follows, without the pass.  The claim is only trusted when the one-pass
+  // figure agrees that the candidate is in the span.
+  const bool known_in_span = ambiguous && dsc[p].self_dup != 0;
+  if (ambiguous && !known_in_span) {
+    if (lane < BSR_NQ_MAX) cf->c[lane] = (lane < nq) ? sh_c[lane] : 0.0;
+    if (lane == 0) {
+      cf->s = s;
+      cf->zz = zz;
+      cf->tau = 1.0 / (s * scale_ref);
+      cf->scale = scale_ref;
+      cf->maxabs = amax;
+      cf->flags = flags;
+      cf->skip = 0;
+      // hand the proposal to the residual pass and k_finalize (the order of the list does not matter to the results)
+      flagged[1 + atomicAdd(&flagged[0], 1)] = p;
+    }
+    return;
+  }
+  if (lane == 0) cf->skip = 1;
+  SolveIn in;
+  in.ck = ck;
+  in.c = sh_c;
+  in.rho2 = known_in_span ? 0.0 : rho2;
+  in.zz = zz;
+  in.wy = known_in_span ? 0.0 : zy - cqy;
+  in.tau = 1.0 / (s * scale_ref);
+  in.s = s;
+  in.sigma = dsc[p].sigma;
+  in.scale = scale_ref;
+  in.maxabs = amax;
+  in.K = K;
+  in.k = k;
+  in.N = N;
+  in.flags = flags;
+  in.rank_floor = rank_floor;
+  in.mh = mhv + p;
+  solve_any(in, lane, out);
+
+}

@@ -511,6 +511,11 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       else if (room >= 2) { ring = room; chunk = 1; }
       if (force_chunk > 0 && chunk > 0) chunk = std::min(chunk, std::min(force_chunk, 2));
       if (force_ring >= 2 && force_ring <= 4 && chunk > 0 && room >= force_ring * chunk) ring = force_ring;
+      // (a batch of 33..39 columns that was given two-block chunks: one-block chunks fit the waves' 64 pieces)
+      if (chunk == 2 && max_ncols * chunk > BSR_STREAM_UNITS_MAX && max_ncols <= BSR_STREAM_UNITS_MAX && force_chunk <= 0) {
+        chunk = 1;
+        ring = std::min(4, room);
+      }
       s.tile_stream = chunk > 0 && max_ncols * chunk <= BSR_STREAM_UNITS_MAX;
       if (!s.tile_stream) { chunk = 0; ring = 1; }
     }

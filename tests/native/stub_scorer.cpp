@@ -358,7 +358,7 @@ int bsr_score_submit_mh(bsr_ctx*, const bsr_node*, const int32_t*, const int32_t
                         const double*, const int32_t*, const int32_t*, int32_t, int32_t*) { return BSR_E_STATE; }
 int bsr_score_wait_mh(bsr_ctx*, int32_t, bsr_score*, bsr_event*) { return BSR_E_STATE; }
 extern "C++" int bsr_internal_submit_mh(bsr_ctx*, int, const bsr_node*, const int32_t*, const int32_t*, const int32_t*, const double*,
-                           int32_t, const double*, const int32_t*, const int32_t*, int32_t) { return BSR_E_STATE; }
+                           int32_t, const double*, const int32_t*, const int32_t*, int32_t, bool) { return BSR_E_STATE; }
 extern "C++" int bsr_internal_wait_mh(bsr_ctx*, int, bsr_score*, bsr_event*) { return BSR_E_STATE; }
 int bsr_yloglike_host(int, int64_t, int32_t, const double*, const double*, double, int32_t, double*, double*, double*,
                       double*, int32_t*) { return BSR_E_NODEVICE; }

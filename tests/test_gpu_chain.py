@@ -51,7 +51,10 @@ def test_reference_traces_through_the_native_engine(name, batch):
     tr = eng.run(batch_per_chain=batch, max_props=g["n_props"] if g["truncated"] else -1, trace_cap=g["n_props"] + 8)
     assert len(tr) == g["n_props"]
     n_chaotic = 0
+    chaotic_ids = []
+    from conftest import exempt_allowed
     from test_host_driver import _ulp_sensitive
+    allowed = exempt_allowed("trace %s" % name)                        # pinned per fixture (None: discover mode)
     cur_nodes = [node_from_spec(t) for t in g["init_trees"]]         # the chain's current trees, replayed from the golden
     for i, (ref, got) in enumerate(zip(g["props"], tr)):
         tag = "%s batch %d proposal %d" % (name, batch, i)
@@ -70,15 +73,22 @@ def test_reference_traces_through_the_native_engine(name, batch):
                 if np.isfinite(want) and not abs(want - got[key]) <= 1e-6 * abs(want):
                     # allowed only for a proposal whose value is chaotic at the ulp level: the oracle's own number must
                     # move under a one-ulp perturbation of X
-                    rec = {"cur_roots": cur_nodes, "proposed": node_from_spec(ref["proposed"]), "count": ref["count"],
-                           "new_sigma": unf(ref["new_sigma"])}
-                    assert key == "yllstar" and _ulp_sensitive(rec, X, y, 1e-6), (tag, key, want, got[key])
+                    # move under a one-ulp perturbation of X -- established in the build container for the pinned
+                    # proposals (tests/golden/exemption_allow.json), measured live only in discover mode
+                    assert key == "yllstar", (tag, key, want, got[key])
+                    if allowed is None:
+                        rec = {"cur_roots": cur_nodes, "proposed": node_from_spec(ref["proposed"]), "count": ref["count"],
+                               "new_sigma": unf(ref["new_sigma"])}
+                        assert _ulp_sensitive(rec, X, y, 1e-6), (tag, key, want, got[key])
+                    else:
+                        assert i in allowed, (tag, key, want, got[key], sorted(allowed))
                     n_chaotic += 1
+                    chaotic_ids.append(i)
         assert ref["accepted"] == bool(got["accepted"]), tag
         if ref["accepted"]:
             cur_nodes[ref["count"]] = node_from_spec(ref["proposed"])
     from conftest import note_exempt
-    note_exempt("trace %s batch %d via native engine" % (name, batch), n_chaotic, len(tr))
+    note_exempt("trace %s" % name, n_chaotic, len(tr), ids=chaotic_ids)
     st = eng.get_numpy_state(0)
     import zlib
     last = g["props"][-1]["rng"]
@@ -91,6 +101,12 @@ def test_reference_traces_through_the_native_engine(name, batch):
         assert np.allclose(r["errs"], farr(g["train_err"]), rtol=1e-8)
     eng.close()
     ctx.close()
+
+
+# what a loose chain's RMSE history may miss the reference's by: the two chains that take this route (pinned by index in
+# tests/golden/exemption_allow.json) measured 4.0e-3 and 3.5e-4 (profiles/r05_exemptions_discover.json) -- sin / cos of
+# 1e12-sized arguments, where the libm build decides the last digits; their final state is pinned to 1e-9 below
+LOOSE_RMSE_DEV = 1e-2
 
 
 @pytest.mark.parametrize("engine", ["native", "python"])
@@ -109,6 +125,7 @@ def test_bsr_fit_f1_matches_reference_end_to_end(engine):
     assert est.stats_["proposals"] == g["total_props"]
     from bsr.node import Express
     loose = 0
+    loose_ids, loose_dev = [], {}
     for c in range(50):
         assert [Express(t) for t in est.roots_[c]] == g["models"][c], c          # accepted trees: exact
         assert len(est.train_err_[c]) == len(g["train_err"][c]), c
@@ -122,12 +139,14 @@ def test_bsr_fit_f1_matches_reference_end_to_end(engine):
         # (sin/cos of 1e12-sized arguments): there only the libm build decides the last digits
         if dev > 1e-7 or dev_b > 1e-5:
             loose += 1
-            assert dev < 5e-2 and np.isfinite(dev_b), (c, dev, dev_b, g["models"][c])
+            loose_ids.append(c)
+            loose_dev[c] = (dev, dev_b)
+            assert dev < LOOSE_RMSE_DEV and np.isfinite(dev_b), (c, dev, dev_b, g["models"][c])
             # ... and ONLY libm's last digits: the chain's final fit against the oracle's intercept fit of the DEVICE's own
             # columns of the same trees (the solver in isolation, as tests/test_gpu_kernels.py does for the scores) to
             # 1e-9 -- a refresh or solver regression cannot hide in the allowance above.  (A chain that ended through the
             # plateau break keeps its pre-accept trees, codes/bsr_class.py:180-182 vs :204: no final state to compare.)
-            if len(want_e) <= 100:
+            if True:   # (every loose chain, whatever its length)
                 import bsr as _bsr
                 import bsr_oracle as _O
                 with np.errstate(all="ignore"):
@@ -138,7 +157,8 @@ def test_bsr_fit_f1_matches_reference_end_to_end(engine):
                 if len(got_e):
                     assert abs(got_e[-1] - orm) <= 1e-9 * max(abs(orm), 1e-300), (c, got_e[-1], orm)
     from conftest import note_exempt
-    note_exempt("config 1 fit, engine %s: chains whose Beta/RMSE history miss 1e-7 / 1e-5" % engine, loose, 50)
+    note_exempt("config 1 fit: chains whose Beta/RMSE history miss 1e-7 / 1e-5", loose, 50, ids=loose_ids,
+                detail={str(c): [float(v) for v in loose_dev[c]] for c in loose_ids})
     assert est.model() == g["model_last"]
     assert est.complexity() == g["complexity"]
     grid = np.array(g["grid"])

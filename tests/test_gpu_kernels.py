@@ -134,27 +134,26 @@ def test_score_batch_vs_oracle(N, d, K, B, seed):
     assert res.tobytes() == res2.tobytes()           # deterministic, bit for bit
     dev_cur = [ctx.get_current(c).T for c in range(2)]
     n_full = n_chaotic = 0
+    chaotic_ids = []
+    # The oracle's scores of exactly this batch come from a fixture written in the build container
+    # (tools/gen_golden_scores.py -> tests/golden/g9_score_batch.json): the 1e-6 end-to-end gate, and which proposals are
+    # ulp-chaotic enough to be exempt from it (the oracle's own value moves under a one-ulp perturbation of X, measured
+    # THERE), do not depend on the numpy build of the box the GPU runs in.
+    fx = load_golden("g9_score_batch.json")["cases"]["N=%d d=%d K=%d B=%d seed=%d" % (N, d, K, B, seed)]
     for i in range(B):
-        with np.errstate(all="ignore"):
-            col = O.allcal(cands[i], Xdf)[:, 0]
-        want = O.score_proposal(cur_cols[chains[i]], ks[i], col, y, sig[i])
+        want = {"rank": fx["rank"][i], "loglik": unf(fx["loglik"][i]), "scale": unf(fx["scale"][i])}
+        assert fx["express"][i] == O.express(cands[i])
         tag = "proposal %d %s rank %r" % (i, O.express(cands[i]), want["rank"])
         assert int(res["rank"][i]) == want["rank"] or (want["rank"] < K and 0 <= res["rank"][i] < K), (tag, res[i])
         assert (res["rank"][i] == K) == (want["rank"] == K), (tag, res[i])
         if want["rank"] == K:
             n_full += 1
             # (1) north-star bound against the oracle end to end: 1e-6 relative on the log-likelihood.  Exception: trees
-            #     that are chaotic at the ulp level (cos(exp(x^6)): the value depends on the libm build) -- the oracle's own
-            #     value must then move under a one-ulp perturbation of X, and such candidates stay rare
+            #     that are chaotic at the ulp level (cos(exp(x^6)): the value depends on the libm build), flagged in the fixture
             if not abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]):
-                vals = []
-                for eps in (2.0 ** -52, -2.0 ** -52, 2.0 ** -51):
-                    with np.errstate(all="ignore"):
-                        colp = O.allcal(cands[i], pd.DataFrame(X * (1.0 + eps)))[:, 0]
-                    vals.append(O.score_proposal(cur_cols[chains[i]], ks[i], colp, y, sig[i])["loglik"])
-                spread = max(abs(v - want["loglik"]) for v in vals)
-                assert spread > 1e-7 * abs(want["loglik"]), (tag, res[i], want, vals)
+                assert fx["chaotic"][i], (tag, res[i], want)
                 n_chaotic += 1
+                chaotic_ids.append(i)
             assert abs(res["scale"][i] - want["scale"]) <= 1e-12 * want["scale"], tag
             # (2) solver in isolation: oracle fed with the device's own columns (removes libm ulp differences
             #     that ill-conditioned trees such as sin(exp(1/x)) amplify)
@@ -167,7 +166,7 @@ def test_score_batch_vs_oracle(N, d, K, B, seed):
             assert np.all(np.abs(res["beta"][i][:K] - w2["beta"]) <= 1e-6 * np.max(np.abs(w2["beta"])) * max(1.0, cond * 1e-6)), (tag, res[i], w2)
     assert n_full > 0
     from conftest import note_exempt
-    note_exempt("score_batch_vs_oracle N=%d d=%d K=%d B=%d seed=%d" % (N, d, K, B, seed), n_chaotic, n_full)
+    note_exempt("score_batch_vs_oracle N=%d d=%d K=%d B=%d seed=%d" % (N, d, K, B, seed), n_chaotic, n_full, ids=chaotic_ids)
     # accept the first full-rank proposal: commit == set_current of the same tape
     i = int(np.argmax(res["rank"] == K))
     ctx.commit(int(chains[i]), int(ks[i]), i)

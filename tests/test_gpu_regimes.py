@@ -73,3 +73,45 @@ def test_the_regime_each_baseline_config_selects(name, N, d, K, chains, max_batc
         assert ctx.last_timing()[0] > 0.0
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("K", [3, 6])
+def test_wildly_scaled_columns_leave_no_nan_in_the_rotations(K):
+    """Column norms up to ~1e270 apart: the Jacobi rotations' reciprocal / reciprocal-square-root estimates (csrc/bsr_solve.h:
+    rot_coeffs) must fall back to the identity rotation where their Newton steps would make NaN of an overflow -- a NaN
+    there spreads into every score of the proposal.  The rank decision is the reference's (matrix_rank, codes/funcs.py:1226)."""
+    import pandas as pd
+    import bsr_oracle as O
+    from conftest import spec_from_node
+    rs = np.random.RandomState(3)
+    N, d = 4000, 6
+    X = rs.uniform(0.5, 3, size=(N, d))
+    y = X[:, 0] + X[:, 1] * X[:, 2] + 0.1 * rs.standard_normal(N)
+    scales = [1e135, 1e-135, 1.0, 1e60, 1e-60, 1e100][:K]
+    cur = [un('ln', leaf(k % d), a, 0.0) for k, a in enumerate(scales)]
+    cands = [leaf(3), un('ln', leaf(4), 1e-130, 0.0), un('ln', leaf(5), 1e130, 0.0), bi('*', leaf(0), leaf(1))]
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=16)
+    try:
+        for k in range(K):
+            ctx.set_current(0, k, flatten(cur[k]))
+        ctx.refresh(0)
+        tapes, ks = [], []
+        for cd in cands:
+            for k in range(K):
+                tapes.append(flatten(cd))
+                ks.append(k)
+        B = min(16, len(tapes))
+        res = ctx.score_batch(tapes[:B], np.zeros(B, np.int32), np.array(ks[:B], np.int32), np.full(B, 0.9))
+        df = pd.DataFrame(X)
+        with np.errstate(all="ignore"):
+            cols = [O.allcal(O.tree_from_json(spec_from_node(t)), df)[:, 0] for t in cur]
+            for i in range(B):
+                out = np.stack(cols, axis=1).copy()
+                out[:, ks[i]] = O.allcal(O.tree_from_json(spec_from_node(cands[i // K])), df)[:, 0]
+                want_rank = int(np.linalg.matrix_rank(out))
+                assert (res["rank"][i] == K) == (want_rank == K), (i, res["rank"][i], want_rank)
+                if res["rank"][i] == K:
+                    assert np.isfinite(res["loglik"][i]) and np.isfinite(res["beta"][i][:K]).all(), (i, res[i])
+                assert not np.isnan(res["smax"][i]) and not np.isnan(res["smin"][i]), (i, res[i])
+    finally:
+        ctx.close()

@@ -85,3 +85,20 @@ def test_single_rank_unknown_node_and_narrow_affinity(shim, tmp_path):
     # two CPUs are not worth a placement
     cpus, _ = pick(shim, tmp_path, "0000:05:00.0", "0-1", -1, 1, 0)
     assert cpus == []
+
+
+def test_ranks_whose_gpus_node_is_unknown_spread_over_all_domains(shim, tmp_path):
+    """numa_node = -1 (VMs, containers): eight ranks take eight DIFFERENT L3 domains spread over both sockets -- dealt by
+    rank modulo the number of domains they would sit on the first domains of socket 0 only."""
+    fake_sysfs(tmp_path, {"0000:%02x:00.0" % (0x10 + r): -1 for r in range(8)})
+    doms = []
+    for r in range(8):
+        cpus, numa = pick(shim, tmp_path, "0000:%02x:00.0" % (0x10 + r), "0-127", r, 8, 5)
+        assert numa == -1 and len(cpus) == 16
+        doms.append(tuple(cpus))
+    assert len(set(doms)) == 8
+    firsts = sorted(d[0] for d in doms)
+    assert any(32 <= f < 64 for f in firsts) and any(f < 32 for f in firsts)      # both sockets' first halves in use
+    # four ranks: every other domain
+    four = [tuple(pick(shim, tmp_path, "0000:%02x:00.0" % (0x10 + r), "0-127", r, 4, 5)[0]) for r in range(4)]
+    assert len(set(four)) == 4
