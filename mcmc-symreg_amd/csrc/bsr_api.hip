@@ -183,7 +183,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
   c->dtype = dtype;
   c->esz = (dtype == BSR_DTYPE_F64) ? 8 : 4;
   c->has_y = (y != nullptr);
+#ifdef BSR_TEST_VARIANTS
   c->rows_per_lane = env_int("BSR_P1_U", 2);
+#else
+  c->rows_per_lane = 2;   // (4 and 8 rows per lane and sweep: built into the test library only)
+#endif
   if (c->rows_per_lane != 2 && c->rows_per_lane != 4 && c->rows_per_lane != 8) c->rows_per_lane = 2;
   // rows per task: 1024 amortises the per-task setup and reductions (~1 us) once there are enough row blocks to go
   // round (measured: +5..13 % at N = 100k..1M); small inputs keep shorter blocks so fewer masked rows are evaluated
@@ -193,7 +197,11 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       (c->rb_rows % (64 * c->rows_per_lane)) != 0)
     c->rb_rows = rb_default;
   if (c->rb_rows % (64 * c->rows_per_lane) != 0) c->rows_per_lane = 2;  // a row block is a whole number of sweeps
+#ifdef BSR_TEST_VARIANTS
   c->no_lds = env_int("BSR_NO_LDS", 1);  // measured: at the headline workload reading X from L2 beats LDS staging
+#else
+  c->no_lds = 1;                         // (k_rows with X staged in LDS, round 1's static grid: test library only)
+#endif
   // derived columns (see kDerivedOps): on unless asked off, the column ids would leave 16 bits, or X is so large that
   // nine copies of it would take more than a third of the device's free memory
   c->n_cols = d;

@@ -902,12 +902,15 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
     block.x = 4 * BSR_WG_WAVES * BSR_WAVE;
   }
   const int n_pg = (MODE == MODE_RESIDUAL) ? 1 : g.n_pg;
-  if (a.feat_list) {
+#ifdef BSR_TEST_VARIANTS
+  if (a.feat_list) {   // (X staged in LDS per row block, BSR_NO_LDS=0: round 1's static grid, kept for the test build)
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
     hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
-  } else {
+  } else
+#endif
+  {
     hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
@@ -916,8 +919,10 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
 template <typename T, int NQ, int MODE>
 static void launch_rows_nq(hipStream_t st, const RowPassArgs<T>& a) {
   switch (a.rows_per_lane) {
-    case 8: launch_rows_u<T, NQ, MODE, 8>(st, a); break;
+#ifdef BSR_TEST_VARIANTS
+    case 8: launch_rows_u<T, NQ, MODE, 8>(st, a); break;   // (BSR_P1_U: rows per lane and sweep, test build only)
     case 4: launch_rows_u<T, NQ, MODE, 4>(st, a); break;
+#endif
     default: launch_rows_u<T, NQ, MODE, 2>(st, a); break;
   }
 }

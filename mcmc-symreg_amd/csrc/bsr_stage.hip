@@ -600,7 +600,9 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
     const size_t n_sched = (size_t)tg.T * tg.n_pass * per_pass;
     if (n_sched > c->tile_sched_cap) return fail(c, BSR_E_TOOBIG, "tile schedule larger than its buffer");
     TapeRec* sc = s.h_sched();
-    tg.per_group = c->tile_whole && tg.chunk_blocks == tg.bps + (tg.n_long > 0 ? 1 : 0) ? most : 0;   // whole slice: the waves pull from the group's list
+    // whole slice: the waves pull from the group's list (fp64; fp32 columns keep k_tile's static schedule over the slice
+    // staged whole -- the same sums, one kernel family fewer in the library)
+    tg.per_group = c->tile_whole && c->dtype == BSR_DTYPE_F64 && tg.chunk_blocks == tg.bps + (tg.n_long > 0 ? 1 : 0) ? most : 0;
     s.recs_bytes = n_sched * sizeof(TapeRec) + ((size_t)P + (size_t)tg.T * tg.per_group) * sizeof(int32_t);
     for (size_t i = 0; i < n_sched; ++i) sc[i].p = -1;
     int32_t* left_idx = reinterpret_cast<int32_t*>(sc + n_sched);   // tapes in cost order -> their records (leftover units)

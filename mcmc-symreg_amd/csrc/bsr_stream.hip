@@ -633,6 +633,8 @@ void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
   hipLaunchKernelGGL((k_stream<KQ, QT, CB, STAMPS, MODE>), grid, block, lds, st, a);
 }
+#ifdef BSR_TEST_VARIANTS
+// (the test build: every interpreter behind BSR_STREAM_ASM, per-wave clock samples, either number of sets of sums)
 template <int KQ, int QT>
 void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   // BSR_STREAM_ASM=0: the C++ interpreter (tape_fast) on one-block chunks too -- the cross-check of the assembly ones;
@@ -665,6 +667,25 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   else if (asm_mode >= 1) launch_one<KQ, QT, 1, false, 1>(st, a, lds);
   else launch_one<KQ, QT, 1, false, 0>(st, a, lds);
 }
+#else
+// The shipped library holds ONE kernel per situation: a batch on one chain's basis takes the block of assembly -- the whole
+// pass in it on one-block chunks (mode 3), a chunk at a time on two-block chunks (mode 2); a batch that spans several
+// chains' bases the assembly interpreter a tape at a time (mode 1; two-block chunks: the C++ interpreter, mode 0).  The
+// other interpreters exist for the byte-equality tests only (build with BSR_EXTRA_FLAGS=-DBSR_TEST_VARIANTS:
+// csrc/build.sh variants; tests/test_gpu_stream.py runs them).
+template <int KQ, int QT>
+void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
+  static_assert((KQ <= 4 && QT == 4) || (KQ >= 5 && QT == 2), "the sets of sums per wave the kernel is built for");
+  const bool chunk_block = a.g.ncols_fixed == KQ;
+  if (a.g.chunk_blocks == 2) {
+    if (chunk_block) launch_one<KQ, QT, 2, false, 2>(st, a, lds);
+    else launch_one<KQ, QT, 2, false, 0>(st, a, lds);
+    return;
+  }
+  if (chunk_block) launch_one<KQ, QT, 1, false, 3>(st, a, lds);
+  else launch_one<KQ, QT, 1, false, 1>(st, a, lds);
+}
+#endif
 
 }  // namespace
 
@@ -676,13 +697,19 @@ size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof
 // whether a batch of this shape takes the chunk block of assembly (K = 3, four sets of sums per wave, one chain's basis):
 // then two-block chunks cost nothing but LDS (bsr_stage.hip: stage_tile's geometry)
 bool stream_chunk_block(int K, int ncols_fixed) {
+#ifdef BSR_TEST_VARIANTS
   static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
+#else
+  const int asm_mode = 3;
+#endif
   return stream_qmax(K) == (K <= 4 ? 4 : 2) && asm_mode >= 2 && ncols_fixed == K;
 }
 
 int stream_qmax(int K) {
+#ifdef BSR_TEST_VARIANTS
   static const int forced = env_int("BSR_STREAM_QT", 0);
   if (forced == 2 || (forced == 4 && K <= 4)) return forced;
+#endif
   return K <= 4 ? 4 : 2;
 }
 
@@ -699,10 +726,12 @@ void launch_stream(hipStream_t st, const TileArgs<double>& a) {
     return;
   }
   switch (a.K) {
+#ifdef BSR_TEST_VARIANTS
     case 1: launch_cb<1, 2>(st, a, lds); break;
     case 2: launch_cb<2, 2>(st, a, lds); break;
     case 3: launch_cb<3, 2>(st, a, lds); break;
     case 4: launch_cb<4, 2>(st, a, lds); break;
+#endif
     case 5: launch_cb<5, 2>(st, a, lds); break;
     case 6: launch_cb<6, 2>(st, a, lds); break;
     case 7: launch_cb<7, 2>(st, a, lds); break;

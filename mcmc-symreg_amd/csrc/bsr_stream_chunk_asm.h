@@ -520,9 +520,9 @@
   ".Lsp_loop%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "s_cmp_ge_i32 s68, s76\n\t"                                                    \
-  "s_cbranch_scc1 .Lsp_wait0%=\n\t"                                              \
+  "s_cbranch_scc1 .Lsp_waitall_%=\n\t"                                              \
   "s_setpc_b64 s[80:81]\n"                                                       \
-  ".Lsp_wait0%=:\n\t"                                                            \
+  ".Lsp_waitall_%=:\n\t"                                                            \
   "s_waitcnt vmcnt(0)\n"                                                         \
   ".Lsp_waited%=:\n\t"                                                           \
   "s_barrier\n\t"   /* chunk s68 has landed for everyone; everyone is done with the chunk before */ \
@@ -532,7 +532,7 @@
   "v_lshl_add_u32 v20, s78, 10, %[lane16]\n\t"                                   \
   "s_add_u32 s10, s74, s70\n\t"                                                  \
   "s_setpc_b64 s[82:83]\n"                                                       \
-  ".Lsp_issued2%=:\n\t"                                                          \
+  ".Lsp_reissue_%=:\n\t"                                                          \
   "s_add_u32 s70, s70, s72\n\t"                                                  \
   "s_cmp_eq_u32 s70, s73\n\t"                                                    \
   "s_cselect_b32 s70, 0, s70\n\t"                                                \
@@ -566,7 +566,7 @@
   BSR_SP_WAIT(7) BSR_SP_WAIT(8)                                                  \
   BSR_SP_PIECE(3, "s[66:67]") BSR_SP_PIECE(2, "s[64:65]") BSR_SP_PIECE(1, "s[62:63]") BSR_SP_PIECE(0, "s[60:61]") \
   ".Lsp_is_none%=:\n\t"                                                          \
-  "s_branch .Lsp_issued2%=\n\t"                                                  \
+  "s_branch .Lsp_reissue_%=\n\t"                                                  \
   BSR_SC_LEAVE_PART                                                              \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \

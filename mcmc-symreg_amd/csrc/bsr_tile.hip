@@ -426,7 +426,7 @@ void launch_kq(hipStream_t st, const TileArgs<T>& a) {
   // a slice that does not fit whole travels through two buffers (fp64: LDS-DMA double buffering)
   const bool multi = g.chunk_blocks < g.bps + (g.n_long > 0 ? 1 : 0);
   const size_t lds = (size_t)g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(T) * ((multi && sizeof(T) == 8) ? g.ring : 1);
-  if (g.per_group > 0) {
+  if constexpr (sizeof(T) == 8) if (g.per_group > 0) {
     static bool attr1 = false;
     if (!attr1) {
       (void)hipFuncSetAttribute((const void*)k_tile1<T, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize,

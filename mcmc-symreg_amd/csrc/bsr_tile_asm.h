@@ -418,22 +418,22 @@
   /* the list is in cost order: its first tapes run at raised priority (a heavy tape on an even share of its SIMD's */ \
   /* issue slots would end long after the list has drained) */                  \
   "s_cmp_lt_u32 s74, 4\n\t"                                                   \
-  "s_cbranch_scc1 .Lta_p3%=\n\t"                                                 \
+  "s_cbranch_scc1 .Lta_prio3_%=\n\t"                                                 \
   "s_cmp_lt_u32 s74, 8\n\t"                                                   \
-  "s_cbranch_scc1 .Lta_p2%=\n\t"                                                 \
+  "s_cbranch_scc1 .Lta_prio2_%=\n\t"                                                 \
   "s_cmp_lt_u32 s74, 16\n\t"                                                  \
-  "s_cbranch_scc1 .Lta_p1%=\n\t"                                                 \
+  "s_cbranch_scc1 .Lta_prio1_%=\n\t"                                                 \
   "s_setprio 0\n\t"                                                              \
-  "s_branch .Lta_pd%=\n"                                                         \
-  ".Lta_p1%=:\n\t"                                                               \
+  "s_branch .Lta_priod_%=\n"                                                         \
+  ".Lta_prio1_%=:\n\t"                                                               \
   "s_setprio 1\n\t"                                                              \
-  "s_branch .Lta_pd%=\n"                                                         \
-  ".Lta_p2%=:\n\t"                                                               \
+  "s_branch .Lta_priod_%=\n"                                                         \
+  ".Lta_prio2_%=:\n\t"                                                               \
   "s_setprio 2\n\t"                                                              \
-  "s_branch .Lta_pd%=\n"                                                         \
-  ".Lta_p3%=:\n\t"                                                               \
+  "s_branch .Lta_priod_%=\n"                                                         \
+  ".Lta_prio3_%=:\n\t"                                                               \
   "s_setprio 3\n"                                                                \
-  ".Lta_pd%=:\n\t"                                                               \
+  ".Lta_priod_%=:\n\t"                                                               \
   "v_mov_b64_e32 v[72:73], 0\n\t"                                                \
   "v_mov_b64_e32 v[74:75], 0\n\t"                                                \
   "v_mov_b64_e32 v[76:77], 0\n\t"                                                \

@@ -13,12 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mcmc-symreg_amd", "csrc")
 
 
-def _report(name):
-    path = os.path.join(CSRC, "build", name + ".resources.txt")
+def _report(name, objdir="build"):
+    path = os.path.join(CSRC, objdir, name + ".resources.txt")
     if not os.path.exists(path):
         if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
             pytest.skip("no hipcc and no build report")
-        subprocess.run(["bash", os.path.join(CSRC, "build.sh")], check=True, capture_output=True)
+        subprocess.run(["bash", os.path.join(CSRC, "build.sh"), "variants" if objdir == "build_variants" else "ship"],
+                       check=True, capture_output=True)
     out = {}
     cur = None
     for m in re.finditer(r"remark: +(Function Name|VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|Occupancy \[waves/SIMD\]): (\S+)",
@@ -34,7 +35,7 @@ def _report(name):
 def test_tile_row_pass_has_no_scratch():
     rep = _report("bsr_tile")
     names = [n for n in rep if "k_tile1I" in n]
-    assert len(names) == 16, names            # double and float, K = 1..8
+    assert len(names) == 8, names             # fp64, K = 1..8 (fp32 columns keep k_tile's static schedule)
     for n in names:
         r = rep[n]
         # stack slots the register allocator reserves without using them show up as 32-64 bytes here (the disassembly
@@ -88,9 +89,10 @@ def test_streaming_row_pass_keeps_compiler_memory_traffic_out_of_its_chunk_loop(
     vector register, NO scratch access and NO vmcnt wait of the compiler's inside the chunk loop, and no call but the
     cold ones (huge-argument sin/cos, tapes for the general stack machine -- whose scratch-indexed stack slots are why
     that machine is out of line)."""
-    rep = _report("bsr_stream")
+    # (the test library holds every interpreter, mode 2 on one-block chunks included; the shipped one modes 1 and 3)
+    rep = _report("bsr_stream", "build_variants")
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    obj = os.path.join(CSRC, "build", "bsr_stream.o")
+    obj = os.path.join(CSRC, "build_variants", "bsr_stream.o")
     if not (os.path.exists(objdump) and os.path.exists(obj)):
         pytest.skip("no llvm-objdump / object file")
     import tempfile
@@ -130,3 +132,44 @@ def test_streaming_row_pass_keeps_compiler_memory_traffic_out_of_its_chunk_loop(
                 (name[0], n_scratch, n_vm, n_call)
             seen += 1
     assert seen == 24
+
+
+def test_the_assembly_tape_loop_of_the_whole_slice_pass_keeps_the_compiler_out():
+    """k_tile1a (the headline configuration's row pass): its tape loop is ONE block of assembly that declares its registers
+    clobbered, so the compiler must not spill vector registers, and its scratch accesses are the register parked around
+    the rare calls (tapes for the C++ interpreter, leftover units) -- outside the block."""
+    rep = _report("bsr_tile_asm")
+    names = [n for n in rep if "k_tile1aILi" in n]
+    assert len(names) == 4, names             # K = 1..4
+    for n in names:
+        assert rep[n]["VGPRs Spill"] == 0 and rep[n]["VGPRs"] <= 128 and rep[n]["Occupancy [waves/SIMD]"] == 4, (n, rep[n])
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(CSRC, "build", "bsr_tile_asm.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("no llvm-objdump / object file")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(obj, os.path.join(tmp, "t.o"))
+        subprocess.run([objdump, "--offloading", "t.o"], cwd=tmp, check=True, capture_output=True)
+        dev = [f for f in os.listdir(tmp) if "gfx950" in f]
+        text = subprocess.run([objdump, "-d", dev[0]], cwd=tmp, check=True, capture_output=True, text=True).stdout
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None:
+            cur.append(line)
+    for n in names:
+        lines = funcs[n]
+        # the block: from the operator table's base (s_getpc_b64 s[78:79], once per kernel: the caller's loop is not
+        # peeled) to its exit (s_setprio 0 behind the last wait)
+        starts = [i for i, l in enumerate(lines) if "s_getpc_b64 s[78:79]" in l]
+        assert len(starts) == 1, (n, len(starts))
+        end = max(i for i, l in enumerate(lines) if "s_setprio 0" in l)
+        block = lines[starts[0]:end]
+        assert len(block) > 1500, (n, len(block))
+        assert not any("scratch_" in l or "s_swappc" in l for l in block), n
+        # the operator table: sixteen 128-byte slots on a 2 KB boundary (the dispatch ORs the slot's offset into the address)
+        tab = [l for l in block if re.search(r"// 0*[0-9A-F]*[08]00: ", l) and "s_branch" in l]
+        assert tab, n

@@ -6,6 +6,9 @@ import pytest
 
 from conftest import node_from_spec, spec_from_node
 
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 import bsr_oracle as O
@@ -302,22 +305,46 @@ def test_work_queue_soak_against_the_static_grid(N, monkeypatch):
             c.set_current(0, k, flatten(trees[k]))
         c.refresh(0)
         return c
-    static = make({"BSR_TILE": "0", "BSR_NO_LDS": "0"})           # static grid, X staged in LDS
-    want = static.score_batch(tapes, zeros, ks, sig).copy()
-    static.close()
+    # the static grid with X staged in LDS (round 1's launch, BSR_NO_LDS=0) lives in the TEST library only
+    # (csrc/build.sh variants): scored there in a child process, compared here with the shipped library's queue
+    import subprocess, sys, tempfile
+    variants = os.path.join(ROOT, "mcmc-symreg_amd", "bsr", "libbsr_hip_variants.so")
+    assert os.path.exists(variants), "build the test library: bash mcmc-symreg_amd/csrc/build.sh variants"
+    with tempfile.TemporaryDirectory() as tmp:
+        rows0, off0 = pack(tapes)
+        np.savez(os.path.join(tmp, "in.npz"), X=X, y=y, rows=rows0, off=off0, ks=ks, sig=sig,
+                 cur_rows=pack([flatten(t) for t in trees[:K]])[0], cur_off=pack([flatten(t) for t in trees[:K]])[1])
+        script = (
+            "import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from bsr.device import DeviceContext\n"
+            "z = np.load(sys.argv[1])\n"
+            "K = len(z['cur_off']) - 1; B = len(z['ks'])\n"
+            "c = DeviceContext(z['X'], z['y'], K=K, n_chains=1, max_batch=B)\n"
+            "for k in range(K): c.set_current(0, k, z['cur_rows'][z['cur_off'][k]:z['cur_off'][k + 1]])\n"
+            "c.refresh(0)\n"
+            "out = np.zeros(B, dtype=__import__('bsr._lib', fromlist=['x']).SCORE_DTYPE)\n"
+            "c.score_packed(z['rows'], z['off'], np.zeros(B, np.int32), z['ks'], z['sig'], out)\n"
+            "np.save(sys.argv[2], np.frombuffer(out.tobytes(), dtype=np.uint8)); c.close()\n" % os.path.join(ROOT, "mcmc-symreg_amd"))
+        env = dict(os.environ, BSR_LIB_PATH=variants, BSR_TILE="0", BSR_NO_LDS="0")
+        p = subprocess.run([sys.executable, "-c", script, os.path.join(tmp, "in.npz"), os.path.join(tmp, "want.npy")],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        want_bytes = np.load(os.path.join(tmp, "want.npy")).tobytes()
     queue = make({"BSR_TILE": "0", "BSR_NO_LDS": "1"})            # ticket queue
     rows, off = pack(tapes)
-    out = np.zeros(B, dtype=want.dtype)
+    from bsr import _lib
+    out = np.zeros(B, dtype=_lib.SCORE_DTYPE)
     tickets = []
     n_launch = 10_000
     for i in range(n_launch):
         tickets.append(queue.score_submit(rows, off, zeros, ks, sig))
         if len(tickets) == 4:
             queue.score_wait(tickets.pop(0), out)
-            assert out.tobytes() == want.tobytes(), i
+            assert out.tobytes() == want_bytes, i
     while tickets:
         queue.score_wait(tickets.pop(0), out)
-        assert out.tobytes() == want.tobytes()
+        assert out.tobytes() == want_bytes
     queue.close()
 
 

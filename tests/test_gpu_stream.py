@@ -124,9 +124,16 @@ def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K
     fewer columns than waves (waves without a piece to copy).  B = 100: two passes over the slice."""
     import subprocess
     out = {}
-    for mode in ("0", "1", "2", "3"):
+    # the shipped library holds one interpreter per situation; the others are in the test library (csrc/build.sh variants)
+    variants = os.path.join(ROOT, "mcmc-symreg_amd", "bsr", "libbsr_hip_variants.so")
+    assert os.path.exists(variants), "build the test library: bash mcmc-symreg_amd/csrc/build.sh variants"
+    for mode in ("0", "1", "2", "3", "ship"):
         path = str(tmp_path / ("res%s.npy" % mode))
-        env = dict(os.environ, BSR_STREAM_ASM=mode)
+        env = dict(os.environ)
+        env.pop("BSR_LIB_PATH", None)
+        env.pop("BSR_STREAM_ASM", None)
+        if mode != "ship":
+            env.update(BSR_STREAM_ASM=mode, BSR_LIB_PATH=variants)
         p = subprocess.run([sys.executable, "-c", _INTERP_SCRIPT, ROOT, path, str(d), str(K), str(B)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, (mode, p.stderr[-2000:])
@@ -135,6 +142,7 @@ def test_the_interpreters_of_the_streaming_pass_agree_bit_for_bit(tmp_path, d, K
     assert (out["0"] == out["1"]).all(), np.nonzero(out["0"] != out["1"])[0][:20]
     assert (out["0"] == out["2"]).all(), np.nonzero(out["0"] != out["2"])[0][:20]
     assert (out["0"] == out["3"]).all(), np.nonzero(out["0"] != out["3"])[0][:20]
+    assert (out["0"] == out["ship"]).all(), np.nonzero(out["0"] != out["ship"])[0][:20]   # ... and the shipped library's
 
 
 @pytest.mark.parametrize("K,chains,d", [(3, 3, 50), (8, 2, 30)])
