@@ -474,6 +474,7 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
         ranks.barrier()
         dt = ranks.max(time.perf_counter() - t0)
         res = [eng.result(c, current=True) for c in range(chains)]
+        memo = [eng.memo_stats(c) for c in range(chains)]
         done = sum(r["n_props"] for r in res) - done0
         recs = [D.pack_record(ranks.rank * chains + c, None, r["beta"], r["sigma"], r["errs"], r["n_props"],
                               r["n_accept"], r["n_rank_rejects"], r["n_discarded"], tapes_in=r["tapes"])
@@ -487,11 +488,97 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
         return {"metric": "consumed MH proposals/s, native sampler, %d chains x batch %d per GPU" % (chains, batch),
                 "value": total / dt, "seconds": dt, "chains_total": chains * ranks.world,
                 "gathered_records": n_gathered,
+                # CONSUMED proposals: a chain's repeats of a candidate already scored in its current state are answered
+                # from the sampler's memo (they are part of what a chain consumes, not of what the GPU scored: the
+                # headline counts GPU-scored proposals only)
+                "memo_answered_fraction_of_generated": sum(m[0] for m in memo) / max(1, sum(m[1] for m in memo)),
                 "discarded_fraction": sum(r["n_discarded"] for r in res) /
                 max(1, sum(r["n_discarded"] + r["n_props"] for r in res))}
     finally:
         eng.close()
         scorer.close()
+
+
+def deep_leg(args, ranks, n_batches=12):
+    """BASELINE configs[4] says "deep trees (depth <= 12)"; the real move mix of a burnt-in chain averages 3-4 nodes per
+    tape, so the c5 leg never shows how the streaming pass behaves on them.  This leg scores batches of 64 candidates
+    GROWN to height 8..12 (the reference's own grow(), codes/funcs.py:74-119, with its depth prior flattened: beta -0.15
+    instead of -1, at most 400 nodes) on the c5 data set and reports nodes per tape, how many tapes the assembly
+    interpreter could take (64-bit programs: <= 16 entries) and the row pass's duration per launch."""
+    import numpy as np
+    from bsr import grow
+    from bsr.node import Node, getHeight, getNum
+    from bsr.proposal import OpTable
+    from bsr.tape import flatten, pack
+    short = argparse.Namespace(**vars(args))
+    short.batch, short.chains = 0, 0
+    wl = build_workload("c5", short, ranks)
+    generate_batches(wl, 2)
+    ctx, B, d, K = wl["ctx"], wl["B"], wl["d"], wl["K"]
+    ops = ['inv', 'ln', 'neg', 'sin', 'cos', 'exp', 'square', 'cubic', '+', '*']
+    w, typ = [0.1] * 10, [1] * 8 + [2, 2]
+    np.random.seed(4242)
+    trees = []
+    while len(trees) < B * n_batches:
+        root = Node(0)
+        grow(root, d, ops, w, typ, -0.15, 1.0, 1.0)
+        h, n = getHeight(root), getNum(root)
+        if 8 <= h <= 12 and n <= 400:
+            trees.append((root, h, n))
+    base = wl["packed"][0]
+    heights = [t[1] for t in trees]
+    nodes = [t[2] for t in trees]
+    packed = []
+    for b in range(n_batches):
+        rows, off = pack([flatten(t[0]) for t in trees[b * B:(b + 1) * B]])
+        out = np.zeros(B, dtype=wl["lib"].SCORE_DTYPE)
+        packed.append((rows, off, base[2], base[3], base[4], out))
+    ctx.set_profiling(1)
+    kern, stats, n_nan = [], {"tapes": 0, "asm_program_tapes": 0, "chain_tapes": 0, "stream_entries": 0}, 0
+    for rep in range(3):
+        for r in packed:
+            t = ctx.score_submit(r[0], r[1], r[2], r[3], r[4])
+            ctx.score_wait(t, r[5])
+            if rep > 0:
+                kern.append(float(ctx.last_timing()[0]))
+            if rep == 2:
+                st = ctx.batch_stats(t)
+                for k in stats:
+                    stats[k] += st[k]
+                n_nan += int(np.sum(r[5]["rank"] < 0))
+    ctx.set_profiling(0)
+    # pipelined throughput over the same batches
+    t0 = time.perf_counter()
+    tickets, n_steps = [], 0
+    while time.perf_counter() - t0 < 0.6:
+        r = packed[n_steps % n_batches]
+        tickets.append((ctx.score_submit(r[0], r[1], r[2], r[3], r[4]), r))
+        if len(tickets) >= 4:
+            t, rr = tickets.pop(0)
+            ctx.score_wait(t, rr[5])
+        n_steps += 1
+    while tickets:
+        t, rr = tickets.pop(0)
+        ctx.score_wait(t, rr[5])
+    dt = time.perf_counter() - t0
+    info = ctx.info()
+    wl["scorer"].close()
+    kern_us = float(np.median(kern))
+    s = 8
+    alg_bytes = int(s * wl["N"] * (min(d, 50) + 1 + (K - 1)))          # every feature is referenced by tapes this long
+    return {"metric": "MH proposals scored/sec, candidates grown to height 8..12 (N=1M, d=50, K=3)",
+            "value": n_steps * B / dt, "unit": "proposals/s", "ms_per_step": 1e3 * dt / n_steps,
+            "avg_nodes_per_tape": float(np.mean(nodes)), "max_nodes_per_tape": int(np.max(nodes)),
+            "height_min_max": [int(np.min(heights)), int(np.max(heights))],
+            "avg_stream_entries_per_tape": stats["stream_entries"] / max(1, stats["tapes"]),
+            "share_of_tapes_for_the_assembly_interpreter": stats["asm_program_tapes"] / max(1, stats["tapes"]),
+            "share_of_chain_tapes": stats["chain_tapes"] / max(1, stats["tapes"]),
+            "nan_candidates": n_nan,
+            "row_pass": info["row_pass"], "row_pass_us_per_launch": kern_us,
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                         "note": "an interpreter at ~%d entries per tape is bound by instruction issue, not by HBM" %
+                                 round(stats["stream_entries"] / max(1, stats["tapes"]))}}
 
 
 def f32_leg(args, ranks):
@@ -649,6 +736,10 @@ def main():
         except Exception as exc:
             ex["c2_native_engine"] = {"error": repr(exc)}
         if ranks.world == 1:
+            try:
+                ex["c5_deep"] = deep_leg(args, ranks)
+            except Exception as exc:
+                ex["c5_deep"] = {"error": repr(exc)}
             try:
                 ex["c5_f32"] = f32_leg(args, ranks)
                 import glob

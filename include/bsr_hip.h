@@ -237,8 +237,16 @@ int bsr_last_timing(bsr_ctx* ctx, double* us5);
  * has no counterpart: it is one thread on one CPU, codes/bsr_class.py:99):
  *   info[0] submission threads   info[1] CPUs the library's threads are placed on (0: not placed)
  *   info[2] 1 if the caller was confined too (BSR_PIN=1)   info[3] CPU budget of this rank, x100
- *   info[4] tape groups T   info[5] row slices   info[6] blocks per slice   info[7] 1: slices staged whole, 0: chunked */
+ *   info[4] tape groups T   info[5] row slices   info[6] blocks per slice
+ *   info[7] the scoring row pass: 1 slices staged whole (k_tile1), 3 the same with the tape loop in assembly (k_tile1a),
+ *           2 slices streamed through LDS (k_stream), 0 chunked k_tile / work-queue k_rows */
 int bsr_ctx_info(const bsr_ctx* ctx, int32_t* info8);
+
+/* How the LAST waited batch of `ticket` was scored, for the bench's depth-stress leg (no reference counterpart):
+ *   stats[0] tapes   stats[1] tapes the row pass's assembly interpreter took (64-bit programs: at most 16-17 entries,
+ *   8 terminals, one value below the accumulator)   stats[2] chain tapes (no value stack at all)
+ *   stats[3] stream entries of the batch after the fusions (a `terminal, +|*` pair or a derived column is one entry) */
+int bsr_batch_stats(const bsr_ctx* ctx, int32_t ticket, int32_t* stats4);
 
 /* Where this process's library threads were placed (once per process, by the first bsr_ctx_create; csrc/bsr_place.h):
  *   info[0] 1 if a placement was made   info[1] its CPUs   info[2] NUMA node of the context's GPU as sysfs reports it
@@ -290,6 +298,11 @@ int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t max_props, bs
 int bsr_engine_chain_result(bsr_engine* e, int32_t chain, bsr_node* tapes, int32_t tape_cap, int32_t* tape_len,
                             double* beta, double* errs, int32_t errs_cap, int32_t* n_errs, int64_t* counters,
                             double* sigma, int32_t current);
+/* The sampler's score memo (no reference counterpart; BSR_ENGINE_MEMO=0 turns it off): a chain that proposes, in an
+ * unchanged state, a (tree incl. ln parameters, slot k) it has had scored before takes rank and SSE from a table and
+ * recomputes the log-likelihood for the proposal's own sigma (codes/funcs.py:1162-1173: SSE does not depend on sigma).
+ * stats[0] = proposals answered from the table, stats[1] = lookups, over the chain's life. */
+int bsr_engine_memo_stats(const bsr_engine* e, int32_t chain, int64_t* stats2);
 int bsr_rng_selftest(uint32_t seed, int32_t n, const int32_t* kind, const int64_t* lo, const int64_t* hi, double* out);
 
 #ifdef __cplusplus

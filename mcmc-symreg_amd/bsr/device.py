@@ -177,6 +177,13 @@ class DeviceContext:
                 "blocks_per_slice": int(v[6]), "slices_whole": int(v[7]) in (1, 3), "streaming": int(v[7]) == 2,
                 "row_pass": {1: "k_tile1", 2: "k_stream", 3: "k_tile1a"}.get(int(v[7]), "k_tile/k_rows")}
 
+    def batch_stats(self, ticket=0):
+        """How the last waited batch of `ticket` was scored (bsr_batch_stats): tapes, of which the assembly interpreter's,
+        of which chains; stream entries after the fusions."""
+        v = np.zeros(4, dtype=np.int32)
+        _lib.check(self._L.bsr_batch_stats(self._h, int(ticket), _lib.ptr(v)), self._h)
+        return {"tapes": int(v[0]), "asm_program_tapes": int(v[1]), "chain_tapes": int(v[2]), "stream_entries": int(v[3])}
+
     def last_timing(self):
         us = np.zeros(5, dtype=np.float64)
         _lib.check(self._L.bsr_last_timing(self._h, _lib.ptr(us)), self._h)

@@ -83,6 +83,12 @@ class NativeEngine:
         self._check(rc)
         return trace[:n.value]
 
+    def memo_stats(self, chain):
+        """(proposals answered from the chain's score memo, lookups) over the chain's life (bsr_engine_memo_stats)."""
+        v = np.zeros(2, dtype=np.int64)
+        self._check(self._L.bsr_engine_memo_stats(self._h, chain, _lib.ptr(v)))
+        return int(v[0]), int(v[1])
+
     def result(self, chain, current=False):
         K = self.K
         cap = 256

@@ -51,6 +51,7 @@ struct BatchSlot {
   size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
   size_t recs_bytes = 0; // ... of which this batch uses so many bytes
   size_t srec_off = 0;   // streaming kernel: its StreamRecs, so many bytes behind off_recs
+  int32_t stat_tapes = 0, stat_fast = 0, stat_chain = 0, stat_entries = 0;   // bsr_batch_stats: the last batch staged here
   size_t tprog_off = 0;  // whole-slice kernel with the assembly tape loop: its TileProgs, so many bytes behind off_recs (0: none)
   // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
   MhRes* d_mh = nullptr;
@@ -186,6 +187,7 @@ struct bsr_ctx {
   // structure of the chains' current trees (bsr_span.h): per tree its linear form, per chain the echelon basis of its K
   // forms -- rebuilt on set_current / commit, handed to the batches in flight as immutable snapshots
   std::vector<bsr_span::LinForm> cur_form;     // [chain*K+k]
+  std::vector<uint64_t> cur_fmask;   // features each current tree reads (bit f mod 64), all ones: unknown
   std::vector<char> cur_form_ok;               // ... valid
   std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span;   // [chain]
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace

@@ -1027,8 +1027,45 @@ struct Cand {
   std::vector<bsr_node> tape;
 };
 
+// Scores of the candidates a chain has had scored in its CURRENT state (emptied by every accepted move).  A score is a
+// function of (candidate column, slot k, the chain's K current columns) and -- through the log-likelihood only -- of the
+// candidate's sigma (codes/funcs.py:1162-1173: SSE does not see it), and a chain proposes the same few mutations of its
+// trees over and over between two accepts: 40-49 % of the consumed proposals repeat a (tree incl. ln parameters, k)
+// already scored (tools/memo_probe.py, profiles/r05_memo_probe.txt).  Those are answered from here: rank and SSE from
+// the table, the log-likelihood recomputed for the candidate's own sigma by the formula the device uses.
+struct ScoreMemo {
+  static constexpr int CAP = 2048;   // slots (open addressing, linear probing); full at CAP / 2 entries: no more inserts
+  std::vector<uint64_t> key;         // 0: empty
+  std::vector<bsr_score> val;
+  int n = 0;
+  int64_t hits = 0, lookups = 0;
+  void clear() {
+    if (n > 0) std::fill(key.begin(), key.end(), 0ull);
+    n = 0;
+  }
+  const bsr_score* find(uint64_t k) {
+    ++lookups;
+    if (n == 0) return nullptr;
+    if (k == 0) k = 1;
+    for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
+      if (key[i] == k) { ++hits; return &val[i]; }
+      if (key[i] == 0) return nullptr;
+    }
+  }
+  void put(uint64_t k, const bsr_score& v) {
+    if (key.empty()) { key.assign(CAP, 0ull); val.resize(CAP); }
+    if (n >= CAP / 2) return;
+    if (k == 0) k = 1;
+    for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
+      if (key[i] == k) return;
+      if (key[i] == 0) { key[i] = k; val[i] = v; ++n; return; }
+    }
+  }
+};
+
 struct ChainS {
   int index = 0;
+  ScoreMemo memo;
   LegacyRng rng;
   std::vector<Tree> roots;
   std::vector<std::vector<bsr_node>> tapes;
@@ -1080,6 +1117,7 @@ struct bsr_engine {
   int K = 0, n_chains = 0, val = 100, y_is_series = 1;
   int nan_reject = 0;  // 0: a NaN candidate aborts like the reference (LinAlgError); 1: treat it as a rank-gate rejection
   int predict_gate = 1;  // speculate the rank gate's verdict (BSR_ENGINE_PREDICT=0: off)
+  int score_memo = 1;    // answer exact repeats of a candidate in an unchanged chain state from a table (BSR_ENGINE_MEMO=0: off)
   int device_mh = 0;     // BSR_ENGINE_DEVICE_MH=1: log-ratio, accept test and first-event scan on the device (k_events).
                          // Off by default: measured 8 % slower end to end (one more launch per batch, 4 KB more
                          // upload) than the 0.2 us per proposal the host spends on the same arithmetic.
@@ -1157,6 +1195,9 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.fs_old_p.assign(K, 0.0);
   c.fs_old_ok.assign(K, 0);
   c.def_ema.assign(K, 0.0);
+  c.gate_memo.clear();        // (a chain object is used again for the next restart: nothing of the last one's state stands)
+  c.gate_pass_memo.clear();
+  c.memo.clear();
   c.ckey.assign(K, 0);
   for (int k = 0; k < K; ++k) c.ckey[k] = canon_key(c.roots[k]);
   rebuild_sibling_spans(c, K);
@@ -1388,7 +1429,7 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
 // as speculated the random stream already stands where it should; *broke_out tells the caller whether an event
 // (accept, gate verdict against the speculation, error) ended the run early -- what was generated behind is then void
 int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot, const bsr_event* ev,
-            bool keep_rng = false, bool* broke_out = nullptr) {
+            bool keep_rng = false, bool* broke_out = nullptr, const int32_t* gpu_index = nullptr) {
   const int K = e->K;
   int used = 0;
   bool broke = false;
@@ -1505,6 +1546,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     ++c.n_accept;
     c.gate_memo.clear();   // (the siblings of every k change with this move)
     c.gate_pass_memo.clear();
+    c.memo.clear();        // (... and so does every score)
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
     c.last_stale = true;
     c.roots[k] = cd.tree;
@@ -1521,8 +1563,30 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
         explicit CtxLock(bsr_ctx* c_) : c(c_) { if (c) bsr_internal_lock(c); }
         ~CtxLock() { if (c) bsr_internal_unlock(c); }
       } lk(batch_slot >= 0 ? e->ctx : nullptr);
-      if (batch_slot >= 0) ECHK(e, bsr_internal_commit(e->ctx, batch_slot, c.index, k, slot0 + (int)i));
-      else ECHK(e, bsr_commit(e->ctx, c.index, k, slot0 + (int)i));
+      // the accepted proposal by its place in the batch the GPU scored -- or, where it was answered from the score memo
+      // (it is in no batch), by its tape: bsr_commit is bsr_set_current of the same tape, bit for bit
+      int at = gpu_index ? gpu_index[slot0 + (int)i] : slot0 + (int)i;
+      int commit_slot = batch_slot;
+      if (at < 0) {
+        // answered from the score memo: its tape is staged in no batch.  An accept is rare (one in hundreds of
+        // proposals): the tape goes to the GPU alone, on this lane's slot (its batch has been waited for), and the
+        // commit is made from THAT batch, as for any other accepted proposal
+        const int32_t off2[2] = {0, (int32_t)cd.tape.size()};
+        const int32_t ch1 = c.index, k1 = k;
+        const double sg1 = cd.new_sigma;
+        bsr_score one;
+        if (batch_slot >= 0) {
+          ECHK(e, bsr_internal_submit(e->ctx, batch_slot, cd.tape.data(), off2, &ch1, &k1, &sg1, 1));
+          ECHK(e, bsr_internal_wait(e->ctx, batch_slot, &one));
+        } else {
+          int32_t tk = -1;
+          ECHK(e, bsr_score_submit(e->ctx, cd.tape.data(), off2, &ch1, &k1, &sg1, 1, &tk));
+          ECHK(e, bsr_score_wait(e->ctx, tk, &one));
+        }
+        at = 0;
+      }
+      if (commit_slot >= 0) ECHK(e, bsr_internal_commit(e->ctx, commit_slot, c.index, k, at));
+      else ECHK(e, bsr_commit(e->ctx, c.index, k, at));
       int rc = refresh_chain(e, c);
       if (rc != BSR_OK) return rc;
       ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
@@ -1574,6 +1638,7 @@ extern "C" int bsr_engine_create(bsr_engine** out, bsr_ctx* ctx, int32_t n_chain
   e->P.fill_depth_tables();
   e->P.set_default_table();
   if (getenv("BSR_ENGINE_PREDICT")) e->predict_gate = atoi(getenv("BSR_ENGINE_PREDICT")) != 0;
+  if (getenv("BSR_ENGINE_MEMO")) e->score_memo = atoi(getenv("BSR_ENGINE_MEMO")) != 0;
   bsr_internal_feature_range(ctx, &e->x_lo, &e->x_hi);
   if (getenv("BSR_ENGINE_DEVICE_MH")) e->device_mh = atoi(getenv("BSR_ENGINE_DEVICE_MH")) != 0;
   if (getenv("BSR_ENGINE_VERIFY_MH")) e->verify_mh = atoi(getenv("BSR_ENGINE_VERIFY_MH")) != 0;
@@ -1670,6 +1735,15 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     std::vector<int32_t> mhflags, spans;
     std::vector<bsr_event> events;
     std::vector<bsr_score> res;
+    // the score memo: which proposals of the batch are answered from their chain's table (their scores, ready), and the
+    // batch that actually goes to the GPU -- the others, compacted; gpu_pos: where a GPU result belongs in `res`
+    std::vector<char> hit;
+    std::vector<bsr_score> hit_val;
+    std::vector<bsr_node> g_rows;
+    std::vector<int32_t> g_off, g_chs, g_ks, gpu_pos, gpu_of;   // gpu_of: a proposal's place in the GPU's batch, -1: none
+    std::vector<double> g_sig;
+    std::vector<bsr_score> g_res;
+    bool compact = false, no_gpu = false;
     std::vector<std::pair<int, int>> span;       // per chain of the group: first proposal, count
     std::vector<std::vector<Cand>> cands;        // per chain: its candidates in this batch
     std::vector<LegacyRng> end_state;            // per chain: the random stream behind its last candidate
@@ -1740,6 +1814,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   }
   const int per_group_cap = std::max(1, max_batch / n_groups);
   const bool use_mh = e->device_mh && !trace && e->K > 1;
+  const bool memo_on = e->score_memo && !use_mh;   // (the device-side MH scan wants every proposal's score on the device)
+  const int K = e->K;
 
   // generates and submits the batch of lane `li`; ahead: behind the candidates the group's other lane has in flight
   auto submit = [&](Group& g, int li, bool ahead) -> int {
@@ -1753,6 +1829,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     L.terms.clear();
     L.mhflags.clear();
     L.spans.assign(1, 0);
+    L.hit.clear();
+    L.hit_val.clear();
+    L.compact = L.no_gpu = false;
+    int n_hit = 0;
     const size_t nc = g.chains.size();
     L.cands.resize(nc);
     L.end_state.resize(nc);
@@ -1786,6 +1866,17 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       g.t_gen += now_s() - tg0;
       L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
+        if (memo_on) {
+          const bsr_score* h = c->memo.find(cd.ghash);
+          L.hit.push_back(h ? 1 : 0);
+          if (h) {
+            bsr_score v = *h;
+            if (v.rank == K)   // the device's formula (csrc/bsr_solve.h), for this candidate's sigma
+              v.loglik = -v.sse / (2 * cd.new_sigma * cd.new_sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * cd.new_sigma * cd.new_sigma);
+            L.hit_val.push_back(v);
+            ++n_hit;
+          }
+        }
         L.rows.insert(L.rows.end(), cd.tape.begin(), cd.tape.end());
         L.off.push_back((int32_t)L.rows.size());
         L.chs.push_back(c->index);
@@ -1806,18 +1897,46 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     int r;
     const int n_sp = (int)L.spans.size() - 1;
     L.events.resize(std::max(1, n_sp));
+    // proposals answered from the memo do not travel: the batch for the GPU is the others, compacted
+    const bsr_node* rows_p = L.rows.data();
+    const int32_t* off_p = L.off.data();
+    const int32_t* chs_p = L.chs.data();
+    const int32_t* ks_p = L.ks.data();
+    const double* sig_p = L.sig.data();
+    int n_gpu = (int)L.chs.size();
+    if (n_hit > 0) {
+      L.compact = true;
+      L.g_rows.clear(); L.g_off.assign(1, 0); L.g_chs.clear(); L.g_ks.clear(); L.g_sig.clear(); L.gpu_pos.clear();
+      L.gpu_of.assign(L.chs.size(), -1);
+      for (size_t i = 0; i < L.chs.size(); ++i) {
+        if (L.hit[i]) continue;
+        L.gpu_of[i] = (int32_t)L.gpu_pos.size();
+        L.g_rows.insert(L.g_rows.end(), L.rows.begin() + L.off[i], L.rows.begin() + L.off[i + 1]);
+        L.g_off.push_back((int32_t)L.g_rows.size());
+        L.g_chs.push_back(L.chs[i]);
+        L.g_ks.push_back(L.ks[i]);
+        L.g_sig.push_back(L.sig[i]);
+        L.gpu_pos.push_back((int32_t)i);
+      }
+      n_gpu = (int)L.g_chs.size();
+      L.g_res.resize(std::max(1, n_gpu));
+      rows_p = L.g_rows.data(); off_p = L.g_off.data(); chs_p = L.g_chs.data(); ks_p = L.g_ks.data(); sig_p = L.g_sig.data();
+    }
+    if (n_gpu == 0) {   // every proposal of the batch is a repeat: nothing to launch
+      L.no_gpu = true;
+      L.inflight = true;
+      return BSR_OK;
+    }
     if (L.slot >= 0)
       r = use_mh ? bsr_internal_submit_mh(e->ctx, L.slot, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(),
                                           L.sig.data(), (int)L.chs.size(), L.terms.data(), L.mhflags.data(),
                                           L.spans.data(), n_sp)
-                 : bsr_internal_submit(e->ctx, L.slot, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(),
-                                       L.sig.data(), (int)L.chs.size());
+                 : bsr_internal_submit(e->ctx, L.slot, rows_p, off_p, chs_p, ks_p, sig_p, n_gpu);
     else
       r = use_mh ? bsr_score_submit_mh(e->ctx, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(), L.sig.data(),
                                        (int)L.chs.size(), L.terms.data(), L.mhflags.data(), L.spans.data(), n_sp,
                                        &L.ticket)
-                 : bsr_score_submit(e->ctx, L.rows.data(), L.off.data(), L.chs.data(), L.ks.data(), L.sig.data(),
-                                    (int)L.chs.size(), &L.ticket);
+                 : bsr_score_submit(e->ctx, rows_p, off_p, chs_p, ks_p, sig_p, n_gpu, &L.ticket);
     g.t_submit += now_s() - ts0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_submit: ") + bsr_last_error(e->ctx));
     L.inflight = true;
@@ -1830,15 +1949,24 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     L.inflight = false;
     const double tw0 = now_s();
     int r;
-    if (use_mh)
+    bsr_score* res_p = L.compact ? L.g_res.data() : L.res.data();
+    if (L.no_gpu)
+      r = BSR_OK;
+    else if (use_mh)
       r = (L.slot >= 0) ? bsr_internal_wait_mh(e->ctx, L.slot, L.res.data(), L.events.data())
                         : bsr_score_wait_mh(e->ctx, L.ticket, L.res.data(), L.events.data());
     else
-      r = (L.slot >= 0) ? bsr_internal_wait(e->ctx, L.slot, L.res.data())
-                        : bsr_score_wait(e->ctx, L.ticket, L.res.data());
+      r = (L.slot >= 0) ? bsr_internal_wait(e->ctx, L.slot, res_p)
+                        : bsr_score_wait(e->ctx, L.ticket, res_p);
     const double tw1 = now_s();
     g.t_wait += tw1 - tw0;
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_wait: ") + bsr_last_error(e->ctx));
+    if (L.compact) {   // the GPU's scores to their places, the memo's next to them
+      for (size_t j = 0; j < L.gpu_pos.size(); ++j) L.res[L.gpu_pos[j]] = L.g_res[j];
+      size_t hv = 0;
+      for (size_t i = 0; i < L.hit.size(); ++i)
+        if (L.hit[i]) L.res[i] = L.hit_val[hv++];
+    }
     int sp = 0;  // chains with proposals in this batch, in order: the spans of the MH scan
     for (size_t i = 0; i < g.chains.size(); ++i) {
       if (L.span[i].second == 0) continue;
@@ -1853,13 +1981,19 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       c.cands.swap(L.cands[i]);
       c.end_state = L.end_state[i];
       c.start_state = L.start_state[i];
+      if (memo_on)   // what the GPU scored for this chain's (unchanged) state: kept for the repeats to come
+        for (size_t q = 0; q < c.cands.size(); ++q) {
+          const size_t at = (size_t)L.span[i].first + q;
+          if (at < L.hit.size() && !L.hit[at]) c.memo.put(c.cands[q].ghash, L.res[at]);
+        }
       bool more_ahead = false;
       for (int ol = 0; ol < 3; ++ol) {
         const Lane& O = g.lane[ol];
         more_ahead = more_ahead || (ol != li && O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0);
       }
       bool broke = false;
-      r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke);
+      r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke,
+                  L.compact ? L.gpu_of.data() : nullptr);
       g.evt_ema = 0.9 * g.evt_ema + (broke ? 0.1 : 0.0);
       if (broke)   // what was generated behind these is void
         for (int ol = 0; ol < 3; ++ol) {
@@ -1967,6 +2101,13 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
             (long long)g, (long long)ps, (long long)ok, (long long)rj);
   }
   return rc;
+}
+
+extern "C" int bsr_engine_memo_stats(const bsr_engine* e, int32_t chain, int64_t* stats2) {
+  if (!e || !stats2 || chain < 0 || chain >= (int)e->chains.size()) return BSR_E_ARG;
+  stats2[0] = e->chains[chain].memo.hits;
+  stats2[1] = e->chains[chain].memo.lookups;
+  return BSR_OK;
 }
 
 extern "C" int bsr_engine_chain_result(bsr_engine* e, int32_t chain, bsr_node* tapes, int32_t tape_cap,

@@ -237,6 +237,14 @@ inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 2
 // the column of one is the column of the other up to sign, bit for bit (equal identities)
 inline bool same_up_to_sign(const LinForm& f, const LinForm& g) { return f.shash == g.shash; }
 
+// features a tape reads, feature f at bit f mod 64
+inline uint64_t feature_mask(const bsr_node* t, int len) {
+  uint64_t m = 0;
+  for (int i = 0; i < len; ++i)
+    if (t[i].opcode == BSR_OP_TERMINAL) m |= 1ull << (t[i].feature & 63);
+  return m;
+}
+
 // Echelon basis of a chain's K forms.
 struct SpanBasis {
   static constexpr int VCAP = 56;   // terms a working vector holds (K <= 8 forms of <= 6 terms and a candidate's)
@@ -266,6 +274,10 @@ struct SpanBasis {
     Vec t;   // the pivot's coefficient is 1, no other row holds it
   };
   std::vector<Row> rows;
+  // features the chain's current trees read, feature f at bit f mod 64 (all ones: unknown).  A candidate that reads a
+  // feature outside them is not looked at (mark_in_span): it could only be in the span through an exact cancellation of
+  // that feature (x5 - x5 + x1), which costs it a residual pass it did not need -- and nothing else.
+  uint64_t feat_mask = ~0ull;
   std::vector<LinForm> forms;   // the K forms themselves (same_up_to_sign against tree k)
   std::vector<char> known;      // form k is valid
 

@@ -692,6 +692,12 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
         fprintf(stderr, "%s\n", l2.c_str());
       }
     }
+    s.stat_tapes = P;
+    s.stat_fast = s.stat_chain = s.stat_entries = 0;
+    for (int i = 0; i < P; ++i) {
+      s.stat_chain += hd[i].chain ? 1 : 0;
+      s.stat_entries += hd[i].n_nodes;
+    }
     s.srec_off = 0;
     if (s.tile_stream) {
       // the streaming kernel's 32-byte view of every set of sums, in schedule order, one record of padding behind the
@@ -712,6 +718,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
           if (op == BSR_OP_LOG) fast = false;
           enc |= (uint64_t)((op + 1) & 15) << (4 * (e - 1));
         }
+        s.stat_fast += fast ? 1 : 0;
         Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : 0) | 64 | ((R.qslot & 0xFF) << 8);
         Q.s = R.s;
         Q.code = fast ? enc : 0;
@@ -773,6 +780,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
               const long a = ++n_all, f = n_fast += fast ? 1 : 0, st = n_stack += (R.chain & 1) ? 0 : 1;
               if (a % 6400 == 0) fprintf(stderr, "tile asm: %ld tapes, %ld for the block, %ld not chains\n", a, f, st);
             }
+            s.stat_fast += fast ? 1 : 0;
             Q.meta = (fast ? (int32_t)0x80000000 : 0) | (R.qslot & 0xFF);
             Q.p = R.p;
             Q.s = R.s;

@@ -139,3 +139,36 @@ def test_eight_ranks_on_one_device_complete_with_eight_records():
     assert all(p["submit_threads"] <= (2 if p["cpu_budget"] >= 6 else 1 if p["cpu_budget"] >= 3 else 0) or
                p["submit_threads"] <= 2 for p in pr)
     assert out["verified"]["byte_identical"]
+
+
+def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch):
+    """The native sampler answers exact repeats of a candidate in an unchanged chain state from a table (rank and SSE kept,
+    the log-likelihood recomputed for the proposal's own sigma: codes/funcs.py:1162-1173).  Four chains with the memo and
+    without it: the same accepted trees, proposal / accept / rank-rejection counts, Beta and RMSE history -- and a good
+    share of the proposals is answered from the table (tools/memo_probe.py measured 40-49 % repeats)."""
+    from bsr import dist as D
+    from bsr.chain import DeviceScorer
+    from bsr.native import NativeEngine
+    X, y = _c4_data()
+    K, val = 3, 60
+    out = {}
+    for memo in ("1", "0"):
+        monkeypatch.setenv("BSR_ENGINE_MEMO", memo)
+        scorer = DeviceScorer(X, y, K, n_chains=4, max_batch=128)
+        eng = NativeEngine(scorer.ctx, 4, X.shape[1], val=val)
+        for c in range(4):
+            eng.seed(c, 2000 + c)
+            eng.init_chain(c)
+        eng.run(batch_per_chain=32)
+        res = [eng.result(c) for c in range(4)]
+        stats = [eng.memo_stats(c) for c in range(4)]
+        eng.close()
+        scorer.close()
+        from bsr.node import Express
+        out[memo] = ([([Express(t) for t in r["roots"]], r["n_props"], r["n_accept"], r["n_rank_rejects"],
+                       r["beta"].tobytes(), tuple(r["errs"])) for r in res], stats)
+    assert out["1"][0] == out["0"][0]
+    hits = sum(s[0] for s in out["1"][1])
+    looks = sum(s[1] for s in out["1"][1])
+    assert sum(s[0] for s in out["0"][1]) == 0
+    assert looks > 0 and hits / looks > 0.15, (hits, looks)

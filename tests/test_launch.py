@@ -172,6 +172,34 @@ def test_only_the_start_up_is_bounded_by_default(tmp_path, monkeypatch):
     assert codes.timed_out == "job"
 
 
+def test_a_sharded_rank_is_up_before_its_chains_run(tmp_path, monkeypatch):
+    """bsr.sharded.run_rank joined the gather only AFTER its chains had run, so fit_sharded's
+    init_timeout (900 s) covered the whole fit.  A rank shaped like run_rank is now: connect first (rendezvous,
+    communicator, first collective, marker), work for longer than init_timeout, gather -- and is left alone; the old
+    order (work, then connect) is what the timeout catches."""
+    sys.path.insert(0, PKG)
+    from bsr.launch import spawn
+    monkeypatch.delenv("BSR_SPAWN_TIMEOUT", raising=False)
+    body = ("import sys, time\nsys.path.insert(0, %r)\nimport numpy as np\nfrom bsr import dist as D\n"
+            "from bsr.launch import rank_env\nrank, world, local = rank_env()\n" % PKG)
+    good = tmp_path / "good.py"
+    good.write_text(body + "g, rdv = D.connect(None, rank, world)\ntime.sleep(4.0)\n"
+                    "recs = D.gather_raw(g, [D.pack_record(rank, None, [0.5], 0.7, [1.0], 3, 1, tapes_in=[])])\n"
+                    "assert [D.unpack_record(r)['chain'] for r in recs] == list(range(world))\n")
+    import inspect
+    from bsr import sharded
+    src = inspect.getsource(sharded.run_rank)
+    assert src.index("D.connect(") < src.index("eng.run("), "run_rank must join the gather before its chains run"
+    t0 = time.time()
+    codes, _ = spawn(2, [str(good)], init_timeout=2.0, relay_rank0_stdout=False, env_extra={"BSR_SHARE_DEVICE": "1"})
+    assert list(codes) == [0, 0] and codes.timed_out is None and time.time() - t0 >= 4.0
+    late = tmp_path / "late.py"
+    late.write_text(body + "time.sleep(30.0)\ng, rdv = D.connect(None, rank, world)\n")
+    t0 = time.time()
+    codes, _ = spawn(2, [str(late)], init_timeout=2.0, relay_rank0_stdout=False, env_extra={"BSR_SHARE_DEVICE": "1"})
+    assert codes.timed_out == "init" and time.time() - t0 < 25.0
+
+
 def test_an_elastic_restart_does_not_read_the_previous_attempts_blobs(tmp_path, monkeypatch):
     """under an external launcher the nonce was the port and the agent's pid -- the same after the agent
     restarts its workers, so a non-zero rank could fetch the previous attempt's unique id and hang in
