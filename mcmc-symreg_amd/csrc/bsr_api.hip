@@ -135,6 +135,7 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.spill) (void)hipFree(s.spill);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.h_done_word) (void)hipHostFree(s.h_done_word);
     for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -344,6 +345,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     }
     c->tile_asm = c->tile_whole && c->dtype == BSR_DTYPE_F64 && tile_asm_takes(K) && env_int("BSR_TILE_ASM", 1) != 0;
     c->tile_split = env_int("BSR_TILE_SPLIT", 1) != 0;
+    c->done_word = env_int("BSR_DONE_WORD", 1) != 0;
     c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
                         (size_t)((max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax) + 1) + 64;
     if (!c->tile_whole && !getenv("BSR_DERIVED_MAX")) c->derived_max = 16;   // chunked: the transcendentals saved are worth more columns
@@ -426,6 +428,8 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     s.chain_slot.assign(std::max(1, n_chains), -1);
     CK(hipHostMalloc((void**)&s.h_out, sizeof(bsr_score) * (max_batch + 1)));
     CK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (hipHostMalloc((void**)&s.h_done_word, 64) == hipSuccess) memset(s.h_done_word, 0, 64);
+    else { (void)hipGetLastError(); s.h_done_word = nullptr; }
     for (auto& e : s.ev) CK(hipEventCreate(&e));
   }
 #undef CK
@@ -629,6 +633,29 @@ struct TailJob {
 };
 static void launcher_push(bsr_ctx* c, const TailJob& job);
 
+// The two steps behind k_solve for the proposals it flagged: the residual pass (w = s z - Q c measured directly) and
+// the finalise step -- fused into the residual pass's last workgroup where that kernel has the registers for the
+// solver (K <= 3) and the hand-over memory is uncached (ensure_partials): one launch fewer.
+static void launch_flagged_tail(bsr_ctx* c, BatchSlot& s, const LaunchGeom& g, int P, int spill_slots, int nq, double rank_floor,
+                                int& rc) {
+  hipStream_t st = s.stream;
+  const bool fuse_fin = s.part2_uncached && residual_can_fuse_finalize(c->K) && c->no_lds;
+  FinArgs fin;
+  memset(&fin, 0, sizeof fin);
+  if (fuse_fin) {
+    fin.ck = c->d_ck; fin.out = s.h_out; fin.mh = s.d_mh; fin.rank_floor = rank_floor;
+    fin.arrive = reinterpret_cast<int32_t*>(s.part2 + s.part_cap * BSR_P2_WORDS);   // counter behind the uncached records
+  }
+  launch_row_pass(c, s, g, s.d_desc(), P, spill_slots, nq, 1, st, fuse_fin ? &fin : nullptr);
+  if (s.timed > 1) {
+    const hipError_t e = hipEventRecord(s.ev[3], st);
+    if (e != hipSuccess && rc == BSR_OK) { set_err(c, (std::string("hipEventRecord: ") + hipGetErrorString(e)).c_str()); rc = BSR_E_HIP; }
+  }
+  if (!fuse_fin)
+    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, P, g.n_rb, s.part2, c->N, s.h_out, rank_floor, s.flag_cur(), s.d_mh,
+                    c->K <= 4 ? 1 : 16);
+}
+
 // Which candidates of the batch lie in the span of their chain's current columns by construction (bsr_span.h): the
 // tree they would replace again, the same with a negation moved, a linear combination of current trees.  k_solve then
 // takes w = 0 without the residual step -- if its own one-pass figure agrees.  fp32 columns: only repeats up to sign
@@ -795,28 +822,27 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
                s.flag_other());
   part(3);
   if (s.timed > 1) step(hipEventRecord(s.ev[2], st), "hipEventRecord");
-  // the finalise step rides behind the residual pass (its last workgroup to finish runs it) where that kernel has the
-  // registers for the solver (K <= 3) and the hand-over memory is uncached (ensure_partials): one launch fewer
-  const bool fuse_fin = j.scoring && s.part2_uncached && residual_can_fuse_finalize(c->K) && c->no_lds;
-  if (j.scoring) {
-    FinArgs fin;
-    memset(&fin, 0, sizeof fin);
-    if (fuse_fin) {
-      fin.ck = c->d_ck; fin.out = s.h_out; fin.mh = s.d_mh; fin.rank_floor = j.rank_floor;
-      fin.arrive = reinterpret_cast<int32_t*>(s.part2 + s.part_cap * BSR_P2_WORDS);   // counter behind the uncached records
-    }
-    launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 1, st, fuse_fin ? &fin : nullptr);
-  }
-  part(4);
-  if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
-  if (j.scoring && !fuse_fin)
-    launch_finalize(st, s.d_desc(), c->d_ck, s.d_coef, j.P, j.g.n_rb, s.part2, c->N, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
-                    c->K <= 4 ? 1 : 16);
+  if (j.scoring) launch_flagged_tail(c, s, j.g, j.P, j.spill_slots, j.nq, j.rank_floor, rc);
+  else if (s.timed > 1) step(hipEventRecord(s.ev[3], st), "hipEventRecord");
   if (j.scoring && s.n_spans > 0)   // the scalar tail of newProp and the first-event scan, one event per chain span
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
   part(5);
-  step(hipEventRecord(s.done, st), "hipEventRecord");
+  // completion: a word in pinned host memory that the queue itself writes behind the batch's last kernel (a stream
+  // write-value command: no kernel, no fence of ours), which the waiter polls -- or the event it blocks on
+  if (s.h_done_word && c->done_word) {
+    s.done_wanted = ++s.done_gen;
+    hipError_t ew = hipStreamWriteValue32(st, s.h_done_word, s.done_wanted, 0);
+    if (ew != hipSuccess) {   // (not supported here after all: the event, from now on)
+      (void)hipGetLastError();
+      c->done_word = 0;
+      s.done_wanted = 0;
+      step(hipEventRecord(s.done, st), "hipEventRecord");
+    }
+  } else {
+    s.done_wanted = 0;
+    step(hipEventRecord(s.done, st), "hipEventRecord");
+  }
   part(6);
   s.tail_rc = rc;
   if (g_host_prof) {
@@ -1025,10 +1051,32 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
     s.pending = false;
     return s.tail_rc;
   }
-  HIPCHK(c, hipEventSynchronize(s.done));
-  HIPCHK(c, hipGetLastError());
+  if (s.done_wanted != 0) {
+    // the queue's own write behind the batch's last kernel: polled (a finished hipEventSynchronize costs the caller
+    // 2.4 us per batch, a quarter of its time); a queue that has not written for two seconds is asked what happened
+    const volatile uint32_t* w = s.h_done_word;
+    long long t_start = 0;
+    for (long spins = 0; *w != s.done_wanted; ++spins) {
+      if (spins < 20000) { __builtin_ia32_pause(); continue; }
+      std::this_thread::yield();
+      if ((spins & 1023) == 0) {
+        const long long now = host_now();
+        if (t_start == 0) t_start = now;
+        else if (now - t_start > 2000000000ll) {
+          const hipError_t q = hipStreamQuery(s.stream);
+          if (q != hipSuccess && q != hipErrorNotReady) { s.pending = false; HIPCHK(c, q); }
+          t_start = now;
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    HIPCHK(c, hipEventSynchronize(s.done));
+    HIPCHK(c, hipGetLastError());
+  }
   s.pending = false;
   if (s.timed) {
+    if (s.done_wanted != 0) HIPCHK(c, hipEventSynchronize(s.ev[s.timed > 1 ? 4 : 1]));   // (timed batches: the events' own clock)
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
     c->last_us[0] = ms * 1e3;

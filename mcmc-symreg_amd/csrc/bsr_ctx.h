@@ -79,6 +79,8 @@ struct BatchSlot {
   size_t flag_stride = 0;
   double* part1 = nullptr;
   double* part2 = nullptr;
+  uint32_t* h_done_word = nullptr;   // pinned: the batch's completion, written by the queue behind its last kernel (hipStreamWriteValue32)
+  uint32_t done_gen = 0, done_wanted = 0;   // ... the value of the batch in flight (0: the event `done` is what the waiter blocks on)
   bool part2_uncached = false;   // part2 and the arrival counter behind it are uncached memory: the finalise step is fused
   size_t part_cap = 0;   // in (proposal,row block) records
   void* spill = nullptr;
@@ -211,6 +213,7 @@ struct bsr_ctx {
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
   int tile_asm = 0;         // whole-slice fp64 contexts of K <= 4: the tape loop in assembly (bsr_tile_asm.hip; BSR_TILE_ASM=0: k_tile1)
   int tile_split = 1;       // ... its staging in two halves (BSR_TILE_SPLIT=0: everything at the first barrier)
+  int done_word = 1;        // a batch's completion by a stream write-value into pinned memory, polled (BSR_DONE_WORD=0: event)
   bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
   bool tile_stream = false; // chunked fp64 context: the streaming kernel (bsr_stream.hip) with its own geometry -- every
   int tile_long = 0;        // block in a slice, the first tile_long slices one block longer, no leftover units

@@ -357,8 +357,14 @@ int bsr_score_batch(bsr_ctx* c, const bsr_node* rows, const int32_t* off, const 
 int bsr_score_submit_mh(bsr_ctx*, const bsr_node*, const int32_t*, const int32_t*, const int32_t*, const double*, int32_t,
                         const double*, const int32_t*, const int32_t*, int32_t, int32_t*) { return BSR_E_STATE; }
 int bsr_score_wait_mh(bsr_ctx*, int32_t, bsr_score*, bsr_event*) { return BSR_E_STATE; }
-extern "C++" int bsr_internal_submit_mh(bsr_ctx*, int, const bsr_node*, const int32_t*, const int32_t*, const int32_t*, const double*,
-                           int32_t, const double*, const int32_t*, const int32_t*, int32_t, bool) { return BSR_E_STATE; }
+// (the device-side MH step is a GPU feature: with spans the stub refuses; without, this is the plain submit -- the sampler
+// passes its lone chain group's batches this way, with staging deferred)
+extern "C++" int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* off, const int32_t* chain,
+                           const int32_t* which_k, const double* sigma, int32_t B, const double*, const int32_t*,
+                           const int32_t*, int32_t n_spans, bool) {
+  if (n_spans > 0) return BSR_E_STATE;
+  return do_submit(c, si, rows, off, chain, which_k, sigma, B);
+}
 extern "C++" int bsr_internal_wait_mh(bsr_ctx*, int, bsr_score*, bsr_event*) { return BSR_E_STATE; }
 int bsr_yloglike_host(int, int64_t, int32_t, const double*, const double*, double, int32_t, double*, double*, double*,
                       double*, int32_t*) { return BSR_E_NODEVICE; }

