@@ -322,7 +322,7 @@ def summarize(wl, tr, ranks, args):
     s = 8 if args.dtype == "f64" else 4
     n_feat = float(np.mean(wl["feat_counts"]))
     alg_bytes = int(s * N * (n_feat + 1 + C * (K - 1)))
-    p1 = tr["kern_us"] * 1e-6
+    p1 = max(tr["kern_us"], 1e-3) * 1e-6
     total_props = ranks.world * P * tr["n_steps"]
     n_unique = len(wl["packed"])
     return {
@@ -689,6 +689,14 @@ def main():
     attach_valu(out, args.workload, wl["B"], wl["C"], args.dtype)
     # which row pass and geometry the context chose (tests/test_gpu_regimes.py pins it per BASELINE config)
     out["config"]["geometry"] = {k: info[k] for k in ("row_pass", "tape_groups", "row_slices", "blocks_per_slice")}
+    # how the batches reached the GPU: AQL packets into the library's own queues (csrc/bsr_aql.h) or HIP launches on the
+    # slots' streams -- and with it the clock of `kernel_us`: the packet processor's start / end timestamps of the row
+    # pass's dispatch packet (read through hsa_amd_profiling_get_dispatch_time, what rocprofv3 reads too), or HIP events
+    # on the stream the kernel was launched on
+    disp = wl["ctx"].dispatch_info()
+    out["dispatch"] = disp
+    out["roofline"]["kernel_us_clock"] = ("dispatch packet timestamps (direct AQL dispatch: no HIP stream on the path)"
+                                          if disp["batches_direct"] > disp["batches_streamed"] else "HIP events on the launch stream")
     n_g = gather_trees(wl, ranks)
     if n_g is not None:
         out["gathered_records"] = n_g

@@ -177,6 +177,13 @@ class DeviceContext:
                 "blocks_per_slice": int(v[6]), "slices_whole": int(v[7]) in (1, 3), "streaming": int(v[7]) == 2,
                 "row_pass": {1: "k_tile1", 2: "k_stream", 3: "k_tile1a"}.get(int(v[7]), "k_tile/k_rows")}
 
+    def dispatch_info(self):
+        """How scoring batches reach the GPU (bsr_dispatch_info): {"direct": the context writes AQL packets into its own
+        queues, "queues", "batches_direct", "batches_streamed"}."""
+        v = np.zeros(4, dtype=np.int64)
+        _lib.check(self._L.bsr_dispatch_info(self._h, _lib.ptr(v)), self._h)
+        return {"direct": bool(v[0]), "queues": int(v[1]), "batches_direct": int(v[2]), "batches_streamed": int(v[3])}
+
     def batch_stats(self, ticket=0):
         """How the last waited batch of `ticket` was scored (bsr_batch_stats): tapes, of which the assembly interpreter's,
         of which chains; stream entries after the fusions."""

@@ -77,6 +77,8 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+static int wait_slot(bsr_ctx* c, BatchSlot& s);
+
 extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   if (g_host_prof && g_n_sub.load() > 0) {
     const double n = (double)g_n_sub.load();
@@ -112,6 +114,8 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   if (!c) return BSR_E_ARG;
   (void)hipSetDevice(c->device);
   launcher_stop(c);
+  for (BatchSlot& s : c->slot)   // (a batch nobody waited for: its kernels, dispatched directly, are on no stream)
+    if (s.pending) (void)wait_slot(c, s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   for (BatchSlot& s : c->slot) {
@@ -136,6 +140,7 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.h_done_word) (void)hipHostFree(s.h_done_word);
+    if (c->aql) aql_slot_destroy(c->aql, &s.aql);
     for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -431,6 +436,19 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     if (hipHostMalloc((void**)&s.h_done_word, 64) == hipSuccess) memset(s.h_done_word, 0, 64);
     else { (void)hipGetLastError(); s.h_done_word = nullptr; }
     for (auto& e : s.ev) CK(hipEventCreate(&e));
+  }
+  if (c->bar_write) {
+    // direct dispatch of the batches' kernels; a refusal (BSR_AQL=0, ROCr says no) leaves the streams
+    const char* why = nullptr;
+    c->aql = aql_device(device, &why);
+    if (!c->aql && env_int("BSR_AQL_VERBOSE", 0)) fprintf(stderr, "bsr: no direct dispatch (%s)\n", why ? why : "?");
+    if (c->aql) {
+      int idx = 0;
+      for (BatchSlot& s : c->slot) {
+        s.aqb.reset(new AqlBatch());
+        if (aql_slot_init(c->aql, &s.aql, idx++) != 0) c->aql_off = true;
+      }
+    }
   }
 #undef CK
   c->x_lo.assign(d, INFINITY);
@@ -747,20 +765,26 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
     s.tail_gen.store(s.tail_wanted, std::memory_order_release);
     return rc;
   }
+  // Direct dispatch (bsr_aql.h): the launch functions below append to the slot's packet list instead of calling the HIP
+  // runtime, and the list goes to one of the context's own queues with a single doorbell write.  Only for a slot
+  // whose stream has nothing in flight, with the input block written through the BAR; batches timed kernel by kernel
+  // (bsr_set_profiling(2)) keep the stream: their events live there; a batch that times its row pass only reads the
+  // packet processor's timestamps of that dispatch.
+  bool use_aql = c->aql && !c->aql_off && j.scoring && s.timed <= 1 && c->bar_write && !s.stream_dirty && s.aql.signal != 0;
+  hipStream_t s0 = s.stream;
   {
-    // upload + row pass on the slot's stream
-    hipStream_t s0 = s.stream;
+    // upload on the slot's stream
     if (c->bar_write && !s.stream_dirty) {
       // the input block goes into device memory by plain stores through the PCIe BAR (write-combined, ~1 us for
       // 16 KB) instead of a copy command: one HIP call fewer per batch.  The slot's previous batch has been waited
       // for, so nothing on the device reads the block now; the stores are globally ordered before the doorbell write
       // of the launch below (fence, then posted writes in order), and every kernel start invalidates the caches
       memcpy(s.d_in, s.h_in, in_bytes);
-      __builtin_ia32_sfence();   // drain the write-combining buffers before anything that rings the doorbell
+      if (!use_aql) __builtin_ia32_sfence();   // drain the write-combining buffers before anything that rings the doorbell
       // ... and read the last word back through the same mapping: a read cannot pass the posted writes in front of
       // it, so when it returns they have reached the device (what the runtime does for device-resident kernel
       // arguments; 2 us on the submission thread: -0.8 % at C2 with two threads, -4 % with one)
-      if (in_bytes >= 8) {
+      if (in_bytes >= 8 && !use_aql) {   // (direct dispatch: the kernel arguments follow, one read-back behind both)
         const volatile uint64_t* last = reinterpret_cast<const volatile uint64_t*>((const char*)s.d_in + ((in_bytes - 8) & ~(size_t)7));
         s.bar_readback = *last;
       }
@@ -772,7 +796,10 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
     }
     s.stream_dirty = false;   // this batch's completion covers everything before it on the stream
     part(1);
-    if (s.timed) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
+  }
+  // every launch of the batch, in stream order (or, collected for direct dispatch, in packet order)
+  auto launches = [&]() {
+    if (s.timed && !aql_target()) step(hipEventRecord(s.ev[0], s0), "hipEventRecord");
     if (tile) {
       const uint64_t* codes = s.d_streams();
       const uint64_t* feats = codes + s.code_words;
@@ -814,9 +841,8 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
     } else {
       launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 0);
     }
-    if (s.timed) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
+    if (s.timed && !aql_target()) step(hipEventRecord(s.ev[1], s0), "hipEventRecord");
     part(2);
-  }
   // results go straight into the slot's pinned host block (device-visible): no download command behind the kernels
   launch_solve(st, s.d_desc(), c->d_ck, j.P, n_part, s.part1, c->N, s.d_coef, s.h_out, j.rank_floor, s.flag_cur(), s.d_mh,
                s.flag_other());
@@ -828,6 +854,43 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
     launch_events(st, s.d_mh, s.d_terms(), s.d_mhflags(), s.d_spans(), s.n_spans, c->K, s.h_ev);
   if (s.timed > 1) step(hipEventRecord(s.ev[4], st), "hipEventRecord");
   part(5);
+  };
+  s.aql_pending = false;
+  if (use_aql) {
+    s.aqb->n = 0;
+    s.aqb->failed = false;
+    aql_target() = s.aqb.get();
+    aql_target_device() = c->aql;
+    launches();
+    aql_target() = nullptr;
+    aql_target_device() = nullptr;
+    if (!s.aqb->failed && s.aqb->n > 0) {
+      aql_stage_args(c->aql, &s.aql, *s.aqb);
+      aql_flush_writes(s.aql.d_kernarg);
+      if (aql_submit(c->aql, &s.aql, *s.aqb, s.timed != 0) == 0) {
+        s.aql_pending = true;
+        s.aql_items = s.aqb->n;
+      }
+    }
+    if (!s.aql_pending) {   // a kernel without a descriptor, a queue in error: the stream from now on
+      c->aql_off = true;
+      use_aql = false;
+      aql_flush_writes(s.d_in);
+    }
+  }
+  if (!s.aql_pending) launches();
+  if (j.scoring) (s.aql_pending ? c->n_direct : c->n_streamed).fetch_add(1, std::memory_order_relaxed);
+  if (s.aql_pending) {
+    part(6);
+    s.done_wanted = 0;
+    s.tail_rc = rc;
+    if (g_host_prof) {
+      g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
+      g_n_issue.fetch_add(1, std::memory_order_relaxed);
+    }
+    s.tail_gen.store(s.tail_wanted, std::memory_order_release);
+    return rc;
+  }
   // completion: a word in pinned host memory that the queue itself writes behind the batch's last kernel (a stream
   // write-value command: no kernel, no fence of ours), which the waiter polls -- or the event it blocks on
   if (s.h_done_word && c->done_word) {
@@ -1051,7 +1114,30 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
     s.pending = false;
     return s.tail_rc;
   }
-  if (s.done_wanted != 0) {
+  bool was_direct = false;
+  if (s.aql_pending) {
+    was_direct = true;
+    // the completion signal of the batch's last packet: a word in host memory the packet processor decrements
+    const char* msg = nullptr;
+    int st = 1;
+    long long t_start = 0;
+    for (long spins = 0; (st = aql_poll(c->aql, &s.aql, &msg)) > 0; ++spins) {
+      if (spins < 20000) { __builtin_ia32_pause(); continue; }
+      std::this_thread::yield();
+      if ((spins & 1023) == 0) {   // a queue that stays silent for a minute: an error, not a hang of the caller
+        const long long now = host_now();
+        if (t_start == 0) t_start = now;
+        else if (now - t_start > 60000000000ll) { st = -1; msg = "nothing for 60 s"; break; }
+      }
+    }
+    s.aql_pending = false;
+    if (st < 0) {
+      s.pending = false;
+      c->aql_off = true;
+      return fail(c, BSR_E_HIP, (std::string("direct dispatch: the queue reported ") + (msg ? msg : "an error")).c_str());
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else if (s.done_wanted != 0) {
     // the queue's own write behind the batch's last kernel: polled (a finished hipEventSynchronize costs the caller
     // 2.4 us per batch, a quarter of its time); a queue that has not written for two seconds is asked what happened
     const volatile uint32_t* w = s.h_done_word;
@@ -1075,7 +1161,11 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
     HIPCHK(c, hipGetLastError());
   }
   s.pending = false;
-  if (s.timed) {
+  if (s.timed && was_direct) {
+    const double us = aql_row_us(c->aql, &s.aql, s.aql_items == 1);
+    for (double& v : c->last_us) v = 0.0;
+    c->last_us[0] = us > 0.0 ? us : 0.0;
+  } else if (s.timed) {
     if (s.done_wanted != 0) HIPCHK(c, hipEventSynchronize(s.ev[s.timed > 1 ? 4 : 1]));   // (timed batches: the events' own clock)
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
@@ -1728,6 +1818,15 @@ extern "C" int bsr_batch_stats(const bsr_ctx* c, int32_t ticket, int32_t* stats4
   if (!c || !stats4 || ticket < 0 || ticket >= BSR_SLOTS) return BSR_E_ARG;
   const BatchSlot& s = c->slot[ticket];
   stats4[0] = s.stat_tapes; stats4[1] = s.stat_fast; stats4[2] = s.stat_chain; stats4[3] = s.stat_entries;
+  return BSR_OK;
+}
+
+extern "C" int bsr_dispatch_info(const bsr_ctx* c, int64_t* info4) {
+  if (!c || !info4) return BSR_E_ARG;
+  info4[0] = (c->aql && !c->aql_off) ? 1 : 0;
+  info4[1] = c->aql ? aql_n_queues(c->aql) : 0;
+  info4[2] = c->n_direct.load();
+  info4[3] = c->n_streamed.load();
   return BSR_OK;
 }
 

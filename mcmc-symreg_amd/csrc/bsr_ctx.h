@@ -80,7 +80,11 @@ struct BatchSlot {
   double* part1 = nullptr;
   double* part2 = nullptr;
   uint32_t* h_done_word = nullptr;   // pinned: the batch's completion, written by the queue behind its last kernel (hipStreamWriteValue32)
-  uint32_t done_gen = 0, done_wanted = 0;   // ... the value of the batch in flight (0: the event `done` is what the waiter blocks on)
+  uint32_t done_gen = 0, done_wanted = 0;
+  AqlSlot aql;                       // direct dispatch (bsr_aql.h): completion signal, kernel-argument block, queue
+  std::unique_ptr<AqlBatch> aqb;     // ... the packets of the batch being issued
+  int aql_items = 0;                 // ... how many packets it had
+  bool aql_pending = false;          // ... the batch in flight went that way: the waiter polls the signal   // ... the value of the batch in flight (0: the event `done` is what the waiter blocks on)
   bool part2_uncached = false;   // part2 and the arrival counter behind it are uncached memory: the finalise step is fused
   size_t part_cap = 0;   // in (proposal,row block) records
   void* spill = nullptr;
@@ -213,6 +217,9 @@ struct bsr_ctx {
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
   int tile_asm = 0;         // whole-slice fp64 contexts of K <= 4: the tape loop in assembly (bsr_tile_asm.hip; BSR_TILE_ASM=0: k_tile1)
   int tile_split = 1;       // ... its staging in two halves (BSR_TILE_SPLIT=0: everything at the first barrier)
+  AqlDevice* aql = nullptr;   // direct AQL dispatch of scoring batches (BSR_AQL=0: HIP launches on the slots' streams)
+  bool aql_off = false;       // ... gave up after a failure (a kernel without descriptor, a queue error)
+  std::atomic<long long> n_direct{0}, n_streamed{0};   // scoring batches issued either way
   int done_word = 1;        // a batch's completion by a stream write-value into pinned memory, polled (BSR_DONE_WORD=0: event)
   bool tile_whole = false;  // every slice of this context fits LDS whole (staged once); else chunked through two buffers
   bool tile_stream = false; // chunked fp64 context: the streaming kernel (bsr_stream.hip) with its own geometry -- every

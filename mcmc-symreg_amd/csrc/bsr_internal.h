@@ -9,6 +9,9 @@
 #include <stdint.h>
 
 #include "../../include/bsr_hip.h"
+#ifndef BSR_HOST_ONLY
+#include "bsr_aql.h"
+#endif
 
 #define BSR_SLOTS (2 * BSR_MAX_INFLIGHT)   // batch slots of a context: the public tickets use the first BSR_MAX_INFLIGHT, the native
                                           // sampler's worker threads a second one each for the batch they generate ahead

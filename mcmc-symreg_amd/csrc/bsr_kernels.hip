@@ -905,13 +905,13 @@ static void launch_rows_u(hipStream_t st, const RowPassArgs<T>& a) {
 #ifdef BSR_TEST_VARIANTS
   if (a.feat_list) {   // (X staged in LDS per row block, BSR_NO_LDS=0: round 1's static grid, kept for the test build)
     const size_t lds = (size_t)(a.nF + 1) * g.rb_rows * sizeof(T);
-    hipLaunchKernelGGL((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
+    bsr_launch((k_rows<T, NQ, U, true, MODE>), grid, block, lds, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
   } else
 #endif
   {
-    hipLaunchKernelGGL((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
+    bsr_launch((k_rows<T, NQ, U, false, MODE>), grid, block, 0, st, a.Xt, a.y, a.ld, a.N, a.codes, a.feats,
                        a.lnp, a.desc, a.coef, a.P, g.rb_rows, g.pg, g.n_rb, n_pg, a.feat_list, a.nF, a.part,
                        (T*)a.spill, a.spill_slots, a.queue, a.queue_clear, a.fin);
   }
@@ -941,19 +941,19 @@ void launch_rows(hipStream_t st, const RowPassArgs<T>& a, int nq, int residual) 
 void launch_solve(hipStream_t st, const PropDesc* desc, const ChainB* ck, int P, int n_rb, const double* part1,
                   int64_t N, PropCoef* coef, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                   int32_t* flagged_next) {
-  hipLaunchKernelGGL(k_solve, dim3((P + BSR_SOLVE_WAVES - 1) / BSR_SOLVE_WAVES), dim3(BSR_SOLVE_WAVES * BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
+  bsr_launch(k_solve, dim3((P + BSR_SOLVE_WAVES - 1) / BSR_SOLVE_WAVES), dim3(BSR_SOLVE_WAVES * BSR_WAVE), 0, st, desc, ck, P, n_rb, part1, N, coef, out, rank_floor,
                      flagged, mh, flagged_next);
 }
 void launch_events(hipStream_t st, const MhRes* mh, const double* terms8, const int32_t* flags, const int32_t* span_off,
                    int n_spans, int K, bsr_event* events) {
-  hipLaunchKernelGGL(k_events, dim3((n_spans + BSR_WAVE - 1) / BSR_WAVE), dim3(BSR_WAVE), 0, st, mh, terms8, flags,
+  bsr_launch(k_events, dim3((n_spans + BSR_WAVE - 1) / BSR_WAVE), dim3(BSR_WAVE), 0, st, mh, terms8, flags,
                      span_off, n_spans, K, events);
 }
 void launch_finalize(hipStream_t st, const PropDesc* desc, const ChainB* ck, const PropCoef* coef, int P, int n_rb,
                      const double* part2, int64_t N, bsr_score* out, double rank_floor, int32_t* flagged, MhRes* mh,
                      int n_wg) {
   // a few proposals per batch at K=3 (one workgroup of four waves), a dozen or more at K=8, each ~10 us of one wave
-  hipLaunchKernelGGL(k_finalize, dim3(n_wg), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
+  bsr_launch(k_finalize, dim3(n_wg), dim3(4 * BSR_WAVE), 0, st, desc, ck, coef, P, n_rb, part2, N, out,
                      rank_floor, flagged, mh);
 }
 template <typename T>

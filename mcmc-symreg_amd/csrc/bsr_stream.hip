@@ -631,7 +631,7 @@ void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
     attr = true;
   }
   const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  hipLaunchKernelGGL((k_stream<KQ, QT, CB, STAMPS, MODE>), grid, block, lds, st, a);
+  bsr_launch((k_stream<KQ, QT, CB, STAMPS, MODE>), grid, block, lds, st, a);
 }
 #ifdef BSR_TEST_VARIANTS
 // (the test build: every interpreter behind BSR_STREAM_ASM, per-wave clock samples, either number of sets of sums)

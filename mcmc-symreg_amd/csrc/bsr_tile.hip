@@ -433,7 +433,7 @@ void launch_kq(hipStream_t st, const TileArgs<T>& a) {
                                 (int)(tile_lds_bytes_max() - 1024));
       attr1 = true;
     }
-    hipLaunchKernelGGL((k_tile1<T, KQ>), grid, block, lds, st, a);
+    bsr_launch((k_tile1<T, KQ>), grid, block, lds, st, a);
     return;
   }
   static bool attr = false;
@@ -442,7 +442,7 @@ void launch_kq(hipStream_t st, const TileArgs<T>& a) {
                               (int)(tile_lds_bytes_max() - 1024));
     attr = true;
   }
-  hipLaunchKernelGGL((k_tile<T, KQ>), grid, block, lds, st, a);
+  bsr_launch((k_tile<T, KQ>), grid, block, lds, st, a);
 }
 
 }  // namespace

@@ -245,7 +245,7 @@ void launch_kq_asm(hipStream_t st, const TileArgs<double>& a) {
                               (int)(tile_lds_bytes_max() - 1024));
     attr = true;
   }
-  hipLaunchKernelGGL((k_tile1a<KQ>), grid, block, lds, st, a);
+  bsr_launch((k_tile1a<KQ>), grid, block, lds, st, a);
 }
 
 }  // namespace

@@ -9,19 +9,21 @@ set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 ROCM="${ROCM_PATH:-/opt/rocm}"
 what="${1:-ship}"
-srcs=(bsr_tile bsr_tile_asm bsr_stream bsr_kernels bsr_api bsr_stage bsr_place bsr_comm bsr_engine bsr_refresh)
+srcs=(bsr_tile bsr_tile_asm bsr_stream bsr_kernels bsr_api bsr_stage bsr_place bsr_comm bsr_engine bsr_refresh bsr_aql)
 
 build_one() {   # <object dir> <output .so> [extra flags...]
   local obj="$1" out="$2"; shift 2
   mkdir -p "$obj"
   local FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -structurizecfg-skip-uniform-regions=true
-               -Wall -Wno-unused-function -Wno-inline-asm ${BSR_EXTRA_FLAGS:-} "$@")
+               -ffunction-sections -fdata-sections -Wall -Wno-unused-function -Wno-inline-asm ${BSR_EXTRA_FLAGS:-} "$@")
   local pids=() s
   for s in "${srcs[@]}"; do
     [ -f "$here/$s.hip" ] || continue
     # the compiler's per-kernel resource report (registers, scratch) is kept next to the object: tests/test_build_resources.py
     # fails when the tile row pass spills to scratch (it did once, silently, for 4.5 us per launch)
-    "$ROCM/bin/hipcc" "${FLAGS[@]}" -Rpass-analysis=kernel-resource-usage -c "$here/$s.hip" -o "$obj/$s.o" 2> "$obj/$s.resources.txt" &
+    # (host code of the units that only launch kernels or run once per context: optimised for size)
+    local hostopt=(); case "$s" in bsr_api|bsr_stage|bsr_engine) ;; *) hostopt=(-Xarch_host -Os) ;; esac
+    "$ROCM/bin/hipcc" "${FLAGS[@]}" "${hostopt[@]}" -Rpass-analysis=kernel-resource-usage -c "$here/$s.hip" -o "$obj/$s.o" 2> "$obj/$s.resources.txt" &
     pids+=($!)
   done
   local rc=0 p
@@ -43,7 +45,7 @@ build_one() {   # <object dir> <output .so> [extra flags...]
   for s in "${srcs[@]}"; do [ -f "$obj/$s.o" ] && [ -f "$here/$s.hip" ] && objs+=("$obj/$s.o"); done
   # (the shipped library without its static symbol table: the C ABI's dynamic symbols stay)
   local strip=(); [ "$obj" = "$here/build" ] && strip=(-Wl,-s)
-  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
+  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -lhsa-runtime64 -Wl,--gc-sections -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
   echo "built $out ($(stat -c %s "$out") bytes)"
 }
 

@@ -1,0 +1,192 @@
+"""Direct AQL dispatch of scoring batches (csrc/bsr_aql.h): the library writes the batch's kernel-dispatch packets into
+ROCr queues of its own instead of calling hipLaunchKernel three to five times.  Same kernels, same arguments, same
+order -- so the same bytes as the HIP-stream path (BSR_AQL=0, a fresh process: the choice is per process and device), for
+every row pass the contexts select, batches in flight on every slot, commits in between (a commit leaves work on the
+slot's stream: the next batch of that slot goes through the stream), the native sampler's device-side MH step, and
+timed batches (the packet processor's own timestamps instead of HIP events).  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "mcmc-symreg_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from test_gpu_dispatch import run_case
+out = {}
+for name in json.loads(sys.argv[1]):
+    res, info = run_case(name)
+    np.save(os.path.join(sys.argv[2], name.replace(" ", "_") + ".npy"), res)
+    out[name] = info
+print(json.dumps(out))
+"""
+
+# name -> (N, d, K, dtype, max_batch, batches, depth)
+CASES = {
+    "c2 whole slices asm": (100_000, 10, 3, "f64", 64, 40, 6),
+    "k8 whole slices": (60_000, 8, 8, "f64", 64, 12, 4),
+    "streaming": (600_000, 12, 3, "f64", 32, 6, 3),
+    "fp32 chunked": (50_000, 6, 2, "f32", 32, 10, 4),
+    "tiny work queue": (700, 4, 1, "f64", 16, 12, 8),
+}
+
+
+def _trees(d, rs, n):
+    from bsr.node import Node
+    from bsr.tape import flatten
+
+    def leaf(f):
+        x = Node(1); x.type = 0; x.feature = np.array([f]); return x
+
+    def un(op, c, a=None, b=None):
+        x = Node(0); x.type, x.operator, x.left, x.a, x.b = 1, op, c, a, b; c.parent = x; return x
+
+    def bi(op, l, r):
+        x = Node(0); x.type, x.operator, x.left, x.right = 2, op, l, r; l.parent = r.parent = x; return x
+
+    out = []
+    for i in range(n):
+        kind = i % 7
+        a, b = leaf(int(rs.randint(d))), leaf(int(rs.randint(d)))
+        if kind == 0: t = bi('*', a, b)
+        elif kind == 1: t = un('sin', bi('+', a, b))
+        elif kind == 2: t = un('ln', un('exp', a), float(rs.uniform(0.5, 1.5)), float(rs.uniform(-1, 1)))
+        elif kind == 3: t = bi('+', un('cos', a), un('square', b))
+        elif kind == 4: t = un('inv', un('ln', un('square', a), 1.0, 1.0))
+        elif kind == 5: t = bi('*', bi('+', a, b), un('cubic', leaf(int(rs.randint(d)))))
+        else: t = a
+        out.append(flatten(t))
+    return out
+
+
+def run_case(name):
+    """Scores the case's batches pipelined over `depth` slots, with a commit + refresh in the middle, and one timed
+    batch; returns (all scores as one array, what the context says about its dispatch)."""
+    from bsr import _lib
+    from bsr.device import DeviceContext, pack
+    N, d, K, dtype, B, n_batches, depth = CASES[name]
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-2, 2, size=(N, d))
+    y = X[:, 0] * X[:, 1] + np.sin(X[:, 2 % d]) + 0.1 * rs.standard_normal(N)
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B, dtype=dtype)
+    cur = _trees(d, rs, 7 * K)[::7][:K] if K <= 1 else _trees(d, rs, 7 * K)[:K]
+    for k in range(K):
+        ctx.set_current(0, k, cur[k])
+    ctx.refresh(0)
+    batches = []
+    for b in range(n_batches):
+        tapes = _trees(d, rs, B)
+        rows, off = pack(tapes)
+        batches.append((rows, off, np.zeros(B, np.int32), rs.randint(K, size=B).astype(np.int32), rs.uniform(0.5, 1.5, size=B)))
+    outs = [np.zeros(B, dtype=_lib.SCORE_DTYPE) for _ in batches]
+    half = n_batches // 2
+    for lo, hi in ((0, half), (half, n_batches)):
+        tickets = []
+        for i in range(lo, hi):
+            tickets.append((ctx.score_submit(*batches[i]), i))
+            if len(tickets) >= depth:
+                t, j = tickets.pop(0)
+                ctx.score_wait(t, outs[j])
+        last = None
+        while tickets:
+            t, j = tickets.pop(0)
+            ctx.score_wait(t, outs[j])
+            last = (t, j)
+        if lo == 0:
+            # accept a full-rank candidate of the last waited batch, then go on: the slot's next batch finds work on its stream
+            t, j = last
+            ok = [i for i in range(B) if outs[j]["rank"][i] == K and np.isfinite(outs[j]["loglik"][i])]
+            if ok:
+                ctx.commit(0, int(batches[j][3][ok[0]]), ok[0])
+                ctx.refresh(0)
+    ctx.set_profiling(1)
+    timed = ctx.score_packed(*batches[0], np.zeros(B, dtype=_lib.SCORE_DTYPE))
+    us = float(ctx.last_timing()[0])
+    ctx.set_profiling(0)
+    info = ctx.dispatch_info()
+    info["row_pass_us"] = us
+    info["row_pass"] = ctx.info()["row_pass"]
+    ctx.close()
+    return np.concatenate(outs + [timed]), info
+
+
+def _other_process(names, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    with tempfile.TemporaryDirectory() as tmp:
+        p = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}, json.dumps(names), tmp], env=env,
+                           capture_output=True, text=True, timeout=1200)
+        assert p.returncode == 0, p.stderr[-3000:]
+        info = json.loads(p.stdout.strip().splitlines()[-1])
+        return {n: np.load(os.path.join(tmp, n.replace(" ", "_") + ".npy")) for n in names}, info
+
+
+def test_direct_dispatch_scores_the_same_bytes_as_the_stream_path():
+    names = list(CASES)
+    streamed, info_s = _other_process(names, {"BSR_AQL": "0"})
+    for n in names:
+        assert not info_s[n]["direct"] and info_s[n]["batches_direct"] == 0, (n, info_s[n])
+    kinds = set()
+    for n in names:
+        got, info = run_case(n)
+        assert info["direct"] and info["queues"] == 4, (n, info)
+        # all but the batch behind the commit (and perhaps the rescoring runs of K = 1) went out as packets
+        assert info["batches_direct"] >= CASES[n][5] - 2, (n, info)
+        if CASES[n][5] // 2 >= 8:    # the second half comes round to the slot the commit was made from: that batch
+            assert info["batches_streamed"] >= 1, (n, info)      # finds the commit's work on its stream and takes the stream
+        assert 0.5 < info["row_pass_us"] < 5e4, (n, info)         # the timed batch: the dispatch's own timestamps
+        assert 0.5 < info_s[n]["row_pass_us"] < 5e4 and 0.25 < info["row_pass_us"] / info_s[n]["row_pass_us"] < 4.0, (n, info, info_s[n])
+        assert got.tobytes() == streamed[n].tobytes(), n
+        kinds.add(info["row_pass"])
+    assert {"k_tile1a", "k_tile1", "k_stream"} <= kinds, kinds
+
+
+def test_the_native_sampler_runs_the_same_chains_either_way():
+    """Device-side MH (spans + k_events behind the batch) through packets and through the stream: same chains."""
+    code = (
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, os.path.join(%r, 'mcmc-symreg_amd'))\n"
+        "from bsr.chain import DeviceScorer\n"
+        "from bsr.native import NativeEngine\n"
+        "from bsr.node import Express\n"
+        "rs = np.random.RandomState(5)\n"
+        "X = rs.uniform(-3, 3, size=(20000, 5)); y = 1.3 * X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(20000)\n"
+        "sc = DeviceScorer(X, y, 2, n_chains=2, max_batch=64)\n"
+        "eng = NativeEngine(sc.ctx, 2, 5, val=80)\n"
+        "for c in range(2):\n"
+        "    eng.seed(c, 300 + c); eng.init_chain(c)\n"
+        "eng.run(batch_per_chain=16)\n"
+        "res = [eng.result(c) for c in range(2)]\n"
+        "info = sc.ctx.dispatch_info()\n"
+        "eng.close(); sc.close()\n"
+        "print(json.dumps({'chains': [[[Express(t) for t in r['roots']], int(r['n_props']), int(r['n_accept']), r['beta'].tobytes().hex(), [float(e) for e in r['errs']]] for r in res], 'info': info}))\n"
+    ) % ROOT
+    outs = {}
+    for aql in ("1", "0"):
+        env = dict(os.environ)
+        env["BSR_AQL"] = aql
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs[aql] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert outs["1"]["info"]["direct"] and outs["1"]["info"]["batches_direct"] > 5, outs["1"]["info"]
+    assert not outs["0"]["info"]["direct"]
+    assert outs["1"]["chains"] == outs["0"]["chains"]
+
+
+def test_the_stream_path_still_passes_the_api_sequences():
+    """tests/test_gpu_ctx_sequence.py once more, in a process that dispatches through HIP streams only."""
+    env = dict(os.environ)
+    env["BSR_AQL"] = "0"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ctx_sequence.py"), "-x", "-q", "-m", "gpu"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
