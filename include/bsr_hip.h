@@ -251,9 +251,10 @@ int bsr_batch_stats(const bsr_ctx* ctx, int32_t ticket, int32_t* stats4);
 /* How scoring batches reach the GPU (no reference counterpart):
  *   info[0] 1 if the context dispatches them itself (AQL packets into its own ROCr queues, csrc/bsr_aql.h), 0 if through
  *           HIP launches on the slots' streams (BSR_AQL=0, no large BAR, or after a failure)
- *   info[1] those queues   info[2] scoring batches dispatched directly so far   info[3] ... through a stream (timed
- *   batches, a slot whose stream still had a commit or a copy in flight, every batch when info[0] is 0) */
-int bsr_dispatch_info(const bsr_ctx* ctx, int64_t* info4);
+ *   info[1] those queues   info[2] scoring batches dispatched directly so far   info[3] ... through a stream (batches
+ *   timed kernel by kernel, a slot whose stream still had a commit or a copy in flight, every batch when info[0] is 0)
+ *   info[4..7] reserved, 0 */
+int bsr_dispatch_info(const bsr_ctx* ctx, int64_t* info8);
 
 /* Where this process's library threads were placed (once per process, by the first bsr_ctx_create; csrc/bsr_place.h):
  *   info[0] 1 if a placement was made   info[1] its CPUs   info[2] NUMA node of the context's GPU as sysfs reports it

@@ -180,7 +180,7 @@ class DeviceContext:
     def dispatch_info(self):
         """How scoring batches reach the GPU (bsr_dispatch_info): {"direct": the context writes AQL packets into its own
         queues, "queues", "batches_direct", "batches_streamed"}."""
-        v = np.zeros(4, dtype=np.int64)
+        v = np.zeros(8, dtype=np.int64)
         _lib.check(self._L.bsr_dispatch_info(self._h, _lib.ptr(v)), self._h)
         return {"direct": bool(v[0]), "queues": int(v[1]), "batches_direct": int(v[2]), "batches_streamed": int(v[3])}
 

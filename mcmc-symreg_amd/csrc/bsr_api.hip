@@ -286,7 +286,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       // tapes per wave instead of two (C2: 96 workgroups, 26.5 us alone instead of 192 at 19.7, but 2 600 instead of
       // 3 900 CU-us per batch: 11.7-11.9 instead of 12.7-13.3 us per pipelined step).  A launch narrower than the
       // machine leaves the other CUs to the batches behind it.
-      const int long_bps = 8;   // (6, 5, 4 and 10 blocks per slice measured 1.2-2.4 us per step slower, interleaved in one box)
+      const int long_bps = std::max(2, std::min(16, env_int("BSR_TILE_BPS", 8)));   // (6, 5, 4 and 10 blocks per slice measured 1.2-2.4 us per step slower, interleaved in one box)
       // slices of WHOLE blocks only (the block that holds row N, N not a multiple of 128, is a leftover unit -- the one place
       // that masks rows): `whole` blocks dealt over the slices, the first `long` of them one block longer -- so a
       // slice count that leaves no slice above long_bps blocks
@@ -702,6 +702,8 @@ static void mark_in_span(bsr_ctx* c, BatchSlot& s, int P) {
 static int stage_submitted(bsr_ctx* c, BatchSlot& s, int B, TailJob* job);
 static hipError_t use_device_fwd(const bsr_ctx* c);
 
+static void publish_direct(bsr_ctx* c, BatchSlot& s, int rc, long long t_issue0);
+
 static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
   const long long t_issue0 = host_now();
   TailJob j = j_in;
@@ -882,13 +884,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
   if (j.scoring) (s.aql_pending ? c->n_direct : c->n_streamed).fetch_add(1, std::memory_order_relaxed);
   if (s.aql_pending) {
     part(6);
-    s.done_wanted = 0;
-    s.tail_rc = rc;
-    if (g_host_prof) {
-      g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
-      g_n_issue.fetch_add(1, std::memory_order_relaxed);
-    }
-    s.tail_gen.store(s.tail_wanted, std::memory_order_release);
+    publish_direct(c, s, rc, t_issue0);
     return rc;
   }
   // completion: a word in pinned host memory that the queue itself writes behind the batch's last kernel (a stream
@@ -914,6 +910,16 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
   }
   s.tail_gen.store(s.tail_wanted, std::memory_order_release);
   return rc;
+}
+
+static void publish_direct(bsr_ctx* c, BatchSlot& s, int rc, long long t_issue0) {
+  s.done_wanted = 0;
+  s.tail_rc = rc;
+  if (g_host_prof) {
+    g_ns_issue.fetch_add(host_now() - t_issue0, std::memory_order_relaxed);
+    g_n_issue.fetch_add(1, std::memory_order_relaxed);
+  }
+  s.tail_gen.store(s.tail_wanted, std::memory_order_release);
 }
 
 // Second submission thread of a context.  It spins for a while after its last job (a sleeping thread would add its
@@ -1821,12 +1827,13 @@ extern "C" int bsr_batch_stats(const bsr_ctx* c, int32_t ticket, int32_t* stats4
   return BSR_OK;
 }
 
-extern "C" int bsr_dispatch_info(const bsr_ctx* c, int64_t* info4) {
-  if (!c || !info4) return BSR_E_ARG;
-  info4[0] = (c->aql && !c->aql_off) ? 1 : 0;
-  info4[1] = c->aql ? aql_n_queues(c->aql) : 0;
-  info4[2] = c->n_direct.load();
-  info4[3] = c->n_streamed.load();
+extern "C" int bsr_dispatch_info(const bsr_ctx* c, int64_t* info8) {
+  if (!c || !info8) return BSR_E_ARG;
+  for (int i = 0; i < 8; ++i) info8[i] = 0;
+  info8[0] = (c->aql && !c->aql_off) ? 1 : 0;
+  info8[1] = c->aql ? aql_n_queues(c->aql) : 0;
+  info8[2] = c->n_direct.load();
+  info8[3] = c->n_streamed.load();
   return BSR_OK;
 }
 

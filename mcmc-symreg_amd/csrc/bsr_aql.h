@@ -5,11 +5,10 @@
 // the gfx950 code objects out of this library's own fat binary and loads them once per device through ROCr, and a
 // launch site names its kernel by the host-side function pointer as before (bsr_launch below).
 //
-// Ordering: a batch's row pass goes to a row queue, the kernels behind it to a tail queue, first a barrier-AND packet
-// on the row pass's completion signal, then every kernel with the barrier bit (it waits for everything in front of it
-// in that queue): the dependencies of back-to-back launches on one HIP stream, without holding a queue for the length
-// of the row pass (aql_submit has the why).  The batch's completion is an HSA signal on its last packet, polled by
-// the waiter.  Nothing here orders against HIP streams: bsr_api.hip only takes this path for a slot whose stream is idle
+// Ordering: the packets of a batch go into one queue in launch order, every packet but the first with the barrier bit
+// (it waits for everything in front of it in that queue): the dependencies of back-to-back launches on one HIP
+// stream; chains go to the device's four queues in turn.  A batch's completion is an HSA signal on its last packet,
+// polled by the waiter.  Nothing here orders against HIP streams: bsr_api.hip only takes this path for a slot whose stream is idle
 // (BatchSlot::stream_dirty) and whose input block went to the device by BAR stores, and falls back to the stream otherwise.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,10 +41,9 @@ struct AqlBatch {
 struct AqlDevice;   // per HIP device: agent, code objects, queues
 struct AqlSlot {    // per batch slot: completion signal, kernarg block in device memory
   uint64_t signal = 0;            // hsa_signal_t::handle: the batch's last packet
-  uint64_t signal_row = 0;        // ... its row pass (what the tail's barrier packet waits for)
+  uint64_t signal_row = 0;        // ... its row pass, for timed batches (the dispatch's start / end timestamps land in it)
   unsigned char* d_kernarg = nullptr;   // device memory, host-writable through the BAR: BSR_AQL_MAX_PACKETS * BSR_AQL_KERNARG_BYTES
-  int queue = 0;                  // which of the device's queues this slot's tails (or whole batches) go to
-  int queue_row = 0;              // ... and its row passes
+  int queue = 0;                  // which of the device's queues the batch in flight went to
 };
 
 // nullptr + message in *err when direct dispatch is not available (no large BAR, ROCr refuses, code objects not found ...)

@@ -30,7 +30,7 @@ struct AqlDevice {
   std::vector<hsa_executable_t> exes;
   std::vector<Queue*> queues;
   double us_per_tick = 0.0;   // of the dispatch timestamps (hsa_amd_profiling_get_dispatch_time)
-  int n_row_queues = 0;   // queues[0 .. n_row_queues) take row passes, the rest the batches' tails (0: no split)
+  std::atomic<unsigned> next_queue{0};
   std::mutex mu;   // kernel table
   std::unordered_map<const void*, AqlKernel*> kernels;
   std::string err;
@@ -191,7 +191,6 @@ AqlDevice* open_device(int hip_device, std::string* why) {
   // more, queues that wait on a barrier hold up the ones behind them on their pipe -- 8.9 us/step with four, 16 with
   // six, 18 with eight (2 048 rows, six batches in flight; HIP streams over GPU_MAX_HW_QUEUES=8 the same)
   const int nq = std::max(1, std::min(16, env_int("BSR_AQL_QUEUES", 4)));
-  d->n_row_queues = std::max(0, std::min(nq - 1, env_int("BSR_AQL_ROW_QUEUES", 0)));
   for (int i = 0; i < nq; ++i) {
     Queue* q = new Queue();
     d->queues.push_back(q);
@@ -270,15 +269,7 @@ int aql_slot_init(AqlDevice* d, AqlSlot* s, int index) {
     return -1;
   }
   s->signal_row = sig2.handle;
-  // the first n_row queues take the row passes, the others the tails (no split: every queue takes whole batches)
-  const int nq = (int)d->queues.size();
-  const int n_row = d->n_row_queues;
-  if (n_row > 0 && n_row < nq) {
-    s->queue_row = index % n_row;
-    s->queue = n_row + index % (nq - n_row);
-  } else {
-    s->queue_row = s->queue = index % nq;
-  }
+  s->queue = index % (int)d->queues.size();   // (rewritten by every submission: chains go to the queues in turn)
   if (hipMalloc((void**)&s->d_kernarg, (size_t)BSR_AQL_MAX_PACKETS * BSR_AQL_KERNARG_BYTES) != hipSuccess) {
     (void)hipGetLastError();
     (void)hsa_signal_destroy(sig);
@@ -387,64 +378,40 @@ void write_dispatch(void* slot, const AqlBatch::Item& it, void* kernarg, uint64_
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
 }
 
-void write_barrier_and(void* slot, uint64_t dep) {
-  hsa_barrier_and_packet_t* p = static_cast<hsa_barrier_and_packet_t*>(slot);
-  p->reserved0 = 0;
-  p->reserved1 = 0;
-  p->dep_signal[0].handle = dep;
-  for (int i = 1; i < 5; ++i) p->dep_signal[i].handle = 0;
-  p->reserved2 = 0;
-  p->completion_signal.handle = 0;
-  const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
-  __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header, __ATOMIC_RELEASE);
-}
-
 }  // namespace
 
 // A batch is a chain: row pass -> k_solve -> residual pass (-> finalise, events).  A hardware queue runs its packets in
-// order, and the GPU has four pipes to run queues on: with a batch's whole chain in one queue (what a HIP stream is),
-// four chains are in flight at most and the pipelined step costs a quarter of a chain's latency -- 45 us / 4 = 11.3 us
-// at C2, whatever the kernels' share of the machine (measured: the step follows depth/latency up to depth 4 and stops
-// there, with HIP streams and with packets of our own alike; more queues than pipes make it worse).
-// So the chain is cut behind its first link.  Row passes of all slots go to the ROW queues without barrier bits: they
-// start as the packet processor reaches them and run side by side as far as the CUs allow.  The rest of each batch
-// goes to one of the TAIL queues behind a barrier-AND packet that waits for its row pass's completion signal: a tail
-// queue is held up by its own batches' small kernels only.
+// order, and the GPU runs four queues side by side (its four compute pipes; the HIP runtime spreads its streams over
+// four queues for the same reason): with a batch's chain in one queue -- what a HIP stream is -- four chains are in
+// flight at most and the pipelined step costs a quarter of a chain's latency: 45 us / 4 = 11.3 us at C2, whatever the
+// kernels' share of the machine (measured: the step follows latency / depth up to depth 4 and stops there, with HIP
+// streams and with packets of our own alike; more queues than pipes make it worse; the row pass in a queue of its own
+// with the tail behind a barrier-AND packet on its completion signal: worse again, 15 against 11 us; batches that wait
+// together sent as one chain, level by level: no change at C2, where the CUs are what is short by then --
+// profiles/r05_direct_dispatch_ab.txt).
 int aql_submit(AqlDevice* d, AqlSlot* s, const AqlBatch& b, bool time_row) {
   if (b.n <= 0 || b.failed) return -1;
-  Queue* R = d->queues[s->queue_row];
-  Queue* T = d->queues[s->queue];
-  if (R->error.load(std::memory_order_relaxed) != 0 || T->error.load(std::memory_order_relaxed) != 0) return -1;
-  // fences.  Results are read by the host: system-scope release behind the last kernel.  Everything else at agent
-  // scope, as the HIP runtime dispatches kernels of one stream: the data between the kernels stays on the device, and
-  // the host's BAR stores (input block, kernel arguments) are in device memory before the doorbell rings
-  // (aql_flush_writes) where an agent-scope acquire finds them.  A system-scope acquire in front of the row pass
-  // cost 10 us per batch (BSR_AQL_FENCE=1; =0: system scope everywhere, 14.0 against 8.8 us/step at 2 048 rows).
+  // fences.  Results are read by the host: system-scope release behind the batch's last kernel.  Everything else at
+  // agent scope, as the HIP runtime dispatches kernels of one stream: the data between the kernels stays on the device,
+  // and the host's BAR stores (input block, kernel arguments) are in device memory before the doorbell rings
+  // (aql_flush_writes) where an agent-scope acquire finds them.  A system-scope acquire in front of the row pass cost
+  // 10 us per batch (BSR_AQL_FENCE=1; =0: system scope everywhere, 14.0 against 8.8 us/step at 2 048 rows).
   static const int fence_mode = env_int("BSR_AQL_FENCE", 2);
-  auto acq = [&](int i) { return (fence_mode == 0 || (fence_mode == 1 && i == 0)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT; };
-  auto rel = [&](int i) { return (fence_mode == 0 || i == b.n - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT; };
+  const int qi = (int)(d->next_queue.fetch_add(1, std::memory_order_relaxed) % d->queues.size());   // chains go to the queues in turn
+  Queue* Q = d->queues[qi];
+  if (Q->error.load(std::memory_order_relaxed) != 0) return -1;
+  s->queue = qi;
   hsa_signal_store_relaxed(hsa_signal_t{s->signal}, 1);
-  if (b.n == 1 || R == T) {
-    // one queue: the first packet depends on nothing in it (another slot's batch may be in front), every later one
-    // waits for the packets before it
-    static const int nobar = env_int("BSR_AQL_TEST_NOBAR", 0);   // TIMING EXPERIMENT ONLY (wrong results): packets 1..nobar without the barrier bit
-    if (time_row && b.n > 1) hsa_signal_store_relaxed(hsa_signal_t{s->signal_row}, 1);
-    Reserve r(T, b.n);
-    for (int i = 0; i < b.n; ++i)
-      write_dispatch(r.packet(i), b.item[i], s->d_kernarg + (size_t)i * BSR_AQL_KERNARG_BYTES,
-                     i == b.n - 1 ? s->signal : ((i == 0 && time_row) ? s->signal_row : 0), i > nobar, acq(i), rel(i));
-    return 0;
-  }
-  hsa_signal_store_relaxed(hsa_signal_t{s->signal_row}, 1);
-  {
-    Reserve r(R, 1);
-    write_dispatch(r.packet(0), b.item[0], s->d_kernarg, s->signal_row, false, acq(0), rel(0));
-  }
-  {
-    Reserve r(T, b.n);
-    write_barrier_and(r.packet(0), s->signal_row);
-    for (int i = 1; i < b.n; ++i)
-      write_dispatch(r.packet(i), b.item[i], s->d_kernarg + (size_t)i * BSR_AQL_KERNARG_BYTES, i == b.n - 1 ? s->signal : 0, true, acq(i), rel(i));
+  if (time_row && b.n > 1) hsa_signal_store_relaxed(hsa_signal_t{s->signal_row}, 1);
+  Reserve r(Q, b.n);
+  for (int i = 0; i < b.n; ++i) {
+    const bool last = i == b.n - 1;
+    const int acq = (fence_mode == 0 || (fence_mode == 1 && i == 0)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    const int rel = (fence_mode == 0 || last) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    // the first packet depends on nothing in its queue (another slot's batch may be in front of it and run beside
+    // it); every later one waits for the packets before it
+    write_dispatch(r.packet(i), b.item[i], s->d_kernarg + (size_t)i * BSR_AQL_KERNARG_BYTES,
+                   last ? s->signal : ((i == 0 && time_row) ? s->signal_row : 0), i > 0, acq, rel);
   }
   return 0;
 }
@@ -461,7 +428,6 @@ double aql_row_us(AqlDevice* d, AqlSlot* s, bool single_packet) {
 int aql_poll(AqlDevice* d, AqlSlot* s, const char** err) {
   if (hsa_signal_load_scacquire(hsa_signal_t{s->signal}) <= 0) return 0;
   int e = d->queues[s->queue]->error.load(std::memory_order_relaxed);
-  if (e == 0) e = d->queues[s->queue_row]->error.load(std::memory_order_relaxed);
   if (e != 0) {
     if (err) *err = hsa_msg((hsa_status_t)e);
     return -1;

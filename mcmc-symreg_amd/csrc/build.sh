@@ -22,7 +22,7 @@ build_one() {   # <object dir> <output .so> [extra flags...]
     # the compiler's per-kernel resource report (registers, scratch) is kept next to the object: tests/test_build_resources.py
     # fails when the tile row pass spills to scratch (it did once, silently, for 4.5 us per launch)
     # (host code of the units that only launch kernels or run once per context: optimised for size)
-    local hostopt=(); case "$s" in bsr_api|bsr_stage|bsr_engine) ;; *) hostopt=(-Xarch_host -Os) ;; esac
+    local hostopt=(); case "$s" in bsr_api|bsr_stage) ;; bsr_engine) hostopt=(-Xarch_host -O2) ;; *) hostopt=(-Xarch_host -Os) ;; esac
     "$ROCM/bin/hipcc" "${FLAGS[@]}" "${hostopt[@]}" -Rpass-analysis=kernel-resource-usage -c "$here/$s.hip" -o "$obj/$s.o" 2> "$obj/$s.resources.txt" &
     pids+=($!)
   done
@@ -45,7 +45,7 @@ build_one() {   # <object dir> <output .so> [extra flags...]
   for s in "${srcs[@]}"; do [ -f "$obj/$s.o" ] && [ -f "$here/$s.hip" ] && objs+=("$obj/$s.o"); done
   # (the shipped library without its static symbol table: the C ABI's dynamic symbols stay)
   local strip=(); [ "$obj" = "$here/build" ] && strip=(-Wl,-s)
-  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -lhsa-runtime64 -Wl,--gc-sections -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
+  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -lhsa-runtime64 -Wl,--gc-sections -Wl,-z,noseparate-code -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
   echo "built $out ($(stat -c %s "$out") bytes)"
 }
 

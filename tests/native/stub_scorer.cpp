@@ -372,7 +372,7 @@ int bsr_set_profiling(bsr_ctx*, int32_t) { return BSR_OK; }
 int bsr_last_timing(bsr_ctx*, double* us5) { for (int i = 0; i < 5; ++i) us5[i] = 0; return BSR_OK; }
 int bsr_ctx_info(const bsr_ctx*, int32_t* v) { for (int i = 0; i < 8; ++i) v[i] = 0; return BSR_OK; }
 int bsr_batch_stats(const bsr_ctx*, int32_t, int32_t* v) { for (int i = 0; i < 4; ++i) v[i] = 0; return BSR_OK; }
-int bsr_dispatch_info(const bsr_ctx*, int64_t* v) { for (int i = 0; i < 4; ++i) v[i] = 0; return BSR_OK; }
+int bsr_dispatch_info(const bsr_ctx*, int64_t* v) { for (int i = 0; i < 8; ++i) v[i] = 0; return BSR_OK; }
 int bsr_place_info(int32_t* v) { for (int i = 0; i < 4; ++i) v[i] = -1; return BSR_OK; }
 int bsr_comm_unique_id(void*) { return BSR_E_COMM; }
 int bsr_comm_init(bsr_ctx*, int32_t, int32_t, const void*) { return BSR_E_COMM; }

@@ -69,6 +69,17 @@ def _trees(d, rs, n):
     return out
 
 
+def _near_span(f):
+    """ln(exp(x_f)): x_f up to rounding -- nearly inside the span of a chain that holds x_f, and not by construction
+    (the canonical forms do not see through it): k_solve flags it for the residual pass."""
+    from bsr.node import Node
+    from bsr.tape import flatten
+    x = Node(1); x.type = 0; x.feature = np.array([f])
+    e = Node(0); e.type, e.operator, e.left = 1, 'exp', x; x.parent = e
+    l = Node(0); l.type, l.operator, l.left, l.a, l.b = 1, 'ln', e, 1.0, 0.0; e.parent = l
+    return flatten(l)
+
+
 def run_case(name):
     """Scores the case's batches pipelined over `depth` slots, with a commit + refresh in the middle, and one timed
     batch; returns (all scores as one array, what the context says about its dispatch)."""
@@ -80,14 +91,21 @@ def run_case(name):
     y = X[:, 0] * X[:, 1] + np.sin(X[:, 2 % d]) + 0.1 * rs.standard_normal(N)
     ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B, dtype=dtype)
     cur = _trees(d, rs, 7 * K)[::7][:K] if K <= 1 else _trees(d, rs, 7 * K)[:K]
+    if K > 1:
+        cur[0] = _trees(d, rs, 7)[6]         # a plain feature ...
+        feat0 = int(cur[0]["feature"][0]) if "feature" in cur[0].dtype.names else 0
     for k in range(K):
         ctx.set_current(0, k, cur[k])
     ctx.refresh(0)
     batches = []
     for b in range(n_batches):
         tapes = _trees(d, rs, B)
+        ks = rs.randint(K, size=B).astype(np.int32)
+        if K > 1 and b % 3 == 0:             # ... and, every third batch, a candidate that all but repeats it on another tree
+            tapes[1] = _near_span(feat0)
+            ks[1] = 1
         rows, off = pack(tapes)
-        batches.append((rows, off, np.zeros(B, np.int32), rs.randint(K, size=B).astype(np.int32), rs.uniform(0.5, 1.5, size=B)))
+        batches.append((rows, off, np.zeros(B, np.int32), ks, rs.uniform(0.5, 1.5, size=B)))
     outs = [np.zeros(B, dtype=_lib.SCORE_DTYPE) for _ in batches]
     half = n_batches // 2
     for lo, hi in ((0, half), (half, n_batches)):
