@@ -197,7 +197,7 @@ AqlDevice* open_device(int hip_device, std::string* why) {
     st = hsa_queue_create(d->agent, 1024, HSA_QUEUE_TYPE_MULTI, queue_error_cb, q, UINT32_MAX, UINT32_MAX, &q->q);
     if (st != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_msg(st));
     // start / end timestamps of a dispatch land in its completion signal (only timed batches hang one on their row pass)
-    if (env_int("BSR_AQL_PROFILE", 1)) (void)hsa_amd_profiling_set_profiler_enabled(q->q, 1);
+    (void)hsa_amd_profiling_set_profiler_enabled(q->q, 1);
   }
   uint64_t hz = 0;
   if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) == HSA_STATUS_SUCCESS && hz > 0) d->us_per_tick = 1e6 / (double)hz;
@@ -258,9 +258,7 @@ const AqlKernel* aql_kernel(AqlDevice* d, const void* host_fn) {
 int aql_slot_init(AqlDevice* d, AqlSlot* s, int index) {
   hsa_signal_t sig;
   // (polled by the host, never waited on through the runtime: no interrupt needed behind the packet)
-  const hsa_status_t sst = env_int("BSR_AQL_SIGNAL", 1) ? hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &sig)
-                                                        : hsa_signal_create(0, 0, nullptr, &sig);
-  if (sst != HSA_STATUS_SUCCESS) return -1;
+  if (hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &sig) != HSA_STATUS_SUCCESS) return -1;
   s->signal = sig.handle;
   hsa_signal_t sig2;
   if (hsa_signal_create(0, 0, nullptr, &sig2) != HSA_STATUS_SUCCESS) {   // (a plain one: its timestamps are read through the runtime)
@@ -338,23 +336,20 @@ void aql_flush_writes(const void* last_device_word) {
 
 namespace {
 
-// Reserves n consecutive packets of a queue; the caller fills them (headers last) and rings the doorbell under the lock.
+// Reserves n consecutive packets of a queue; the caller fills them (headers last); the doorbell is rung when the
+// reservation goes out of scope.  Held under the queue's lock: a batch's packets stay together, doorbell values ascend.
 struct Reserve {
   Queue* Q;
   uint64_t first;
   int n;
   Reserve(Queue* q, int count) : Q(q), n(count) {
-    while (Q->lock.test_and_set(std::memory_order_acquire)) _mm_pause();
     first = hsa_queue_add_write_index_relaxed(Q->q, (uint64_t)n);
     while (first + (uint64_t)n - hsa_queue_load_read_index_scacquire(Q->q) > Q->q->size) _mm_pause();   // (1024 packets: never in practice)
   }
   void* packet(int i) const {
     return static_cast<unsigned char*>(Q->q->base_address) + ((first + (uint64_t)i) & (Q->q->size - 1)) * 64;
   }
-  ~Reserve() {
-    hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)(first + (uint64_t)n - 1));
-    Q->lock.clear(std::memory_order_release);
-  }
+  ~Reserve() { hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)(first + (uint64_t)n - 1)); }
 };
 
 void write_dispatch(void* slot, const AqlBatch::Item& it, void* kernarg, uint64_t completion, bool barrier, int acq, int rel) {
@@ -395,24 +390,35 @@ int aql_submit(AqlDevice* d, AqlSlot* s, const AqlBatch& b, bool time_row) {
   // agent scope, as the HIP runtime dispatches kernels of one stream: the data between the kernels stays on the device,
   // and the host's BAR stores (input block, kernel arguments) are in device memory before the doorbell rings
   // (aql_flush_writes) where an agent-scope acquire finds them.  A system-scope acquire in front of the row pass cost
-  // 10 us per batch (BSR_AQL_FENCE=1; =0: system scope everywhere, 14.0 against 8.8 us/step at 2 048 rows).
-  static const int fence_mode = env_int("BSR_AQL_FENCE", 2);
+  // 10 us per batch; system scope on every packet 14.0 against 8.8 us/step at 2 048 rows
+  // (profiles/r05_direct_dispatch_ab.txt).
   const int qi = (int)(d->next_queue.fetch_add(1, std::memory_order_relaxed) % d->queues.size());   // chains go to the queues in turn
   Queue* Q = d->queues[qi];
   if (Q->error.load(std::memory_order_relaxed) != 0) return -1;
   s->queue = qi;
   hsa_signal_store_relaxed(hsa_signal_t{s->signal}, 1);
   if (time_row && b.n > 1) hsa_signal_store_relaxed(hsa_signal_t{s->signal_row}, 1);
-  Reserve r(Q, b.n);
-  for (int i = 0; i < b.n; ++i) {
-    const bool last = i == b.n - 1;
-    const int acq = (fence_mode == 0 || (fence_mode == 1 && i == 0)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-    const int rel = (fence_mode == 0 || last) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-    // the first packet depends on nothing in its queue (another slot's batch may be in front of it and run beside
-    // it); every later one waits for the packets before it
-    write_dispatch(r.packet(i), b.item[i], s->d_kernarg + (size_t)i * BSR_AQL_KERNARG_BYTES,
-                   last ? s->signal : ((i == 0 && time_row) ? s->signal_row : 0), i > 0, acq, rel);
+  // A batch that would wrap around the end of the ring goes out as two reservations, each with its own doorbell write:
+  // the hardware does not care, but a profiler's intercepting queue (rocprofv3 with --stats or --pmc) hands "the
+  // packets written so far" to its tool as one contiguous block and ran off the end of the ring on the first batch
+  // that straddled it.
+  while (Q->lock.test_and_set(std::memory_order_acquire)) _mm_pause();
+  const uint64_t at = hsa_queue_load_write_index_relaxed(Q->q) & (Q->q->size - 1);
+  const int n_first = (int)std::min<uint64_t>((uint64_t)b.n, Q->q->size - at);
+  for (int lo = 0; lo < b.n; lo += (lo == 0 ? n_first : b.n)) {
+    const int cnt = (lo == 0) ? n_first : b.n - n_first;
+    Reserve r(Q, cnt);
+    for (int i = lo; i < lo + cnt; ++i) {
+      const bool last = i == b.n - 1;
+      const int acq = HSA_FENCE_SCOPE_AGENT;
+      const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+      // the first packet depends on nothing in its queue (another slot's batch may be in front of it and run beside
+      // it); every later one waits for the packets before it
+      write_dispatch(r.packet(i - lo), b.item[i], s->d_kernarg + (size_t)i * BSR_AQL_KERNARG_BYTES,
+                     last ? s->signal : ((i == 0 && time_row) ? s->signal_row : 0), i > 0, acq, rel);
+    }
   }
+  Q->lock.clear(std::memory_order_release);
   return 0;
 }
 

@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--chains", type=int, default=0)
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--pipelined", type=int, default=0,
+                    help="that many batches in flight for 3000 steps in front of the read-out: the stamps are then of "
+                         "workgroups of the LAST launches, which ran beside other batches' kernels (clock, staging and "
+                         "lifetime under load; the launch-wide figures -- start spread, end -- mix launches)")
     a = ap.parse_args()
     args = argparse.Namespace(batch=a.batch, chains=a.chains, dtype="f64", burnin=300)
     ranks = bench.Ranks()
@@ -39,12 +43,25 @@ def main():
         ctx.set_profiling(1)
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
         kern = ctx.last_timing()[0]
+    if a.pipelined > 0:
+        tickets = []
+        for i in range(3000):
+            r = wl["packed"][i % 8]
+            tickets.append((ctx.score_submit_prepared(r[7]), r))
+            if len(tickets) >= a.pipelined:
+                t, rr = tickets.pop(0)
+                ctx.score_wait_ptr(t, rr[8])
+        print("pipelined: %d batches in flight AT the read-out" % a.pipelined)
     L = ctx._L
     L.bsr_debug_tile_stamps.restype = C.c_int
     L.bsr_debug_tile_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     buf = np.zeros((1024, 16, 8), dtype=np.uint64)
     geom = np.zeros(5, dtype=np.int32)
     n = L.bsr_debug_tile_stamps(ctx._h, buf.ctypes.data, 1024, geom.ctypes.data)
+    if a.pipelined > 0:
+        while tickets:
+            t, rr = tickets.pop(0)
+            ctx.score_wait_ptr(t, rr[8])
     if n <= 0:
         print("no stamps (BSR_TILE_STAMPS=1 and a tile launch are needed)", n)
         return
