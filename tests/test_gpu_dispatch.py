@@ -208,3 +208,45 @@ def test_the_stream_path_still_passes_the_api_sequences():
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ctx_sequence.py"), "-x", "-q", "-m", "gpu"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+
+
+def test_packets_wrap_around_the_queues_many_times():
+    """Four rings of 1024 packets: 6000 pipelined batches of three packets each go round every ring four times, some of them
+    straddling the end (sent as two reservations: csrc/bsr_aql.hip aql_submit).  Every batch must come back with the bytes
+    its twin had the first time round."""
+    from bsr import _lib
+    from bsr.device import DeviceContext, pack
+    rs = np.random.RandomState(3)
+    N, d, K, B = 3000, 5, 2, 16
+    X = rs.uniform(-2, 2, size=(N, d))
+    y = X[:, 0] * X[:, 1] + 0.1 * rs.standard_normal(N)
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
+    try:
+        cur = _trees(d, rs, 7)
+        for k in range(K):
+            ctx.set_current(0, k, cur[k])
+        ctx.refresh(0)
+        batches = []
+        for b in range(7):
+            rows, off = pack(_trees(d, rs, B))
+            batches.append(ctx.prepare(rows, off, np.zeros(B, np.int32), rs.randint(K, size=B).astype(np.int32), rs.uniform(0.5, 1.5, size=B)))
+        first = [None] * len(batches)
+        outs = [np.zeros(B, dtype=_lib.SCORE_DTYPE) for _ in range(8)]
+        tickets = []
+        n_total, bad = 6000, 0
+        for i in range(n_total + 8):
+            if i < n_total:
+                tickets.append((ctx.score_submit_prepared(batches[i % 7]), i))
+            if len(tickets) >= 8 or (i >= n_total and tickets):
+                t, j = tickets.pop(0)
+                o = outs[j % 8]
+                ctx.score_wait(t, o)
+                if first[j % 7] is None:
+                    first[j % 7] = o.tobytes()
+                elif o.tobytes() != first[j % 7]:
+                    bad += 1
+        info = ctx.dispatch_info()
+        assert info["direct"] and info["batches_direct"] >= n_total, info
+        assert bad == 0, bad
+    finally:
+        ctx.close()
