@@ -1049,6 +1049,14 @@ struct ScoreMemo {
     if (n > 0) std::fill(key.begin(), key.end(), 0ull);
     n = 0;
   }
+  const bsr_score* peek(uint64_t k) const {   // (find without the statistics: the generator's look)
+    if (n == 0) return nullptr;
+    if (k == 0) k = 1;
+    for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
+      if (key[i] == k) return &val[i];
+      if (key[i] == 0) return nullptr;
+    }
+  }
   const bsr_score* find(uint64_t k) {
     ++lookups;
     if (n == 0) return nullptr;
@@ -1363,7 +1371,7 @@ std::string tree_text(const Tree& t, int i) {
 
 // `ahead`: candidates of this chain generated before and not consumed yet (a batch in flight: they are assumed to
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
-void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
+void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on = false) {
   c.cands.clear();
   c.cands.reserve((size_t)std::max(0, max_n));
   c.gen_start = c.rng;   // (one copy of the stream's state per batch; the candidates carry positions in it)
@@ -1383,13 +1391,22 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0) {
     cd.Q = mv.Q;
     cd.Qinv = mv.Qinv;
     cd.action = mv.action;
-    flatten(cd.tree, cd.tree.root, cd.tape);
     cd.before_u = mark_of(c.rng);
     cd.ghash = tree_hash_full(cd.tree, cd.tree.root) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
-    cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape) ||
-                  (e->predict_gate && std::find(c.gate_memo.begin(), c.gate_memo.end(), cd.ghash) != c.gate_memo.end());
-    if (cd.pred_def && std::find(c.gate_pass_memo.begin(), c.gate_pass_memo.end(), cd.ghash) != c.gate_pass_memo.end())
-      cd.pred_def = false;
+    // A candidate the chain has had scored in its current state (ScoreMemo: more than half of what a chain generates
+    // between two accepts) is not sent to the GPU again -- so it needs no tape here (an accept flattens it then), and
+    // its rank is not a guess: the table has the gate's verdict.
+    const bsr_score* known = memo_on ? c.memo.peek(cd.ghash) : nullptr;
+    if (known && known->rank >= 0) {
+      cd.tape.clear();
+      cd.pred_def = e->predict_gate && known->rank < e->K;
+    } else {
+      flatten(cd.tree, cd.tree.root, cd.tape);
+      cd.pred_def = predict_gate_reject(e, c, cd.tree, k, cd.tape) ||
+                    (e->predict_gate && std::find(c.gate_memo.begin(), c.gate_memo.end(), cd.ghash) != c.gate_memo.end());
+      if (cd.pred_def && std::find(c.gate_pass_memo.begin(), c.gate_pass_memo.end(), cd.ghash) != c.gate_pass_memo.end())
+        cd.pred_def = false;
+    }
     cd.u = cd.pred_def ? kNaN : c.rng.uniform();  // a proposal speculated as gate-rejected draws no uniform
     {  // the scalar terms of codes/funcs.py:1230-1296 that do not depend on the score
       fstruc(cd.tree, cd.tree.root, e->P, cd.new_sa2, cd.new_sb2, &cd.sn_s, &cd.sn_p);
@@ -1555,6 +1572,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.memo.clear();        // (... and so does every score)
     c.last_roots = c.roots;  // the list built before this newProp: stale by this accept if the chain stops now
     c.last_stale = true;
+    if (cd.tape.empty()) flatten(cd.tree, cd.tree.root, cd.tape);   // (a candidate answered from the score memo: generated without its tape)
     c.roots[k] = cd.tree;
     c.ckey[k] = canon_key(cd.tree);
     c.tapes[k] = cd.tape;
@@ -1867,7 +1885,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props - n_ahead);
       const double tg0 = now_s();
-      if (room > 0) generate(e, *c, room, n_ahead);
+      if (room > 0) generate(e, *c, room, n_ahead, memo_on);
       else c->cands.clear();
       g.t_gen += now_s() - tg0;
       L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
