@@ -969,11 +969,11 @@ uint64_t tree_hash_full(const Tree& t, int root) {
   BSR_SCRATCH(int, o);
   preorder(t, root, o);
   uint64_t h = 1469598103934665603ull;
-  auto mix = [&](uint64_t v) {
-    for (int k = 0; k < 8; ++k) {
-      h ^= (v >> (8 * k)) & 0xFF;
-      h *= 1099511628211ull;
-    }
+  auto mix = [&](uint64_t v) {   // (a word at a time: multiply-xorshift, two multiplications instead of FNV's eight)
+    h = (h ^ v) * 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 29;
   };
   for (int i : o) {
     const TNode& nd = t.n[i];
@@ -1371,7 +1371,7 @@ std::string tree_text(const Tree& t, int i) {
 
 // `ahead`: candidates of this chain generated before and not consumed yet (a batch in flight: they are assumed to
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
-void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on = false) {
+void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on = false, bool device_mh = true) {
   c.cands.clear();
   c.cands.reserve((size_t)std::max(0, max_n));
   c.gen_start = c.rng;   // (one copy of the stream's state per batch; the candidates carry positions in it)
@@ -1415,14 +1415,18 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on =
         c.fs_old_ok[k] = 1;
       }
       cd.mhflags = (cd.change != CH_NONE ? BSR_MH_JUMP : 0) | (cd.pred_def ? BSR_MH_NO_UNIFORM : 0);
-      cd.terms[0] = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
-      cd.terms[1] = (cd.change != CH_NONE) ? (c.fs_old_s[k] + c.fs_old_p[k]) - (cd.sn_s + cd.sn_p) : (c.fs_old_s[k] - cd.sn_s);
-      cd.terms[2] = flog(pymax(1e-5, fdiv(cd.Qinv, cd.Q)));
-      cd.terms[3] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.hratio)) : 0.0;
-      cd.terms[4] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.detjacob)) : 0.0;
-      cd.terms[5] = flog(invgamma_pdf(cd.new_sigma, 4));
-      cd.terms[6] = flog(invgamma_pdf(c.sigma, 4));
-      cd.terms[7] = cd.pred_def ? kNaN : flog(cd.u);
+      if (device_mh) {   // (only the device-side MH step reads them: six logarithms per candidate the host-side step forms itself)
+        cd.terms[0] = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
+        cd.terms[1] = (cd.change != CH_NONE) ? (c.fs_old_s[k] + c.fs_old_p[k]) - (cd.sn_s + cd.sn_p) : (c.fs_old_s[k] - cd.sn_s);
+        cd.terms[2] = flog(pymax(1e-5, fdiv(cd.Qinv, cd.Q)));
+        cd.terms[3] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.hratio)) : 0.0;
+        cd.terms[4] = (cd.change != CH_NONE) ? flog(pymax(1e-5, cd.detjacob)) : 0.0;
+        cd.terms[5] = flog(invgamma_pdf(cd.new_sigma, 4));
+        cd.terms[6] = flog(invgamma_pdf(c.sigma, 4));
+        cd.terms[7] = cd.pred_def ? kNaN : flog(cd.u);
+      } else {
+        for (double& v : cd.terms) v = 0.0;
+      }
     }
     ++total;
     count = (count + 1) % e->K;
@@ -1885,7 +1889,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props - n_ahead);
       const double tg0 = now_s();
-      if (room > 0) generate(e, *c, room, n_ahead, memo_on);
+      if (room > 0) generate(e, *c, room, n_ahead, memo_on, use_mh);
       else c->cands.clear();
       g.t_gen += now_s() - tg0;
       L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
