@@ -472,8 +472,10 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
     from bsr.native import NativeEngine
     W = WORKLOADS["c4"]
     X, y = synth(W["N"], W["d"], seed=0)
+    from bsr.native import batch_shape
+    tc, tb = batch_shape(chains, batch, W["K"])     # (as BSR.fit and bsr.sharded create their contexts)
     scorer = DeviceScorer(X, y, W["K"], n_chains=chains, max_batch=chains * batch, device=ranks.device(),
-                          dtype=args.dtype)
+                          dtype=args.dtype, typical_chains=tc, typical_batch=tb)
     eng = NativeEngine(scorer.ctx, chains, W["d"], val=10 ** 9)
     eng.set_nan_policy(True)     # a throughput leg: a NaN candidate is a rejection, not the reference's LinAlgError
     try:

@@ -130,6 +130,17 @@ int bsr_device_count(int* count);
  * BSR_PIN=0: no placement at all; BSR_PIN_CPUS gives the CPU list. */
 int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor,
                    const double* y, int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype);
+
+/* bsr_ctx_create for a caller that knows what its batches look like (no reference counterpart): `typical_chains` distinct
+ * chains and `typical_batch` proposals per batch at most, as a rule (0: the context's limits, = bsr_ctx_create).  The
+ * row pass's geometry -- how long a slice of rows a workgroup keeps in LDS -- is fixed for the life of a context (a
+ * proposal's sums must not depend on the batch it travels in) and has to leave room for a batch's columns: the features,
+ * y, and K basis columns per chain IN THE BATCH.  The native sampler submits its chains in groups (a quarter of them per
+ * batch): a context sized for every chain at once would cut the rows into three times as many, shorter slices than
+ * those batches need.  A batch beyond the typical still scores, to the same bytes, through the chunked kernel. */
+int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X_rowmajor, const double* y,
+                         int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype, int32_t typical_chains,
+                         int32_t typical_batch);
 int bsr_ctx_destroy(bsr_ctx* ctx);
 const char* bsr_last_error(const bsr_ctx* ctx); /* ctx may be NULL: last error of a failed create */
 

@@ -57,6 +57,7 @@ def lib():
         "bsr_abi_version": (C.c_int, []),
         "bsr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "bsr_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, i64, i32, vp, vp, i32, i32, i32, i32]),
+        "bsr_ctx_create_tuned": (C.c_int, [C.POINTER(vp), C.c_int, i64, i32, vp, vp, i32, i32, i32, i32, i32, i32]),
         "bsr_ctx_destroy": (C.c_int, [vp]),
         "bsr_last_error": (C.c_char_p, [vp]),
         "bsr_eval_tapes": (C.c_int, [vp, vp, vp, i32, vp, vp, vp]),
@@ -105,7 +106,7 @@ def lib():
     return L
 
 
-EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_destroy", "bsr_last_error",
+EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_create_tuned", "bsr_ctx_destroy", "bsr_last_error",
            "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_score_submit",
            "bsr_score_wait", "bsr_score_submit_mh", "bsr_score_wait_mh", "bsr_fit_beta",
            "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_ctx_info", "bsr_batch_stats", "bsr_dispatch_info", "bsr_place_info", "bsr_comm_unique_id",

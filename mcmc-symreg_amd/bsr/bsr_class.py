@@ -168,8 +168,12 @@ class BSR(BaseEstimator, RegressorMixin):
         T = self._table()
         seeds = self.chain_seeds
         n_slots = 1 if seeds is None else max(1, min(self.chains_per_launch, len(seeds), self.itrNum))
+        tc, tb = (0, 0)
+        if self.engine == "native":
+            from .native import batch_shape
+            tc, tb = batch_shape(n_slots, self.batch, K)
         scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, self.batch * n_slots), device=self.device,
-                              dtype=self.dtype)
+                              dtype=self.dtype, typical_chains=tc, typical_batch=tb)
         self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
         results = []
         try:

@@ -51,9 +51,10 @@ class Scorer:
 class DeviceScorer(Scorer):
     """HIP path.  Raises at construction when libbsr_hip.so or a GPU is missing: there is no CPU fallback."""
 
-    def __init__(self, X, y, K, n_chains=1, max_batch=64, device=0, dtype="f64"):
+    def __init__(self, X, y, K, n_chains=1, max_batch=64, device=0, dtype="f64", typical_chains=0, typical_batch=0):
         from .device import DeviceContext
-        self.ctx = DeviceContext(X, y, K=K, n_chains=n_chains, max_batch=max_batch, device=device, dtype=dtype)
+        self.ctx = DeviceContext(X, y, K=K, n_chains=n_chains, max_batch=max_batch, device=device, dtype=dtype,
+                                 typical_chains=typical_chains, typical_batch=typical_batch)
         self.K = K
         self.max_batch = max_batch
 

@@ -10,7 +10,10 @@ from .tape import NODE_DTYPE, pack
 class DeviceContext:
     """Owns one bsr_ctx.  X: (N,d) array-like, y: (N,) or None.  Not thread-safe (one per device per thread)."""
 
-    def __init__(self, X, y=None, K=0, n_chains=0, max_batch=64, device=0, dtype="f64"):
+    def __init__(self, X, y=None, K=0, n_chains=0, max_batch=64, device=0, dtype="f64", typical_chains=0, typical_batch=0):
+        """typical_chains / typical_batch: what a batch of this caller looks like as a rule (distinct chains, proposals),
+        where that is less than n_chains / max_batch -- the row pass's geometry is then chosen for those batches
+        (bsr_ctx_create_tuned; wider batches still score, to the same bytes)."""
         L = _lib.lib()
         X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
         if X.ndim != 2:
@@ -23,8 +26,13 @@ class DeviceContext:
             raise ValueError("y has %d rows, X has %d" % (yv.shape[0], self.N))
         self._h = C.c_void_p()
         dt = _lib.DTYPE_F64 if dtype in ("f64", "float64") else _lib.DTYPE_F32
-        rc = L.bsr_ctx_create(C.byref(self._h), device, self.N, self.d, _lib.ptr(X),
-                              None if yv is None else _lib.ptr(yv), self.K, self.n_chains, self.max_batch, dt)
+        if typical_chains or typical_batch:
+            rc = L.bsr_ctx_create_tuned(C.byref(self._h), device, self.N, self.d, _lib.ptr(X),
+                                        None if yv is None else _lib.ptr(yv), self.K, self.n_chains, self.max_batch, dt,
+                                        int(typical_chains), int(typical_batch))
+        else:
+            rc = L.bsr_ctx_create(C.byref(self._h), device, self.N, self.d, _lib.ptr(X),
+                                  None if yv is None else _lib.ptr(yv), self.K, self.n_chains, self.max_batch, dt)
         _lib.check(rc, None)
         self._L = L
         self._mh_pending = {}

@@ -14,6 +14,19 @@ from .tape import NODE_DTYPE, unflatten
 MAX_RECORD_NODES = 4096
 
 
+def batch_shape(n_chains, batch_per_chain, K):
+    """(typical_chains, typical_batch) of the batches the native sampler submits for `n_chains` chains: its worker threads
+    take the chains in up to four groups (csrc/bsr_engine.hip: bsr_engine_run; BSR_ENGINE_GROUPS) and a batch holds one
+    group's proposals.  For DeviceScorer / DeviceContext, so that the row pass's geometry fits THOSE batches.  K == 1 and
+    traced runs submit every chain at once: the context's limits then."""
+    import os
+    if K <= 1 or n_chains <= 1:
+        return 0, 0
+    groups = max(1, min(8, int(os.environ.get("BSR_ENGINE_GROUPS", "4") or 4), n_chains))
+    per = -(-n_chains // groups)
+    return per, per * int(batch_per_chain)
+
+
 class NativeEngine:
     def __init__(self, ctx, n_chains, n_feature, beta=-1, val=100, y_is_series=True):
         self._L = _lib.lib()

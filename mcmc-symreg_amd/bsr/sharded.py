@@ -35,7 +35,10 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
     n_slots = max(1, min(chains_per_launch, len(mine)))
     own = scorer is None
     if own:
-        scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, batch * n_slots), device=device, dtype=dtype)
+        from .native import batch_shape
+        tc, tb = batch_shape(n_slots, batch, K)
+        scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, batch * n_slots), device=device, dtype=dtype,
+                              typical_chains=tc, typical_batch=tb)
     recs = []
     stats = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0, "chains": len(mine)}
     try:

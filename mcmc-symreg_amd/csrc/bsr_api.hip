@@ -168,11 +168,18 @@ static int upload_data(bsr_ctx* c, const double* X, const double* y) {
 
 extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X, const double* y,
                               int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype) {
+  return bsr_ctx_create_tuned(out, device, N, d, X, y, K, n_chains, max_batch, dtype, 0, 0);
+}
+
+extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_t d, const double* X, const double* y,
+                                    int32_t K, int32_t n_chains, int32_t max_batch, int32_t dtype, int32_t typical_chains,
+                                    int32_t typical_batch) {
   if (!out) return BSR_E_ARG;
   *out = nullptr;
   if (!X || N <= 0 || d <= 0 || d > 65536) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad X/N/d");
   if (K < 0 || K > BSR_MAX_K || n_chains < 0 || max_batch <= 0)
     return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad K/n_chains/max_batch");
+  if (typical_chains < 0 || typical_batch < 0) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create_tuned: bad typical_chains/typical_batch");
   if (dtype != BSR_DTYPE_F64 && dtype != BSR_DTYPE_F32) return fail(nullptr, BSR_E_ARG, "bsr_ctx_create: bad dtype");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
@@ -275,8 +282,14 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
     // that a group's columns -- its tapes' features, y, the basis -- leave room for chunks of a few blocks.
     c->tile_qmax = tile_qmax(std::max(1, K));
     c->tile_blocks = (int)((N + BSR_TILE_BLOCK - 1) / BSR_TILE_BLOCK);
-    const int want = std::max(1, std::min(8, (max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax)));
-    const size_t worst_cols = (size_t)d + 1 + (size_t)std::max(1, n_chains) * std::max(1, K);
+    // The batch the geometry is chosen for: the context's limits, or what the caller says its batches look like
+    // (bsr_ctx_create_tuned: the native sampler's chain groups submit a quarter of the chains at a time).  A wider
+    // batch still scores, to the same bytes, over the same slices -- through the chunked kernel where its columns no
+    // longer fit LDS whole.
+    const int geo_chains = std::max(1, typical_chains > 0 ? std::min((int)n_chains, (int)typical_chains) : (int)n_chains);
+    const int geo_batch = std::max(1, typical_batch > 0 ? std::min((int)max_batch, (int)typical_batch) : (int)max_batch);
+    const int want = std::max(1, std::min(8, (geo_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax)));
+    const size_t worst_cols = (size_t)d + 1 + (size_t)geo_chains * std::max(1, K);
     const size_t budget = tile_lds_bytes_max() - 1024;
     for (int attempt = 0; attempt < 2; ++attempt) {
       c->tile_cus = c->n_cu - c->aux_cus;
@@ -293,7 +306,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       const int whole = (int)(N / BSR_TILE_BLOCK);
       const int long_slices = (whole + long_bps - 1) / long_bps;
       // (from 32 slices on: a short data set keeps the many short slices -- one batch at a time is what it is scored in)
-      const bool long_ok = max_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
+      const bool long_ok = geo_batch <= 4 * BSR_TILE_WAVES && long_slices >= 32 && long_slices <= c->n_cu &&
                            worst_cols * (size_t)long_bps * BSR_TILE_BLOCK * c->esz <= budget && !getenv("BSR_TILE_T") &&
                            env_int("BSR_TILE_LONG", 1);
       if (long_ok) c->tile_cus = long_slices;
@@ -306,7 +319,7 @@ extern "C" int bsr_ctx_create(bsr_ctx** out, int device, int64_t N, int32_t d, c
       int T = 0;
       if (long_ok && fits_whole(1)) T = 1;
       for (int t = 4; t >= 1 && T == 0; t >>= 1)
-        if (t <= (max_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES && c->tile_cus % t == 0 && fits_whole(t)) T = t;
+        if (t <= (geo_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES && c->tile_cus % t == 0 && fits_whole(t)) T = t;
       if (T == 0 && fits_whole(1)) T = 1;
       c->tile_whole = T > 0;
       if (!c->tile_whole) {

@@ -234,6 +234,10 @@ extern "C" {
 int bsr_abi_version(void) { return BSR_ABI_VERSION; }
 int bsr_device_count(int* n) { if (n) *n = 1; return BSR_OK; }
 const char* bsr_last_error(const bsr_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int bsr_ctx_create_tuned(bsr_ctx** out, int dev, int64_t N, int32_t d, const double* X, const double* y, int32_t K,
+                         int32_t n_chains, int32_t max_batch, int32_t dtype, int32_t, int32_t) {
+  return bsr_ctx_create(out, dev, N, d, X, y, K, n_chains, max_batch, dtype);
+}
 int bsr_ctx_create(bsr_ctx** out, int, int64_t N, int32_t d, const double* X, const double* y, int32_t K,
                    int32_t n_chains, int32_t max_batch, int32_t) {
   if (!out || !X || N <= 0 || d <= 0 || K < 0 || K > BSR_MAX_K) return BSR_E_ARG;

@@ -115,3 +115,55 @@ def test_wildly_scaled_columns_leave_no_nan_in_the_rotations(K):
                 assert not np.isnan(res["smax"][i]) and not np.isnan(res["smin"][i]), (i, res[i])
     finally:
         ctx.close()
+
+
+def test_a_context_tuned_for_its_callers_batches_keeps_every_batch_on_the_same_sums():
+    """bsr_ctx_create_tuned: eight chains, 256 proposals at most, but batches of two chains and 64 proposals as a rule (the
+    native sampler's chain groups).  The geometry is the single chain's (98 long slices, the assembly tape loop) instead
+    of 256 slices of three blocks; a batch of all eight chains still scores -- through the chunked kernel, its columns
+    no longer fit LDS whole -- and every proposal gets the bytes it gets in a narrow batch, and the oracle's value."""
+    import pandas as pd
+    import bsr_oracle as O
+    from conftest import spec_from_node
+    rs = np.random.RandomState(4)
+    N, d, K, C = 100_000, 10, 3, 8
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
+    pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(4)), un('square', leaf(5)), bi('+', leaf(6), leaf(7)),
+            un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cubic', leaf(8)), leaf(9)]
+    plain = DeviceContext(X, y, K=K, n_chains=C, max_batch=256)
+    assert (plain.info()["row_slices"], plain.info()["blocks_per_slice"]) == (256, 3), plain.info()
+    plain.close()
+    ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=256, typical_chains=2, typical_batch=64)
+    try:
+        info = ctx.info()
+        assert (info["row_pass"], info["tape_groups"], info["row_slices"], info["blocks_per_slice"]) == ("k_tile1a", 1, 98, 7), info
+        cur = []
+        for c in range(C):
+            trees = [pool[(c + k) % len(pool)] for k in range(K)]
+            cur.append(trees)
+            for k in range(K):
+                ctx.set_current(c, k, flatten(trees[k]))
+            ctx.refresh(c)
+        cands = [bi('+', un('sin', leaf(i % d)), leaf((i + 3) % d)) if i % 3 else bi('*', leaf(i % d), un('cos', leaf((i + 1) % d)))
+                 for i in range(256)]
+        tapes = [flatten(t) for t in cands]
+        chains = (np.arange(256) // 32).astype(np.int32)
+        ks = rs.randint(K, size=256).astype(np.int32)
+        sig = rs.uniform(0.5, 1.5, size=256)
+        wide = ctx.score_batch(tapes, chains, ks, sig)
+        for g in range(4):
+            sel = np.arange(g * 64, (g + 1) * 64)
+            narrow = ctx.score_batch([tapes[i] for i in sel], chains[sel], ks[sel], sig[sel])
+            assert narrow.tobytes() == wide[sel].tobytes(), g
+        df = pd.DataFrame(X)
+        for i in range(0, 256, 37):
+            c = int(chains[i])
+            cols = [O.allcal(O.tree_from_json(spec_from_node(t)), df)[:, 0] for t in cur[c]]
+            out = np.stack(cols, axis=1).copy()
+            out[:, ks[i]] = O.allcal(O.tree_from_json(spec_from_node(cands[i])), df)[:, 0]
+            want = O.yloglike(pd.Series(y), out, float(sig[i]))
+            if wide["rank"][i] == K and np.isfinite(want):
+                assert abs(wide["loglik"][i] - want) <= 1e-6 * max(1.0, abs(want)), (i, wide["loglik"][i], want)
+    finally:
+        ctx.close()
