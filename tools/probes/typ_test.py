@@ -1,3 +1,5 @@
+"""Probe: narrow (two chains, 64 proposals) against wide (eight chains, 256) batches on one context, byte for byte.
+  python tools/probes/typ_test.py [tuned]   -- tuned: bsr_ctx_create_tuned(typical_chains=2, typical_batch=64)"""
 import os, sys
 sys.path.insert(0, "mcmc-symreg_amd"); sys.path.insert(0, "tests")
 import numpy as np
@@ -6,7 +8,8 @@ from test_gpu_dispatch import _trees
 rs = np.random.RandomState(4)
 N, d, K, C = 100_000, 10, 3, 8
 X = rs.uniform(-3, 3, size=(N, d)); y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
-ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=256)
+tuned = len(sys.argv) > 1 and sys.argv[1] == 'tuned'
+ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=256, typical_chains=2 if tuned else 0, typical_batch=64 if tuned else 0)
 print(ctx.info())
 for c in range(C):
     cur = _trees(d, rs, 7 * K)[:K]
