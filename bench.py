@@ -69,9 +69,11 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=float, default=15.0,
                     help="seconds of CPU oracle work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--depth", type=int, default=6,
-                    help="batches in flight, 1..8 (1 = synchronous calls); 6 of the context's 8 slots measure best: "
-                         "beyond that a batch only waits longer for CUs (DESIGN 7)")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="batches in flight, 1..8 (1 = synchronous calls); 0: 8 where K <= 4, 6 above.  The GPU runs four "
+                         "chains of dependent kernels at a time (DESIGN 7.1) and the batches behind them wait in the queues, "
+                         "so that a chain's end is followed by the next one's start without a host round trip; with the "
+                         "long k_solve of K >= 5 more than six only wait longer (C2: 8 measures 1 %% above 6; C3: 6 %% below)")
     ap.add_argument("--extras", type=int, default=-1,
                     help="1: also run short legs of the other configs (c3, c5, c4's per-GPU share, native-engine chain "
                          "throughput) and report them under 'extra'; 0: headline only; -1: on for the default workload")
@@ -187,6 +189,10 @@ def generate_batches(wl, n_unique):
     return wl
 
 
+def pick_depth(depth, K):
+    return depth if depth > 0 else (8 if K <= 4 else 6)
+
+
 def timed_region(wl, ranks, steps, warmup, depth, min_time):
     """W warm-up steps, then R x `steps` timed steps between barriers (R chosen so the region lasts >= min_time),
     several batches in flight; HIP events bracket the row pass of every 16th batch on the stream it runs on."""
@@ -198,7 +204,7 @@ def timed_region(wl, ranks, steps, warmup, depth, min_time):
         ctx.score_packed(r[0], r[1], r[2], r[3], r[4], r[5])
     kern_us = np.zeros(5)
     n_timed = [0]
-    depth = max(1, min(8, depth))
+    depth = max(1, min(8, pick_depth(depth, wl["K"])))
     TIMED_EVERY = 16   # (a timed batch costs the caller three extra calls and the stream two event records)
 
     def run_steps(n, first):
@@ -686,7 +692,7 @@ def main():
            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic"}
     out.update(summarize(wl, tr, ranks, args))
-    out["batches_in_flight"] = max(1, min(8, args.depth))
+    out["batches_in_flight"] = max(1, min(8, pick_depth(args.depth, wl["K"])))
     out["verified"] = tr["verified"]
     # per rank: its own step time, the threads and CPUs the library chose for it (what an 8-rank run on a 16-CPU quota
     # actually gets: DESIGN 6)
