@@ -310,14 +310,36 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
                            worst_cols * (size_t)long_bps * BSR_TILE_BLOCK * c->esz <= budget && !getenv("BSR_TILE_T") &&
                            env_int("BSR_TILE_LONG", 1);
       if (long_ok) c->tile_cus = long_slices;
+      // Batches wider than that, of several chains (config 4's eight chains x 32 proposals in one launch): tape groups BY
+      // CHAIN over the same long slices.  A group then stages its own chains' basis columns only -- two chains of eight:
+      // 17 columns instead of 35 -- so the long slice fits LDS whole for every group, where every chain's columns
+      // forced 256 slices of three blocks (half a workgroup's time was its launch ramp, first staging round and
+      // reduction).  T x long_slices workgroups: more than CUs, they take them as they come free.
+      int by_chain_T = 0;
+      size_t group_cols = worst_cols;
+      if (!long_ok && c->dtype == BSR_DTYPE_F64 && geo_chains >= 2 && long_slices >= 32 && long_slices <= c->n_cu &&
+          !getenv("BSR_TILE_T") && env_int("BSR_TILE_LONG", 1) && env_int("BSR_TILE_BY_CHAIN", 1)) {
+        for (int t = 2; t <= 8 && by_chain_T == 0; t *= 2) {
+          const size_t cols_t = (size_t)d + 1 + (size_t)((geo_chains + t - 1) / t) * std::max(1, K);
+          if (t <= geo_chains && (geo_batch + t - 1) / t <= 4 * BSR_TILE_WAVES &&
+              cols_t * (size_t)long_bps * BSR_TILE_BLOCK * c->esz <= budget) {
+            by_chain_T = t;
+            group_cols = cols_t;
+          }
+        }
+      }
+      c->tile_by_chain = by_chain_T > 0;
+      if (by_chain_T > 0) c->tile_cus = long_slices * by_chain_T;
       // blocks of the longest slice when `whole` blocks are dealt over tile_cus / t slices
       auto slice_blocks = [&](int t) { const int sl = std::max(1, c->tile_cus / t); return std::max(1, (whole + sl - 1) / sl); };
-      auto fits_whole = [&](int t) { return worst_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
+      auto fits_whole = [&](int t) { return group_cols * (size_t)slice_blocks(t) * BSR_TILE_BLOCK * c->esz <= budget; };
       // slices that fit LDS whole (even for the widest batch) are staged once and the waves pull their tapes (k_tile1):
       // the largest T in {4, 2, 1} with a tape per wave at most -- fewer tapes per wave and longer slices (fewer lane
       // reductions, record fetches and decodes per row), while every group stages the slice's columns again
       int T = 0;
-      if (long_ok && fits_whole(1)) T = 1;
+      if (by_chain_T > 0 && fits_whole(by_chain_T)) T = by_chain_T;
+      else c->tile_by_chain = false;
+      if (T == 0 && long_ok && fits_whole(1)) T = 1;
       for (int t = 4; t >= 1 && T == 0; t >>= 1)
         if (t <= (geo_batch + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES && c->tile_cus % t == 0 && fits_whole(t)) T = t;
       if (T == 0 && fits_whole(1)) T = 1;

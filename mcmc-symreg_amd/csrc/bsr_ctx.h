@@ -63,6 +63,7 @@ struct BatchSlot {
   bool tile = false;
   bool tile_possible = false;   // stage_tapes: nothing rules the tile pass out for the staged batch (stage_tile decides)
   int tile_chains = 0;                // distinct chains of the batch (their basis columns are staged in LDS)
+  int tile_group_chains = 0;          // ... per tape group (= tile_chains unless the groups are chain groups)
   std::vector<int32_t> chain_slot;    // chain -> index among the batch's chains, -1 if absent
   std::vector<int32_t> batch_chains;  // the batch's chains in first-seen order
   std::vector<double> wave_load;      // scratch of the tile schedule
@@ -214,6 +215,7 @@ struct bsr_ctx {
   // tile pass geometry, fixed for the life of the context (a proposal's partial sums must not depend on the batch)
   int tile_on = 1;
   int tile_T = 1, tile_slices = 256, tile_bps = 1, tile_blocks = 1, tile_left = 0;
+  bool tile_by_chain = false;   // the tape groups are chain groups: a group stages its own chains' basis columns only (bsr_api.hip geometry)
   int tile_qmax = 4;        // sets of sums per wave (tile_qmax(K))
   int tile_asm = 0;         // whole-slice fp64 contexts of K <= 4: the tape loop in assembly (bsr_tile_asm.hip; BSR_TILE_ASM=0: k_tile1)
   int tile_split = 1;       // ... its staging in two halves (BSR_TILE_SPLIT=0: everything at the first barrier)

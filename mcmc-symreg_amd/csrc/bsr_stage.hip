@@ -142,7 +142,7 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
         }
       std::fill(s.slot_of.begin(), s.slot_of.begin() + c->d, -1);
     }
-    const long fixed = (long)n_base + 1 + (long)tile_chains * c->K;
+    const long fixed = (long)n_base + 1 + (long)((c->tile_by_chain && c->tile_T > 1) ? (tile_chains + c->tile_T - 1) / c->tile_T : tile_chains) * c->K;
     size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps + (c->tile_long > 0 ? 1 : 0)) * BSR_TILE_BLOCK * c->esz);
     long room = (long)fit - fixed;
     if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
@@ -421,6 +421,7 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
   // No tape may need more value-stack slots than the register stack holds.
   {
     const int T = c->tile_T, K = c->K;
+    const int group_chains = (c->tile_by_chain && T > 1) ? (tile_chains + T - 1) / T : tile_chains;   // basis column sets a group stages
     const int cap = (n + T - 1) / T;   // tapes per group at most (keeps the groups' passes even)
     // tapes by cost, heaviest first (stable: equal costs keep batch order)
     cost_order(s.order_tmp, s.order_keys, n, [&](int i) { return loc[i].cost; });
@@ -439,7 +440,9 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
     for (int oi = 0; oi < n; ++oi) {
       const int i = s.order_tmp[oi];
       int g = 0;
-      if (T > 1 && c->tile_whole) {
+      if (T > 1 && c->tile_by_chain) {
+        g = s.chain_slot[s.h_desc()[i].ck] % T;   // chain groups: the batch's chains dealt round robin
+      } else if (T > 1 && c->tile_whole) {
         // the slice sits in LDS whole: columns are cheap, balance the cost -- dealt back and forth (0 1 1 0 ...), so that
         // no group gets the heavier tape of every round (LPT inside the group follows)
         const int r = oi / T, k = oi - r * T;
@@ -483,11 +486,23 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
       }
       s.grp_nF[g] = nf;
       hcols[(size_t)g * s.cols_stride + nf] = c->y;
-      for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
-        for (int k = 0; k < K; ++k)
-          hcols[(size_t)g * s.cols_stride + nf + 1 + ci * K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * K + k);
-      max_ncols = std::max(max_ncols, nf + 1 + tile_chains * K);
+      if (c->tile_by_chain && T > 1) {
+        // the group's own chains (batch chain ci belongs to group ci % T, as its (ci / T)-th); the places of a group
+        // that holds fewer chains than the fullest repeat y: staged, never read
+        for (int gc = 0; gc < group_chains; ++gc) {
+          const size_t ci = (size_t)gc * T + g;
+          for (int k = 0; k < K; ++k)
+            hcols[(size_t)g * s.cols_stride + nf + 1 + gc * K + k] =
+                ci < s.batch_chains.size() ? col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * K + k) : (const void*)c->y;
+        }
+      } else {
+        for (size_t ci = 0; ci < s.batch_chains.size(); ++ci)
+          for (int k = 0; k < K; ++k)
+            hcols[(size_t)g * s.cols_stride + nf + 1 + ci * K + k] = col_ptr(c, c->Q, (int64_t)s.batch_chains[ci] * K + k);
+      }
+      max_ncols = std::max(max_ncols, nf + 1 + group_chains * K);
     }
+    s.tile_group_chains = group_chains;
     // the whole slice in LDS at once, or chunks through two buffers (f32: one, staged through registers): as many
     // blocks as fit, a whole number of chain passes where there is room for one
     const size_t budget = tile_lds_bytes_max() - 1024;
@@ -562,7 +577,8 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
   PropDesc* hd = s.h_desc();
   for (int i = 0; i < n; ++i) {
     hd[i].grp = loc[i].grp;
-    hd[i].qslot = s.grp_nF[loc[i].grp] + 1 + s.chain_slot[hd[i].ck] * c->K;   // slot of the chain's basis in the group's LDS map
+    const int in_group = (c->tile_by_chain && c->tile_T > 1) ? s.chain_slot[hd[i].ck] / c->tile_T : s.chain_slot[hd[i].ck];
+    hd[i].qslot = s.grp_nF[loc[i].grp] + 1 + in_group * c->K;   // slot of the chain's basis in the group's LDS map
   }
 }
 
@@ -586,7 +602,7 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
     tg.n_long = c->tile_long;
     tg.n_part = n_part;
     tg.ncols = s.tile_ncols;
-    tg.ncols_fixed = s.tile_chains * c->K;
+    tg.ncols_fixed = s.tile_group_chains * c->K;
     tg.chunk_blocks = s.tile_chunk;
     tg.ring = s.tile_ring;
     tg.qmax = s.tile_stream ? c->tile_qmax : tile_qmax(c->K);   // (a streaming context's batch that takes k_tile after all)

@@ -38,7 +38,7 @@ def bi(op, l, r):
 CASES = [
     ("C2", 100_000, 10, 3, 1, 64, "f64", ("k_tile1a", 1, 98, 7)),
     ("C3", 100_000, 10, 8, 1, 64, "f64", ("k_tile1", 1, 192, 4)),
-    ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1a", None, None, None)),
+    ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1a", 4, 98, 7)),
     ("C5", 1_000_000, 50, 3, 1, 64, "f64", ("k_stream", 1, 256, 30)),
     ("C5 f32", 1_000_000, 50, 3, 1, 64, "f32", ("k_tile/k_rows", None, None, None)),
 ]
@@ -131,8 +131,10 @@ def test_a_context_tuned_for_its_callers_batches_keeps_every_batch_on_the_same_s
     y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
     pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(4)), un('square', leaf(5)), bi('+', leaf(6), leaf(7)),
             un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cubic', leaf(8)), leaf(9)]
+    # (a context for every chain at once: four chain groups over the same long slices, below)
     plain = DeviceContext(X, y, K=K, n_chains=C, max_batch=256)
-    assert (plain.info()["row_slices"], plain.info()["blocks_per_slice"]) == (256, 3), plain.info()
+    pi = plain.info()
+    assert (pi["row_pass"], pi["tape_groups"], pi["row_slices"], pi["blocks_per_slice"]) == ("k_tile1a", 4, 98, 7), pi
     plain.close()
     ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=256, typical_chains=2, typical_batch=64)
     try:
@@ -165,5 +167,60 @@ def test_a_context_tuned_for_its_callers_batches_keeps_every_batch_on_the_same_s
             want = O.yloglike(pd.Series(y), out, float(sig[i]))
             if wide["rank"][i] == K and np.isfinite(want):
                 assert abs(wide["loglik"][i] - want) <= 1e-6 * max(1.0, abs(want)), (i, wide["loglik"][i], want)
+    finally:
+        ctx.close()
+
+
+def test_chain_groups_score_every_batch_shape_to_the_same_bytes():
+    """Eight chains, up to 256 proposals per batch: the tape groups are CHAIN groups (batch chain i in group i mod 4), each
+    staging its own chains' basis columns next to the features and y -- 17 columns instead of 35, so the eight-block slice
+    fits LDS whole.  A proposal's bytes must not depend on the batch it travels in: all eight chains at once, two chains,
+    one chain, five chains with gaps (groups of unequal size, one of them with a single chain) -- and the oracle's value."""
+    import pandas as pd
+    import bsr_oracle as O
+    from conftest import spec_from_node
+    rs = np.random.RandomState(6)
+    N, d, K, C = 60_000, 8, 3, 8
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rs.standard_normal(N)
+    pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', leaf(4)), un('square', leaf(5)), bi('+', leaf(6), leaf(7)),
+            un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cubic', leaf(1)), leaf(7)]
+    ctx = DeviceContext(X, y, K=K, n_chains=C, max_batch=256)
+    try:
+        info = ctx.info()
+        assert info["tape_groups"] == 4 and info["slices_whole"] and info["row_pass"] == "k_tile1a", info
+        cur = []
+        for c in range(C):
+            trees = [pool[(2 * c + k) % len(pool)] for k in range(K)]
+            cur.append(trees)
+            for k in range(K):
+                ctx.set_current(c, k, flatten(trees[k]))
+            ctx.refresh(c)
+        cands = [bi('+', un('sin', leaf(i % d)), leaf((i + 3) % d)) if i % 3 else bi('*', leaf(i % d), un('cos', leaf((i + 1) % d)))
+                 for i in range(256)]
+        tapes = [flatten(t) for t in cands]
+        chains = (np.arange(256) // 32).astype(np.int32)
+        ks = rs.randint(K, size=256).astype(np.int32)
+        sig = rs.uniform(0.5, 1.5, size=256)
+        wide = ctx.score_batch(tapes, chains, ks, sig)
+        assert (wide["rank"] == K).sum() > 200
+        shapes = [np.arange(0, 64), np.arange(96, 128), np.concatenate([np.arange(32, 64), np.arange(128, 160), np.arange(224, 256)]),
+                  np.concatenate([np.arange(0, 5), np.arange(70, 100), np.arange(130, 131), np.arange(200, 256)]),
+                  np.arange(255, -1, -1)]
+        for sel in shapes:
+            got = ctx.score_batch([tapes[i] for i in sel], chains[sel], ks[sel], sig[sel])
+            assert got.tobytes() == wide[sel].tobytes(), (len(sel), sel[:3])
+        df = pd.DataFrame(X)
+        n_checked = 0
+        for i in range(0, 256, 23):
+            c = int(chains[i])
+            cols = [O.allcal(O.tree_from_json(spec_from_node(t)), df)[:, 0] for t in cur[c]]
+            out = np.stack(cols, axis=1).copy()
+            out[:, ks[i]] = O.allcal(O.tree_from_json(spec_from_node(cands[i])), df)[:, 0]
+            want = O.yloglike(pd.Series(y), out, float(sig[i]))
+            if wide["rank"][i] == K and np.isfinite(want):
+                assert abs(wide["loglik"][i] - want) <= 1e-6 * max(1.0, abs(want)), (i, wide["loglik"][i], want)
+                n_checked += 1
+        assert n_checked >= 6
     finally:
         ctx.close()
