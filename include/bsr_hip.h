@@ -259,6 +259,12 @@ int bsr_ctx_info(const bsr_ctx* ctx, int32_t* info8);
  *   stats[3] stream entries of the batch after the fusions (a `terminal, +|*` pair or a derived column is one entry) */
 int bsr_batch_stats(const bsr_ctx* ctx, int32_t ticket, int32_t* stats4);
 
+/* Diagnostics for tools/tile_stamps.py (no reference counterpart; off unless BSR_TILE_STAMPS is set when the context is
+ * created): the shader-clock samples of the last tile-pass launch, out[workgroups][16 waves][8] uint64;
+ * geom5 = {tape groups, row slices, blocks per slice, blocks, workgroups * 100 + 1}.  Returns the number of workgroups
+ * copied (<= max_wgs), 0 when stamps are off, BSR_E_* (< 0) on failure. */
+int bsr_debug_tile_stamps(bsr_ctx* ctx, unsigned long long* out, int32_t max_wgs, int32_t* geom5);
+
 /* How scoring batches reach the GPU (no reference counterpart):
  *   info[0] 1 if the context dispatches them itself (AQL packets into its own ROCr queues, csrc/bsr_aql.h), 0 if through
  *           HIP launches on the slots' streams (BSR_AQL=0, no large BAR, or after a failure)

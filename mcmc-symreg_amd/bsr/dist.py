@@ -67,12 +67,24 @@ def record_bytes(buf):
 
 
 def unpack_record(buf):
+    """The record that starts at buf[0].  Every length in the header is checked against the buffer (ValueError on a
+    short or corrupt record, as split_records raises: no assert that `python -O` would drop, no silently truncated
+    slice)."""
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    if buf.size < HEADER_BYTES:
+        raise ValueError("chain record of %d bytes is shorter than its header (%d)" % (buf.size, HEADER_BYTES))
     ni = HEADER_I32 * 4
     hi = buf[:ni].view(np.int32)
     hf = buf[ni:HEADER_BYTES].view(np.float64)
-    K, n_errs = int(hi[1]), int(hi[4])
-    assert buf.size >= int(hi[9]) >= HEADER_BYTES
+    K, n_errs, total = int(hi[1]), int(hi[4]), int(hi[9])
+    if not 0 <= K <= MAX_K:
+        raise ValueError("corrupt chain record: K = %d (0..%d)" % (K, MAX_K))
+    if n_errs < 0 or any(int(hi[16 + k]) < 0 for k in range(K)):
+        raise ValueError("corrupt chain record: negative history or tape length")
+    want = HEADER_BYTES + n_errs * 8 + sum(int(hi[16 + k]) for k in range(K)) * NODE_DTYPE.itemsize
+    if want != total or total > buf.size:
+        raise ValueError("corrupt chain record: header says %d bytes, its parts add up to %d, buffer holds %d"
+                         % (total, want, buf.size))
     at = HEADER_BYTES
     he = buf[at:at + n_errs * 8].view(np.float64)
     at += n_errs * 8
@@ -84,7 +96,6 @@ def unpack_record(buf):
         lens.append(n)
         tapes.append(t)
         roots.append(unflatten(t) if n > 0 else None)
-    assert at == int(hi[9])
     return {"chain": int(hi[0]), "K": K, "n_props": int(hi[2]), "n_accept": int(hi[3]), "n_errs": n_errs,
             "n_rank_rejects": int(hi[6]), "n_discarded": int(hi[7]),
             "errs": [float(v) for v in he], "errs_truncated": False,      # (both kept for callers of the fixed-size

@@ -114,6 +114,10 @@ extern "C" int bsr_ctx_destroy(bsr_ctx* c) {
   if (!c) return BSR_E_ARG;
   (void)hipSetDevice(c->device);
   launcher_stop(c);
+  if (c->poisoned.load()) {   // a batch that never completed may still run: nothing it can reach is freed or destroyed
+    delete c;
+    return BSR_OK;
+  }
   for (BatchSlot& s : c->slot)   // (a batch nobody waited for: its kernels, dispatched directly, are on no stream)
     if (s.pending) (void)wait_slot(c, s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1116,6 +1120,8 @@ static int prepare_job(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool resta
 
 // Enqueues upload + kernels + result download for the P descriptors staged in slot `s`.
 static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage = true) {
+  if (c->poisoned.load(std::memory_order_relaxed))
+    return fail(c, BSR_E_STATE, "the context is poisoned: a directly dispatched batch never completed (destroy the context)");
   TailJob job;
   int rc = prepare_job(c, s, P, scoring, restage, &job);
   if (rc != BSR_OK) return rc;
@@ -1134,6 +1140,9 @@ static int enqueue(bsr_ctx* c, BatchSlot& s, int P, bool scoring, bool restage =
   return BSR_OK;
 }
 
+// how long a directly dispatched batch may stay silent before its context is given up (BSR_DEBUG_AQL_TIMEOUT_MS: the
+// poisoned-context path under test, tests/test_gpu_dispatch.py)
+static const long long g_aql_timeout_ns = 1000000ll * (long long)env_int("BSR_DEBUG_AQL_TIMEOUT_MS", 60000);
 static int wait_slot_impl(bsr_ctx* c, BatchSlot& s);
 static int wait_slot(bsr_ctx* c, BatchSlot& s) {
   if (!g_host_prof || !s.pending) return wait_slot_impl(c, s);
@@ -1163,19 +1172,24 @@ static int wait_slot_impl(bsr_ctx* c, BatchSlot& s) {
     int st = 1;
     long long t_start = 0;
     for (long spins = 0; (st = aql_poll(c->aql, &s.aql, &msg)) > 0; ++spins) {
+      if (g_aql_timeout_ns < 0) { st = -1; msg = "nothing (BSR_DEBUG_AQL_TIMEOUT_MS < 0: the first unfinished poll counts as silence)"; break; }
       if (spins < 20000) { __builtin_ia32_pause(); continue; }
       std::this_thread::yield();
       if ((spins & 1023) == 0) {   // a queue that stays silent for a minute: an error, not a hang of the caller
         const long long now = host_now();
         if (t_start == 0) t_start = now;
-        else if (now - t_start > 60000000000ll) { st = -1; msg = "nothing for 60 s"; break; }
+        else if (now - t_start > g_aql_timeout_ns) { st = -1; msg = "nothing for 60 s (the time limit of a batch)"; break; }
       }
     }
     s.aql_pending = false;
     if (st < 0) {
+      // the packets may still be queued or running: nothing of this context may be staged over, resubmitted or freed
+      // (the slot's buffers used to be reusable -- and freed by bsr_ctx_destroy -- under a batch still in flight)
       s.pending = false;
       c->aql_off = true;
-      return fail(c, BSR_E_HIP, (std::string("direct dispatch: the queue reported ") + (msg ? msg : "an error")).c_str());
+      c->poisoned = true;
+      return fail(c, BSR_E_HIP, (std::string("direct dispatch: the queue reported ") + (msg ? msg : "an error") +
+                                 "; the context accepts no further batches (destroy it: its device buffers are left allocated)").c_str());
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   } else if (s.done_wanted != 0) {

@@ -220,6 +220,10 @@ struct bsr_ctx {
   int tile_asm = 0;         // whole-slice fp64 contexts of K <= 4: the tape loop in assembly (bsr_tile_asm.hip; BSR_TILE_ASM=0: k_tile1)
   int tile_split = 1;       // ... its staging in two halves (BSR_TILE_SPLIT=0: everything at the first barrier)
   AqlDevice* aql = nullptr;   // direct AQL dispatch of scoring batches (BSR_AQL=0: HIP launches on the slots' streams)
+  // a directly dispatched batch never completed (queue error, or silence for a minute): its packets may still be queued
+  // or running and may still write the slot's buffers.  The context refuses further batches and bsr_ctx_destroy frees
+  // nothing the GPU can reach (leaked on purpose: a stuck queue must not write into recycled memory)
+  std::atomic<bool> poisoned{false};
   std::atomic<bool> aql_off{false};   // ... gave up after a failure (a kernel without descriptor, a queue error); set by any thread
   std::atomic<long long> n_direct{0}, n_streamed{0};   // scoring batches issued either way
   int done_word = 1;        // a batch's completion by a stream write-value into pinned memory, polled (BSR_DONE_WORD=0: event)

@@ -965,15 +965,20 @@ uint64_t tree_hash(const Tree& t, int root) {  // FNV-1a over the pre-order (typ
 
 // ... and over everything that decides the column: the ln nodes' parameters too (two trees with the same key compute
 // the same column, bit for bit)
-uint64_t tree_hash_full(const Tree& t, int root) {
+// *check (optional): a second, independently mixed word over the same stream of node words (rotate-xor-add; two cheap
+// operations per word) -- what the score memo compares next to the 64-bit key, so that a key collision between two
+// different trees is a miss and not a wrong score.
+uint64_t tree_hash_full(const Tree& t, int root, uint32_t* check = nullptr) {
   BSR_SCRATCH(int, o);
   preorder(t, root, o);
   uint64_t h = 1469598103934665603ull;
+  uint64_t h2 = 0x243F6A8885A308D3ull;
   auto mix = [&](uint64_t v) {   // (a word at a time: multiply-xorshift, two multiplications instead of FNV's eight)
     h = (h ^ v) * 0xff51afd7ed558ccdull;
     h ^= h >> 33;
     h *= 0xc4ceb9fe1a85ec53ull;
     h ^= h >> 29;
+    h2 = ((h2 << 7) | (h2 >> 57)) + (v ^ 0x9E3779B97F4A7C15ull) * 0x100000001B3ull;
   };
   for (int i : o) {
     const TNode& nd = t.n[i];
@@ -986,6 +991,7 @@ uint64_t tree_hash_full(const Tree& t, int root) {
       mix(b);
     }
   }
+  if (check) *check = (uint32_t)(h2 ^ (h2 >> 32)) + (uint32_t)o.size();
   return h;
 }
 
@@ -1026,6 +1032,7 @@ struct Cand {
   int action;
   bool pred_def = false;  // speculated as a rank-gate rejection: no accept-uniform was drawn behind it
   uint64_t ghash = 0;     // tree_hash_full of the candidate, mixed with k (the gate's memory below)
+  uint32_t gcheck = 0;    // the hash's second word (ScoreMemo compares both)
   double sn_s = 0, sn_p = 0;  // fStruc of the proposed tree (structure / ln-parameter parts)
   double terms[8];            // what the device-side MH step needs (include/bsr_hip.h: bsr_score_submit_mh)
   int mhflags = 0;
@@ -1042,37 +1049,43 @@ struct Cand {
 struct ScoreMemo {
   static constexpr int CAP = 2048;   // slots (open addressing, linear probing); full at CAP / 2 entries: no more inserts
   std::vector<uint64_t> key;         // 0: empty
+  std::vector<uint32_t> chk;         // second hash word of the tree behind the key: a key that matches with another check
+                                     // word is a collision -- a miss (the candidate goes to the GPU), never a wrong score
   std::vector<bsr_score> val;
   int n = 0;
-  int64_t hits = 0, lookups = 0;
+  int64_t hits = 0, lookups = 0, collisions = 0;
   void clear() {
     if (n > 0) std::fill(key.begin(), key.end(), 0ull);
     n = 0;
   }
-  const bsr_score* peek(uint64_t k) const {   // (find without the statistics: the generator's look)
+  const bsr_score* peek(uint64_t k, uint32_t ck) const {   // (find without the statistics: the generator's look)
     if (n == 0) return nullptr;
     if (k == 0) k = 1;
     for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
-      if (key[i] == k) return &val[i];
+      if (key[i] == k) return chk[i] == ck ? &val[i] : nullptr;
       if (key[i] == 0) return nullptr;
     }
   }
-  const bsr_score* find(uint64_t k) {
+  const bsr_score* find(uint64_t k, uint32_t ck) {
     ++lookups;
     if (n == 0) return nullptr;
     if (k == 0) k = 1;
     for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
-      if (key[i] == k) { ++hits; return &val[i]; }
+      if (key[i] == k) {
+        if (chk[i] != ck) { ++collisions; return nullptr; }
+        ++hits;
+        return &val[i];
+      }
       if (key[i] == 0) return nullptr;
     }
   }
-  void put(uint64_t k, const bsr_score& v) {
-    if (key.empty()) { key.assign(CAP, 0ull); val.resize(CAP); }
+  void put(uint64_t k, uint32_t ck, const bsr_score& v) {
+    if (key.empty()) { key.assign(CAP, 0ull); chk.assign(CAP, 0u); val.resize(CAP); }
     if (n >= CAP / 2) return;
     if (k == 0) k = 1;
     for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 53) & (CAP - 1);; i = (i + 1) & (CAP - 1)) {
       if (key[i] == k) return;
-      if (key[i] == 0) { key[i] = k; val[i] = v; ++n; return; }
+      if (key[i] == 0) { key[i] = k; chk[i] = ck; val[i] = v; ++n; return; }
     }
   }
 };
@@ -1392,11 +1405,11 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on =
     cd.Qinv = mv.Qinv;
     cd.action = mv.action;
     cd.before_u = mark_of(c.rng);
-    cd.ghash = tree_hash_full(cd.tree, cd.tree.root) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
+    cd.ghash = tree_hash_full(cd.tree, cd.tree.root, &cd.gcheck) * 0x9E3779B97F4A7C15ull + (uint64_t)k;
     // A candidate the chain has had scored in its current state (ScoreMemo: more than half of what a chain generates
     // between two accepts) is not sent to the GPU again -- so it needs no tape here (an accept flattens it then), and
     // its rank is not a guess: the table has the gate's verdict.
-    const bsr_score* known = memo_on ? c.memo.peek(cd.ghash) : nullptr;
+    const bsr_score* known = memo_on ? c.memo.peek(cd.ghash, cd.gcheck) : nullptr;
     if (known && known->rank >= 0) {
       cd.tape.clear();
       cd.pred_def = e->predict_gate && known->rank < e->K;
@@ -1448,6 +1461,61 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
   return logR + flog(invgamma_pdf(c.new_sigma, 4)) - flog(invgamma_pdf(sigma, 4));
 }
 
+// The device half of an accepted move (codes/bsr_class.py:211-252): the accepted tree's column into the chain's cache,
+// the basis and both fits refreshed, the RMSE appended, stop rule 2.  at >= 0: the accepted proposal's place in the batch
+// last scored on batch_slot (or, batch_slot < 0, in the context's last waited batch); at < 0: the proposal was answered
+// from the score memo and is in no batch -- its tape (c.tapes[k], already the chain's own) is scored alone first, on
+// that slot, and committed from there: bsr_commit re-runs the staged tape, the same bytes whichever batch staged it.
+struct DeferredAccept {
+  ChainS* c;
+  int k;
+  bsr_trace* tr;
+};
+int finish_accept(bsr_engine* e, ChainS& c, int k, int batch_slot, int at, bsr_trace* tr) {
+  double rmse;
+  {
+    struct CtxLock {
+      bsr_ctx* c;
+      explicit CtxLock(bsr_ctx* c_) : c(c_) { if (c) bsr_internal_lock(c); }
+      ~CtxLock() { if (c) bsr_internal_unlock(c); }
+    } lk(batch_slot >= 0 ? e->ctx : nullptr);
+    if (at < 0) {
+      const std::vector<bsr_node>& tape = c.tapes[k];
+      const int32_t off2[2] = {0, (int32_t)tape.size()};
+      const int32_t ch1 = c.index, k1 = k;
+      const double sg1 = c.sigma;
+      bsr_score one;
+      if (batch_slot >= 0) {
+        ECHK(e, bsr_internal_submit(e->ctx, batch_slot, tape.data(), off2, &ch1, &k1, &sg1, 1));
+        ECHK(e, bsr_internal_wait(e->ctx, batch_slot, &one));
+      } else {
+        int32_t tk = -1;
+        ECHK(e, bsr_score_submit(e->ctx, tape.data(), off2, &ch1, &k1, &sg1, 1, &tk));
+        ECHK(e, bsr_score_wait(e->ctx, tk, &one));
+      }
+      at = 0;
+    }
+    if (batch_slot >= 0) ECHK(e, bsr_internal_commit(e->ctx, batch_slot, c.index, k, at));
+    else ECHK(e, bsr_commit(e->ctx, c.index, k, at));
+    int rc = refresh_chain(e, c);
+    if (rc != BSR_OK) return rc;
+    ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
+  }
+  c.errs.push_back(rmse);
+  if (tr) tr->rmse = rmse;
+  const int m = std::min<int>(10, (int)c.errs.size());  // codes/bsr_class.py:248-252
+  if (c.errs.size() > 100) {
+    double mn = kInf, sum = 0;
+    for (int j = 0; j < m; ++j) {
+      const double v = c.errs[c.errs.size() - m + j];
+      mn = std::min(mn, v);
+      sum += v;
+    }
+    if (1 - mn / (sum / m) < 0.05) c.done = true;
+  }
+  return BSR_OK;
+}
+
 // batch_slot < 0: the batch was scored through the public ticket API (one thread); otherwise by a worker thread that
 // owns that batch slot, and the accept path takes the context lock (commit, refresh and fit share the main stream)
 // ev != nullptr: the device has already formed every log-ratio and found the first proposal of the run that is not
@@ -1456,7 +1524,8 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
 // as speculated the random stream already stands where it should; *broke_out tells the caller whether an event
 // (accept, gate verdict against the speculation, error) ended the run early -- what was generated behind is then void
 int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch_slot, const bsr_event* ev,
-            bool keep_rng = false, bool* broke_out = nullptr, const int32_t* gpu_index = nullptr) {
+            bool keep_rng = false, bool* broke_out = nullptr, const int32_t* gpu_index = nullptr,
+            std::vector<DeferredAccept>* deferred = nullptr) {
   const int K = e->K;
   int used = 0;
   bool broke = false;
@@ -1539,7 +1608,11 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
       if (c.gate_pass_memo.size() < 256) c.gate_pass_memo.push_back(cd.ghash);
       tail_invalid = true;
     }
-    const double yllstar = sc.loglik;
+    // Without the device-side MH scan the log-likelihood is formed HERE from the scored SSE (the device's formula,
+    // csrc/bsr_solve.h, evaluated by the host's libm -- as `yll` below always was): a proposal answered from the score
+    // memo and the same proposal scored by the GPU then give the same bits, so the memo cannot move a chain.
+    const double yllstar = ev ? sc.loglik
+                              : -sc.sse / (2 * cd.new_sigma * cd.new_sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * cd.new_sigma * cd.new_sigma);
     const double yll = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
     const double sn_s = cd.sn_s, sn_p = cd.sn_p;  // fStruc of the proposed tree, computed when it was generated
     if (!c.fs_old_ok[k]) {
@@ -1584,57 +1657,25 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     c.sigma = cd.new_sigma;
     c.siga[k] = cd.new_sa2;
     c.sigb[k] = cd.new_sb2;
-    double rmse;
-    {
-      struct CtxLock {
-        bsr_ctx* c;
-        explicit CtxLock(bsr_ctx* c_) : c(c_) { if (c) bsr_internal_lock(c); }
-        ~CtxLock() { if (c) bsr_internal_unlock(c); }
-      } lk(batch_slot >= 0 ? e->ctx : nullptr);
-      // the accepted proposal by its place in the batch the GPU scored -- or, where it was answered from the score memo
-      // (it is in no batch), by its tape: bsr_commit is bsr_set_current of the same tape, bit for bit
-      int at = gpu_index ? gpu_index[slot0 + (int)i] : slot0 + (int)i;
-      int commit_slot = batch_slot;
-      if (at < 0) {
-        // answered from the score memo: its tape is staged in no batch.  An accept is rare (one in hundreds of
-        // proposals): the tape goes to the GPU alone, on this lane's slot (its batch has been waited for), and the
-        // commit is made from THAT batch, as for any other accepted proposal
-        const int32_t off2[2] = {0, (int32_t)cd.tape.size()};
-        const int32_t ch1 = c.index, k1 = k;
-        const double sg1 = cd.new_sigma;
-        bsr_score one;
-        if (batch_slot >= 0) {
-          ECHK(e, bsr_internal_submit(e->ctx, batch_slot, cd.tape.data(), off2, &ch1, &k1, &sg1, 1));
-          ECHK(e, bsr_internal_wait(e->ctx, batch_slot, &one));
-        } else {
-          int32_t tk = -1;
-          ECHK(e, bsr_score_submit(e->ctx, cd.tape.data(), off2, &ch1, &k1, &sg1, 1, &tk));
-          ECHK(e, bsr_score_wait(e->ctx, tk, &one));
-        }
-        at = 0;
-      }
-      if (commit_slot >= 0) ECHK(e, bsr_internal_commit(e->ctx, commit_slot, c.index, k, at));
-      else ECHK(e, bsr_commit(e->ctx, c.index, k, at));
-      int rc = refresh_chain(e, c);
-      if (rc != BSR_OK) return rc;
-      ECHK(e, bsr_fit_beta(e->ctx, c.index, c.Beta.data(), &rmse));
-    }
-    c.errs.push_back(rmse);
     c.total = 0;
     for (int j = 0; j < K; ++j)
       if (j != k) c.def_ema[j] = 0.0;  // their sibling set has changed
     replay_to(c.rng, c.start_state, cd.before_u);
     c.rng.uniform();
-    if (tr) tr->rmse = rmse;
-    const int m = std::min<int>(10, (int)c.errs.size());  // codes/bsr_class.py:248-252
-    if (c.errs.size() > 100) {
-      double mn = kInf, sum = 0;
-      for (int j = 0; j < m; ++j) {
-        const double v = c.errs[c.errs.size() - m + j];
-        mn = std::min(mn, v);
-        sum += v;
-      }
-      if (1 - mn / (sum / m) < 0.05) c.done = true;
+    // the accepted proposal by its place in the batch the GPU scored -- or, where it was answered from the score memo
+    // (it is in no batch), by its tape
+    const int at = gpu_index ? gpu_index[slot0 + (int)i] : slot0 + (int)i;
+    if (at < 0) {
+      // Answered from the score memo: its tape is staged in no batch, so it goes to the GPU alone and the commit is made
+      // from THAT one-tape batch.  Not here: the one-tape batch takes the lane's slot (or moves the context's "last waited
+      // batch"), and the chains of this batch that are consumed behind this one still commit by their place in it.  The
+      // device half of the accept waits until every chain of the batch has been consumed (finish_accept, run by the
+      // caller); nothing the other chains do depends on this chain's refreshed state.
+      if (!deferred) return efail(e, BSR_E_STATE, "a memo-answered accept needs the caller's deferred list");
+      deferred->push_back({&c, k, tr});
+    } else {
+      int rc = finish_accept(e, c, k, batch_slot, at, tr);
+      if (rc != BSR_OK) return rc;
     }
     broke = true;
     break;
@@ -1843,7 +1884,6 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   const int per_group_cap = std::max(1, max_batch / n_groups);
   const bool use_mh = e->device_mh && !trace && e->K > 1;
   const bool memo_on = e->score_memo && !use_mh;   // (the device-side MH scan wants every proposal's score on the device)
-  const int K = e->K;
 
   // generates and submits the batch of lane `li`; ahead: behind the candidates the group's other lane has in flight
   auto submit = [&](Group& g, int li, bool ahead) -> int {
@@ -1895,13 +1935,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
         if (memo_on) {
-          const bsr_score* h = c->memo.find(cd.ghash);
+          const bsr_score* h = c->memo.find(cd.ghash, cd.gcheck);
           L.hit.push_back(h ? 1 : 0);
-          if (h) {
-            bsr_score v = *h;
-            if (v.rank == K)   // the device's formula (csrc/bsr_solve.h), for this candidate's sigma
-              v.loglik = -v.sse / (2 * cd.new_sigma * cd.new_sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * cd.new_sigma * cd.new_sigma);
-            L.hit_val.push_back(v);
+          if (h) {   // rank and SSE; the log-likelihood for this candidate's own sigma is formed where it is used (consume)
+            L.hit_val.push_back(*h);
             ++n_hit;
           }
         }
@@ -1996,6 +2033,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         if (L.hit[i]) L.res[i] = L.hit_val[hv++];
     }
     int sp = 0;  // chains with proposals in this batch, in order: the spans of the MH scan
+    std::vector<DeferredAccept> deferred;   // accepts answered from the score memo: their device half runs behind the loop
     for (size_t i = 0; i < g.chains.size(); ++i) {
       if (L.span[i].second == 0) continue;
       ChainS& c = *g.chains[i];
@@ -2012,7 +2050,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       if (memo_on)   // what the GPU scored for this chain's (unchanged) state: kept for the repeats to come
         for (size_t q = 0; q < c.cands.size(); ++q) {
           const size_t at = (size_t)L.span[i].first + q;
-          if (at < L.hit.size() && !L.hit[at]) c.memo.put(c.cands[q].ghash, L.res[at]);
+          if (at < L.hit.size() && !L.hit[at]) c.memo.put(c.cands[q].ghash, c.cands[q].gcheck, L.res[at]);
         }
       bool more_ahead = false;
       for (int ol = 0; ol < 3; ++ol) {
@@ -2021,13 +2059,20 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       }
       bool broke = false;
       r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke,
-                  L.compact ? L.gpu_of.data() : nullptr);
+                  L.compact ? L.gpu_of.data() : nullptr, &deferred);
       g.evt_ema = 0.9 * g.evt_ema + (broke ? 0.1 : 0.0);
       if (broke)   // what was generated behind these is void
         for (int ol = 0; ol < 3; ++ol) {
           Lane& O = g.lane[ol];
           if (ol != li && O.inflight && i < O.valid.size()) O.valid[i] = 0;
         }
+      if (r != BSR_OK) return r;
+    }
+    // every chain of the batch has been consumed: the lane's slot is free for the one-tape batches of the accepts that
+    // were answered from the memo (run inside the loop they replaced the staged batch the later chains of it
+    // still committed from)
+    for (const DeferredAccept& d : deferred) {
+      r = finish_accept(e, *d.c, d.k, L.slot, -1, d.tr);
       if (r != BSR_OK) return r;
     }
     g.t_consume += now_s() - tw1;

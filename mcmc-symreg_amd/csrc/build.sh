@@ -45,7 +45,7 @@ build_one() {   # <object dir> <output .so> [extra flags...]
   for s in "${srcs[@]}"; do [ -f "$obj/$s.o" ] && [ -f "$here/$s.hip" ] && objs+=("$obj/$s.o"); done
   # (the shipped library without its static symbol table: the C ABI's dynamic symbols stay)
   local strip=(); [ "$obj" = "$here/build" ] && strip=(-Wl,-s)
-  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -lhsa-runtime64 -Wl,--gc-sections -Wl,-z,noseparate-code -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
+  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -L"$ROCM/lib" -lrccl -lhsa-runtime64 -Wl,--gc-sections -Wl,--version-script="$here/exports.map" -Wl,-z,noseparate-code -Wl,-rpath,"$ROCM/lib" "${strip[@]}" -o "$out"
   echo "built $out ($(stat -c %s "$out") bytes)"
 }
 

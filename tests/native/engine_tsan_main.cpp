@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE.  Drives the product's native sampler (csrc/bsr_engine.hip) with worker threads and batches
 // generated ahead, against the CPU stand-in of the data side (stub_scorer.cpp), for ThreadSanitizer.  Prints one
 // digest line per chain: the chains' outcomes must not depend on how they were grouped over threads.
-//   engine_tsan <n_chains> <props_per_chain>     (groups / look-ahead through BSR_ENGINE_GROUPS / BSR_ENGINE_LOOKAHEAD)
+//   engine_tsan <n_chains> <props_per_chain> [trace_cap]    (groups / look-ahead / score memo through BSR_ENGINE_GROUPS /
+//   BSR_ENGINE_LOOKAHEAD / BSR_ENGINE_MEMO; trace_cap > 0: the traced, single-threaded ticket path with all chains in one batch)
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -13,6 +14,7 @@
 int main(int argc, char** argv) {
   const int n_chains = argc > 1 ? atoi(argv[1]) : 8;
   const long props = argc > 2 ? atol(argv[2]) : 300;
+  const long trace_cap = argc > 3 ? atol(argv[3]) : 0;
   const int N = 200, d = 3, K = 3;
   std::vector<double> X((size_t)N * d), y(N);
   uint64_t s = 12345;
@@ -31,7 +33,8 @@ int main(int argc, char** argv) {
     if (bsr_engine_init_chain(e, c) != BSR_OK) { fprintf(stderr, "init: %s\n", bsr_engine_last_error(e)); return 4; }
   }
   int64_t n_trace = 0;
-  const int rc = bsr_engine_run(e, 16, props, nullptr, 0, &n_trace, 8 * 64);
+  std::vector<bsr_trace> trace((size_t)(trace_cap > 0 ? trace_cap : 1));
+  const int rc = bsr_engine_run(e, 16, props, trace_cap > 0 ? trace.data() : nullptr, trace_cap, &n_trace, 8 * 64);
   if (rc != BSR_OK) { fprintf(stderr, "run: %d %s\n", rc, bsr_engine_last_error(e)); return 5; }
   for (int c = 0; c < n_chains; ++c) {
     std::vector<bsr_node> tapes((size_t)K * 512);

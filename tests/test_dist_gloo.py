@@ -96,3 +96,25 @@ def test_record_roundtrip():
     assert [Express(t) for t in u["roots"]] == [Express(t) for t in roots]
     assert np.array_equal(u["beta"].reshape(-1), np.arange(4.0)) and u["best_rmse"] == 0.7
     assert D.shard(7, 3, 1) == [1, 4]
+
+
+def test_a_corrupt_or_short_record_raises_instead_of_truncating():
+    """unpack_record checked its variable-length header with asserts only (gone under `python -O`; slices of
+    a short buffer truncate silently).  Every way a record can disagree with its buffer raises ValueError."""
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-symreg_amd"))
+    import pytest
+    from bsr import dist as D
+    from conftest import load_golden, node_from_spec
+    g = load_golden("g2_grow.json")
+    roots = [node_from_spec(c["tree"]) for c in g["cases"][:3]]
+    rec = D.pack_record(7, roots, np.arange(4.0), 0.5, [1.0, 0.7], 123, 2)
+    with pytest.raises(ValueError):
+        D.unpack_record(rec[:-8])                       # short buffer
+    with pytest.raises(ValueError):
+        D.unpack_record(rec[:D.HEADER_BYTES - 8])       # not even a header
+    for word, value in ((1, D.MAX_K + 1), (1, -1), (4, -3), (4, 5), (16, -1), (16, 10 ** 6), (9, rec.size + 8)):
+        bad = rec.copy()
+        bad[:D.HEADER_I32 * 4].view(np.int32)[word] = value
+        with pytest.raises(ValueError):
+            D.unpack_record(bad)
+    assert D.unpack_record(np.concatenate([rec, rec]))["chain"] == 7   # a longer buffer is fine: the header bounds the record

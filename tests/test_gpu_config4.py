@@ -141,28 +141,37 @@ def test_eight_ranks_on_one_device_complete_with_eight_records():
     assert out["verified"]["byte_identical"]
 
 
-def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch):
+@pytest.mark.parametrize("n_chains,groups", [(4, 4), (8, 4), (8, 2), (16, 4), (8, 1), (4, 0)])
+def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch, n_chains, groups):
     """The native sampler answers exact repeats of a candidate in an unchanged chain state from a table (rank and SSE kept,
-    the log-likelihood recomputed for the proposal's own sigma: codes/funcs.py:1162-1173).  Four chains with the memo and
-    without it: the same accepted trees, proposal / accept / rank-rejection counts, Beta and RMSE history -- and a good
+    the log-likelihood formed on the host for the proposal's own sigma: codes/funcs.py:1162-1173).  Chains with the memo
+    and without it: the same accepted trees, proposal / accept / rank-rejection counts, Beta and RMSE history -- and a good
     share of the proposals is answered from the table (tools/memo_probe.py measured 40-49 % repeats in long chains; these
-    short ones -- sixty accepted samples -- repeat less: 7 % here)."""
-    from bsr import dist as D
+    short ones -- sixty accepted samples -- repeat less: 7 % here).
+    Groups that hold SEVERAL chains (8 chains in 4 or 2 groups, 16 in 4: what `sharded.run_rank` and the bench run) are
+    the case round 5's advisor broke: an accept answered from the memo used to resubmit a one-tape batch on the lane's
+    slot while later chains of the same batch still committed by their index in it.  groups = 0: the traced,
+    single-threaded ticket path (slot = -1, bsr_commit through the last waited batch)."""
     from bsr.chain import DeviceScorer
     from bsr.native import NativeEngine
     X, y = _c4_data()
     K, val = 3, 60
     out = {}
+    if groups > 0:
+        monkeypatch.setenv("BSR_ENGINE_GROUPS", str(groups))
     for memo in ("1", "0"):
         monkeypatch.setenv("BSR_ENGINE_MEMO", memo)
-        scorer = DeviceScorer(X, y, K, n_chains=4, max_batch=128)
-        eng = NativeEngine(scorer.ctx, 4, X.shape[1], val=val)
-        for c in range(4):
+        scorer = DeviceScorer(X, y, K, n_chains=n_chains, max_batch=32 * n_chains)
+        eng = NativeEngine(scorer.ctx, n_chains, X.shape[1], val=val)
+        for c in range(n_chains):
             eng.seed(c, 2000 + c)
             eng.init_chain(c)
-        eng.run(batch_per_chain=32)
-        res = [eng.result(c) for c in range(4)]
-        stats = [eng.memo_stats(c) for c in range(4)]
+        if groups == 0:
+            eng.run(batch_per_chain=32, trace_cap=200000)
+        else:
+            eng.run(batch_per_chain=32)
+        res = [eng.result(c) for c in range(n_chains)]
+        stats = [eng.memo_stats(c) for c in range(n_chains)]
         eng.close()
         scorer.close()
         from bsr.node import Express

@@ -250,3 +250,54 @@ def test_packets_wrap_around_the_queues_many_times():
         assert bad == 0, bad
     finally:
         ctx.close()
+
+
+POISON_WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "mcmc-symreg_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from bsr import _lib
+from bsr.device import DeviceContext
+from bsr.tape import pack
+from test_gpu_dispatch import _trees
+rs = np.random.RandomState(3)
+N, d, K = 400_000, 6, 3
+X = rs.uniform(-3, 3, size=(N, d)); y = rs.standard_normal(N)
+ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=64)
+cur = _trees(d, rs, K)
+for k in range(K):
+    ctx.set_current(0, k, cur[k])
+ctx.refresh(0)
+assert ctx.dispatch_info()["direct"], "direct dispatch is off on this box"
+tapes = _trees(d, rs, 64)
+rows, off = pack(tapes)
+ch = np.zeros(64, np.int32); ks = (np.arange(64) %% K).astype(np.int32); sg = np.full(64, 0.7)
+out = np.zeros(64, dtype=_lib.SCORE_DTYPE)
+t = ctx.score_submit(rows, off, ch, ks, sg)
+try:
+    ctx.score_wait(t, out)
+    print("NO_TIMEOUT")
+except _lib.BsrError as e:
+    print("WAIT_ERROR", e.code)
+try:
+    ctx.score_submit(rows, off, ch, ks, sg)
+    print("SUBMIT_ACCEPTED")
+except _lib.BsrError as e:
+    print("SUBMIT_REFUSED", e.code)
+time.sleep(0.2)           # (the abandoned batch ends on its own; nothing it writes has been freed)
+ctx.close()
+print("CLOSED")
+"""
+
+
+def test_a_batch_that_never_completes_poisons_its_context():
+    """when the wait for a directly dispatched batch gives up (queue error, a minute of silence) the packets
+    may still be queued or running.  The context must then refuse further batches (the slot's buffers would be staged
+    over under the GPU) and bsr_ctx_destroy must leave everything the GPU can reach allocated.  The give-up is forced
+    with BSR_DEBUG_AQL_TIMEOUT_MS=-1 (the first unfinished poll counts as silence) in a process of its own."""
+    r = subprocess.run([sys.executable, "-c", POISON_WORKER % {"root": ROOT}],
+                       env=dict(os.environ, BSR_DEBUG_AQL_TIMEOUT_MS="-1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.split()
+    assert "WAIT_ERROR" in lines and "SUBMIT_REFUSED" in lines and "CLOSED" in lines and "SUBMIT_ACCEPTED" not in lines, r.stdout

@@ -301,6 +301,15 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(_lib.EXPORTS)
+    # ... and exports NOTHING else: the dynamic symbol table is the C ABI (csrc/exports.map); the C++ internals
+    # (aql_*, launch_*, kernel host stubs) used to have default visibility
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        so = os.path.join(root, "mcmc-symreg_amd", "bsr", "libbsr_hip.so")
+        out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+        dyn = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+        assert dyn == declared, sorted(dyn ^ declared)[:20]
     assert L.bsr_abi_version() == 1
     assert _lib.SCORE_DTYPE.itemsize == 120
     if _lib.device_count() == 0:

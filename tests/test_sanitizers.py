@@ -93,3 +93,37 @@ def test_the_sampler_predicts_most_rank_gate_rejections(tmp_path):
     assert n == 16000 and rej > 100, m.group(0)
     assert hit >= 0.85 * rej, m.group(0)
     assert false_alarm <= 0.1 * hit, m.group(0)
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_memo_answered_accepts_in_groups_of_several_chains(tmp_path):
+    """an accepted proposal that was answered from the score memo is in no GPU batch; its one-tape
+    batch used to take the lane's slot INSIDE the loop over the batch's chains, and every later chain of that batch
+    that accepted a GPU-scored proposal then committed by its index into the replaced batch (BSR_E_STATE, or -- index 0
+    -- the wrong tape).  Groups of several chains (what `sharded.run_rank` and the bench run), long enough for two
+    accepts in one batch: the memo must change nothing -- same digests with BSR_ENGINE_MEMO=1 and 0, whatever the
+    grouping, also on the traced single-threaded path (all chains in one batch, commits through `last waited`)."""
+    exe = str(tmp_path / "engine_host")
+    src = [os.path.join(ROOT, "mcmc-symreg_amd", "csrc", "bsr_engine.hip"), os.path.join(ROOT, "tests", "native", "stub_scorer.cpp"),
+           os.path.join(ROOT, "tests", "native", "engine_tsan_main.cpp")]
+    cmd = ["g++", "-std=c++17", "-O2", "-DBSR_HOST_ONLY", "-pthread", "-I" + os.path.join(ROOT, "include")]
+    for f in src:
+        cmd += ["-x", "c++", f]
+    b = subprocess.run(cmd + ["-o", exe], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-4000:]
+    for n_chains in (4, 8, 16):
+        outs = {}
+        for groups in ("1", "2", "4"):
+            for memo in ("1", "0"):
+                r = subprocess.run([exe, str(n_chains), "150000"], env=dict(os.environ, BSR_ENGINE_GROUPS=groups, BSR_ENGINE_MEMO=memo),
+                                   capture_output=True, text=True, timeout=900)
+                assert r.returncode == 0, (n_chains, groups, memo, r.stderr[-2000:])
+                outs[(groups, memo)] = r.stdout
+        for memo in ("1", "0"):   # traced: one group, no worker threads, bsr_commit through the last waited batch
+            r = subprocess.run([exe, str(n_chains), "150000", "1000"], env=dict(os.environ, BSR_ENGINE_MEMO=memo),
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, (n_chains, "traced", memo, r.stderr[-2000:])
+            outs[("traced", memo)] = r.stdout
+        first = outs[("1", "0")]
+        assert len(first.splitlines()) == n_chains
+        assert all(v == first for v in outs.values()), [k for k, v in outs.items() if v != first]

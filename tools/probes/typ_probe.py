@@ -1,5 +1,5 @@
 """Probe: narrow (two chains, 64 proposals) against wide (eight chains, 256) batches on one context, byte for byte.
-  python tools/probes/typ_test.py [tuned]   -- tuned: bsr_ctx_create_tuned(typical_chains=2, typical_batch=64)"""
+  python tools/probes/typ_probe.py [tuned]   -- tuned: bsr_ctx_create_tuned(typical_chains=2, typical_batch=64)"""
 import os, sys
 sys.path.insert(0, "mcmc-symreg_amd"); sys.path.insert(0, "tests")
 import numpy as np
