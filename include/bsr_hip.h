@@ -84,6 +84,11 @@ typedef struct bsr_node {
 #define BSR_F_NAN 2u          /* ... holds NaN: reference raises LinAlgError at codes/funcs.py:1226 */
 #define BSR_F_RANKDEF 4u      /* rank(new_outputs) < K : rejected by the gate at codes/funcs.py:1226-1228 */
 #define BSR_F_SCALE_RETRY 8u  /* K==1 only: column magnitude outside the accumulation range; rescored internally */
+#define BSR_F_SV_BOUNDS 16u   /* the rank gate was settled by bounds far from its threshold (csrc/bsr_solve.h: solve_fast):
+                               * smin is a lower bound of sigma_min (rank = K) or an upper bound (rank < K), smax an upper
+                               * bound of sigma_max, each within sqrt(K); with rank < K, `rank` is itself a bound (< K) and
+                               * loglik / sse / beta are NaN -- the reference returns before ylogLike there
+                               * (codes/funcs.py:1226-1228).  Unset: singular values by one-sided Jacobi, everything exact. */
 
 /* Data-side result of one Metropolis-Hastings proposal: everything
  * codes/funcs.py:1212-1235 (newProp) takes from the N rows. */
@@ -92,9 +97,11 @@ typedef struct bsr_score {
   double sse;               /* sum((y - XX@Beta)^2),               codes/funcs.py:1162 */
   double scale;             /* max|new_outputs|,                    codes/funcs.py:1149 */
   double maxabs;            /* max|candidate column| */
-  double smin, smax;        /* extreme singular values of new_outputs (relative to an internal power-of-two scale) */
+  double smin, smax;        /* extreme singular values of new_outputs (relative to an internal power-of-two scale);
+                             * bounds when flags & BSR_F_SV_BOUNDS */
   double beta[BSR_MAX_K];   /* OLS weights on the scaled columns,   codes/funcs.py:1154-1155 */
-  int32_t rank;             /* np.linalg.matrix_rank(new_outputs); 0 if inf present; -1 if NaN present */
+  int32_t rank;             /* np.linalg.matrix_rank(new_outputs); 0 if inf present; -1 if NaN present; with
+                             * BSR_F_SV_BOUNDS and rank < K: some value < K (the gate's verdict is what the path uses) */
   uint32_t flags;
 } bsr_score;
 
@@ -264,6 +271,11 @@ int bsr_batch_stats(const bsr_ctx* ctx, int32_t ticket, int32_t* stats4);
  * geom5 = {tape groups, row slices, blocks per slice, blocks, workgroups * 100 + 1}.  Returns the number of workgroups
  * copied (<= max_wgs), 0 when stamps are off, BSR_E_* (< 0) on failure. */
 int bsr_debug_tile_stamps(bsr_ctx* ctx, unsigned long long* out, int32_t max_wgs, int32_t* geom5);
+/* BSR_TILE_STAMPS=R keeps the stamps of the last R tile-pass launches (launch n in block n mod R), word 5 of a wave's
+ * record = HW_ID | XCC_ID << 32 (which CU it ran on), words 7 / 6 = start / end on the 100 MHz clock: the busy intervals
+ * of every CU over many pipelined launches (tools/cu_occupancy.py).  out[R][slots][16][8] uint64; info4 = {R, workgroup
+ * slots per block, workgroups per launch, launches so far}.  Returns the blocks copied, 0 when stamps are off. */
+int bsr_debug_tile_stamp_ring(bsr_ctx* ctx, unsigned long long* out, int32_t max_blocks, int32_t* info4);
 
 /* How scoring batches reach the GPU (no reference counterpart):
  *   info[0] 1 if the context dispatches them itself (AQL packets into its own ROCr queues, csrc/bsr_aql.h), 0 if through

@@ -109,7 +109,7 @@ def lib():
 EXPORTS = ["bsr_abi_version", "bsr_device_count", "bsr_ctx_create", "bsr_ctx_create_tuned", "bsr_ctx_destroy", "bsr_last_error",
            "bsr_eval_tapes", "bsr_set_current", "bsr_commit", "bsr_refresh", "bsr_score_batch", "bsr_score_submit",
            "bsr_score_wait", "bsr_score_submit_mh", "bsr_score_wait_mh", "bsr_fit_beta",
-           "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_ctx_info", "bsr_batch_stats", "bsr_debug_tile_stamps", "bsr_dispatch_info", "bsr_place_info", "bsr_comm_unique_id",
+           "bsr_get_current", "bsr_yloglike_host", "bsr_set_profiling", "bsr_last_timing", "bsr_ctx_info", "bsr_batch_stats", "bsr_debug_tile_stamps", "bsr_debug_tile_stamp_ring", "bsr_dispatch_info", "bsr_place_info", "bsr_comm_unique_id",
            "bsr_comm_init", "bsr_comm_allgather", "bsr_comm_destroy", "bsr_engine_create", "bsr_engine_destroy",
            "bsr_engine_last_error", "bsr_engine_set_nan_policy", "bsr_engine_set_ops", "bsr_engine_seed", "bsr_engine_set_rng", "bsr_engine_get_rng",
            "bsr_engine_init_chain", "bsr_engine_run", "bsr_engine_chain_result", "bsr_engine_memo_stats", "bsr_rng_selftest"]

@@ -262,6 +262,7 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
     c->tile_on = env_int("BSR_TILE", 1);
 
     c->selfdup = env_int("BSR_SELFDUP", 1);
+    c->solve_exact = env_int("BSR_SOLVE_EXACT", 0);
     c->reorder = env_int("BSR_REORDER", 1);
     c->chain_eval = env_int("BSR_CHAIN_EVAL", 1);
     // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
@@ -408,10 +409,13 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
       c->n_cols = d;
       for (BatchSlot& s : c->slot) s.slot_of.assign(c->n_cols, -1);
     }
-    if (env_int("BSR_TILE_STAMPS", 0)) {
-      const size_t nb = (size_t)std::max(c->n_cu, c->tile_cus) * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS * sizeof(unsigned long long);
+    if (env_int("BSR_TILE_STAMPS", 0) > 0) {
+      // BSR_TILE_STAMPS=R: a ring of R launches' stamps (launch n writes block n mod R; R = 1: the last launch's)
+      c->stamp_ring = std::min(4096, env_int("BSR_TILE_STAMPS", 0));
+      c->stamp_block_words = (size_t)std::max(c->n_cu, c->tile_cus) * BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS;
+      const size_t nb = c->stamp_block_words * (size_t)c->stamp_ring * sizeof(unsigned long long);
       if (hipMalloc((void**)&c->d_stamps, nb) == hipSuccess) (void)hipMemset(c->d_stamps, 0, nb);
-      else c->d_stamps = nullptr;
+      else { c->d_stamps = nullptr; c->stamp_ring = 0; }
     }
   }
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -771,6 +775,10 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
   memset(&tg, 0, sizeof tg);
   const long long tq0 = g_host_prof ? host_now() : 0;
   if (j.scoring && j.restage && c->selfdup) mark_in_span(c, s, j.P);
+  if (j.scoring && c->solve_exact) {   // bit 1 of self_dup: no fast tier for this proposal (csrc/bsr_solve.h)
+    PropDesc* hd = s.h_desc();
+    for (int i = 0; i < j.P; ++i) hd[i].self_dup |= 2;
+  }
   const long long tq1 = g_host_prof ? host_now() : 0;
   long long tq2 = tq1;
   if (j.maybe_tile) {
@@ -852,7 +860,9 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
         a.colsrc = (decltype(TT::colsrc))s.d_cols();
         a.cols_stride = s.cols_stride;
         a.N = c->N; a.codes = codes; a.feats = feats_lds; a.lnp = lnp; a.desc = s.d_desc(); a.sched = s.d_sched();
-        a.part = s.part1; a.P = j.P; a.K = c->K; a.stamps = c->d_stamps;
+        a.part = s.part1; a.P = j.P; a.K = c->K;
+        a.stamps = c->d_stamps ? c->d_stamps + (size_t)(c->stamp_seq.fetch_add(1, std::memory_order_relaxed) % (uint32_t)c->stamp_ring) * c->stamp_block_words
+                               : nullptr;
         a.srec = s.tile_stream ? reinterpret_cast<const StreamRec*>(s.d_in + s.off_recs + s.srec_off) : nullptr;
         a.tprog = (s.tprog_off != 0 && tg.per_group > 0) ? reinterpret_cast<const TileProg*>(s.d_in + s.off_recs + s.tprog_off) : nullptr;
         a.split_stage = c->tile_split;
@@ -1558,6 +1568,8 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
                            const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
                            const int32_t* mhflags, const int32_t* span_off, int32_t n_spans, bool defer) {
   if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
+  if (c->poisoned.load(std::memory_order_relaxed))
+    return fail(c, BSR_E_STATE, "the context is poisoned: a directly dispatched batch never completed (destroy the context)");
   HIPCHK(c, use_device_fwd(c));
   for (int i = 0; i < B; ++i) {
     int rc = chain_ok(c, chain[i], which_k[i]);
@@ -1814,6 +1826,7 @@ extern "C" int bsr_yloglike_host(int device, int64_t N, int32_t K, const double*
   bsr_ctx* c = nullptr;
   int rc = bsr_ctx_create(&c, device, N, K, outputs, y, K, 1, 1, BSR_DTYPE_F64);
   if (rc != BSR_OK) return rc;
+  c->solve_exact = 1;   // ylogLike has no rank gate in front of it: a value for deficient inputs too (codes/funcs.py:1147-1174)
   bsr_node t;
   memset(&t, 0, sizeof t);
   t.opcode = BSR_OP_TERMINAL;
@@ -1866,6 +1879,23 @@ extern "C" int bsr_debug_tile_stamps(bsr_ctx* c, unsigned long long* out, int32_
     geom5[0] = c->tile_T; geom5[1] = c->tile_slices; geom5[2] = c->tile_bps; geom5[3] = c->tile_blocks;
     geom5[4] = c->tile_cus * 100 + 1;
   }
+  return n;
+}
+
+// The whole ring (BSR_TILE_STAMPS=R): out[R][block_workgroups][16][8] uint64; info4 = {R, workgroup slots per block,
+// workgroups of a launch, tile launches so far}.  Returns the number of blocks copied (<= max_blocks).
+extern "C" int bsr_debug_tile_stamp_ring(bsr_ctx* c, unsigned long long* out, int32_t max_blocks, int32_t* info4) {
+  if (!c || !out || !info4) return BSR_E_ARG;
+  if (!c->d_stamps) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  const int n = std::min<int>(max_blocks, c->stamp_ring);
+  if (hipMemcpy(out, c->d_stamps, (size_t)n * c->stamp_block_words * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return BSR_E_HIP;
+  info4[0] = c->stamp_ring;
+  info4[1] = (int32_t)(c->stamp_block_words / (BSR_TILE_WAVES * BSR_TILE_STAMP_WORDS));
+  info4[2] = c->tile_cus;
+  info4[3] = (int32_t)c->stamp_seq.load();
   return n;
 }
 

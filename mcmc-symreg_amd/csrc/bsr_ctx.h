@@ -197,6 +197,7 @@ struct bsr_ctx {
   std::vector<uint64_t> cur_fmask;   // features each current tree reads (bit f mod 64), all ones: unknown
   std::vector<char> cur_form_ok;               // ... valid
   std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span;   // [chain]
+  int solve_exact = 0;                         // BSR_SOLVE_EXACT=1: every proposal's singular values by Jacobi (round 5's k_solve; the standalone ylogLike)
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)
   int chain_eval = 1;   // BSR_CHAIN_EVAL: chain tapes take the register-resident pass of the tile kernel
@@ -231,7 +232,10 @@ struct bsr_ctx {
   bool tile_stream = false; // chunked fp64 context: the streaming kernel (bsr_stream.hip) with its own geometry -- every
   int tile_long = 0;        // block in a slice, the first tile_long slices one block longer, no leftover units
   size_t tile_sched_cap = 0;
-  unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=1: per-wave clock samples of the last tile launch
+  unsigned long long* d_stamps = nullptr;   // BSR_TILE_STAMPS=R: per-wave clock samples of the last R tile launches (a ring)
+  int stamp_ring = 0;                       // R
+  size_t stamp_block_words = 0;             // one launch's block: [workgroups][16 waves][8] words
+  std::atomic<uint32_t> stamp_seq{0};       // tile launches so far (launch n writes block n mod R)
   // profiling: 0 off, 1 events around the row pass only, 2 events around every kernel
   int prof = 0;
   double last_us[5] = {0, 0, 0, 0, 0};

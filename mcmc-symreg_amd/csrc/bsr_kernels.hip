@@ -394,7 +394,10 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
       in.N = N;
       in.flags = cfp->flags;
       in.rank_floor = fin.rank_floor;
+      in.exact = (dsc[p].self_dup & 2) ? 1 : 0;
       in.mh = fin.mh + p;
+      // (Jacobi for every flagged proposal here: the fast tier's registers would spill this 16-wave kernel's 128, and a
+      // candidate that had to come this way is as a rule inside the band around the tolerance or deficient anyway)
       if constexpr (NQ >= 1 && NQ <= 4) solve_regs<NQ>(in, lane, fin.out + p);
       else if constexpr (NQ >= 5) solve_cols<NQ>(in, lane, fin.out + p);
     };
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(4 * BSR_WAVE) void k_finalize(const PropDesc* __res
   in.N = N;
   in.flags = cf->flags;
   in.rank_floor = rank_floor;
+  in.exact = (dsc[p].self_dup & 2) ? 1 : 0;
   in.mh = mhv + p;
   solve_any(in, lane, outv + p);
   }

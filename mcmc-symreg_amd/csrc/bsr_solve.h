@@ -32,6 +32,7 @@ struct SolveIn {
   int64_t N;
   uint32_t flags;
   double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
+  int exact;          // 1: singular values by Jacobi whatever the margin (BSR_SOLVE_EXACT=1; the standalone ylogLike)
   MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
 };
 template <int K>
@@ -351,7 +352,215 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fast tier (round 6).  Almost every proposal is far from the rank gate's threshold, on one side or the other, and
+// the (K+1) x K factor S is nearly triangular already: its first k columns ARE (R's own), columns k..K-2 carry one
+// subdiagonal entry (R with column k taken out is upper Hessenberg) and only the candidate's column is dense.  So:
+//   1. K - k Givens rotations of adjacent rows make S = G [T; 0], T upper triangular K x K; g = G^T h.
+//   2. The gate from T alone, by bounds: sigma_min <= min |t_jj| and sigma_max >= the largest column norm -- a quarter
+//      of the tolerance below => rank < K for certain; sigma_min >= 1 / |T^-1|_F and sigma_max <= |T|_F (T^-1 by back
+//      substitution) -- four tolerances above => rank = K for certain.  In between (a band a few hundred wide around
+//      N eps, where also numpy's own SVD of the N x K matrix is within rounding of its threshold) and for anything
+//      that is not finite: the one-sided Jacobi SVD below, as for every proposal until round 5.
+//   3. rank = K: the ridge fit min |g1 - tau T b|^2 + 1e-6 |b|^2 (codes/funcs.py:1151-1155) by Givens rotations of
+//      [tau T; 1e-3 I] (K (K + 1) / 2 of them: backward stable at any condition number the gate lets through, no
+//      normal equations), b by back substitution, the misfit as the residual VECTOR g1 - tau T b plus the frame
+//      direction the columns do not span (g_K) -- the quantities of the Jacobi path, computed from a QR instead of an SVD.
+//   4. rank < K: the reference returns before ylogLike (codes/funcs.py:1226-1228): there is no log-likelihood to
+//      report -- loglik, sse and beta are NaN, rank is a bound (the diagonal entries above the tolerance, at most
+//      K - 1), BSR_F_SV_BOUNDS says so.  (The standalone ylogLike entry point, which has no gate, asks for the exact
+//      tier: bit 1 of PropDesc::self_dup.)
+// smin / smax of a proposal settled here are the bounds used (within sqrt(K) of the singular values), flagged
+// BSR_F_SV_BOUNDS.  All lanes compute the same values; every index is static.
+// A dependent chain of ~40 (K = 3) to ~400 (K = 8) instructions instead of five or six Jacobi sweeps of 3 x ~90 / 7 x ~150.
+template <int K>
+__device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_score* out) {
+  constexpr int M = K + 1;
+  const int k = in.k;
+  const ChainB* ck = in.ck;
+  const double rel_w = 0.5 * (double)((in.N > (int64_t)K) ? in.N : (int64_t)K) * 2.220446049250313e-16;
+  const double rho = (in.rho2 > fmax(1e-30, rel_w * rel_w) * in.zz) ? sqrt(in.rho2) : 0.0;
+  double W[M][K], g[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) W[i][j] = factor_entry(in, K, i, j, rho);
+#pragma unroll
+  for (int i = 0; i < M; ++i) g[i] = (i < K) ? ck->qy[i < K ? i : 0] : ((rho > 0.0) ? in.wy / rho : 0.0);
+  const double hK = g[K];
+  double colmax2 = 0.0;   // the largest squared column norm: sigma_max^2 is at least that
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) n2 = fma(W[i][j], W[i][j], n2);
+    colmax2 = fmax(colmax2, n2);
+  }
+  // 1. rows (m, m + 1) for the Hessenberg columns m = k..K-2, then rows (K-1, K) for the candidate's column
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    if (m >= k || m == K - 1) {
+      const double a = W[m][m], b = W[m + 1][m];
+      if (b != 0.0) {
+        const double n2 = fma(a, a, b * b);
+        const double ri = rot_rsq(n2);
+        const double cs = a * ri, sn = b * ri;
+        W[m][m] = n2 * ri;
+        W[m + 1][m] = 0.0;
+#pragma unroll
+        for (int j = m + 1; j < K; ++j) {
+          const double t0 = W[m][j], t1 = W[m + 1][j];
+          W[m][j] = fma(cs, t0, sn * t1);
+          W[m + 1][j] = fma(cs, t1, -(sn * t0));
+        }
+        const double g0 = g[m], g1 = g[m + 1];
+        g[m] = fma(cs, g0, sn * g1);
+        g[m + 1] = fma(cs, g1, -(sn * g0));
+      }
+    }
+  }
+  // 2. T^-1 (upper triangular) by back substitution, the bounds, the verdict
+  double Y[K][K];
+  double mind = INFINITY, frobT2 = 0.0, frobY2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    mind = fmin(mind, fabs(W[j][j]));
+#pragma unroll
+    for (int i = 0; i <= j; ++i) frobT2 = fma(W[i][j], W[i][j], frobT2);
+  }
+  const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
+  const double tolrel = fmax(dimmax * 2.220446049250313e-16, in.rank_floor);
+  const double smax_lb = sqrt(colmax2), smax_ub = sqrt(frobT2);
+  if (!(isfinite(smax_ub) && smax_ub > 0.0)) return false;
+  if (mind < 0.25 * tolrel * smax_lb) {   // 4. rank < K for certain
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) cnt += (fabs(W[j][j]) > tolrel * smax_ub) ? 1 : 0;
+    if (cnt > K - 1) cnt = K - 1;
+    if (lane == 0) {
+      out->loglik = NAN;
+      out->sse = NAN;
+      out->scale = in.scale;
+      out->maxabs = in.maxabs;
+      out->smin = mind / in.s;
+      out->smax = smax_ub / in.s;
+      out->rank = cnt;
+      out->flags = in.flags | BSR_F_RANKDEF | BSR_F_SV_BOUNDS;
+      in.mh->loglik = NAN;
+      in.mh->rank = cnt;
+#pragma unroll
+      for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = (i < K) ? NAN : 0.0;
+    }
+    return true;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) Y[j][j] = 1.0 / W[j][j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+#pragma unroll
+    for (int i = j - 1; i >= 0; --i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int l = i + 1; l <= j; ++l) acc = fma(W[i][l], Y[l][j], acc);
+      Y[i][j] = -(acc * Y[i][i]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int i = 0; i <= j; ++i) frobY2 = fma(Y[i][j], Y[i][j], frobY2);
+  const double smin_lb = rot_rsq(frobY2);   // 1 / |T^-1|_F
+  if (!(smin_lb > 4.0 * tolrel * smax_ub)) return false;   // the band around the tolerance (or NaN): the exact tier decides
+  // 3. ridge: rotate [tau T; sqrt(1e-6) I | g1; 0] to triangular form, row of the identity by row
+  const double tau = in.tau;
+  double T2[K][K], g2[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    g2[i] = g[i];
+#pragma unroll
+    for (int j = i; j < K; ++j) T2[i][j] = tau * W[i][j];
+  }
+#pragma unroll
+  for (int e = 0; e < K; ++e) {
+    double E[K], ge = 0.0;   // the identity's row e: sqrt(eps) at column e, filled in to the right as it is rotated away
+#pragma unroll
+    for (int j = 0; j < K; ++j) E[j] = (j == e) ? 1e-3 : 0.0;
+#pragma unroll
+    for (int j = e; j < K; ++j) {
+      const double a = T2[j][j], b = E[j];
+      const double n2 = fma(a, a, b * b);
+      const double ri = rot_rsq(n2);
+      const double cs = a * ri, sn = b * ri;
+      T2[j][j] = n2 * ri;
+#pragma unroll
+      for (int l = j + 1; l < K; ++l) {
+        const double t0 = T2[j][l], t1 = E[l];
+        T2[j][l] = fma(cs, t0, sn * t1);
+        E[l] = fma(cs, t1, -(sn * t0));
+      }
+      const double q0 = g2[j];
+      g2[j] = fma(cs, q0, sn * ge);
+      ge = fma(cs, ge, -(sn * q0));
+    }
+  }
+  double bt[K];
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    double acc = g2[i];
+#pragma unroll
+    for (int l = i + 1; l < K; ++l) acc = fma(-T2[i][l], bt[l], acc);
+    bt[i] = acc / T2[i][i];
+  }
+  double misfit = g[K] * g[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double r = g[i];
+#pragma unroll
+    for (int l = i; l < K; ++l) r = fma(-(tau * W[i][l]), bt[l], r);
+    misfit = fma(r, r, misfit);
+  }
+  const double sse = fmax(0.0, ck->yperp2 - hK * hK) + misfit;
+  const double sigma = in.sigma;
+  const double ll = -sse / (2 * sigma * sigma) - 0.5 * (double)in.N * log(2 * M_PI * sigma * sigma);
+  if (!isfinite(ll)) return false;
+  if (lane == 0) {
+    out->loglik = ll;
+    out->sse = sse;
+    out->scale = in.scale;
+    out->maxabs = in.maxabs;
+    out->smin = smin_lb / in.s;
+    out->smax = smax_ub / in.s;
+    out->rank = K;
+    out->flags = in.flags | BSR_F_SV_BOUNDS;
+    in.mh->loglik = ll;
+    in.mh->rank = K;
+#pragma unroll
+    for (int i = 0; i < BSR_MAX_K; ++i) out->beta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
+      out->beta[tree] = bt[i];
+    }
+  }
+  return true;
+}
+
 __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score* out) {
+  if (!in.exact) {   // (wave-uniform: every lane holds the same numbers)
+    bool done;
+    switch (in.K) {
+      case 1: done = solve_fast<1>(in, lane, out); break;
+      case 2: done = solve_fast<2>(in, lane, out); break;
+      case 3: done = solve_fast<3>(in, lane, out); break;
+      case 4: done = solve_fast<4>(in, lane, out); break;
+      case 5: done = solve_fast<5>(in, lane, out); break;
+      case 6: done = solve_fast<6>(in, lane, out); break;
+      case 7: done = solve_fast<7>(in, lane, out); break;
+      default: done = solve_fast<8>(in, lane, out); break;
+    }
+    if (done) return;
+  }
   switch (in.K) {
     case 1: solve_regs<1>(in, lane, out); break;
     case 2: solve_regs<2>(in, lane, out); break;
@@ -470,7 +679,7 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   // what used to be flagged): then w = 0 exactly, which is what the residual pass would measure (|w|^2 ~ 1e-32 |s z|^2,
   // below the cut) -- the same arithmetic follows, without the pass.  The claim is only trusted when the one-pass
   // figure agrees that the candidate is in the span.
-  const bool known_in_span = ambiguous && dsc[p].self_dup != 0;
+  const bool known_in_span = ambiguous && (dsc[p].self_dup & 1) != 0;
   if (ambiguous && !known_in_span) {
     if (lane < BSR_NQ_MAX) cf->c[lane] = (lane < nq) ? sh_c[lane] : 0.0;
     if (lane == 0) {
@@ -503,6 +712,7 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   in.N = N;
   in.flags = flags;
   in.rank_floor = rank_floor;
+  in.exact = (dsc[p].self_dup & 2) ? 1 : 0;
   in.mh = mhv + p;
   solve_any(in, lane, out);
 

@@ -126,7 +126,13 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_tile1a(TileArgs<do
   unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
 #define TSTAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
-  if (stamp && lane == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+  if (stamp && lane == 0) {
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    // where the wave runs: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13], simd_id [5:4]) and XCC_ID [3:0] -- the busy
+    // intervals of every CU from the stamps of many launches (tools/cu_occupancy.py)
+    stamp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
   if (threadIdx.x == 0) s_next = BSR_TILE_WAVES;
   // Staging by LDS-DMA in two halves: blocks [0, 4) of every column and the math tables; when those have landed for
   // everyone, blocks [4, nb) are requested and the waves start on the first half.  (Requested all at once, a wave's

@@ -180,3 +180,26 @@ def test_g7_rng_primitives():
     for x, m, s, v in g["norm_pdf"]:
         z = (x - m) / s
         assert abs(np.exp(-z * z / 2.0) / np.sqrt(2 * np.pi) / s - v) <= 4e-16 * abs(v)
+
+
+def test_g4_oracle_rank_gate_on_the_reference_captures():
+    """G4: the oracle's gate (score_proposal: np.linalg.matrix_rank on the assembled new_outputs, codes/funcs.py:1226)
+    returns what the reference's own call returned on every captured / constructed matrix, whichever column is the
+    candidate.  (The captures are within 1e3 x of the tolerance: this pins the call and its default tolerance, and --
+    through the versions recorded in the fixture -- the LAPACK build the ranks came from.)"""
+    g = load_golden("g4_rank.json")
+    with np.load(os.path.join(GOLDEN, "g4_rank.npz")) as z:
+        mats = [z["M%d" % i] for i in range(len(g["cases"]))]
+    n_near = 0
+    for m, M in zip(g["cases"], mats):
+        N, K = M.shape
+        assert (N, K) == (m["N"], m["K"])
+        rs = np.random.RandomState(1)
+        y = rs.standard_normal(N)
+        for k in (0, K - 1):
+            cur = M.copy()
+            cur[:, k] = rs.standard_normal(N)          # the old tree k: the gate must not see it
+            got = O.score_proposal(cur, k, M[:, k], y, 1.0)
+            assert got["rank"] == m["rank"], (m["origin"], k, got["rank"], m["rank"])
+        n_near += 0.3 <= m["ratio_over_tol"] <= 3
+    assert n_near >= 20        # the fixture does hold the neighbourhood of the threshold

@@ -12,6 +12,7 @@ Fixtures:
   g1_edge.json        allcal edge semantics per opcode          (funcs.py:175-220)
   g2_grow.json        grow + allcal on seeded random trees      (funcs.py:74-119,175-220)
   g3_yloglike.json    ylogLike incl. scale/duplicate/zero cases (funcs.py:1147-1174)
+  g4_rank.json/npz    the rank gate's inputs near its threshold, captured at the reference's own call (funcs.py:1226)
   g5_trace_*.json/npz per-proposal newProp traces of BSR.fit    (funcs.py:1184-1306)
   g6_fit_f1.json      BSR(3,50).fit end to end on f1, seed 0    (bsr_class.py:77-278)
   g7_rng.json         RNG primitives as consumed by the path    
@@ -249,6 +250,92 @@ def g3():
     add("good_fit", y2, O, 0.05)
     dump("g3_yloglike.json", {"versions": VERSIONS, "cases": cases})
 
+
+
+def g4():
+    """The rank gate's own inputs (codes/funcs.py:1226: `np.linalg.matrix_rank(new_outputs) < K`), where it is closest to
+    its threshold.  np.linalg.matrix_rank is hooked (never edited) while the reference runs seeded chains; every finite
+    `new_outputs` whose sigma_min / sigma_max lies within 1e3 x of the tolerance max(N, K) eps is kept with the rank the
+    reference's own call returned, plus the same call on constructed sets: a column that repeats another up to a
+    perturbation of 1e-9 ... 1e-15, columns of scales 1e9 ... 1e16 apart, exact sums, for K = 2, 3, 5, 8."""
+    eps = np.finfo(np.float64).eps
+    mats, meta = [], []
+    orig = np.linalg.matrix_rank
+    seen = set()
+    quota = {}
+
+    def note(M, r, origin):
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        if not np.all(np.isfinite(M)):
+            return
+        sv = np.linalg.svd(M, compute_uv=False)
+        if not sv[0] > 0:
+            return
+        tol = max(M.shape) * eps
+        ratio = float(sv[-1] / sv[0])
+        key = zlib.crc32(M.tobytes())
+        if key in seen:
+            return
+        if origin.startswith("chain"):
+            if not (1e-3 * tol <= ratio <= 1e3 * tol):
+                return
+            # fixtures stay small: per configuration the first captures of each distance class (the closest class whole)
+            cls = 0 if 0.3 * tol <= ratio <= 3 * tol else (1 if 0.03 * tol <= ratio <= 30 * tol else 2)
+            cap = {0: 40, 1: 16, 2: 8}[cls] * (1 if M.shape[0] <= 100 else 0.5)
+            kq = (origin.split(" seed=")[0], cls)
+            quota[kq] = quota.get(kq, 0) + 1
+            if quota[kq] > cap:
+                return
+        seen.add(key)
+        mats.append(M)
+        meta.append({"origin": origin, "N": int(M.shape[0]), "K": int(M.shape[1]), "rank": int(r),
+                     "ratio_over_tol": fnum(ratio / tol), "sv_min": fnum(sv[-1]), "sv_max": fnum(sv[0])})
+
+    cur = {"origin": None}
+
+    def rank_w(M, *a, **k):
+        r = orig(M, *a, **k)
+        if cur["origin"] is not None:
+            note(M, r, cur["origin"])
+        return r
+
+    np.linalg.matrix_rank = rank_w
+    try:
+        for name, (X, y), K, seeds in (("f1", data_f1(100), 3, range(0, 12)),
+                                       ("synth_d10", data_synth(1000, 10, seed=0), 3, range(1000, 1006)),
+                                       ("synth_K8", data_synth(500, 5, seed=1), 8, range(1001, 1005))):
+            for seed in seeds:
+                cur["origin"] = "chain %s K=%d seed=%d" % (name, K, seed)
+                np.random.seed(seed)
+                est = RC.BSR(treeNum=K, itrNum=1, val=100)
+                with np.errstate(all="ignore"):
+                    est.fit(X, y)
+        cur["origin"] = None
+        rs = np.random.RandomState(44)
+        for K in (2, 3, 5, 8):
+            for N in ((100, 1000) if K == 3 else (100,)):
+                for e in range(9, 16):
+                    O = rs.normal(size=(N, K))
+                    O[:, K - 1] = O[:, 0] + 10.0 ** -e * rs.normal(size=N)
+                    note(O, rank_w(O), "constructed near-repeat 1e-%d" % e)
+                for e in (9, 11, 12, 13, 14, 15, 16):
+                    O = rs.normal(size=(N, K))
+                    O[:, rs.randint(K)] *= 10.0 ** e
+                    note(O, rank_w(O), "constructed scale 1e%d" % e)
+                if K >= 3:
+                    O = rs.normal(size=(N, K))
+                    O[:, K - 1] = O[:, 0] + O[:, 1]
+                    note(O, rank_w(O), "constructed exact sum")
+                    O = rs.normal(size=(N, K))
+                    O[:, 1] = (O[:, 0] + 1e-12 * rs.normal(size=N)) * 1e6
+                    note(O, rank_w(O), "constructed near-repeat 1e-12 at scale 1e6")
+    finally:
+        np.linalg.matrix_rank = orig
+    n_chain = sum(1 for m in meta if m["origin"].startswith("chain"))
+    print("g4: %d matrices (%d from chains, %d constructed)" % (len(mats), n_chain, len(mats) - n_chain))
+    dump("g4_rank.json", {"versions": VERSIONS, "cases": meta,
+                          "note": "matrix i is M<i> in g4_rank.npz; rank = the reference's own np.linalg.matrix_rank call"})
+    np.savez_compressed(os.path.join(OUT, "g4_rank.npz"), **{"M%d" % i: m for i, m in enumerate(mats)})
 
 # ---------------------------------------------------------------- G5 / G6 tracing
 class Tracer:
@@ -522,6 +609,6 @@ def g8():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g5b", "g6", "g7", "g8"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5b", "g6", "g7", "g8"]
     for t in todo:
         globals()[t]()
