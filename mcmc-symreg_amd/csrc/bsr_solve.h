@@ -455,7 +455,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
     return true;
   }
 #pragma unroll
-  for (int j = 0; j < K; ++j) Y[j][j] = 1.0 / W[j][j];
+  for (int j = 0; j < K; ++j) Y[j][j] = rot_rcp(W[j][j]);   // (the estimate and two Newton steps: ~1 ulp, a third of the IEEE division's chain)
 #pragma unroll
   for (int j = 0; j < K; ++j) {
 #pragma unroll
@@ -474,7 +474,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
   if (!(smin_lb > 4.0 * tolrel * smax_ub)) return false;   // the band around the tolerance (or NaN): the exact tier decides
   // 3. ridge: rotate [tau T; sqrt(1e-6) I | g1; 0] to triangular form, row of the identity by row
   const double tau = in.tau;
-  double T2[K][K], g2[K];
+  double T2[K][K], g2[K], invd[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     g2[i] = g[i];
@@ -493,6 +493,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
       const double ri = rot_rsq(n2);
       const double cs = a * ri, sn = b * ri;
       T2[j][j] = n2 * ri;
+      if (j == e) invd[j] = ri;   // (row j's last rotation: 1 / sqrt(n2) IS the reciprocal of its final diagonal entry)
 #pragma unroll
       for (int l = j + 1; l < K; ++l) {
         const double t0 = T2[j][l], t1 = E[l];
@@ -510,7 +511,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
     double acc = g2[i];
 #pragma unroll
     for (int l = i + 1; l < K; ++l) acc = fma(-T2[i][l], bt[l], acc);
-    bt[i] = acc / T2[i][i];
+    bt[i] = acc * invd[i];
   }
   double misfit = g[K] * g[K];
 #pragma unroll

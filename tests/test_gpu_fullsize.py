@@ -72,10 +72,10 @@ def test_fullsize_properties(N, d, K):
     # (2) a candidate equal to a sibling (K>1) or identically zero is rank-deficient: rejected by the gate
     if K > 1:
         r = ctx.score_batch([tapes[1], flatten(un('neg', cur[1]))], [0, 0], [0, 0], [sig, sig])
-        assert r["rank"][0] == K - 1 and r["rank"][1] == K - 1
+        assert 0 <= r["rank"][0] < K and 0 <= r["rank"][1] < K and (r["flags"][0] & 4) and (r["flags"][1] & 4)
     zero = flatten(bi('+', leaf(0), un('neg', leaf(0))))
     r = ctx.score_batch([zero], [0], [0], [sig])
-    assert r["rank"][0] == K - 1 and (r["flags"][0] & 4)
+    assert 0 <= r["rank"][0] < K and (r["flags"][0] & 4)
     # (3) OLS is invariant to an affine-free rescaling of the candidate column (ridge 1e-6 on unit-scaled columns)
     cand = un('sin', bi('+', leaf(0), leaf(1)))
     scaled = un('ln', un('sin', bi('+', leaf(0), leaf(1))), 0.125, 0.0)
@@ -129,7 +129,7 @@ def test_fp32_vs_fp64_loglik_tolerance(N, d):
     s64, r64 = out["f64"]
     s32, r32 = out["f32"]
     assert abs(s32 - s64) <= 2e-5 * s64
-    assert np.array_equal(r64["rank"], r32["rank"]) and list(r64["rank"]) == [3, 3, 3, 3, 3, 2]
+    assert np.array_equal(r64["rank"] == K, r32["rank"] == K) and list(r64["rank"] == K) == [True] * 5 + [False]
     ok = r64["rank"] == K
     rel = np.abs(r32["loglik"][ok] - r64["loglik"][ok]) / np.abs(r64["loglik"][ok])
     assert np.all(rel <= 5e-5), rel          # fp32 tolerance of the log-posterior on well-conditioned trees
@@ -190,7 +190,12 @@ def test_fullsize_real_mix_values_against_the_oracle(N, d, K, deep):
         col = ocol(trees[i])
         want = O.score_proposal(cur, ks[i], col, y, sig[i])
         tag = "proposal %d tree %d rank %r" % (i, ks[i], want["rank"])
-        assert int(res["rank"][i]) == want["rank"], (tag, res[i])
+        # (a gate verdict settled by bounds -- flags & 16, csrc/bsr_solve.h -- reports SOME rank < K: the reference
+        # only asks `rank < K`, codes/funcs.py:1226)
+        if res["flags"][i] & 16 and want["rank"] < K:
+            assert 0 <= int(res["rank"][i]) < K, (tag, res[i])
+        else:
+            assert int(res["rank"][i]) == want["rank"], (tag, res[i])
         if want["rank"] != K:
             continue
         n_full += 1
@@ -239,3 +244,60 @@ def test_the_span_shortcut_changes_no_byte_on_the_real_move_mix(K, monkeypatch):
     for a, b in zip(on, off):
         assert a.tobytes() == b.tobytes()
     assert sum(int((a["rank"] == K).sum()) for a in on) > 6 * 64
+
+
+def test_fp32_real_mix_at_config_5_against_the_oracle():
+    """BASELINE configs[4], row (g): the fp32 context (f32 storage and tree arithmetic, f64 sums) at N = 1M, d = 50 on 64
+    proposals of the real move mix from a chain the fp32 context itself burnt in -- against the ORACLE (fp64 numpy), not
+    against the fp64 HIP path.  Tolerance ("fp32"): inputs and every tree operation carry an eps_f32 = 6e-8
+    relative rounding, the sums are f64; the log-likelihood of a full-rank proposal moves by ~eps_f32 x the condition number
+    of the scaled column set.  Asserted: the gate agrees with the oracle's except where the smallest singular value is
+    within the f32 rank floor (32 eps_f32 sigma_max, which the f32 gate treats as deficient -- flips go ONLY towards
+    deficient, a handful per batch at most); |dloglik| / |loglik| <= 2e-5 x max(1, cond / 100) for every proposal both
+    call full rank, median <= 5e-6."""
+    import pandas as pd
+    import bsr_oracle as O
+    from conftest import spec_from_node
+    from bsr.chain import Chain, DeviceScorer, run_chains
+    N, d, K = 1_000_000, 50, 3
+    X, y = synth(N, d)
+    scorer = DeviceScorer(X, y, K, n_chains=1, max_batch=72, dtype="f32")
+    np.random.seed(1000)
+    ch = Chain(0, scorer, N, d, K, val=10 ** 9)
+    run_chains([ch], scorer, batch_per_chain=32, max_props=200)
+    cands = ch.generate(64)
+    tapes, trees, ks, sig = [c.tape for c in cands], [c.root for c in cands], [c.k for c in cands], [c.new_sigma for c in cands]
+    res = scorer.ctx.score_batch(tapes, [0] * 64, ks, sig)
+    Xdf = pd.DataFrame(X)
+
+    def ocol(node):
+        with np.errstate(all="ignore"):
+            return O.allcal(O.tree_from_json(spec_from_node(node)), Xdf, False)[:, 0]
+    cur = np.stack([ocol(r) for r in ch.roots], axis=1)
+    rels, flips_def, flips_full, worst = [], 0, 0, None
+    for i in range(64):
+        want = O.score_proposal(cur, ks[i], ocol(trees[i]), y, sig[i])
+        got_full, want_full = int(res["rank"][i]) == K, want["rank"] == K
+        if got_full != want_full:
+            if want_full:
+                flips_def += 1
+                M = cur.copy()
+                M[:, ks[i]] = ocol(trees[i])
+                sv = np.linalg.svd(M, compute_uv=False)
+                assert sv[-1] <= 64 * 1.1920929e-7 * sv[0], (i, sv, res[i])       # inside the f32 rank floor (x2 slack)
+            else:
+                flips_full += 1
+            continue
+        if not want_full:
+            continue
+        cond = max(1.0, float(res["smax"][i] / max(res["smin"][i], 1e-300)))
+        rel = abs(res["loglik"][i] - want["loglik"]) / abs(want["loglik"])
+        rels.append(rel)
+        if worst is None or rel / max(1.0, cond / 100) > worst[0]:
+            worst = (rel / max(1.0, cond / 100), i, rel, cond)
+        assert rel <= 2e-5 * max(1.0, cond / 100), (i, rel, cond, res[i], want)
+    scorer.close()
+    print("fp32 vs oracle at N=1M: %d full-rank in both, median rel %.2e, max %.2e, worst (scaled) %r; flips towards "
+          "deficient %d, towards full %d" % (len(rels), float(np.median(rels)), float(np.max(rels)), worst, flips_def, flips_full))
+    assert len(rels) >= 32 and flips_full == 0 and flips_def <= 6
+    assert np.median(rels) <= 5e-6
