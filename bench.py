@@ -658,7 +658,7 @@ def deep_leg(args, ranks, n_batches=12):
 
 
 def f32_leg(args, ranks):
-    """BASELINE configs[4]: the fp32 context (f32 storage and tree arithmetic, f64 accumulation) against the fp64 one at
+    """BASELINE configs[4]: the fp32 context (f32 storage; where the slices stream -- this config -- f64 arithmetic on the stored values) against the fp64 one at
     N = 1M, d = 50: throughput and roofline of the f32 row pass (s = 4 bytes), and -- on the SAME chain state and the
     SAME 64 real-mix proposals -- how far its log-likelihoods, rank decisions and accept decisions move."""
     import numpy as np

@@ -356,7 +356,11 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
         }
         // fp64: the streaming kernel (bsr_stream.hip) -- four sets of sums per wave at K <= 4, so ONE tape group takes a
         // batch of 64 and every column streams from HBM once per launch; BSR_STREAM=0: the chunked k_tile as before
-        c->tile_stream = c->dtype == BSR_DTYPE_F64 && env_int("BSR_STREAM", 1) != 0;
+        // fp32 columns (round 6): the same kernel with f32 STORAGE -- half the bytes through HBM and the ring, every value
+        // converted where it is read, the interpreter and the sums the f64 ones (K <= 4: the chunk block of assembly;
+        // BSR_STREAM_F32=0: the chunked k_tile<float> with f32 tree arithmetic, as until round 5)
+        c->tile_stream = env_int("BSR_STREAM", 1) != 0 &&
+                         (c->dtype == BSR_DTYPE_F64 || (K <= 4 && env_int("BSR_STREAM_F32", 1) != 0));
         if (c->tile_stream) {
           c->tile_qmax = stream_qmax(std::max(1, K));
           T = 1;
@@ -393,7 +397,11 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
     c->done_word = env_int("BSR_DONE_WORD", 1) != 0;
     c->tile_sched_cap = (size_t)c->tile_T * BSR_TILE_WAVES * c->tile_qmax *
                         (size_t)((max_batch + BSR_TILE_WAVES * c->tile_qmax - 1) / (BSR_TILE_WAVES * c->tile_qmax) + 1) + 64;
-    if (!c->tile_whole && !getenv("BSR_DERIVED_MAX")) c->derived_max = 16;   // chunked: the transcendentals saved are worth more columns
+    // chunked: the transcendentals saved are worth more columns (C5, BSR_DERIVED_MAX 0 / 4 / 8 / 16 / 24 / 32: 95.6 / 82.7 / 80.8 /
+    // 74.6-77.2 / 76.2 / 77.4 us per launch in f64 -- the kernel is bound by instruction issue, not by HBM: a column read
+    // instead of recomputed pays even at 1.37 x the algorithmic traffic; f32 storage, half the bytes and LDS per column:
+    // 8 / 16 / 24 / 32: 83.9 / 78.0 / 74.1 / 73.3 us, profiles/r06_derived_sweep_c5.txt)
+    if (!c->tile_whole && !getenv("BSR_DERIVED_MAX")) c->derived_max = (c->esz == 4 && c->tile_stream) ? 24 : 16;
     // a data set of which not even one block of a narrow group (eight features or all of them, y, one chain's basis)
     // fits two LDS buffers never takes the tile pass: the work-queue row pass (bsr_kernels.hip: k_rows) serves it
     c->tile_ever = c->tile_on && (size_t)(std::min(d, 8) + 1 + std::max(1, K)) * 2 * BSR_TILE_BLOCK * c->esz <= budget;
@@ -887,7 +895,8 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
       } else {
         TileArgs<float> a;
         fill(a);
-        launch_tile<float>(s0, a);
+        if (s.tile_stream) launch_stream_f32(s0, a);
+        else launch_tile<float>(s0, a);
       }
     } else {
       launch_row_pass(c, s, j.g, s.d_desc(), j.P, j.spill_slots, j.nq, 0);

@@ -228,6 +228,7 @@ struct TileArgs {
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
 void launch_stream(hipStream_t st, const TileArgs<double>& a);   // bsr_stream.hip: fp64 slices that stream through LDS
+void launch_stream_f32(hipStream_t st, const TileArgs<float>& a);   // ... f32 storage, f64 arithmetic (K <= 4)
 void launch_tile_asm(hipStream_t st, const TileArgs<double>& a); // bsr_tile_asm.hip: whole slices, tape loop in assembly (a.tprog)
 #endif
 size_t tile_lds_bytes_max();

@@ -396,8 +396,13 @@ __global__ __launch_bounds__((RowsShape<LDS, MODE>::waves * BSR_WAVE), (RowsShap
       in.rank_floor = fin.rank_floor;
       in.exact = (dsc[p].self_dup & 2) ? 1 : 0;
       in.mh = fin.mh + p;
-      // (Jacobi for every flagged proposal here: the fast tier's registers would spill this 16-wave kernel's 128, and a
-      // candidate that had to come this way is as a rule inside the band around the tolerance or deficient anyway)
+      // the same tiers as k_solve / k_finalize (solve_any): a proposal's bytes must not depend on the route it took
+      // (the span shortcut settles in k_solve what the residual route settles here: tests compare the two byte for byte).
+      // The fast tier's registers on top of this kernel's exceed its 128: a few spills in this tail, run by the launch's
+      // last workgroup for a handful of proposals (tests/test_build_resources.py bounds them)
+      if constexpr (NQ >= 1) {
+        if (!in.exact && solve_fast<NQ>(in, lane, fin.out + p)) return;
+      }
       if constexpr (NQ >= 1 && NQ <= 4) solve_regs<NQ>(in, lane, fin.out + p);
       else if constexpr (NQ >= 5) solve_cols<NQ>(in, lane, fin.out + p);
     };

@@ -511,7 +511,15 @@ void stage_tile(bsr_ctx* c, BatchSlot& s, int n) {
     static const int force_chunk = env_int("BSR_TILE_CHUNK", 0);   // test hooks: chunks of at most this many blocks,
     static const int force_ring = env_int("BSR_TILE_RING", 0);     // a ring of this many buffers
     s.tile_stream = false;
-    if (c->tile_stream) {
+    if (c->tile_stream && c->esz == 4) {
+      // f32 storage: a unit of the ring is 1 KiB = 256 rows of one column (one LDS-DMA instruction): chunks of two blocks,
+      // as many buffers as LDS holds (at most four); the waves copy at most 64 units per chunk
+      const int room2 = (int)((budget - stream_ln_bytes(c->tile_qmax)) / ((size_t)max_ncols * 1024));
+      if (room2 >= 2) { chunk = 2; ring = std::min(4, room2); }
+      if (force_ring >= 2 && force_ring <= 4 && chunk > 0 && room2 >= force_ring) ring = force_ring;
+      s.tile_stream = chunk > 0 && max_ncols <= BSR_STREAM_UNITS_MAX && group_chains == 1;   // (one chain's basis: the chunk block)
+      if (!s.tile_stream) { chunk = 0; ring = 1; }
+    } else if (c->tile_stream) {
       // the streaming kernel: chunks of one 128-row block through the deepest ring LDS holds (what is in flight keeps HBM
       // busy); two-block chunks where even four of those fit (a narrow batch).  Its waves copy at most 64 (column, block)
       // pieces per chunk; a wider batch takes k_tile over the same slices (the same sums, bit for bit).
@@ -738,7 +746,8 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
         Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : 0) | 64 | ((R.qslot & 0xFF) << 8);
         Q.s = R.s;
         Q.code = fast ? enc : 0;
-        Q.first = (int32_t)(R.f0 & 0xFFu) << (tg.chunk_blocks == 2 ? 11 : 10);   // (its byte offset in a chunk buffer)
+        // (its byte offset in a chunk buffer: a column of a chunk is 1 KiB per f64 block -- and 1 KiB per two f32 blocks)
+        Q.first = (int32_t)(R.f0 & 0xFFu) << ((tg.chunk_blocks == 2 && c->esz == 8) ? 11 : 10);
         uint64_t slots = 0;
         for (int t = 1; t < 8; ++t) {
           const uint64_t w = (t < 4) ? R.f0 : R.f1;

@@ -272,8 +272,111 @@ __device__ __attribute__((noinline)) double2 generic_block(const TileArgs<double
   return make_double2(zb[0], zb[1]);
 }
 
-template <int KQ, int QT, int CB, bool STAMPS, int MODE>
+
+// ---------------------------------------------------------------------------------------------------------------
+// f32 STORAGE (round 6, BASELINE configs[4]'s fp32 context where the slices stream): the columns -- X, y, the basis, the
+// derived columns -- are f32 in HBM and in the LDS ring, half the bytes of everything that moves; every value is
+// converted to f64 where it is read (exact) and the interpreter, the sums and the records are the f64 ones.  A unit of
+// the ring (1 KiB, one LDS-DMA instruction) is 256 rows of one column: a chunk is two 128-row blocks, evaluated one
+// after the other by the chunk block of assembly (BSR_STREAM_CHUNKF_ASM_K*: ds_read_b64 + v_cvt_f64_f32 where the f64
+// block has ds_read_b128).  What the C++ side of the kernel reads itself goes through these two loaders.
+template <int U>
+struct LdsColsF32 {
+  const float* sx;
+  int rb_rows;
+  int off;
+  __device__ __forceinline__ void load(int slot, double (&v)[U]) const {
+    const float* col = sx + slot * rb_rows + off;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      const float2 f = *reinterpret_cast<const float2*>(col + j * 128);
+      v[2 * j] = (double)f.x;
+      v[2 * j + 1] = (double)f.y;
+    }
+  }
+};
+template <int U>
+struct PtrColsF32 {
+  const float* const CONSTANT_AS* colsrc;
+  int64_t r0;
+  __device__ __forceinline__ void load(int slot, double (&v)[U]) const {
+    const float* col = colsrc[slot] + r0;
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) {
+      const float2 f = *reinterpret_cast<const float2*>(col + j * 128);
+      v[2 * j] = (double)f.x;
+      v[2 * j + 1] = (double)f.y;
+    }
+  }
+};
+__device__ __attribute__((noinline)) double2 generic_block_f32(const TileArgs<double>* ka, const TapeRec* recp, const float* cur,
+                                                               int row0, int lane) {
+  const uint64_t v = (uint64_t)(size_t)ka, r = (uint64_t)(size_t)recp;
+  const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)v), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const uint32_t rlo = __builtin_amdgcn_readfirstlane((uint32_t)r), rhi = __builtin_amdgcn_readfirstlane((uint32_t)(r >> 32));
+  using AT = TileArgs<double> CONSTANT_AS;
+  const AT& a = *(const AT*)(size_t)(((uint64_t)vhi << 32) | vlo);
+  const TapeRec CONSTANT_AS* rec = (const TapeRec CONSTANT_AS*)(size_t)(((uint64_t)rhi << 32) | rlo);
+  TapeHead hd;
+  hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+  hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+  hd.ln_near = (const double*)rec->ln;
+  hd.n_ln = rec->n_ln;
+  hd.n_term = rec->n_term;
+  double zb[2];
+  LdsColsF32<2> ldr{cur, BSR_TILE_BLOCK * (int)a.g.chunk_blocks, row0};
+  run_tape_head<double, 2, BSR_REG_STACK, LdsColsF32<2>, false, true>(
+      hd, a.codes + rec->code_off, a.feats + rec->feat_off, a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, zb,
+      (double*)nullptr, lane);
+  return make_double2(zb[0], zb[1]);
+}
+// the block that holds row N (leftover_unit of bsr_tile_common.h with f32 columns read through the pointer table)
+template <int KQ>
+__device__ __attribute__((noinline)) void leftover_call_f32(const TileArgs<double>* ka, int lane, int tk) {
+  const uint64_t v = (uint64_t)(size_t)ka;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  using AT = TileArgs<double> CONSTANT_AS;
+  const AT& a = *(const AT*)(size_t)(((uint64_t)hi << 32) | lo);
+  const TileGeom CONSTANT_AS& g = a.g;
+  constexpr int U = BSR_TILE_U;
+  const int32_t CONSTANT_AS* left_idx = as_const(reinterpret_cast<const int32_t*>(a.sched + (size_t)g.T * g.n_pass * BSR_TILE_WAVES * g.qmax));
+  const int ti = tk / g.n_left, bi = tk - ti * g.n_left;
+  const TapeRec CONSTANT_AS* rec = as_const(a.sched + left_idx[ti]);
+  const int p = rec->p;
+  const int blk = g.n_slices * g.bps + g.n_long + bi;
+  const int64_t row0 = (int64_t)blk * BSR_TILE_BLOCK + 2 * lane;
+  const int qslot = rec->qslot, grp = rec->grp;
+  const float* const CONSTANT_AS* colsrc = (const float* const CONSTANT_AS*)group_cols<double, AT>(a, grp);
+  const float2 yf = *reinterpret_cast<const float2*>(colsrc[a.grp_nF[grp & 7]] + row0);
+  const double2 yv = make_double2((double)yf.x, (double)yf.y);
+  double2 qv[KQ > 0 ? KQ : 1];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    const float2 qf = *reinterpret_cast<const float2*>(colsrc[qslot + i] + row0);
+    qv[i] = make_double2((double)qf.x, (double)qf.y);
+  }
+  TapeHead hd;
+  hd.code0 = rec->code0; hd.code1 = rec->code1; hd.f0 = rec->f0; hd.f1 = rec->f1;
+  hd.la = rec->ln[0]; hd.lb = rec->ln[1];
+  hd.ln_near = (const double*)rec->ln;
+  hd.n_ln = rec->n_ln;
+  hd.n_term = rec->n_term;
+  const double s = rec->s;
+  double z[U];
+  PtrColsF32<U> ldr{colsrc, row0};
+  run_tape_head<double, U, BSR_REG_STACK, PtrColsF32<U>, false>(hd, a.codes + rec->code_off, a.feats + rec->feat_off,
+                                                                a.lnp + 2 * (size_t)rec->ln_off, rec->n_nodes, ldr, z, (double*)nullptr, lane);
+  TapeAcc<KQ> A;
+  A.clear();
+  if ((int64_t)(blk + 1) * BSR_TILE_BLOCK <= a.N) accumulate_v<double, KQ, false>(A, z, yv, qv, s, row0, a.N);
+  else accumulate_v<double, KQ, true>(A, z, yv, qv, s, row0, a.N);
+  store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
+}
+
+template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<double> a) {
+  static_assert(!F32 || (CB == 2 && MODE == 2 && KQ <= 4 && QT == 4 && !STAMPS),
+                "f32 storage: 256-row chunks (two blocks), the chunk block of assembly, four sets of sums per wave");
   // MODE 0: the C++ interpreter (tape_fast); 1: the assembly interpreter, a tape at a time (bsr_stream_asm.h);
   // 2: a wave's four tapes of a chunk in one block of assembly (bsr_stream_chunk_asm.h: K = 3, every tape on one basis);
   // 3: the loop over the slice's chunks inside that block too (the kernel's default where 2 applies)
@@ -299,7 +402,9 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   const double* const CONSTANT_AS* colsrc = group_cols<double>(a, tg);
   const int y_slot = a.grp_nF[tg & 7];
   const int ncols = y_slot + 1 + a.g.ncols_fixed;
-  double2* ln_all = reinterpret_cast<double2*>(sx + (size_t)R * buf_elems);
+  // (f32 storage: a column of the chunk buffer holds chunk_rows f32 values)
+  constexpr uint32_t ESZ = F32 ? 4u : 8u;
+  double2* ln_all = reinterpret_cast<double2*>(smem + (size_t)R * buf_elems * ESZ);
   unsigned long long* stamp = STAMPS ? a.stamps + ((size_t)blockIdx.x * BSR_TILE_WAVES + wave) * BSR_TILE_STAMP_WORDS : nullptr;
 #define TSTAMP(i) do { if (STAMPS && lane == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(0);
@@ -319,13 +424,15 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   // chunk) -- to byte u * 1024 of the ring buffer.  Column bases are fetched from the group's table when a chunk is
   // requested (scalar loads, issued in front of the barrier the wave waits at anyway): held in scalar registers for the
   // life of the kernel they were spilled, and every reload of a spilled scalar is a vector instruction.
-  const int n_units = ncols * CB;
+  const int n_units = F32 ? ncols : ncols * CB;   // (f32 storage: one 1 KiB unit is the chunk's 256 rows of a column)
   const int n_mine = max(0, (n_units - wave + BSR_TILE_WAVES - 1) / BSR_TILE_WAVES);   // the wave's pieces of a whole chunk
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sx;
-  const uint32_t buf_bytes = (uint32_t)buf_elems * 8u, ring_bytes = buf_bytes * (uint32_t)R;
+  const uint32_t buf_bytes = (uint32_t)buf_elems * ESZ, ring_bytes = buf_bytes * (uint32_t)R;
   // (two-block chunks: u % 2 == wave % 2 for every piece of the wave; the last chunk of a slice of an odd number of
   // blocks holds block 0 only: the odd waves then copy nothing)
-  auto pieces = [&](int j) { return (CB == 2 && (j + 1) * CB > nb && (wave & 1)) ? 0 : n_mine; };
+  // (f32 storage: a unit always holds both blocks; the second half of a slice's last, odd chunk is the next slice's first
+  // block -- or the column's padding -- copied and never evaluated)
+  auto pieces = [&](int j) { return (!F32 && CB == 2 && (j + 1) * CB > nb && (wave & 1)) ? 0 : n_mine; };
   struct Bases { uint64_t p[NUMAX]; };
   auto fetch_bases = [&]() {
     Bases B;
@@ -334,7 +441,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       int u = min(wave + BSR_TILE_WAVES * k, n_units - 1);   // (a piece the wave does not have reads a valid entry)
       asm volatile("" : "+s"(u));   // (not loop-invariant to the compiler: hoisted, the bases would live -- spilled -- in
                                     // scalar registers for the whole kernel again)
-      B.p[k] = (uint64_t)(size_t)colsrc[u / CB];
+      B.p[k] = (uint64_t)(size_t)colsrc[F32 ? u : u / CB];
     }
     return B;
   };
@@ -343,7 +450,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     int np = pieces(j);
     asm volatile("" : "+s"(np));   // (compared where it is used: precomputed, the four conditions are four spilled lane masks)
     const uint32_t buf = lds0 + boff + (uint32_t)wave * 1024u;
-    const uint32_t voff = (uint32_t)lane * 16u + (uint32_t)(b0 + j * CB + (CB == 2 ? (wave & 1) : 0)) * 1024u;
+    const uint32_t voff = F32 ? (uint32_t)lane * 16u + (uint32_t)(b0 + j * CB) * 512u
+                              : (uint32_t)lane * 16u + (uint32_t)(b0 + j * CB + (CB == 2 ? (wave & 1) : 0)) * 1024u;
 #pragma unroll
     for (int k = 0; k < NUMAX; ++k) {
       if (k < np) {
@@ -454,7 +562,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       if (ci == 0 && pass == 0) TSTAMP(1);
       if (STAMPS) t_busy = __builtin_amdgcn_s_memtime();
       const double* cur = reinterpret_cast<const double*>(smem + cur_off);
-      const uint32_t lc = lds0 + cur_off + (uint32_t)lane * 16u;   // LDS address of the lane's pair in column 0
+      const uint32_t lc = lds0 + cur_off + (uint32_t)lane * (F32 ? 8u : 16u);   // LDS address of the lane's pair in column 0
       cur_off += buf_bytes;
       if (cur_off == ring_bytes) cur_off = 0;
       const double* lane_col = cur + 2 * lane;
@@ -484,7 +592,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         double z0, z1, s00, s01;
         asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
                           "=v"(sv[4]));   // (no value yet: nothing to initialise)
-        const uint32_t yo = (uint32_t)y_slot << (CB == 2 ? 11 : 10);
+        const uint32_t yo = (uint32_t)y_slot << ((CB == 2 && !F32) ? 11 : 10);
         const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
         // (two-block chunks: the same block of assembly on either half -- a lane's rows reach its sums in the order of
         // one-block chunks, block by block: the same sums bit for bit, with half the barriers)
@@ -504,10 +612,15 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   else asm volatile(P##8 BSR_SC_OPERANDS(BSR_SC_SUMS_8) BSR_STREAM_CHUNK_CLOBBERS_K8)
 #pragma unroll 1
         for (int jb = 0; jb < nbc; ++jb) {
-          const uint32_t lcb = lc + (uint32_t)jb * 1024u;
+          const uint32_t lcb = lc + (uint32_t)jb * (F32 ? 512u : 1024u);
           resume = 0;
           for (;;) {
-            if constexpr (CB == 2) {
+            if constexpr (F32) {
+              if constexpr (KQ == 1) asm volatile(BSR_STREAM_CHUNKF_ASM_K1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);
+              else if constexpr (KQ == 2) asm volatile(BSR_STREAM_CHUNKF_ASM_K2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);
+              else if constexpr (KQ == 3) asm volatile(BSR_STREAM_CHUNKF_ASM_K3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);
+              else asm volatile(BSR_STREAM_CHUNKF_ASM_K4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4);
+            } else if constexpr (CB == 2) {
               BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K);
             } else {
               BSR_SC_EMIT(BSR_STREAM_CHUNK_ASM_K);
@@ -515,8 +628,13 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
             if (st == 0) break;
             const uint32_t what = st & 15u;
             if (what == 1) {
-              const double2 zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
-                                               my + (st >> 4), cur, jb * BSR_TILE_BLOCK + 2 * lane, lane);
+              double2 zb;
+              if constexpr (F32)
+                zb = generic_block_f32((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), my + (st >> 4),
+                                       reinterpret_cast<const float*>(cur), jb * BSR_TILE_BLOCK + 2 * lane, lane);
+              else
+                zb = generic_block((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(),
+                                   my + (st >> 4), cur, jb * BSR_TILE_BLOCK + 2 * lane, lane);
               z0 = zb.x;
               z1 = zb.y;
             } else {   // sin / cos of huge arguments (exp never leaves the block)
@@ -614,24 +732,26 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
   // the block that holds row N, if N is not a multiple of 128: unit u of the launch goes to wave u mod (workgroups x 16)
   if (a.g.n_left > 0) {
     const int n_units_left = a.P * a.g.n_left, n_waves = (int)gridDim.x * BSR_TILE_WAVES;
-    for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units_left; tk += n_waves)
-      leftover_call<KQ>((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), lane, tk);
+    for (int tk = wave * (int)gridDim.x + (int)blockIdx.x; tk < n_units_left; tk += n_waves) {
+      if constexpr (F32) leftover_call_f32<KQ>((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), lane, tk);
+      else leftover_call<KQ>((const TileArgs<double>*)__builtin_amdgcn_kernarg_segment_ptr(), lane, tk);
+    }
   }
   TSTAMP(4);
   if (STAMPS && lane == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
 #undef TSTAMP
 }
 
-template <int KQ, int QT, int CB, bool STAMPS, int MODE>
+template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false>
 void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS, MODE, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(tile_lds_bytes_max() - 1024));
     attr = true;
   }
   const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  bsr_launch((k_stream<KQ, QT, CB, STAMPS, MODE>), grid, block, lds, st, a);
+  bsr_launch((k_stream<KQ, QT, CB, STAMPS, MODE, F32>), grid, block, lds, st, a);
 }
 #ifdef BSR_TEST_VARIANTS
 // (the test build: every interpreter behind BSR_STREAM_ASM, per-wave clock samples, either number of sets of sums)
@@ -711,6 +831,20 @@ int stream_qmax(int K) {
   if (forced == 2 || (forced == 4 && K <= 4)) return forced;
 #endif
   return K <= 4 ? 4 : 2;
+}
+
+// f32 storage (K <= 4; TileArgs<float> has TileArgs<double>'s layout: the column pointers are addresses to the kernel)
+void launch_stream_f32(hipStream_t st, const TileArgs<float>& af) {
+  static_assert(sizeof(TileArgs<float>) == sizeof(TileArgs<double>), "one argument block");
+  const TileArgs<double>& a = reinterpret_cast<const TileArgs<double>&>(af);
+  const TileGeom& g = a.g;
+  const size_t lds = (size_t)g.ring * g.ncols * 1024 + stream_ln_bytes(g.qmax);
+  switch (a.K) {
+    case 1: launch_one<1, 4, 2, false, 2, true>(st, a, lds); break;
+    case 2: launch_one<2, 4, 2, false, 2, true>(st, a, lds); break;
+    case 3: launch_one<3, 4, 2, false, 2, true>(st, a, lds); break;
+    default: launch_one<4, 4, 2, false, 2, true>(st, a, lds); break;
+  }
 }
 
 void launch_stream(hipStream_t st, const TileArgs<double>& a) {

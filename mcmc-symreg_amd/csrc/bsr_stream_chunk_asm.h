@@ -38,15 +38,24 @@
   "s_lshr_b64 s[22:23], s[22:23], 8\n\t"         \
   "v_lshl_add_u32 v20, s10, " SH ", %[lc]\n\t"
 
+// The lane's two rows of a column of the staged chunk (address in v20) into the accumulator / the operand.  f64 storage:
+// one ds_read_b128, left in flight (every operator starts by waiting for it).  f32 storage (round 6: columns kept as f32
+// in HBM and LDS, the arithmetic stays f64): one ds_read_b64 into temporaries that are free wherever a terminal is read,
+// waited for, converted -- v_cvt_f64_f32 is exact, so a row's value depends on its stored f32 bits alone.
+#define BSR_SC_LDA_F64 "ds_read_b128 v[0:3], v20\n\t"
+#define BSR_SC_LDO_F64 "ds_read_b128 v[8:11], v20\n\t" "s_waitcnt lgkmcnt(0)\n\t"
+#define BSR_SC_LDA_F32 "ds_read_b64 v[12:13], v20\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_cvt_f64_f32_e32 v[0:1], v12\n\t" "v_cvt_f64_f32_e32 v[2:3], v13\n\t"
+#define BSR_SC_LDO_F32 "ds_read_b64 v[12:13], v20\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_cvt_f64_f32_e32 v[8:9], v12\n\t" "v_cvt_f64_f32_e32 v[10:11], v13\n\t"
 #define BSR_SC_BIN(ins, neg)                                                     \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   ins " v[0:1], v[4:5], " neg "v[0:1]\n\t"                                       \
   ins " v[2:3], v[6:7], " neg "v[2:3]\n\t"                                       \
   BSR_SC_DISPATCH
-#define BSR_SC_BIN_T(ins, SH)                                                    \
+#define BSR_SC_BIN_T(ins, SH, LDO)                                               \
   BSR_SC_SLOT_ADDR(SH)                                                             \
-  "ds_read_b128 v[8:11], v20\n\t"                                                \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  LDO                                                                            \
   ins " v[0:1], v[0:1], v[8:9]\n\t"                                              \
   ins " v[2:3], v[2:3], v[10:11]\n\t"                                            \
   BSR_SC_DISPATCH
@@ -228,14 +237,14 @@
 #define BSR_SC_R0_8(q) BSR_SC_R0_7(q) BSR_SC_FH0(q)
 #define BSR_SC_R1_8(q) BSR_SC_R1_7(q) BSR_SC_FH1(q)
 
-#define BSR_SC_TAPE(q, qnext, R0, R1)                                            \
+#define BSR_SC_TAPE(q, qnext, R0, R1, LDA)                                       \
   "s_setprio 3-" #q "\n\t"   /* the waves that are behind go first (below) */   \
   BSR_SC_TAPE_REGS(q)                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "s_cmp_lt_i32 s16, 0\n\t"                                                      \
   "s_cbranch_scc0 .Lsc_slow" #q "_%=\n\t"                                        \
   "v_add_u32_e32 v20, s17, %[lc]\n\t"                                            \
-  "ds_read_b128 v[0:3], v20\n\t"                                                 \
+  LDA                                                                            \
   BSR_SC_DISPATCH                                                                \
   ".Lsc_slow" #q "_%=:\n\t"   /* no tape in this set of sums, or one for the stack machine */ \
   "s_bitcmp1_b32 s16, 6\n\t"                                                     \
@@ -285,8 +294,9 @@
   "s_mov_b32 s27, s25\n\t"
 // four tapes per wave (K <= 4), or two (K >= 5: a set of sums is 8 + 3 registers pairs; the labels of tapes 2 and 3 that
 // the shared resume / leave code names then stand behind the last tape and are never reached)
-#define BSR_SC_TAPES4(R0, R1) BSR_SC_TAPE(0, 1, R0, R1) BSR_SC_TAPE(1, 2, R0, R1) BSR_SC_TAPE(2, 3, R0, R1) BSR_SC_TAPE(3, 4, R0, R1)
-#define BSR_SC_TAPES2(R0, R1) BSR_SC_TAPE(0, 1, R0, R1) BSR_SC_TAPE(1, 2, R0, R1) ".Lsc_acc2_%=:\n.Lsc_acc3_%=:\n\t"
+#define BSR_SC_TAPES4_(R0, R1, LDA) BSR_SC_TAPE(0, 1, R0, R1, LDA) BSR_SC_TAPE(1, 2, R0, R1, LDA) BSR_SC_TAPE(2, 3, R0, R1, LDA) BSR_SC_TAPE(3, 4, R0, R1, LDA)
+#define BSR_SC_TAPES4(R0, R1) BSR_SC_TAPES4_(R0, R1, BSR_SC_LDA_F64)
+#define BSR_SC_TAPES2(R0, R1) BSR_SC_TAPE(0, 1, R0, R1, BSR_SC_LDA_F64) BSR_SC_TAPE(1, 2, R0, R1, BSR_SC_LDA_F64) ".Lsc_acc2_%=:\n.Lsc_acc3_%=:\n\t"
 #define BSR_SC_TAPES_1 BSR_SC_TAPES4(BSR_SC_R0_1, BSR_SC_R1_1)
 #define BSR_SC_TAPES_2 BSR_SC_TAPES4(BSR_SC_R0_2, BSR_SC_R1_2)
 #define BSR_SC_TAPES_3 BSR_SC_TAPES4(BSR_SC_R0_3, BSR_SC_R1_3)
@@ -317,7 +327,8 @@
   "v_mov_b64_e32 v[6:7], %[s1]\n\t"                                              \
   BSR_SC_DISPATCH
 // the operator table (2 KB-aligned: the dispatch ORs a slot's offset into its address) and the operators too long for a slot
-#define BSR_SC_TABLE_PART(SH, YQ)                                                \
+#define BSR_SC_TABLE_PART(SH, YQ) BSR_SC_TABLE_PART_(SH, YQ, BSR_SC_LDA_F64, BSR_SC_LDO_F64)
+#define BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO)                                     \
   ".p2align 11\n"                                                                \
   ".Lsc_tab%=:\n\t"                                                              \
   "s_setpc_b64 s[28:29]\n\t"   /* 0: end of the tape */                          \
@@ -359,10 +370,10 @@
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "v_mov_b64_e32 v[4:5], v[0:1]\n\t"                                             \
   "v_mov_b64_e32 v[6:7], v[2:3]\n\t"                                             \
-  "ds_read_b128 v[0:3], v20\n\t"                                                 \
+  LDA                                                                            \
   BSR_SC_DISPATCH                                                                \
-  BSR_SC_SLOT("12") BSR_SC_BIN_T("v_add_f64", SH)                                 \
-  BSR_SC_SLOT("13") BSR_SC_BIN_T("v_mul_f64", SH)                                 \
+  BSR_SC_SLOT("12") BSR_SC_BIN_T("v_add_f64", SH, LDO)                            \
+  BSR_SC_SLOT("13") BSR_SC_BIN_T("v_mul_f64", SH, LDO)                            \
   BSR_SC_SLOT("14") BSR_SC_BIN("v_add_f64", "-") /* sub */                       \
   BSR_SC_SLOT("15") /* div, protected like inv */                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
@@ -441,7 +452,8 @@
   "s_cbranch_scc1 .Lsc_exit%=\n\t"                                               \
   "s_add_u32 %[st], %[st], 16\n"
 
-#define BSR_STREAM_CHUNK_ASM_(SH, YQ, TP)                                        \
+#define BSR_STREAM_CHUNK_ASM_(SH, YQ, TP) BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, BSR_SC_LDA_F64, BSR_SC_LDO_F64)
+#define BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, LDA, LDO)                             \
   "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
   BSR_SC_TABLE_BASE                                                              \
   YQ   /* y and the basis columns of the lane's rows, once for the four tapes */ \
@@ -451,7 +463,7 @@
   "s_mov_b32 %[st], 0\n\t"                                                       \
   "s_branch .Lsc_exit%=\n"                                                       \
   BSR_SC_RESUME_PART                                                             \
-  BSR_SC_TABLE_PART(SH, YQ)                                              \
+  BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO)                                           \
   BSR_SC_LEAVE_PART                                                              \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"
@@ -593,6 +605,36 @@
 #define BSR_STREAM_PASS_ASM_K2 BSR_STREAM_PASS_ASM_(BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2)
 #define BSR_STREAM_PASS_ASM_K3 BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
 #define BSR_STREAM_PASS_ASM_K4 BSR_STREAM_PASS_ASM_(BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
+
+// f32 storage (K <= 4): a column of the chunk buffer is 1 KiB = 256 rows of f32, evaluated as two blocks of 128 rows (%[lc]:
+// the half's address + lane * 8); y and the basis through the temporaries v[8:17] (free at the head of a chunk and behind
+// sin / cos / exp), waited for and converted at once
+#define BSR_SCF_YQ_HEAD                                                 \
+  "v_add_u32_e32 v20, %[yo], %[lc]\n\t"                                 \
+  "ds_read_b64 v[8:9], v20\n\t"
+#define BSR_SCF_CVT(d0, d1, s0, s1) "v_cvt_f64_f32_e32 " d0 ", " s0 "\n\t" "v_cvt_f64_f32_e32 " d1 ", " s1 "\n\t"
+#define BSR_SCF_YQ1 BSR_SCF_YQ_HEAD "ds_read_b64 v[10:11], v20 offset:1024\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
+  BSR_SCF_CVT("v[24:25]", "v[26:27]", "v8", "v9") BSR_SCF_CVT("v[28:29]", "v[30:31]", "v10", "v11")
+#define BSR_SCF_YQ2 BSR_SCF_YQ_HEAD "ds_read_b64 v[10:11], v20 offset:1024\n\t" "ds_read_b64 v[12:13], v20 offset:2048\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" BSR_SCF_CVT("v[24:25]", "v[26:27]", "v8", "v9") BSR_SCF_CVT("v[28:29]", "v[30:31]", "v10", "v11") \
+  BSR_SCF_CVT("v[32:33]", "v[34:35]", "v12", "v13")
+#define BSR_SCF_YQ3 BSR_SCF_YQ_HEAD "ds_read_b64 v[10:11], v20 offset:1024\n\t" "ds_read_b64 v[12:13], v20 offset:2048\n\t" \
+  "ds_read_b64 v[14:15], v20 offset:3072\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
+  BSR_SCF_CVT("v[24:25]", "v[26:27]", "v8", "v9") BSR_SCF_CVT("v[28:29]", "v[30:31]", "v10", "v11") \
+  BSR_SCF_CVT("v[32:33]", "v[34:35]", "v12", "v13") BSR_SCF_CVT("v[36:37]", "v[38:39]", "v14", "v15")
+#define BSR_SCF_YQ4 BSR_SCF_YQ_HEAD "ds_read_b64 v[10:11], v20 offset:1024\n\t" "ds_read_b64 v[12:13], v20 offset:2048\n\t" \
+  "ds_read_b64 v[14:15], v20 offset:3072\n\t" "ds_read_b64 v[16:17], v20 offset:4096\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
+  BSR_SCF_CVT("v[24:25]", "v[26:27]", "v8", "v9") BSR_SCF_CVT("v[28:29]", "v[30:31]", "v10", "v11") \
+  BSR_SCF_CVT("v[32:33]", "v[34:35]", "v12", "v13") BSR_SCF_CVT("v[36:37]", "v[38:39]", "v14", "v15") \
+  BSR_SCF_CVT("v[40:41]", "v[42:43]", "v16", "v17")
+#define BSR_SCF_TAPES_1 BSR_SC_TAPES4_(BSR_SC_R0_1, BSR_SC_R1_1, BSR_SC_LDA_F32)
+#define BSR_SCF_TAPES_2 BSR_SC_TAPES4_(BSR_SC_R0_2, BSR_SC_R1_2, BSR_SC_LDA_F32)
+#define BSR_SCF_TAPES_3 BSR_SC_TAPES4_(BSR_SC_R0_3, BSR_SC_R1_3, BSR_SC_LDA_F32)
+#define BSR_SCF_TAPES_4 BSR_SC_TAPES4_(BSR_SC_R0_4, BSR_SC_R1_4, BSR_SC_LDA_F32)
+#define BSR_STREAM_CHUNKF_ASM_K1 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ1, BSR_SCF_TAPES_1, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
+#define BSR_STREAM_CHUNKF_ASM_K2 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ2, BSR_SCF_TAPES_2, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
+#define BSR_STREAM_CHUNKF_ASM_K3 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ3, BSR_SCF_TAPES_3, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
+#define BSR_STREAM_CHUNKF_ASM_K4 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ4, BSR_SCF_TAPES_4, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
 
 #define BSR_SC_YQ_A5 BSR_SC_YQ5("1024", "2048", "3072", "4096", "5120")
 #define BSR_SC_YQ_A6 BSR_SC_YQ6("1024", "2048", "3072", "4096", "5120", "6144")

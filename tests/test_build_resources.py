@@ -60,14 +60,22 @@ def test_tile_row_pass_has_no_scratch():
 
 
 def test_default_work_queue_row_pass_has_no_scratch():
-    """k_rows<T, K, U=2, ., .> is what scores data sets beyond LDS (config 5) and re-evaluates accepted trees."""
+    """k_rows<T, K, U=2, ., .> is what scores data sets beyond LDS (config 5) and re-evaluates accepted trees.
+    Exception (round 6): the residual pass of K <= 3 (mode 1), whose LAST workgroup solves the batch's flagged proposals
+    itself (the fused finalise step) with the same two-tier solver as k_solve (csrc/bsr_solve.h: the fast tier's
+    registers on top of the row pass's exceed 128): a few spilled registers in that tail -- behind the row loop, run by
+    one workgroup for a handful of proposals; the launch measures what it did without them (4.35 us per batch at C2,
+    profiles/r05n_* and r06_* kernel stats).  Bounded here so that it stays a tail."""
     rep = _report("bsr_kernels")
     seen = 0
     for n, r in rep.items():
-        m = re.match(r"_Z6k_rowsI([df])Li(\d)ELi2ELb[01]ELi[012]E", n)
+        m = re.match(r"_Z6k_rowsI([df])Li(\d)ELi2ELb[01]ELi([012])E", n)
         if not m or int(m.group(2)) > 7:
             continue
         seen += 1
+        if m.group(3) == "1" and 1 <= int(m.group(2)) <= 3:
+            assert r["ScratchSize [bytes/lane]"] <= 160 and r["VGPRs Spill"] <= 36, (n, r)
+            continue
         assert r["ScratchSize [bytes/lane]"] == 0, (n, r)
     assert seen >= 16
 

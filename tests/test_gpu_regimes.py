@@ -40,7 +40,7 @@ CASES = [
     ("C3", 100_000, 10, 8, 1, 64, "f64", ("k_tile1", 1, 192, 4)),
     ("C4 share", 100_000, 10, 3, 8, 256, "f64", ("k_tile1a", 4, 98, 7)),
     ("C5", 1_000_000, 50, 3, 1, 64, "f64", ("k_stream", 1, 256, 30)),
-    ("C5 f32", 1_000_000, 50, 3, 1, 64, "f32", ("k_tile/k_rows", None, None, None)),
+    ("C5 f32", 1_000_000, 50, 3, 1, 64, "f32", ("k_stream", 1, 256, 30)),
 ]
 
 

@@ -155,3 +155,70 @@ def test_a_streaming_context_of_several_chains_scores_each_proposal_as_its_chain
                         "--chains", str(chains), "--d", str(d)], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "MULTI-CHAIN STREAM CHECK OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
     assert "multi-chain context: k_stream" in p.stdout
+
+
+@pytest.mark.parametrize("N,d,K", [(300_077, 50, 3), (600_077, 40, 2), (300_077, 40, 4)])
+def test_streaming_pass_with_f32_storage(N, d, K):
+    """Round 6, BASELINE configs[4]'s fp32 context where the slices stream: k_stream with f32 STORAGE -- X, y, the basis and
+    the derived columns are f32 in HBM and in the LDS ring (half the bytes of everything that moves), every value is
+    converted to f64 where it is read and the interpreter, the sums and the records are the f64 ones.  The same batch as
+    the f64 test (every operator, a pushed operand, tapes for the stack machine, repeats, N not a multiple of 128: the
+    leftover block), against the oracle ON THE INPUTS AS STORED (X and y rounded to f32: what "f32 storage, f64 arithmetic"
+    computes on -- a candidate with a pole inside the data's range, inv(x0 + x1 + 4), moves by 1e-3 under the rounding of
+    its inputs alone, in any arithmetic): the gate's verdicts equal except flips towards deficient inside the f32 rank
+    floor; log-likelihoods within 2e-5 x max(1, cond / 100) (the current columns, the basis and the derived columns are
+    f32 values too); and every score repeats bit for bit whatever shares its launch (reversed batch, alone)."""
+    import stream_check as S
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    B = 64
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B, dtype="f32")
+    try:
+        info = ctx.info()
+        assert info["row_pass"] == "k_stream", info
+        leaf, un, bi = S.leaf, S.un, S.bi
+        pool = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('ln', un('exp', leaf(3)), 0.7, -0.2), un('cos', leaf(4))]
+        cur = pool[:K]
+        for k, t in enumerate(cur):
+            ctx.set_current(0, k, flatten(t))
+        ctx.refresh(0)
+        trees = S.make_tapes(d, B)
+        tapes = [flatten(t) for t in trees]
+        chains = np.zeros(B, dtype=np.int32)
+        ks = (np.arange(B) % K).astype(np.int32)
+        sig = np.full(B, 0.8)
+        res = ctx.score_batch(tapes, chains, ks, sig).copy()
+        df = pd.DataFrame(X.astype(np.float32).astype(np.float64))
+        y = y.astype(np.float32).astype(np.float64)
+        n_full = flips = 0
+        worst = 0.0
+        with np.errstate(all="ignore"):
+            cols = np.stack([O.allcal(S.ocopy(t), df)[:, 0] for t in cur], axis=1)
+            for i, t in enumerate(trees):
+                col = O.allcal(S.ocopy(t), df)[:, 0]
+                want = O.score_proposal(cols, int(ks[i]), col, y, 0.8)
+                got_full, want_full = int(res["rank"][i]) == K, want["rank"] == K
+                if got_full != want_full:
+                    assert want_full and not got_full, (i, res[i], want)       # only towards deficient ...
+                    M = cols.copy()
+                    M[:, int(ks[i])] = col
+                    sv = np.linalg.svd(M, compute_uv=False)
+                    assert sv[-1] <= 64 * 1.1920929e-7 * sv[0], (i, sv)          # ... and only inside the f32 rank floor
+                    flips += 1
+                    continue
+                if want_full and np.isfinite(want["loglik"]):
+                    n_full += 1
+                    cond = max(1.0, float(res["smax"][i] / max(res["smin"][i], 1e-300)))
+                    rel = abs(float(res["loglik"][i]) - want["loglik"]) / abs(want["loglik"])
+                    worst = max(worst, rel / max(1.0, cond / 100))
+                    assert rel <= 2e-5 * max(1.0, cond / 100), (i, i % 12, rel, cond, float(res["loglik"][i]), want["loglik"])
+        assert n_full >= B // 3 and flips <= 4, (n_full, flips)
+        rev = ctx.score_batch(tapes[::-1], chains, ks[::-1].copy(), sig).copy()[::-1]
+        assert rev.tobytes() == res.tobytes()
+        for i in range(0, B, 5):
+            one = ctx.score_batch(tapes[i:i + 1], chains[:1], ks[i:i + 1], sig[:1])
+            assert one.tobytes() == res[i:i + 1].tobytes(), i
+        print("f32 storage N=%d d=%d K=%d: %d full-rank, %d flips, worst scaled rel %.2e" % (N, d, K, n_full, flips, worst))
+    finally:
+        ctx.close()
