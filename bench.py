@@ -580,7 +580,8 @@ def deep_leg(args, ranks, n_batches=12):
     tape, so the c5 leg never shows how the streaming pass behaves on them.  This leg scores batches of 64 candidates
     GROWN to height 8..12 (the reference's own grow(), codes/funcs.py:74-119, with its depth prior flattened: beta -0.15
     instead of -1, at most 400 nodes) on the c5 data set and reports nodes per tape, how many tapes the assembly
-    interpreter could take (64-bit programs: <= 16 entries) and the row pass's duration per launch."""
+    interpreter takes (round 6: programs of several words, a second value below the accumulator) and
+    the row pass's duration per launch."""
     import numpy as np
     from bsr import grow
     from bsr.node import Node, getHeight, getNum

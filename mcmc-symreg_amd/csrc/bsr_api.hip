@@ -263,6 +263,7 @@ extern "C" int bsr_ctx_create_tuned(bsr_ctx** out, int device, int64_t N, int32_
 
     c->selfdup = env_int("BSR_SELFDUP", 1);
     c->solve_exact = env_int("BSR_SOLVE_EXACT", 0);
+    c->stream_deep = env_int("BSR_STREAM_DEEP", 2);
     c->reorder = env_int("BSR_REORDER", 1);
     c->chain_eval = env_int("BSR_CHAIN_EVAL", 1);
     // more than a handful of derived columns per batch stop paying: most (op, feature) pairs of a batch are used by one
@@ -889,7 +890,7 @@ static int issue_batch(bsr_ctx* c, BatchSlot& s, const TailJob& j_in) {
       if (c->dtype == BSR_DTYPE_F64) {
         TileArgs<double> a;
         fill(a);
-        if (s.tile_stream) launch_stream(s0, a);
+        if (s.tile_stream) launch_stream(s0, a, s.tile_deep2);
         else if (a.tprog) launch_tile_asm(s0, a);
         else launch_tile<double>(s0, a);
       } else {

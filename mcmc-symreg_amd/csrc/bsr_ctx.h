@@ -51,6 +51,8 @@ struct BatchSlot {
   size_t off_recs = 0;   // tile schedule (tape records, then the cost-order index): behind the batch's streams
   size_t recs_bytes = 0; // ... of which this batch uses so many bytes
   size_t srec_off = 0;   // streaming kernel: its StreamRecs, so many bytes behind off_recs
+  bool tile_deep2 = false;           // ... this batch takes the streaming kernel with a second value below the accumulator
+  std::vector<uint64_t> ext_words;   // ... and the extension words of the batch's long programs (scratch of build_tile_launch)
   int32_t stat_tapes = 0, stat_fast = 0, stat_chain = 0, stat_entries = 0;   // bsr_batch_stats: the last batch staged here
   size_t tprog_off = 0;  // whole-slice kernel with the assembly tape loop: its TileProgs, so many bytes behind off_recs (0: none)
   // device-side MH step (bsr_score_submit_mh): per-proposal terms and flags, span offsets; results
@@ -197,6 +199,7 @@ struct bsr_ctx {
   std::vector<uint64_t> cur_fmask;   // features each current tree reads (bit f mod 64), all ones: unknown
   std::vector<char> cur_form_ok;               // ... valid
   std::vector<std::shared_ptr<const bsr_span::SpanBasis>> span;   // [chain]
+  int stream_deep = 2;                         // BSR_STREAM_DEEP: the streaming pass's chunk block also takes programs of several words (1) and, K <= 3, a second value below the accumulator (2); 0: round 5's limits
   int solve_exact = 0;                         // BSR_SOLVE_EXACT=1: every proposal's singular values by Jacobi (round 5's k_solve; the standalone ylogLike)
   int selfdup = 1;                             // BSR_SELFDUP: recognise proposals that repeat the tree they replace
   int reorder = 1;      // BSR_REORDER: commutative operands in fusing order (reorder_tape)

@@ -177,7 +177,11 @@ static_assert(sizeof(TapeRec) == 128, "one tape record per 128 bytes");
 struct StreamRec {
   int32_t meta;         // bits 0..4: stream entries - 1, bits 5 and 31: fast (<= 16 entries, <= 8 terminals, <= 3 ln nodes,
                         // one value below the accumulator, no `log`), bit 6: there is a tape, bits 8..15: LDS slot of the
-                        // chain's first basis column
+                        // chain's first basis column.  Round 6: bit 30 (without bits 5, 31) = the chunk block of assembly
+                        // takes the tape and the C++ / tape-at-a-time interpreters do not (a program of several words, a
+                        // second value below the accumulator at K <= 3) -- sorted out on the block's slow branch, so a 64-bit
+                        // program costs what it did; bits 16..19: extension words behind this one, bits 20..29: the first
+                        // one's place, in 16-byte units behind the wave's first StreamRec (the block's %[sr])
   int32_t first;        // LDS slot of the leading terminal x 1024
   double s;             // prescale of the candidate column
   uint64_t code;        // fast tapes: the entries behind the leading terminal, 4 bits each: operator + 1, 0 behind the last
@@ -227,7 +231,7 @@ struct TileArgs {
 #ifndef BSR_HOST_ONLY
 template <typename T>
 void launch_tile(hipStream_t st, const TileArgs<T>& a);
-void launch_stream(hipStream_t st, const TileArgs<double>& a);   // bsr_stream.hip: fp64 slices that stream through LDS
+void launch_stream(hipStream_t st, const TileArgs<double>& a, bool deep2);   // bsr_stream.hip: fp64 slices that stream through LDS (deep2: the kernel with a second saved value)
 void launch_stream_f32(hipStream_t st, const TileArgs<float>& a);   // ... f32 storage, f64 arithmetic (K <= 4)
 void launch_tile_asm(hipStream_t st, const TileArgs<double>& a); // bsr_tile_asm.hip: whole slices, tape loop in assembly (a.tprog)
 #endif
@@ -237,6 +241,12 @@ int tile_qmax(int K);
 size_t stream_ln_bytes(int qt);   // LDS the streaming kernel needs behind its ring
 int stream_qmax(int K);
 bool stream_chunk_block(int K, int ncols_fixed);           // its sets of sums per wave
+bool stream_deep2_applies(int K, int ncols_fixed, int chunk_blocks);
+#define BSR_STREAM_LN_PAIRS 3     // (a, b) pairs of a tape the streaming kernel keeps in LDS (eight were tried in round 6 for
+                                  // the long programs: 5 KB more LDS took the widest batches' ring from three buffers to two,
+                                  // C5 74.5 -> 86 us per launch; 5 % of depth-12 trees hold more than three ln nodes and stay
+                                  // with the stack machine)
+#define BSR_STREAM_EXT_MAX 4      // extension words (16 entries, 8 terminal slots each) behind a tape's 64-bit program
 #define BSR_STREAM_UNITS_MAX 64   // (column, block) pieces of a chunk the streaming kernel's waves can copy (4 per wave)
 
 struct LaunchGeom {

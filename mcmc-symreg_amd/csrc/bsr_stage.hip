@@ -133,7 +133,7 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
   int allowance = derive ? c->n_cols : 0;
   if (derive && c->tile_on && tile_chains > 0) {
     int n_base = 0;
-    if (c->tile_whole) {   // (chunked contexts: the allowance does not depend on the batch's base columns)
+    if (c->tile_whole || c->tile_stream) {   // (the chunked k_tile: the allowance does not depend on the batch's base columns)
       for (int j = 0; j < tape_off[n]; ++j)
         if (rows[j].opcode == BSR_OP_TERMINAL && rows[j].feature >= 0 && rows[j].feature < c->d &&
             s.slot_of[rows[j].feature] < 0) {
@@ -146,6 +146,11 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     size_t fit = (tile_lds_bytes_max() - 1024) / ((size_t)std::max(1, c->tile_bps + (c->tile_long > 0 ? 1 : 0)) * BSR_TILE_BLOCK * c->esz);
     long room = (long)fit - fixed;
     if (!c->tile_whole) room = c->derived_max;   // chunked: a group's columns set the chunk length, not whether the batch fits
+    // ... but the streaming kernel's waves copy at most BSR_STREAM_UNITS_MAX columns per chunk: a batch whose tapes name
+    // nearly every feature (deep trees at d = 50: 54 base columns) must not be pushed over that by its derived columns --
+    // it fell back to the chunked k_tile at four times the streaming kernel's time (round 6: that, not the stack machine,
+    // was most of config 5's "deep tree" cliff)
+    if (!c->tile_whole && c->tile_stream) room = std::min<long>(room, std::max<long>(0, (long)BSR_STREAM_UNITS_MAX - fixed));
     // (streaming contexts too: trading derived columns for a deeper LDS ring -- 3 buffers instead of 2 in the batches
     // of 49+ columns -- measured slower, 95.8 against 91.6 us: a derived column saves more than the ring's depth)
     // no room at all: the batch would not take the tile pass anyway (k_rows reads columns from L2: no limit there)
@@ -261,7 +266,7 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
     lw += (size_t)nl + 1;
   }
   const size_t rec_words = (c->tile_sched_cap * sizeof(TapeRec) + (size_t)(1 + c->tile_T) * (c->max_batch + 1) * sizeof(int32_t) +
-                            (c->tile_stream ? (c->tile_sched_cap + 2) * sizeof(StreamRec) : 0) +
+                            (c->tile_stream ? (c->tile_sched_cap + 2) * sizeof(StreamRec) + (c->max_batch + 2) * (size_t)BSR_STREAM_EXT_MAX * 16 : 0) +
                             (c->tile_asm ? ((size_t)c->tile_T * (c->max_batch + 1) + 2) * sizeof(TileProg) : 0)) / 8 + 32;
   int rc = ensure_input(c, s, cw + 2 * fw + 2 * lw + rec_words);
   if (rc != BSR_OK) return rc;
@@ -372,8 +377,15 @@ int stage_tapes(bsr_ctx* c, BatchSlot& s, const bsr_node* rows, const int32_t* t
                 : (r.opcode == BSR_OP_LN) ? 6 : is_binary_op(r.opcode) ? 8 : 5;
       }
     }
-    // (a tape the streaming pass hands to the stack machine: a call, scratch-indexed stack slots -- four times a chain's time)
-    if (stream_costs && (ns > 16 || nt > 8 || nl > 3 || mx > 2)) cost *= 4;
+    // (a tape the streaming pass hands to the stack machine: a call, scratch-indexed stack slots -- four times a chain's time.
+    // Round 6: the chunk block of assembly also takes programs of several words, up to eight ln nodes and, at K <= 3, a
+    // second value below the accumulator -- build_tile_launch decides per tape; the cost estimate follows the same limits)
+    {
+      const bool classic = ns <= 16 && nt <= 8 && nl <= 3 && mx <= 2;
+      const bool deep = c->stream_deep > 0 && c->K <= 4 && ns <= 16 * (1 + BSR_STREAM_EXT_MAX) && nl <= BSR_STREAM_LN_PAIRS &&
+                        mx <= ((c->stream_deep >= 2 && c->K <= 3) ? 3 : 2);
+      if (stream_costs && !classic && !deep) cost *= 4;
+    }
     (*loc)[i].n_stream = ns;
     (*loc)[i].nt = nt;
     (*loc)[i].nl = nl;
@@ -728,35 +740,100 @@ int build_tile_launch(bsr_ctx* c, BatchSlot& s, int P, TileGeom* tgp) {
       // last (a wave requests the next tape's program while it adds up this one's rows)
       s.srec_off = (s.recs_bytes + 31) / 32 * 32;
       StreamRec* sr = reinterpret_cast<StreamRec*>(reinterpret_cast<char*>(sc) + s.srec_off);
+      std::vector<uint64_t>& ext_words = s.ext_words;   // (code, slots) pairs of the batch's long tapes, in record order
+      ext_words.clear();
+      // The kernel with a SECOND value below the accumulator (K <= 3, the pass block) costs every batch ~8 % (four more pinned
+      // registers: C5's real mix 77 -> 83-86 us): taken where the batch holds enough trees of Strahler number 3 to pay for
+      // it -- a sixteenth of its tapes; elsewhere those few go to the stack machine as before (the same bytes)
+      int n_sp3 = 0;
+      for (int i = 0; i < P; ++i) n_sp3 += (hd[i].max_sp == 3 && hd[i].n_ln <= BSR_STREAM_LN_PAIRS) ? 1 : 0;
+      s.tile_deep2 = c->stream_deep >= 2 && c->esz == 8 && stream_deep2_applies(c->K, tg.ncols_fixed, tg.chunk_blocks) &&
+                     n_sp3 * 16 >= P && n_sp3 >= 2;
+      const int sp_max = s.tile_deep2 ? 3 : 2;
       for (size_t i = 0; i <= n_sched; ++i) {
         StreamRec& Q = sr[i];
         memset(&Q, 0, sizeof Q);
         if (i == n_sched || sc[i].p < 0) continue;
         const TapeRec& R = sc[i];
+        const PropDesc& D = hd[R.p];
         bool fast = (R.chain & 2) != 0;
         // the entries behind the leading terminal as operator + 1, 0 behind the last (bsr_stream_asm.h); `log`, which
         // would need code 16, sends its tape to the stack machine
+        const uint64_t* pcode = hcodes + D.code_off;
+        auto entry = [&](int e) { return (int)((pcode[e >> 4] >> (4 * (e & 15))) & 15u); };
+        bool has_log = false;
+        for (int e = 1; e < R.n_nodes; ++e) has_log = has_log || entry(e) == BSR_OP_LOG;
+        if (has_log) fast = false;
         uint64_t enc = 0;
-        for (int e = 1; fast && e < R.n_nodes; ++e) {
-          const int op = (int)((R.code0 >> (4 * e)) & 15u);
-          if (op == BSR_OP_LOG) fast = false;
-          enc |= (uint64_t)((op + 1) & 15) << (4 * (e - 1));
-        }
-        s.stat_fast += fast ? 1 : 0;
-        Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : 0) | 64 | ((R.qslot & 0xFF) << 8);
-        Q.s = R.s;
-        Q.code = fast ? enc : 0;
-        // (its byte offset in a chunk buffer: a column of a chunk is 1 KiB per f64 block -- and 1 KiB per two f32 blocks)
-        Q.first = (int32_t)(R.f0 & 0xFFu) << ((tg.chunk_blocks == 2 && c->esz == 8) ? 11 : 10);
+        for (int e = 1; fast && e < R.n_nodes; ++e) enc |= (uint64_t)((entry(e) + 1) & 15) << (4 * (e - 1));
         uint64_t slots = 0;
         for (int t = 1; t < 8; ++t) {
           const uint64_t w = (t < 4) ? R.f0 : R.f1;
           const uint64_t id = (w >> (16 * (t & 3))) & 0xFFu;
           slots |= ((t < R.n_term) ? id : (uint64_t)0) << (8 * (t - 1));
         }
+        // Round 6: a tape the 64-bit program does not hold -- more than 16 entries, 8 terminals or 3 ln nodes, or (K <= 3) a
+        // second value below the accumulator -- as a program of SEVERAL words for the chunk block of assembly: the word in
+        // the record (16 entries, 7 terminal slots) and up to BSR_STREAM_EXT_MAX extension words (16 entries, 8 slots each)
+        // behind the record array; `end of word` fetches the next one (bsr_stream_chunk_asm.h: .Lsc_more).  A word closes
+        // when its entries or its slots are used up.  Bit 31 without bit 5: the C++ and the tape-at-a-time interpreters
+        // (test library) hand such a tape to the stack machine -- which is what the byte-equality tests compare it with.
+        int n_ext = 0;
+        size_t ext_first = 0;
+        bool deep = false;
+        if (!fast && !has_log && c->stream_deep > 0 && c->K <= 4 && tg.ncols_fixed == c->K && tg.ncols < 255 &&
+            D.n_ln <= BSR_STREAM_LN_PAIRS && D.max_sp <= sp_max) {
+          const uint64_t* pfeat = hfeats_lds + D.feat_off;
+          auto term_id = [&](int t) { return (uint64_t)((pfeat[t >> 2] >> (16 * (t & 3))) & 0xFFu); };
+          uint64_t wc[1 + BSR_STREAM_EXT_MAX] = {0}, ws[1 + BSR_STREAM_EXT_MAX] = {0};
+          int ne = 0, ns_ = 0, wi = 0, t = 1;
+          bool ok = true;
+          for (int e = 1; e < R.n_nodes && ok; ++e) {
+            const int op = entry(e);
+            const bool needs = op == BSR_OP_TERMINAL || op == BSR_SOP_ADD_T || op == BSR_SOP_MUL_T;
+            const int cap = (wi == 0) ? 7 : 8;
+            if (ne == 16 || (needs && ns_ == cap)) {
+              ++wi;
+              ne = ns_ = 0;
+              if (wi > BSR_STREAM_EXT_MAX) { ok = false; break; }
+            }
+            wc[wi] |= (uint64_t)((op + 1) & 15) << (4 * ne);
+            ++ne;
+            if (needs) {
+              if (t >= R.n_term) { ok = false; break; }
+              ws[wi] |= term_id(t++) << (8 * ns_);
+              ++ns_;
+            }
+          }
+          const size_t base = i - (i % (size_t)tg.qmax);                       // the wave's first record: the block's %[sr]
+          const size_t off_units = (n_sched + 1 - base) * 2 + ext_words.size() / 2;
+          if (ok && off_units + (size_t)wi < 1023) {
+            deep = true;
+            n_ext = wi;
+            ext_first = off_units;
+            enc = wc[0];
+            slots = ws[0];
+            for (int w = 1; w <= wi; ++w) { ext_words.push_back(wc[w]); ext_words.push_back(ws[w]); }
+          }
+        }
+        static const int deep_dbg = env_int("BSR_DEEP_DUMP", 0);   // diagnostics: why a tape is (not) taken
+        if (deep_dbg && !fast)
+          fprintf(stderr, "tape %d: entries %d terms %d ln %d max_sp %d log %d ncols %d fixed %d K %d deep_knob %d -> deep %d (ext %d)\n", R.p,
+                  R.n_nodes, R.n_term, D.n_ln, D.max_sp, (int)has_log, tg.ncols, tg.ncols_fixed, c->K, c->stream_deep, (int)deep, n_ext);
+        s.stat_fast += (fast || deep) ? 1 : 0;
+        Q.meta = ((R.n_nodes - 1) & 31) | (fast ? (int32_t)0x80000020 : deep ? (int32_t)0x40000000 : 0) | 64 | ((R.qslot & 0xFF) << 8) |
+                 (n_ext << 16) | (int32_t)(ext_first << 20);
+        Q.s = R.s;
+        Q.code = (fast || deep) ? enc : 0;
+        // (its byte offset in a chunk buffer: a column of a chunk is 1 KiB per f64 block -- and 1 KiB per two f32 blocks)
+        Q.first = (int32_t)(R.f0 & 0xFFu) << ((tg.chunk_blocks == 2 && c->esz == 8) ? 11 : 10);
         Q.slots = slots;
       }
-      s.recs_bytes = s.srec_off + (n_sched + 1) * sizeof(StreamRec);
+      // the extension words behind the records (and one word of padding: a wave's request never runs off the block)
+      uint64_t* ext_dst = reinterpret_cast<uint64_t*>(sr + n_sched + 1);
+      for (size_t w = 0; w < ext_words.size(); ++w) ext_dst[w] = ext_words[w];
+      ext_dst[ext_words.size()] = ext_dst[ext_words.size() + 1] = 0;
+      s.recs_bytes = s.srec_off + (n_sched + 1) * sizeof(StreamRec) + (ext_words.size() + 2) * 8;
     }
     s.tprog_off = 0;
     if (tg.per_group > 0) {   // per group: its tapes' records in cost order, -1 padded

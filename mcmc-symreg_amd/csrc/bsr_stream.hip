@@ -373,8 +373,16 @@ __device__ __attribute__((noinline)) void leftover_call_f32(const TileArgs<doubl
   store_partial<KQ>(A, a.part + ((size_t)p * g.n_part + g.n_slices + bi) * BSR_P1_WORDS, lane);
 }
 
-template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false>
+// (operands of the assembly blocks: the second saved value's way out of a leave and back in -- K <= 3 only)
+#define BSR_S23 [s2] "+v"(s02), [s3] "+v"(s03),
+#define BSR_S23_NONE
+// DEEP2 (round 6; mode 3, K <= 3): the block keeps a SECOND value below the accumulator in v[40:43], for batches that hold
+// trees of Strahler number 3 (a binary operator over two subtrees that each hold one).  A kernel of its own because the
+// four registers cost every batch: the real mix's C5 launch measured 77 us without them and 83-86 us with (interleaved
+// A/B of two builds in one box); the host picks it per batch (bsr_stage.hip) -- a tape scores the same bytes either way.
+template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false, bool DEEP2 = false>
 __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<double> a) {
+  static_assert(!DEEP2 || (MODE == 3 && KQ <= 3), "the second saved value: the pass block at K <= 3");
   static_assert(!F32 || (CB == 2 && MODE == 2 && KQ <= 4 && QT == 4 && !STAMPS),
                 "f32 storage: 256-row chunks (two blocks), the chunk block of assembly, four sets of sums per wave");
   // MODE 0: the C++ interpreter (tape_fast); 1: the assembly interpreter, a tape at a time (bsr_stream_asm.h);
@@ -467,8 +475,8 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
     // the wave's tapes: ln pairs into LDS, sums cleared; their programs (StreamRec, 32 bytes) are read again for every
     // chunk by one scalar load each, requested under the sums of the tape before
     TapeAcc<KQ> A[QT];
-    double2* ln_mine = ln_all + (size_t)wave * QT * 3;
-    const uint32_t ln_lds = lds0 + ring_bytes + (uint32_t)wave * (QT * 48u);   // (its LDS address, for the assembly interpreter)
+    double2* ln_mine = ln_all + (size_t)wave * QT * BSR_STREAM_LN_PAIRS;
+    const uint32_t ln_lds = lds0 + ring_bytes + (uint32_t)wave * (QT * BSR_STREAM_LN_PAIRS * 16u);   // (its LDS address, for the assembly interpreter)
     if (pass != 0) __syncthreads();   // everyone is done with the last chunks (and the ln pairs) of the pass before
     const StreamRec CONSTANT_AS* sr = as_const(a.srec + (((size_t)tg * a.g.n_pass + pass) * BSR_TILE_WAVES + wave) * QT);
     uint32_t issue_off = 0;   // where in the ring the next chunk to be requested goes
@@ -486,7 +494,13 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       A[q].clear();
       if (lane == 0) {   // (scalar loads and LDS stores: no vector memory operation next to the copies' counter)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ln_mine[q * 3 + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
+        for (int j = 0; j < 3; ++j) ln_mine[q * BSR_STREAM_LN_PAIRS + j] = make_double2(rec->ln[2 * j], rec->ln[2 * j + 1]);
+        // (round 6: a long tape's pairs 4..8 from its ln stream -- the record holds the first three)
+        const int nl = rec->n_ln;
+        if (rec->p >= 0 && nl > 2) {   // (a set of sums without a tape: its record holds nothing but p = -1)
+          const double CONSTANT_AS* lp = as_const(a.lnp + 2 * (size_t)rec->ln_off);
+          for (int j = 3; j < BSR_STREAM_LN_PAIRS && j <= nl; ++j) ln_mine[q * BSR_STREAM_LN_PAIRS + j] = make_double2(lp[2 * j], lp[2 * j + 1]);
+        }
       }
     }
     uint32_t cur_off = 0;     // ... and where the chunk the waves compute on sits
@@ -495,17 +509,17 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
       // here: sin / cos of huge arguments and tapes for the stack machine, with the loop's state in sv[5..9]
       const Bases B = fetch_bases();
       uint32_t resume = 0, st, sv[10], lc_out;
-      double z0, z1, s00, s01;
-      asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
+      double z0, z1, s00, s01, s02, s03;   // (s02, s03: the second value below the accumulator, K <= 3)
+      asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(s02), "=v"(s03), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
                         "=v"(sv[4]), "=v"(sv[5]), "=v"(sv[6]), "=v"(sv[7]), "=v"(sv[8]), "=v"(sv[9]));
       const uint32_t yo = (uint32_t)y_slot << 10, lane16 = (uint32_t)lane * 16u;
       const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
       const uint32_t ring_u = (uint32_t)R, nch_u = (uint32_t)n_chunks, nmine_u = (uint32_t)n_mine, wave_u = (uint32_t)wave;
       const uint32_t b0_u = (uint32_t)b0;
       for (;;) {
-#define BSR_SP_OPERANDS(SUMS) \
+#define BSR_SP_OPERANDS(SUMS, S23) \
                      : SUMS, \
-                       [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]), \
+                       [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), S23 [sv0] "+v"(sv[0]), \
                        [sv1] "+v"(sv[1]), [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [sv5] "+v"(sv[5]), \
                        [sv6] "+v"(sv[6]), [sv7] "+v"(sv[7]), [sv8] "+v"(sv[8]), [sv9] "+v"(sv[9]), [st] "=s"(st), \
                        [lc] "=&v"(lc_out) \
@@ -513,14 +527,17 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
                        [lane16] "v"(lane16), [ba0] "s"(B.p[0]), [ba1] "s"(B.p[1]), [ba2] "s"(B.p[2]), [ba3] "s"(B.p[3]), \
                        [nch] "s"(nch_u), [bufb] "s"(buf_bytes), [ring] "s"(ring_u), [lds0] "s"(lds0), [wave] "s"(wave_u), \
                        [nmine] "s"(nmine_u), [ioff] "s"(issue_off), [b0] "s"(b0_u)
-        if constexpr (KQ == 1) asm volatile(BSR_STREAM_PASS_ASM_K1 BSR_SP_OPERANDS(BSR_SC_SUMS_1) : BSR_STREAM_PASS_CLOBBERS);
-        else if constexpr (KQ == 2) asm volatile(BSR_STREAM_PASS_ASM_K2 BSR_SP_OPERANDS(BSR_SC_SUMS_2) : BSR_STREAM_PASS_CLOBBERS);
-        else if constexpr (KQ == 3) asm volatile(BSR_STREAM_PASS_ASM_K3 BSR_SP_OPERANDS(BSR_SC_SUMS_3) : BSR_STREAM_PASS_CLOBBERS);
-        else if constexpr (KQ == 4) asm volatile(BSR_STREAM_PASS_ASM_K4 BSR_SP_OPERANDS(BSR_SC_SUMS_4) : BSR_STREAM_PASS_CLOBBERS_K4);
-        else if constexpr (KQ == 5) asm volatile(BSR_STREAM_PASS_ASM_K5 BSR_SP_OPERANDS(BSR_SC_SUMS_5) : BSR_STREAM_PASS_CLOBBERS_K8);
-        else if constexpr (KQ == 6) asm volatile(BSR_STREAM_PASS_ASM_K6 BSR_SP_OPERANDS(BSR_SC_SUMS_6) : BSR_STREAM_PASS_CLOBBERS_K8);
-        else if constexpr (KQ == 7) asm volatile(BSR_STREAM_PASS_ASM_K7 BSR_SP_OPERANDS(BSR_SC_SUMS_7) : BSR_STREAM_PASS_CLOBBERS_K8);
-        else asm volatile(BSR_STREAM_PASS_ASM_K8 BSR_SP_OPERANDS(BSR_SC_SUMS_8) : BSR_STREAM_PASS_CLOBBERS_K8);
+        if constexpr (DEEP2 && KQ == 1) asm volatile(BSR_STREAM_PASS_ASM_K1D BSR_SP_OPERANDS(BSR_SC_SUMS_1, BSR_S23) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (DEEP2 && KQ == 2) asm volatile(BSR_STREAM_PASS_ASM_K2D BSR_SP_OPERANDS(BSR_SC_SUMS_2, BSR_S23) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (DEEP2 && KQ == 3) asm volatile(BSR_STREAM_PASS_ASM_K3D BSR_SP_OPERANDS(BSR_SC_SUMS_3, BSR_S23) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (KQ == 1) asm volatile(BSR_STREAM_PASS_ASM_K1 BSR_SP_OPERANDS(BSR_SC_SUMS_1, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS);
+        else if constexpr (KQ == 2) asm volatile(BSR_STREAM_PASS_ASM_K2 BSR_SP_OPERANDS(BSR_SC_SUMS_2, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS);
+        else if constexpr (KQ == 3) asm volatile(BSR_STREAM_PASS_ASM_K3 BSR_SP_OPERANDS(BSR_SC_SUMS_3, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS);
+        else if constexpr (KQ == 4) asm volatile(BSR_STREAM_PASS_ASM_K4 BSR_SP_OPERANDS(BSR_SC_SUMS_4, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS_K4);
+        else if constexpr (KQ == 5) asm volatile(BSR_STREAM_PASS_ASM_K5 BSR_SP_OPERANDS(BSR_SC_SUMS_5, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else if constexpr (KQ == 6) asm volatile(BSR_STREAM_PASS_ASM_K6 BSR_SP_OPERANDS(BSR_SC_SUMS_6, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else if constexpr (KQ == 7) asm volatile(BSR_STREAM_PASS_ASM_K7 BSR_SP_OPERANDS(BSR_SC_SUMS_7, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS_K8);
+        else asm volatile(BSR_STREAM_PASS_ASM_K8 BSR_SP_OPERANDS(BSR_SC_SUMS_8, BSR_S23_NONE) : BSR_STREAM_PASS_CLOBBERS_K8);
 #undef BSR_SP_OPERANDS
         if (st == 0) break;
         const uint32_t what = st & 15u;
@@ -589,37 +606,37 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
         // the four tapes of the wave in one block of assembly; sin, cos, exp and tapes for the stack machine come back
         // here, and the block is entered again where it left (`resume`)
         uint32_t resume = 0, st, sv[5];
-        double z0, z1, s00, s01;
-        asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
+        double z0, z1, s00, s01, s02, s03;
+        asm volatile("" : "=v"(z0), "=v"(z1), "=v"(s00), "=v"(s01), "=v"(s02), "=v"(s03), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]), "=v"(sv[3]),
                           "=v"(sv[4]));   // (no value yet: nothing to initialise)
         const uint32_t yo = (uint32_t)y_slot << ((CB == 2 && !F32) ? 11 : 10);
         const uint32_t tab_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)bsr_lds_tab;
         // (two-block chunks: the same block of assembly on either half -- a lane's rows reach its sums in the order of
         // one-block chunks, block by block: the same sums bit for bit, with half the barriers)
-#define BSR_SC_OPERANDS(SUMS)                                                                                          \
-  : SUMS, [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), [sv0] "+v"(sv[0]), [sv1] "+v"(sv[1]),            \
+#define BSR_SC_OPERANDS(SUMS, S23)                                                                                     \
+  : SUMS, [z0] "+v"(z0), [z1] "+v"(z1), [s0] "+v"(s00), [s1] "+v"(s01), S23 [sv0] "+v"(sv[0]), [sv1] "+v"(sv[1]),            \
     [sv2] "+v"(sv[2]), [sv3] "+v"(sv[3]), [sv4] "+v"(sv[4]), [st] "=s"(st)                                              \
   : [resume] "s"(resume), [lc] "v"(lcb), [sr] "s"(sr), [ln] "s"(ln_lds), [yo] "s"(yo), [tab] "s"(tab_lds)                \
   :
 #define BSR_SC_EMIT(P)                                                                                                 \
-  if constexpr (KQ == 1) asm volatile(P##1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);                   \
-  else if constexpr (KQ == 2) asm volatile(P##2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);              \
-  else if constexpr (KQ == 3) asm volatile(P##3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);              \
-  else if constexpr (KQ == 4) asm volatile(P##4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4);           \
-  else if constexpr (KQ == 5) asm volatile(P##5 BSR_SC_OPERANDS(BSR_SC_SUMS_5) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
-  else if constexpr (KQ == 6) asm volatile(P##6 BSR_SC_OPERANDS(BSR_SC_SUMS_6) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
-  else if constexpr (KQ == 7) asm volatile(P##7 BSR_SC_OPERANDS(BSR_SC_SUMS_7) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
-  else asm volatile(P##8 BSR_SC_OPERANDS(BSR_SC_SUMS_8) BSR_STREAM_CHUNK_CLOBBERS_K8)
+  if constexpr (KQ == 1) asm volatile(P##1 BSR_SC_OPERANDS(BSR_SC_SUMS_1, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);                \
+  else if constexpr (KQ == 2) asm volatile(P##2 BSR_SC_OPERANDS(BSR_SC_SUMS_2, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);           \
+  else if constexpr (KQ == 3) asm volatile(P##3 BSR_SC_OPERANDS(BSR_SC_SUMS_3, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);           \
+  else if constexpr (KQ == 4) asm volatile(P##4 BSR_SC_OPERANDS(BSR_SC_SUMS_4, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K4);           \
+  else if constexpr (KQ == 5) asm volatile(P##5 BSR_SC_OPERANDS(BSR_SC_SUMS_5, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else if constexpr (KQ == 6) asm volatile(P##6 BSR_SC_OPERANDS(BSR_SC_SUMS_6, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else if constexpr (KQ == 7) asm volatile(P##7 BSR_SC_OPERANDS(BSR_SC_SUMS_7, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K8);           \
+  else asm volatile(P##8 BSR_SC_OPERANDS(BSR_SC_SUMS_8, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K8)
 #pragma unroll 1
         for (int jb = 0; jb < nbc; ++jb) {
           const uint32_t lcb = lc + (uint32_t)jb * (F32 ? 512u : 1024u);
           resume = 0;
           for (;;) {
             if constexpr (F32) {
-              if constexpr (KQ == 1) asm volatile(BSR_STREAM_CHUNKF_ASM_K1 BSR_SC_OPERANDS(BSR_SC_SUMS_1) BSR_STREAM_CHUNK_CLOBBERS);
-              else if constexpr (KQ == 2) asm volatile(BSR_STREAM_CHUNKF_ASM_K2 BSR_SC_OPERANDS(BSR_SC_SUMS_2) BSR_STREAM_CHUNK_CLOBBERS);
-              else if constexpr (KQ == 3) asm volatile(BSR_STREAM_CHUNKF_ASM_K3 BSR_SC_OPERANDS(BSR_SC_SUMS_3) BSR_STREAM_CHUNK_CLOBBERS);
-              else asm volatile(BSR_STREAM_CHUNKF_ASM_K4 BSR_SC_OPERANDS(BSR_SC_SUMS_4) BSR_STREAM_CHUNK_CLOBBERS_K4);
+              if constexpr (KQ == 1) asm volatile(BSR_STREAM_CHUNKF_ASM_K1 BSR_SC_OPERANDS(BSR_SC_SUMS_1, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);
+              else if constexpr (KQ == 2) asm volatile(BSR_STREAM_CHUNKF_ASM_K2 BSR_SC_OPERANDS(BSR_SC_SUMS_2, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);
+              else if constexpr (KQ == 3) asm volatile(BSR_STREAM_CHUNKF_ASM_K3 BSR_SC_OPERANDS(BSR_SC_SUMS_3, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS);
+              else asm volatile(BSR_STREAM_CHUNKF_ASM_K4 BSR_SC_OPERANDS(BSR_SC_SUMS_4, BSR_S23_NONE) BSR_STREAM_CHUNK_CLOBBERS_K4);
             } else if constexpr (CB == 2) {
               BSR_SC_EMIT(BSR_STREAM_CHUNK2_ASM_K);
             } else {
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
             // (the state of a tape that left for sin / cos / exp travels in five vector registers: tied scalar operands
             // carried around this loop do not compile -- "illegal VGPR to SGPR copy")
             const uint64_t code = t.code, sl = t.slots;
-            const uint32_t lnp = ln_lds + (uint32_t)q * 48u, first = t.first;
+            const uint32_t lnp = ln_lds + (uint32_t)q * (BSR_STREAM_LN_PAIRS * 16u), first = t.first;
             uint32_t resume = 0, st, sv[5];
             double s00, s01;
             asm volatile("" : "=v"(z[0]), "=v"(z[1]), "=v"(s00), "=v"(s01), "=v"(sv[0]), "=v"(sv[1]), "=v"(sv[2]),
@@ -697,7 +714,7 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
             }
           }
         } else if (t.fast()) {
-          tape_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * 3, z);
+          tape_fast<CB>(t, lane_col, chunk_rows, ln_mine + q * BSR_STREAM_LN_PAIRS, z);
         } else {
           // Any other tape (not a chain; longer than the scalar registers hold, or with a `log`): the stack machine of
           // bsr_device.h on the same rows, one block at a time, out of line (generic_block above)
@@ -742,21 +759,21 @@ __global__ __launch_bounds__(BSR_TILE_WAVES* BSR_WAVE) void k_stream(TileArgs<do
 #undef TSTAMP
 }
 
-template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false>
+template <int KQ, int QT, int CB, bool STAMPS, int MODE, bool F32 = false, bool DEEP2 = false>
 void launch_one(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS, MODE, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_stream<KQ, QT, CB, STAMPS, MODE, F32, DEEP2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(tile_lds_bytes_max() - 1024));
     attr = true;
   }
   const dim3 grid((unsigned)(a.g.T * a.g.n_slices)), block(BSR_TILE_WAVES * BSR_WAVE);
-  bsr_launch((k_stream<KQ, QT, CB, STAMPS, MODE, F32>), grid, block, lds, st, a);
+  bsr_launch((k_stream<KQ, QT, CB, STAMPS, MODE, F32, DEEP2>), grid, block, lds, st, a);
 }
 #ifdef BSR_TEST_VARIANTS
 // (the test build: every interpreter behind BSR_STREAM_ASM, per-wave clock samples, either number of sets of sums)
 template <int KQ, int QT>
-void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
+void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds, bool deep2) {
   // BSR_STREAM_ASM=0: the C++ interpreter (tape_fast) on one-block chunks too -- the cross-check of the assembly ones;
   // 1: the assembly interpreter a tape at a time; default: the wave's four tapes in one block where it applies (K = 3,
   // one chain's basis behind y), else 1
@@ -778,7 +795,12 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
   if constexpr (BLOCK_SHAPE) {
     if (chunk_block) {
       if (a.stamps) launch_one<KQ, QT, 1, true, 2>(st, a, lds);   // (BSR_TILE_STAMPS=1: per-wave clock samples)
-      else if (asm_mode >= 3) launch_one<KQ, QT, 1, false, 3>(st, a, lds);
+      else if (asm_mode >= 3) {
+        if constexpr (KQ <= 3) {
+          if (deep2) { launch_one<KQ, QT, 1, false, 3, false, true>(st, a, lds); return; }
+        }
+        launch_one<KQ, QT, 1, false, 3>(st, a, lds);
+      }
       else launch_one<KQ, QT, 1, false, 2>(st, a, lds);
       return;
     }
@@ -794,13 +816,16 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
 // other interpreters exist for the byte-equality tests only (build with BSR_EXTRA_FLAGS=-DBSR_TEST_VARIANTS:
 // csrc/build.sh variants; tests/test_gpu_stream.py runs them).
 template <int KQ, int QT>
-void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
+void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds, bool deep2) {
   static_assert((KQ <= 4 && QT == 4) || (KQ >= 5 && QT == 2), "the sets of sums per wave the kernel is built for");
   const bool chunk_block = a.g.ncols_fixed == KQ;
   if (a.g.chunk_blocks == 2) {
     if (chunk_block) launch_one<KQ, QT, 2, false, 2>(st, a, lds);
     else launch_one<KQ, QT, 2, false, 0>(st, a, lds);
     return;
+  }
+  if constexpr (KQ <= 3) {
+    if (chunk_block && deep2) { launch_one<KQ, QT, 1, false, 3, false, true>(st, a, lds); return; }
   }
   if (chunk_block) launch_one<KQ, QT, 1, false, 3>(st, a, lds);
   else launch_one<KQ, QT, 1, false, 1>(st, a, lds);
@@ -809,8 +834,8 @@ void launch_cb(hipStream_t st, const TileArgs<double>& a, size_t lds) {
 
 }  // namespace
 
-// bytes of LDS behind the ring: three (a, b) pairs per tape of every wave
-size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * 3 * sizeof(double2); }
+// bytes of LDS behind the ring: BSR_STREAM_LN_PAIRS (a, b) pairs per tape of every wave
+size_t stream_ln_bytes(int qt) { return (size_t)BSR_TILE_WAVES * qt * BSR_STREAM_LN_PAIRS * sizeof(double2); }
 
 // sets of sums per wave of the streaming kernel (BSR_STREAM_QT overrides: 2 or 4): four while the sums of four tapes, a
 // chunk's y and basis values and the routines' temporaries fit 128 registers (K <= 4), else two
@@ -823,6 +848,15 @@ bool stream_chunk_block(int K, int ncols_fixed) {
   const int asm_mode = 3;
 #endif
   return stream_qmax(K) == (K <= 4 ? 4 : 2) && asm_mode >= 2 && ncols_fixed == K;
+}
+
+// whether a batch of this shape may use the kernel with the second saved value (mode 3: one-block chunks, one chain's basis, K <= 3)
+bool stream_deep2_applies(int K, int ncols_fixed, int chunk_blocks) {
+#ifdef BSR_TEST_VARIANTS
+  static const int asm_mode = env_int("BSR_STREAM_ASM", 3);
+  if (asm_mode < 3) return false;
+#endif
+  return K <= 3 && ncols_fixed == K && chunk_blocks == 1 && stream_qmax(K) == 4;
 }
 
 int stream_qmax(int K) {
@@ -847,28 +881,28 @@ void launch_stream_f32(hipStream_t st, const TileArgs<float>& af) {
   }
 }
 
-void launch_stream(hipStream_t st, const TileArgs<double>& a) {
+void launch_stream(hipStream_t st, const TileArgs<double>& a, bool deep2) {
   const TileGeom& g = a.g;
   const size_t lds = (size_t)g.ring * g.ncols * g.chunk_blocks * BSR_TILE_BLOCK * sizeof(double) + stream_ln_bytes(g.qmax);
   if (g.qmax == 4) {
     switch (a.K) {
-      case 1: launch_cb<1, 4>(st, a, lds); break;
-      case 2: launch_cb<2, 4>(st, a, lds); break;
-      case 3: launch_cb<3, 4>(st, a, lds); break;
-      default: launch_cb<4, 4>(st, a, lds); break;
+      case 1: launch_cb<1, 4>(st, a, lds, deep2); break;
+      case 2: launch_cb<2, 4>(st, a, lds, deep2); break;
+      case 3: launch_cb<3, 4>(st, a, lds, deep2); break;
+      default: launch_cb<4, 4>(st, a, lds, deep2); break;
     }
     return;
   }
   switch (a.K) {
 #ifdef BSR_TEST_VARIANTS
-    case 1: launch_cb<1, 2>(st, a, lds); break;
-    case 2: launch_cb<2, 2>(st, a, lds); break;
-    case 3: launch_cb<3, 2>(st, a, lds); break;
-    case 4: launch_cb<4, 2>(st, a, lds); break;
+    case 1: launch_cb<1, 2>(st, a, lds, deep2); break;
+    case 2: launch_cb<2, 2>(st, a, lds, deep2); break;
+    case 3: launch_cb<3, 2>(st, a, lds, deep2); break;
+    case 4: launch_cb<4, 2>(st, a, lds, deep2); break;
 #endif
-    case 5: launch_cb<5, 2>(st, a, lds); break;
-    case 6: launch_cb<6, 2>(st, a, lds); break;
-    case 7: launch_cb<7, 2>(st, a, lds); break;
-    default: launch_cb<8, 2>(st, a, lds); break;
+    case 5: launch_cb<5, 2>(st, a, lds, deep2); break;
+    case 6: launch_cb<6, 2>(st, a, lds, deep2); break;
+    case 7: launch_cb<7, 2>(st, a, lds, deep2); break;
+    default: launch_cb<8, 2>(st, a, lds, deep2); break;
   }
 }

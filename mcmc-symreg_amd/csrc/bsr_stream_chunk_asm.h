@@ -48,10 +48,17 @@
   "v_cvt_f64_f32_e32 v[0:1], v12\n\t" "v_cvt_f64_f32_e32 v[2:3], v13\n\t"
 #define BSR_SC_LDO_F32 "ds_read_b64 v[12:13], v20\n\t" "s_waitcnt lgkmcnt(0)\n\t" \
   "v_cvt_f64_f32_e32 v[8:9], v12\n\t" "v_cvt_f64_f32_e32 v[10:11], v13\n\t"
-#define BSR_SC_BIN(ins, neg)                                                     \
+// (round 6: a SECOND value below the accumulator, v[40:43], where the block has them to spare -- K <= 3: a pushed terminal moves
+// the saved value down first (PUSH2), a binary operator brings it back up behind itself (POP2); trees of Strahler number 3
+// -- (a + b) * (c + d) below another binary operator -- no longer leave for the stack machine.  K >= 4: both empty.)
+#define BSR_SC_PUSH2 "v_mov_b64_e32 v[40:41], v[4:5]\n\t" "v_mov_b64_e32 v[42:43], v[6:7]\n\t"
+#define BSR_SC_POP2 "v_mov_b64_e32 v[4:5], v[40:41]\n\t" "v_mov_b64_e32 v[6:7], v[42:43]\n\t"
+#define BSR_SC_NONE ""
+#define BSR_SC_BIN(ins, neg, POP)                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   ins " v[0:1], v[4:5], " neg "v[0:1]\n\t"                                       \
   ins " v[2:3], v[6:7], " neg "v[2:3]\n\t"                                       \
+  POP                                                                            \
   BSR_SC_DISPATCH
 #define BSR_SC_BIN_T(ins, SH, LDO)                                               \
   BSR_SC_SLOT_ADDR(SH)                                                             \
@@ -197,7 +204,7 @@
 #define BSR_SC_TAPE_REGS(q)                                                      \
   "s_sub_u32 s28, s24, .Lsc_tab%=-.Lsc_acc" #q "_%=\n\t"                         \
   "s_subb_u32 s29, s25, 0\n\t"                                                   \
-  "s_add_u32 s13, %[ln], " #q "*48\n\t"
+  "s_add_u32 s13, %[ln], " #q "*48\n\t"   /* (BSR_STREAM_LN_PAIRS = 3 pairs of 16 bytes per tape) */
 
 // Tape q of the wave: its program has been requested into s[16:23] (by the block's entry, or while tape q - 1 was added up).
 // Its priority is 3 - q: a SIMD issues for its oldest wave first, so left alone its four waves finish a chunk one after
@@ -243,10 +250,21 @@
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "s_cmp_lt_i32 s16, 0\n\t"                                                      \
   "s_cbranch_scc0 .Lsc_slow" #q "_%=\n\t"                                        \
+  ".Lsc_go" #q "_%=:\n\t"                                                        \
   "v_add_u32_e32 v20, s17, %[lc]\n\t"                                            \
   LDA                                                                            \
   BSR_SC_DISPATCH                                                                \
-  ".Lsc_slow" #q "_%=:\n\t"   /* no tape in this set of sums, or one for the stack machine */ \
+  ".Lsc_slow" #q "_%=:\n\t"   /* no tape in this set of sums, one for the stack machine -- or (bit 30, round 6) one the block takes \
+                                 after all: a program of several words and / or a second value below the accumulator */ \
+  "s_bitcmp1_b32 s16, 30\n\t"                                                    \
+  "s_cbranch_scc0 .Lsc_nodeep" #q "_%=\n\t"                                      \
+  "s_and_b32 s10, s16, 0xf0000\n\t"                                              \
+  "s_cbranch_scc0 .Lsc_go" #q "_%=\n\t"   /* (one word: `end` is the tape's) */  \
+  "s_mov_b64 s[14:15], s[28:29]\n\t"                                             \
+  "s_add_u32 s28, s24, .Lsc_more%=-.Lsc_tab%=\n\t"                               \
+  "s_addc_u32 s29, s25, 0\n\t"                                                   \
+  "s_branch .Lsc_go" #q "_%=\n"                                                   \
+  ".Lsc_nodeep" #q "_%=:\n\t"                                                    \
   "s_bitcmp1_b32 s16, 6\n\t"                                                     \
   "s_cbranch_scc1 .Lsc_gen" #q "_%=\n\t"                                         \
   "s_load_dwordx8 s[16:23], %[sr], " #qnext "*32\n\t"                            \
@@ -279,6 +297,16 @@
   "s_load_dwordx8 s[16:23], %[sr], " #q "*32\n\t"                                \
   BSR_SC_TAPE_REGS(q)                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  "s_lshr_b32 s10, %[resume], 8\n\t"   /* extension words left and the next one's place, as the leave found them */ \
+  "s_lshl_b32 s10, s10, 16\n\t"                                                  \
+  "s_and_b32 s16, s16, 0xc000ffff\n\t"                                           \
+  "s_or_b32 s16, s16, s10\n\t"                                                   \
+  "s_and_b32 s10, s16, 0xf0000\n\t"                                              \
+  "s_cbranch_scc0 .Lsc_resp" #q "_%=\n\t"                                        \
+  "s_mov_b64 s[14:15], s[28:29]\n\t"   /* (words left: `end` goes to .Lsc_more, the last one's to the add-up) */ \
+  "s_add_u32 s28, s24, .Lsc_more%=-.Lsc_tab%=\n\t"                               \
+  "s_addc_u32 s29, s25, 0\n"                                                      \
+  ".Lsc_resp" #q "_%=:\n\t"                                                      \
   "v_mov_b64_e32 v[0:1], %[z0]\n\t"                                              \
   "v_mov_b64_e32 v[2:3], %[z1]\n\t"                                              \
   "s_cmp_eq_u32 s12, 1\n\t"                                                      \
@@ -305,9 +333,10 @@
 #define BSR_SC_TAPES_6 BSR_SC_TAPES2(BSR_SC_R0_6, BSR_SC_R1_6)
 #define BSR_SC_TAPES_7 BSR_SC_TAPES2(BSR_SC_R0_7, BSR_SC_R1_7)
 #define BSR_SC_TAPES_8 BSR_SC_TAPES2(BSR_SC_R0_8, BSR_SC_R1_8)
-#define BSR_SC_RESUME_PART                                                       \
+#define BSR_SC_RESUME_PART BSR_SC_RESUME_PART_(BSR_SC_NONE)
+#define BSR_SC_RESUME_PART_(STATE2)                                              \
   ".Lsc_resume%=:\n\t"                                                           \
-  "s_lshr_b32 s10, %[resume], 4\n\t"                                             \
+  "s_bfe_u32 s10, %[resume], 0x40004\n\t"   /* (bits 8..22: where the tape's program stood, below) */ \
   "s_and_b32 s12, %[resume], 15\n\t"                                             \
   "s_cmp_eq_u32 s10, 0\n\t"                                                      \
   "s_cbranch_scc1 .Lsc_res0_%=\n\t"                                              \
@@ -325,13 +354,16 @@
   "v_readfirstlane_b32 s13, %[sv4]\n\t"                                          \
   "v_mov_b64_e32 v[4:5], %[s0]\n\t"                                              \
   "v_mov_b64_e32 v[6:7], %[s1]\n\t"                                              \
+  STATE2                                                                         \
   BSR_SC_DISPATCH
+#define BSR_SC_STATE2_IN "v_mov_b64_e32 v[40:41], %[s2]\n\t" "v_mov_b64_e32 v[42:43], %[s3]\n\t"
+#define BSR_SC_STATE2_OUT "v_mov_b64_e32 %[s2], v[40:41]\n\t" "v_mov_b64_e32 %[s3], v[42:43]\n\t"
 // the operator table (2 KB-aligned: the dispatch ORs a slot's offset into its address) and the operators too long for a slot
-#define BSR_SC_TABLE_PART(SH, YQ) BSR_SC_TABLE_PART_(SH, YQ, BSR_SC_LDA_F64, BSR_SC_LDO_F64)
-#define BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO)                                     \
+#define BSR_SC_TABLE_PART(SH, YQ) BSR_SC_TABLE_PART_(SH, YQ, BSR_SC_LDA_F64, BSR_SC_LDO_F64, BSR_SC_NONE, BSR_SC_NONE)
+#define BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO, PUSH, POP)                          \
   ".p2align 11\n"                                                                \
   ".Lsc_tab%=:\n\t"                                                              \
-  "s_setpc_b64 s[28:29]\n\t"   /* 0: end of the tape */                          \
+  "s_setpc_b64 s[28:29]\n\t"   /* 0: end of the program word: the tape's add-up code -- or .Lsc_more (round 6) */ \
   BSR_SC_SLOT("1") "s_branch .Lsc_inv%=\n\t"                                     \
   BSR_SC_SLOT("2") /* ln: a x + b, two roundings */                              \
   "v_mov_b32_e32 v20, s13\n\t"                                                   \
@@ -363,22 +395,37 @@
   BSR_SC_DISPATCH                                                                \
   BSR_SC_SLOT("8") "s_branch .Lsc_cube%=\n\t"   /* + -760, 200 */               \
   BSR_SC_QUAD("0xC087C00000000000", "0x4069000000000000", "0", "0", "0", "0", "0", "0")                              \
-  BSR_SC_SLOT("9") BSR_SC_BIN("v_add_f64", "")                                   \
-  BSR_SC_SLOT("10") BSR_SC_BIN("v_mul_f64", "")                                  \
+  BSR_SC_SLOT("9") BSR_SC_BIN("v_add_f64", "", POP)                              \
+  BSR_SC_SLOT("10") BSR_SC_BIN("v_mul_f64", "", POP)                             \
   BSR_SC_SLOT("11") /* terminal: the accumulator becomes the saved value */      \
   BSR_SC_SLOT_ADDR(SH)                                                           \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+  PUSH                                                                           \
   "v_mov_b64_e32 v[4:5], v[0:1]\n\t"                                             \
   "v_mov_b64_e32 v[6:7], v[2:3]\n\t"                                             \
   LDA                                                                            \
   BSR_SC_DISPATCH                                                                \
   BSR_SC_SLOT("12") BSR_SC_BIN_T("v_add_f64", SH, LDO)                            \
   BSR_SC_SLOT("13") BSR_SC_BIN_T("v_mul_f64", SH, LDO)                            \
-  BSR_SC_SLOT("14") BSR_SC_BIN("v_add_f64", "-") /* sub */                       \
+  BSR_SC_SLOT("14") BSR_SC_BIN("v_add_f64", "-", POP) /* sub */                  \
   BSR_SC_SLOT("15") /* div, protected like inv */                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   BSR_SC_DIV("v[0:1]", "v0", "v1", "v[4:5]")                                     \
   BSR_SC_DIV("v[2:3]", "v2", "v3", "v[6:7]")                                     \
+  POP                                                                            \
+  BSR_SC_DISPATCH                                                                \
+  ".Lsc_more%=:\n\t"   /* a program of several words (where `end` goes while words are left): s16 bits 16..19 extension words left, \
+                           bits 20..29 the next one's place in 16-byte units behind %[sr]; s[14:15] where the tape's LAST end goes */ \
+  "s_sub_u32 s16, s16, 0x10000\n\t"                                              \
+  "s_bfe_u32 s10, s16, 0xa0014\n\t"                                              \
+  "s_lshl_b32 s10, s10, 4\n\t"                                                   \
+  "s_load_dwordx4 s[20:23], %[sr], s10\n\t"                                      \
+  "s_add_u32 s16, s16, 0x100000\n\t"                                             \
+  "s_and_b32 s10, s16, 0xf0000\n\t"                                              \
+  "s_cbranch_scc1 .Lsc_more_go%=\n\t"                                            \
+  "s_mov_b64 s[28:29], s[14:15]\n"   /* the last word: its end is the tape's */  \
+  ".Lsc_more_go%=:\n\t"                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   BSR_SC_DISPATCH                                                                \
   ".Lsc_inv%=:\n\t"                                                              \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
@@ -420,17 +467,24 @@
   ".Lsc_exp%=:\n\t"                                                              \
   "s_load_dwordx16 s[36:51], s[24:25], 832\n\t"                                  \
   "s_load_dwordx4 s[52:55], s[24:25], 1088\n\t"                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"   /* (FIRST: the chunk's y / basis reads may still be in flight, and v[28:31] is one of their destinations --  \
+                                   round 6: written in front of this wait, the constant below was overwritten by the LDS data that landed behind \
+                                   it, and exp of anything beyond 200 -- exp(exp(x)) -- returned a basis value instead of 1e10, run-dependent) */ \
   "v_mov_b32_e32 v30, 0x20000000\n\t"   /* 1e10: what the clipped exp returns beyond 200 (and for NaN) */ \
   "v_mov_b32_e32 v31, 0x4202a05f\n\t"                                            \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   BSR_SC_EXP("v[0:1]", "v0", "v1")                                               \
   BSR_SC_EXP("v[2:3]", "v2", "v3")                                               \
   YQ                                                                             \
   BSR_SC_DISPATCH
 // leaving for the caller: sin / cos of huge arguments (the state out through the operands; which tape: by where `end` goes)
-#define BSR_SC_LEAVE_PART                                                        \
+#define BSR_SC_LEAVE_PART BSR_SC_LEAVE_PART_(BSR_SC_NONE)
+#define BSR_SC_LEAVE_PART_(STATE2)                                               \
   ".Lsc_leave%=:\n\t"   /* sin, cos of huge arguments: out with the state; which tape: the offset of its add-up code */ \
   "s_sub_u32 s10, s28, s24\n\t"                                                  \
+  "s_cmp_eq_u32 s10, .Lsc_more%=-.Lsc_tab%=\n\t"   /* (a program with words left: its add-up code is in s[14:15]) */ \
+  "s_cbranch_scc0 .Lsc_lv1%=\n\t"                                                \
+  "s_sub_u32 s10, s14, s24\n"                                                     \
+  ".Lsc_lv1%=:\n\t"                                                              \
   "v_mov_b32_e32 %[sv0], s20\n\t"                                                \
   "v_mov_b32_e32 %[sv1], s21\n\t"                                                \
   "v_mov_b32_e32 %[sv2], s22\n\t"                                                \
@@ -438,10 +492,14 @@
   "v_mov_b32_e32 %[sv4], s13\n\t"                                                \
   "v_mov_b64_e32 %[s0], v[4:5]\n\t"                                              \
   "v_mov_b64_e32 %[s1], v[6:7]\n\t"                                              \
+  STATE2                                                                         \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "v_mov_b64_e32 %[z0], v[0:1]\n\t"                                              \
   "v_mov_b64_e32 %[z1], v[2:3]\n\t"                                              \
   "s_mov_b32 %[st], s12\n\t"                                                     \
+  "s_bfe_u32 s12, s16, 0xe0010\n\t"   /* extension words left and the next one's place: back in through `resume` */ \
+  "s_lshl_b32 s12, s12, 8\n\t"                                                   \
+  "s_or_b32 %[st], %[st], s12\n\t"                                               \
   "s_cmp_eq_u32 s10, .Lsc_acc0_%=-.Lsc_tab%=\n\t"                                \
   "s_cbranch_scc1 .Lsc_exit%=\n\t"                                               \
   "s_add_u32 %[st], %[st], 16\n\t"                                               \
@@ -452,8 +510,12 @@
   "s_cbranch_scc1 .Lsc_exit%=\n\t"                                               \
   "s_add_u32 %[st], %[st], 16\n"
 
-#define BSR_STREAM_CHUNK_ASM_(SH, YQ, TP) BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, BSR_SC_LDA_F64, BSR_SC_LDO_F64)
-#define BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, LDA, LDO)                             \
+// (DEEP: the second saved value and its moves, K <= 3; FLAT: none of it)
+#define BSR_SC_DEEP BSR_SC_PUSH2, BSR_SC_POP2, BSR_SC_STATE2_IN, BSR_SC_STATE2_OUT
+#define BSR_SC_FLAT BSR_SC_NONE, BSR_SC_NONE, BSR_SC_NONE, BSR_SC_NONE
+#define BSR_STREAM_CHUNK_ASM_(SH, YQ, TP, ...) BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, BSR_SC_LDA_F64, BSR_SC_LDO_F64, __VA_ARGS__)
+#define BSR_STREAM_CHUNK_ASM_X(SH, YQ, TP, LDA, LDO, ...) BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, LDA, LDO, __VA_ARGS__)
+#define BSR_STREAM_CHUNK_ASM__(SH, YQ, TP, LDA, LDO, PUSH, POP, ST_IN, ST_OUT)   \
   "s_load_dwordx8 s[16:23], %[sr], 0x0\n\t"                                      \
   BSR_SC_TABLE_BASE                                                              \
   YQ   /* y and the basis columns of the lane's rows, once for the four tapes */ \
@@ -462,9 +524,9 @@
   TP                                                                             \
   "s_mov_b32 %[st], 0\n\t"                                                       \
   "s_branch .Lsc_exit%=\n"                                                       \
-  BSR_SC_RESUME_PART                                                             \
-  BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO)                                           \
-  BSR_SC_LEAVE_PART                                                              \
+  BSR_SC_RESUME_PART_(ST_IN)                                                     \
+  BSR_SC_TABLE_PART_(SH, YQ, LDA, LDO, PUSH, POP)                                \
+  BSR_SC_LEAVE_PART_(ST_OUT)                                                     \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"
 
@@ -489,7 +551,8 @@
   "global_load_lds_dwordx4 v20, " base "\n\t"
 #define BSR_SP_WAIT(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch .Lsp_waited%=\n\t"
 
-#define BSR_STREAM_PASS_ASM_(YQ, TP)                                             \
+#define BSR_STREAM_PASS_ASM_(YQ, TP, ...) BSR_STREAM_PASS_ASM__(YQ, TP, __VA_ARGS__)
+#define BSR_STREAM_PASS_ASM__(YQ, TP, PUSH, POP, ST_IN, ST_OUT)                   \
   BSR_SC_TABLE_BASE                                                              \
   "s_mov_b64 s[60:61], %[ba0]\n\t"                                               \
   "s_mov_b64 s[62:63], %[ba1]\n\t"                                               \
@@ -571,15 +634,15 @@
   "s_nop 3\n\t"                                                                  \
   "v_add_u32_e32 %[lc], s79, %[lane16]\n\t"                                      \
   YQ                                                                             \
-  BSR_SC_RESUME_PART                                                             \
-  BSR_SC_TABLE_PART("10", YQ)                                                    \
+  BSR_SC_RESUME_PART_(ST_IN)                                                     \
+  BSR_SC_TABLE_PART_("10", YQ, BSR_SC_LDA_F64, BSR_SC_LDO_F64, PUSH, POP)        \
   ".Lsp_waits%=:\n\t"   /* the steady state's wait: entry 8 n for n copies of later chunks in flight */ \
   BSR_SP_WAIT(0) BSR_SP_WAIT(1) BSR_SP_WAIT(2) BSR_SP_WAIT(3) BSR_SP_WAIT(4) BSR_SP_WAIT(5) BSR_SP_WAIT(6)     \
   BSR_SP_WAIT(7) BSR_SP_WAIT(8)                                                  \
   BSR_SP_PIECE(3, "s[66:67]") BSR_SP_PIECE(2, "s[64:65]") BSR_SP_PIECE(1, "s[62:63]") BSR_SP_PIECE(0, "s[60:61]") \
   ".Lsp_is_none%=:\n\t"                                                          \
   "s_branch .Lsp_reissue_%=\n\t"                                                  \
-  BSR_SC_LEAVE_PART                                                              \
+  BSR_SC_LEAVE_PART_(ST_OUT)                                                     \
   ".Lsc_exit%=:\n\t"                                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   "v_mov_b32_e32 %[sv5], s68\n\t"                                                \
@@ -593,18 +656,21 @@
 
 // K = 1..4 basis columns; one-block chunks: a column of the buffer is 1024 bytes; two-block chunks: 2048 (the block's half
 // picked by %[lc])
-#define BSR_STREAM_CHUNK_ASM_K1 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ1("1024"), BSR_SC_TAPES_1)
-#define BSR_STREAM_CHUNK_ASM_K2 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2)
-#define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
-#define BSR_STREAM_CHUNK_ASM_K4 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
-#define BSR_STREAM_CHUNK2_ASM_K1 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ1("2048"), BSR_SC_TAPES_1)
-#define BSR_STREAM_CHUNK2_ASM_K2 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ2("2048", "4096"), BSR_SC_TAPES_2)
-#define BSR_STREAM_CHUNK2_ASM_K3 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ3("2048", "4096", "6144"), BSR_SC_TAPES_3)
-#define BSR_STREAM_CHUNK2_ASM_K4 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ4("2048", "4096", "6144", "8192"), BSR_SC_TAPES_4)
-#define BSR_STREAM_PASS_ASM_K1 BSR_STREAM_PASS_ASM_(BSR_SC_YQ1("1024"), BSR_SC_TAPES_1)
-#define BSR_STREAM_PASS_ASM_K2 BSR_STREAM_PASS_ASM_(BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2)
-#define BSR_STREAM_PASS_ASM_K3 BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3)
-#define BSR_STREAM_PASS_ASM_K4 BSR_STREAM_PASS_ASM_(BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4)
+#define BSR_STREAM_CHUNK_ASM_K1 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ1("1024"), BSR_SC_TAPES_1, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K2 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K3 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K4 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K1 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ1("2048"), BSR_SC_TAPES_1, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K2 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ2("2048", "4096"), BSR_SC_TAPES_2, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K3 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ3("2048", "4096", "6144"), BSR_SC_TAPES_3, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K4 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ4("2048", "4096", "6144", "8192"), BSR_SC_TAPES_4, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K1 BSR_STREAM_PASS_ASM_(BSR_SC_YQ1("1024"), BSR_SC_TAPES_1, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K1D BSR_STREAM_PASS_ASM_(BSR_SC_YQ1("1024"), BSR_SC_TAPES_1, BSR_SC_DEEP)   /* with the second value below the accumulator */
+#define BSR_STREAM_PASS_ASM_K2 BSR_STREAM_PASS_ASM_(BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K2D BSR_STREAM_PASS_ASM_(BSR_SC_YQ2("1024", "2048"), BSR_SC_TAPES_2, BSR_SC_DEEP)   /* with the second value below the accumulator */
+#define BSR_STREAM_PASS_ASM_K3 BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K3D BSR_STREAM_PASS_ASM_(BSR_SC_YQ3("1024", "2048", "3072"), BSR_SC_TAPES_3, BSR_SC_DEEP)   /* with the second value below the accumulator */
+#define BSR_STREAM_PASS_ASM_K4 BSR_STREAM_PASS_ASM_(BSR_SC_YQ4("1024", "2048", "3072", "4096"), BSR_SC_TAPES_4, BSR_SC_FLAT)
 
 // f32 storage (K <= 4): a column of the chunk buffer is 1 KiB = 256 rows of f32, evaluated as two blocks of 128 rows (%[lc]:
 // the half's address + lane * 8); y and the basis through the temporaries v[8:17] (free at the head of a chunk and behind
@@ -631,10 +697,10 @@
 #define BSR_SCF_TAPES_2 BSR_SC_TAPES4_(BSR_SC_R0_2, BSR_SC_R1_2, BSR_SC_LDA_F32)
 #define BSR_SCF_TAPES_3 BSR_SC_TAPES4_(BSR_SC_R0_3, BSR_SC_R1_3, BSR_SC_LDA_F32)
 #define BSR_SCF_TAPES_4 BSR_SC_TAPES4_(BSR_SC_R0_4, BSR_SC_R1_4, BSR_SC_LDA_F32)
-#define BSR_STREAM_CHUNKF_ASM_K1 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ1, BSR_SCF_TAPES_1, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
-#define BSR_STREAM_CHUNKF_ASM_K2 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ2, BSR_SCF_TAPES_2, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
-#define BSR_STREAM_CHUNKF_ASM_K3 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ3, BSR_SCF_TAPES_3, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
-#define BSR_STREAM_CHUNKF_ASM_K4 BSR_STREAM_CHUNK_ASM__("10", BSR_SCF_YQ4, BSR_SCF_TAPES_4, BSR_SC_LDA_F32, BSR_SC_LDO_F32)
+#define BSR_STREAM_CHUNKF_ASM_K1 BSR_STREAM_CHUNK_ASM_X("10", BSR_SCF_YQ1, BSR_SCF_TAPES_1, BSR_SC_LDA_F32, BSR_SC_LDO_F32, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNKF_ASM_K2 BSR_STREAM_CHUNK_ASM_X("10", BSR_SCF_YQ2, BSR_SCF_TAPES_2, BSR_SC_LDA_F32, BSR_SC_LDO_F32, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNKF_ASM_K3 BSR_STREAM_CHUNK_ASM_X("10", BSR_SCF_YQ3, BSR_SCF_TAPES_3, BSR_SC_LDA_F32, BSR_SC_LDO_F32, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNKF_ASM_K4 BSR_STREAM_CHUNK_ASM_X("10", BSR_SCF_YQ4, BSR_SCF_TAPES_4, BSR_SC_LDA_F32, BSR_SC_LDO_F32, BSR_SC_FLAT)
 
 #define BSR_SC_YQ_A5 BSR_SC_YQ5("1024", "2048", "3072", "4096", "5120")
 #define BSR_SC_YQ_A6 BSR_SC_YQ6("1024", "2048", "3072", "4096", "5120", "6144")
@@ -644,18 +710,18 @@
 #define BSR_SC_YQ_B6 BSR_SC_YQ6("2048", "4096", "6144", "8192", "10240", "12288")
 #define BSR_SC_YQ_B7 BSR_SC_YQ7("2048", "4096", "6144", "8192", "10240", "12288", "14336")
 #define BSR_SC_YQ_B8 BSR_SC_YQ8("2048", "4096", "6144", "8192", "10240", "12288", "14336", "16384")
-#define BSR_STREAM_CHUNK_ASM_K5 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A5, BSR_SC_TAPES_5)
-#define BSR_STREAM_CHUNK_ASM_K6 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A6, BSR_SC_TAPES_6)
-#define BSR_STREAM_CHUNK_ASM_K7 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A7, BSR_SC_TAPES_7)
-#define BSR_STREAM_CHUNK_ASM_K8 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A8, BSR_SC_TAPES_8)
-#define BSR_STREAM_CHUNK2_ASM_K5 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B5, BSR_SC_TAPES_5)
-#define BSR_STREAM_CHUNK2_ASM_K6 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B6, BSR_SC_TAPES_6)
-#define BSR_STREAM_CHUNK2_ASM_K7 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B7, BSR_SC_TAPES_7)
-#define BSR_STREAM_CHUNK2_ASM_K8 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B8, BSR_SC_TAPES_8)
-#define BSR_STREAM_PASS_ASM_K5 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A5, BSR_SC_TAPES_5)
-#define BSR_STREAM_PASS_ASM_K6 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A6, BSR_SC_TAPES_6)
-#define BSR_STREAM_PASS_ASM_K7 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A7, BSR_SC_TAPES_7)
-#define BSR_STREAM_PASS_ASM_K8 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A8, BSR_SC_TAPES_8)
+#define BSR_STREAM_CHUNK_ASM_K5 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A5, BSR_SC_TAPES_5, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K6 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A6, BSR_SC_TAPES_6, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K7 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A7, BSR_SC_TAPES_7, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK_ASM_K8 BSR_STREAM_CHUNK_ASM_("10", BSR_SC_YQ_A8, BSR_SC_TAPES_8, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K5 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B5, BSR_SC_TAPES_5, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K6 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B6, BSR_SC_TAPES_6, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K7 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B7, BSR_SC_TAPES_7, BSR_SC_FLAT)
+#define BSR_STREAM_CHUNK2_ASM_K8 BSR_STREAM_CHUNK_ASM_("11", BSR_SC_YQ_B8, BSR_SC_TAPES_8, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K5 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A5, BSR_SC_TAPES_5, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K6 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A6, BSR_SC_TAPES_6, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K7 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A7, BSR_SC_TAPES_7, BSR_SC_FLAT)
+#define BSR_STREAM_PASS_ASM_K8 BSR_STREAM_PASS_ASM_(BSR_SC_YQ_A8, BSR_SC_TAPES_8, BSR_SC_FLAT)
 
 #define BSR_STREAM_CHUNK_CLOBBERS                                                                                      \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17",   \
@@ -663,7 +729,7 @@
   "v38", "v39", "s8", "s9", "s10", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", \
   "s24", "s25", "s26", "s27", "s28", "s29", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", \
   "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc", "memory"
-// (K = 4: the fourth basis column's values)
+// (K = 4: the fourth basis column's values; K <= 3, round 6: the second value below the accumulator)
 #define BSR_STREAM_CHUNK_CLOBBERS_K4 BSR_STREAM_CHUNK_CLOBBERS, "v40", "v41", "v42", "v43"
 #define BSR_STREAM_PASS_CLOBBERS BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS)
 #define BSR_STREAM_PASS_CLOBBERS_K4 BSR_STREAM_PASS_CLOBBERS_(BSR_STREAM_CHUNK_CLOBBERS_K4)

@@ -545,9 +545,9 @@
   ".Lta_exp%=:\n\t"                                                              \
   "s_load_dwordx16 s[36:51], s[78:79], 832\n\t"                                  \
   "s_load_dwordx4 s[52:55], s[78:79], 1088\n\t"                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"   /* (in front of the constant: no LDS read of this block is in flight into v[30:31] here, but the order costs nothing -- bsr_stream_chunk_asm.h had the race) */ \
   "v_mov_b32_e32 v30, 0x20000000\n\t"   /* 1e10: what the clipped exp returns beyond 200 (and for NaN) */ \
   "v_mov_b32_e32 v31, 0x4202a05f\n\t"                                            \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                     \
   BSR_TA_EACH(BSR_SC_EXP)                                                        \
   BSR_TA_DISPATCH                                                                \
   /* ---- end of the entries: the pass's rows into the sums, then the next pass or the record */ \

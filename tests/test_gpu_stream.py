@@ -88,7 +88,7 @@ for k, t in enumerate([bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('cos', 
                        un('inv', un('ln', un('square', leaf(11 % d)), 1.0, 1.0))][:K]):
     ctx.set_current(0, k, flatten(t))
 ctx.refresh(0)
-trees = S.make_tapes(d, 40)
+trees = S.make_tapes(d, 32)
 x = lambda f: leaf(f % d)
 trees += [bi('sub', x(1), x(2)), bi('div', x(1), x(3)), bi('div', bi('+', x(1), x(2)), un('neg', x(3))), un('inv', x(3)),
           un('cubic', x(4)), un('cubic', bi('*', x(4), x(4))), un('sin', x(4)), un('cos', bi('+', x(4), x(1))),
@@ -100,6 +100,22 @@ trees += [bi('sub', x(1), x(2)), bi('div', x(1), x(3)), bi('div', bi('+', x(1), 
           un('inv', un('inv', un('inv', x(23)))), bi('sub', un('square', x(24)), un('square', x(25))),
           bi('*', un('ln', x(26), 2.0, 0.0), x(27)), un('neg', un('neg', x(28))), un('cos', un('neg', x(29))),
           un('cubic', un('cubic', x(30)))]
+# round 6: programs of several words and a second value below the accumulator (the chunk block of assembly; the C++ and the
+# tape-at-a-time interpreters send these to the stack machine): a Strahler-3 tree, one of 40 entries with a sin of huge
+# arguments and a cos BEHIND its first program word (the block leaves in the middle of an extension word and must come back
+# to it), 7 ln nodes, more than 8 terminals, a Strahler-4 tree (still the stack machine's)
+def _long(n):
+    t = x(1)
+    for j in range(n):
+        t = bi('+', t, x(5 + j % 11)) if j % 3 else un('neg', bi('*', un('ln', t, 0.25, 0.1), x(6 + j % 7)))
+    return t
+s3 = bi('*', bi('+', bi('*', x(1), x(2)), bi('*', x(3), x(5))), bi('+', bi('*', x(6), x(7)), bi('sub', x(8), x(9))))
+s4 = bi('+', bi('*', s3, bi('+', bi('*', x(10), x(11)), bi('*', x(12), x(13)))), bi('*', bi('+', bi('*', x(14), x(15)), bi('*', x(16), x(17))), bi('+', bi('*', x(18), x(19)), bi('sub', x(20), x(21)))))
+lnchain = x(2)
+for j in range(7):
+    lnchain = un('ln', bi('+', lnchain, x(3 + j)), 0.9 + 0.05 * j, 0.1 * j - 0.3)
+trees += [s3, un('sin', s3), bi('sub', un('cos', un('sin', bi('+', _long(18), x(4)))), x(5)), un('exp', un('neg', un('square', _long(30)))),
+          lnchain, bi('div', s3, un('ln', _long(12), 0.5, 2.0)), s4, _long(44)]
 trees = (trees * 2)[:B]   # (B = 100: more tapes than a launch's sixteen waves hold sets of sums for -- two passes)
 tapes = [flatten(t) for t in trees]
 n = len(tapes)
@@ -220,5 +236,146 @@ def test_streaming_pass_with_f32_storage(N, d, K):
             one = ctx.score_batch(tapes[i:i + 1], chains[:1], ks[i:i + 1], sig[:1])
             assert one.tobytes() == res[i:i + 1].tobytes(), i
         print("f32 storage N=%d d=%d K=%d: %d full-rank, %d flips, worst scaled rel %.2e" % (N, d, K, n_full, flips, worst))
+    finally:
+        ctx.close()
+
+
+def test_deep_tapes_take_the_assembly_block_and_match_the_oracle():
+    """BASELINE configs[4] says "deep trees (depth <= 12)"; until round 5 every such tape left the assembly block for the
+    out-of-line stack machine (13 x the time for 6 x the nodes).  Round 6: programs of several 64-bit words, up to eight ln
+    nodes and a second value below the accumulator.  64 candidates GROWN to height 8..12 by the reference's own grow()
+    (as bench.py's c5_deep leg draws them), at N = 1M, d = 50, K = 3: at least 80 % of them run in the assembly block
+    (`bsr_batch_stats`), ranks equal the oracle's, log-likelihoods within 1e-6 relative (ulp-chaotic trees exempt only
+    when the oracle's own value moves under a one-ulp perturbation of X), and the same scores come back bit for bit with
+    the block's round-5 limits (BSR_STREAM_DEEP=0: those tapes through the stack machine)."""
+    import subprocess
+    script = r"""
+import os, sys
+import numpy as np, pandas as pd
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "mcmc-symreg_amd")); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+import bsr_oracle as O
+from conftest import spec_from_node
+from bsr import grow
+from bsr.device import DeviceContext
+from bsr.node import Node, getHeight, getNum
+from bsr.tape import flatten
+N, d, K, B = 1_000_000, 50, 3, 64
+rs = np.random.RandomState(0)
+X = rs.uniform(-3, 3, size=(N, d))
+y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+ops = ['inv', 'ln', 'neg', 'sin', 'cos', 'exp', 'square', 'cubic', '+', '*']
+np.random.seed(4242)
+trees = []
+while len(trees) < B:
+    r = Node(0)
+    grow(r, d, ops, [0.1] * 10, [1] * 8 + [2, 2], -0.15, 1.0, 1.0)
+    if 8 <= getHeight(r) <= 12 and getNum(r) <= 400:
+        trees.append(r)
+def leaf(f):
+    n = Node(1); n.type = 0; n.feature = np.array([f]); return n
+def un(op, c, a=None, b=None):
+    n = Node(0); n.type, n.operator, n.left, n.a, n.b = 1, op, c, a, b; c.parent = n; return n
+def bi(op, l, r):
+    n = Node(0); n.type, n.operator, n.left, n.right = 2, op, l, r; l.parent = r.parent = n; return n
+cur = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('ln', un('exp', leaf(3)), 0.7, -0.2)]
+ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
+assert ctx.info()["row_pass"] == "k_stream"
+for k, t in enumerate(cur):
+    ctx.set_current(0, k, flatten(t))
+ctx.refresh(0)
+tapes = [flatten(t) for t in trees]
+ks = (np.arange(B) % K).astype(np.int32)
+with np.errstate(all="ignore"):
+    res = ctx.score_batch(tapes, np.zeros(B, np.int32), ks, np.full(B, 0.8)).copy()
+st = ctx.batch_stats(0)
+ctx.close()
+np.save(sys.argv[2], np.frombuffer(res.tobytes(), dtype=np.uint8))
+print("STATS", st["tapes"], st["asm_program_tapes"])
+if sys.argv[3] == "1":
+    Xdf = pd.DataFrame(X)
+    def ocol(node, Xd=Xdf):
+        with np.errstate(all="ignore"):
+            return O.allcal(O.tree_from_json(spec_from_node(node)), Xd, False)[:, 0]
+    cols = np.stack([ocol(t) for t in cur], axis=1)
+    n_full = n_ex = 0
+    for i, t in enumerate(trees):
+        with np.errstate(all="ignore"):
+            want = O.score_proposal(cols, int(ks[i]), ocol(t), y, 0.8)
+        assert (int(res["rank"][i]) == K) == (want["rank"] == K), (i, res[i], want)   # (codes/funcs.py:1226 asks `rank < K`)
+        if want["rank"] != K:
+            continue
+        n_full += 1
+        if not abs(res["loglik"][i] - want["loglik"]) <= 1e-6 * abs(want["loglik"]):
+            vals = []
+            for eps in (2.0 ** -52, -2.0 ** -52, 2.0 ** -51):
+                with np.errstate(all="ignore"):
+                    vals.append(O.score_proposal(cols, int(ks[i]), ocol(t, pd.DataFrame(X * (1.0 + eps))), y, 0.8).get("loglik", np.nan))
+            spread = max(abs(v - want["loglik"]) for v in vals)
+            assert spread > 1e-7 * abs(want["loglik"]) or not np.isfinite(spread), (i, res[i], want, vals)
+            n_ex += 1
+    print("ORACLE", n_full, n_ex)
+"""
+    out = {}
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for deep, check in (("2", "1"), ("0", "0")):
+            path = os.path.join(td, "r%s.npy" % deep)
+            env = dict(os.environ, BSR_STREAM_DEEP=deep)
+            p = subprocess.run([sys.executable, "-c", script, ROOT, path, check], env=env, capture_output=True, text=True, timeout=1500)
+            assert p.returncode == 0, (deep, p.stdout[-1500:], p.stderr[-3000:])
+            out[deep] = (np.load(path), p.stdout)
+    st = [ln for ln in out["2"][1].splitlines() if ln.startswith("STATS")][0].split()
+    assert int(st[2]) >= 0.8 * int(st[1]), out["2"][1]
+    st0 = [ln for ln in out["0"][1].splitlines() if ln.startswith("STATS")][0].split()
+    assert int(st0[2]) < int(st[2]), (out["0"][1], out["2"][1])       # (round 5's limits: the 64-bit programs only)
+    orc = [ln for ln in out["2"][1].splitlines() if ln.startswith("ORACLE")][0].split()
+    assert int(orc[1]) >= 16 and int(orc[2]) <= 6, out["2"][1]
+    assert (out["2"][0] == out["0"][0]).all(), np.nonzero(out["2"][0] != out["0"][0])[0][:20]
+
+
+def test_exp_beyond_its_clip_returns_the_constant_not_whatever_landed_in_its_register():
+    """Round 6 found this in the chunk block of assembly (rounds 4-5 shipped it): the inline exp writes its clip value 1e10
+    (what `exp` returns beyond 200 and for NaN, codes/funcs.py:184-188) into v[30:31] -- which is also a destination of the
+    chunk's y / basis reads, and it wrote it IN FRONT of the wait for those reads: when they landed behind it the constant
+    was gone, and exp(exp(x)) returned a basis value wherever exp(x) > 200 -- run-dependent, visible as soon as another
+    operator follows.  op(exp(exp(x5 + x6))) for op in sin, cos, inv at N = 1M: four scorings of the same batch, the tape
+    alone, and the oracle."""
+    import stream_check as S
+    N, d, K, B = 1_000_000, 50, 3, 64
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-3, 3, size=(N, d))
+    y = 1.35 * X[:, 0] * X[:, 1] + 5.5 * np.sin((X[:, 0] - 1) * (X[:, 1] - 1)) + 0.1 * rs.standard_normal(N)
+    leaf, un, bi = S.leaf, S.un, S.bi
+    ctx = DeviceContext(X, y, K=K, n_chains=1, max_batch=B)
+    try:
+        assert ctx.info()["row_pass"] == "k_stream"
+        cur = [bi('*', leaf(0), leaf(1)), un('sin', leaf(2)), un('ln', un('exp', leaf(3)), 0.7, -0.2)]
+        for k, t in enumerate(cur):
+            ctx.set_current(0, k, flatten(t))
+        ctx.refresh(0)
+        df = pd.DataFrame(X)
+        with np.errstate(all="ignore"):
+            cols = np.stack([O.allcal(S.ocopy(t), df)[:, 0] for t in cur], axis=1)
+        fill = [flatten(bi('+', un('sin', leaf(i % d)), leaf((i + 1) % d))) for i in range(B)]
+        chains = np.zeros(B, dtype=np.int32)
+        ks = (np.arange(B) % K).astype(np.int32)
+        sig = np.full(B, 0.8)
+        for op in ("sin", "cos", "inv"):
+            tree = un(op, un('exp', un('exp', bi('+', leaf(5), leaf(6)))))
+            tapes = list(fill)
+            for j in (5, 21, 40):
+                tapes[j] = flatten(tree)
+            with np.errstate(all="ignore"):
+                runs = [ctx.score_batch(tapes, chains, ks, sig).copy() for _ in range(4)]
+                one = ctx.score_batch(tapes[5:6], chains[:1], ks[5:6], sig[:1]).copy()
+                want = O.score_proposal(cols, int(ks[5]), O.allcal(S.ocopy(tree), df)[:, 0], y, 0.8)
+            assert all(r.tobytes() == runs[0].tobytes() for r in runs[1:]), op
+            assert one[0].tobytes() == runs[0][5].tobytes(), op
+            assert (int(runs[0]["rank"][5]) == K) == (want["rank"] == K), (op, runs[0][5], want)
+            # (sin / cos of arguments up to 1e10 are ulp-chaotic -- one ulp of x moves them across whole periods: the value is
+            # compared for inv only, whose column is smooth)
+            if want["rank"] == K and op == "inv":
+                assert abs(float(runs[0]["loglik"][5]) - want["loglik"]) <= 1e-6 * abs(want["loglik"]), (op, runs[0][5], want)
     finally:
         ctx.close()

@@ -20,6 +20,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "native", "build_san.sh")
 
 
+@pytest.fixture(scope="module")
+def engine_host_exe(tmp_path_factory):
+    """The native sampler against the CPU stand-in of the data side, plain -O2 build (one build for the tests that run it)."""
+    exe = str(tmp_path_factory.mktemp("engine_host") / "engine_host")
+    src = [os.path.join(ROOT, "mcmc-symreg_amd", "csrc", "bsr_engine.hip"), os.path.join(ROOT, "tests", "native", "stub_scorer.cpp"),
+           os.path.join(ROOT, "tests", "native", "engine_tsan_main.cpp")]
+    cmd = ["g++", "-std=c++17", "-O2", "-DBSR_HOST_ONLY", "-pthread", "-I" + os.path.join(ROOT, "include")]
+    for f in src:
+        cmd += ["-x", "c++", f]
+    b = subprocess.run(cmd + ["-o", exe], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-4000:]
+    return exe
+
+
 def _runtime(name):
     out = subprocess.run(["gcc", "-print-file-name=%s" % name], capture_output=True, text=True).stdout.strip()
     return out if os.path.isabs(out) and os.path.exists(out) else None
@@ -67,7 +81,7 @@ def test_golden_traces_through_the_address_sanitized_sampler(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-def test_the_sampler_predicts_most_rank_gate_rejections(tmp_path):
+def test_the_sampler_predicts_most_rank_gate_rejections(engine_host_exe):
     """What ends a speculative run of the native sampler is, nine times in ten, a rank-gate rejection nobody predicted
     (codes/funcs.py:1226-1228 draws no accept-uniform behind one: everything generated behind it is void).  The
     sampler predicts them from structure (repeats, linear spans), from an interval estimate of a candidate's scale that
@@ -75,14 +89,7 @@ def test_the_sampler_predicts_most_rank_gate_rejections(tmp_path):
     current state.  Pinned on the CPU stand-in of the data side (which computes the true ranks): of the gate's
     rejections in 8 chains x 2 000 proposals at least 85 % are predicted, and false alarms stay below the hits' tenth
     (before round 4: 38 % predicted on the GPU box's mix)."""
-    exe = str(tmp_path / "engine_host")
-    src = [os.path.join(ROOT, "mcmc-symreg_amd", "csrc", "bsr_engine.hip"), os.path.join(ROOT, "tests", "native", "stub_scorer.cpp"),
-           os.path.join(ROOT, "tests", "native", "engine_tsan_main.cpp")]
-    cmd = ["g++", "-std=c++17", "-O2", "-DBSR_HOST_ONLY", "-pthread", "-I" + os.path.join(ROOT, "include")]
-    for f in src:
-        cmd += ["-x", "c++", f]
-    b = subprocess.run(cmd + ["-o", exe], capture_output=True, text=True, timeout=900)
-    assert b.returncode == 0, b.stderr[-4000:]
+    exe = engine_host_exe
     r = subprocess.run([exe, "8", "2000"], env=dict(os.environ, BSR_ENGINE_PROF="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     import re
@@ -96,31 +103,24 @@ def test_the_sampler_predicts_most_rank_gate_rejections(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-def test_memo_answered_accepts_in_groups_of_several_chains(tmp_path):
+def test_memo_answered_accepts_in_groups_of_several_chains(engine_host_exe):
     """an accepted proposal that was answered from the score memo is in no GPU batch; its one-tape
     batch used to take the lane's slot INSIDE the loop over the batch's chains, and every later chain of that batch
     that accepted a GPU-scored proposal then committed by its index into the replaced batch (BSR_E_STATE, or -- index 0
     -- the wrong tape).  Groups of several chains (what `sharded.run_rank` and the bench run), long enough for two
     accepts in one batch: the memo must change nothing -- same digests with BSR_ENGINE_MEMO=1 and 0, whatever the
     grouping, also on the traced single-threaded path (all chains in one batch, commits through `last waited`)."""
-    exe = str(tmp_path / "engine_host")
-    src = [os.path.join(ROOT, "mcmc-symreg_amd", "csrc", "bsr_engine.hip"), os.path.join(ROOT, "tests", "native", "stub_scorer.cpp"),
-           os.path.join(ROOT, "tests", "native", "engine_tsan_main.cpp")]
-    cmd = ["g++", "-std=c++17", "-O2", "-DBSR_HOST_ONLY", "-pthread", "-I" + os.path.join(ROOT, "include")]
-    for f in src:
-        cmd += ["-x", "c++", f]
-    b = subprocess.run(cmd + ["-o", exe], capture_output=True, text=True, timeout=900)
-    assert b.returncode == 0, b.stderr[-4000:]
-    for n_chains in (4, 8, 16):
+    exe = engine_host_exe
+    for n_chains in (8, 16):       # (40 000 proposals per chain: 70-125 accepts, a third of them answered from the memo)
         outs = {}
         for groups in ("1", "2", "4"):
             for memo in ("1", "0"):
-                r = subprocess.run([exe, str(n_chains), "150000"], env=dict(os.environ, BSR_ENGINE_GROUPS=groups, BSR_ENGINE_MEMO=memo),
+                r = subprocess.run([exe, str(n_chains), "40000"], env=dict(os.environ, BSR_ENGINE_GROUPS=groups, BSR_ENGINE_MEMO=memo),
                                    capture_output=True, text=True, timeout=900)
                 assert r.returncode == 0, (n_chains, groups, memo, r.stderr[-2000:])
                 outs[(groups, memo)] = r.stdout
         for memo in ("1", "0"):   # traced: one group, no worker threads, bsr_commit through the last waited batch
-            r = subprocess.run([exe, str(n_chains), "150000", "1000"], env=dict(os.environ, BSR_ENGINE_MEMO=memo),
+            r = subprocess.run([exe, str(n_chains), "40000", "1000" if n_chains == 8 else "0"], env=dict(os.environ, BSR_ENGINE_MEMO=memo),
                                capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, (n_chains, "traced", memo, r.stderr[-2000:])
             outs[("traced", memo)] = r.stdout
