@@ -5,12 +5,12 @@ o=gpurun_out/r06
 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 for w in c2 c3 c5; do
   bash tools/profile_bench.sh r06_$w --workload $w --batch 64 > $o/profile_$w.txt 2>&1
-  cp gpurun_out/prof_r06_$w/kernel_stats.csv $o/kernel_stats_bench_${w}_B64_depth1.csv
+  cp gpurun_out/prof_r06_$w/kernel_stats.csv $o/kernel_stats_bench_${w}_B64.csv
   cp gpurun_out/prof_r06_$w/traffic.json $o/traffic_${w}_B64.json
   cp gpurun_out/prof_r06_$w/bench_stats.json $o/${w}_B64_bench_under_rocprof.json
 done
 bash tools/profile_bench.sh r06_c5f32 --workload c5 --batch 64 --dtype f32 > $o/profile_c5_f32.txt 2>&1
-cp gpurun_out/prof_r06_c5f32/kernel_stats.csv $o/kernel_stats_bench_c5_f32_B64_depth1.csv
+cp gpurun_out/prof_r06_c5f32/kernel_stats.csv $o/kernel_stats_bench_c5_f32_B64.csv
 cp gpurun_out/prof_r06_c5f32/traffic.json $o/traffic_c5_f32_B64.json
 for w in c2 c3; do   # the pipelined default too: what the kernels take while eight (six) batches share the chip
   bash tools/r06_stats.sh r06 $w > /dev/null 2>&1
