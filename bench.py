@@ -540,13 +540,16 @@ def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
             eng.seed(c, 1000 + ranks.rank * chains + c)
             eng.init_chain(c)
         eng.run(batch_per_chain=batch, max_props=200)            # warm-up
+        # ONE call of `seconds` (as BSR.fit makes one): a calibration run sizes it.  (Until round 6 the leg called run()
+        # in steps of 4 000 proposals per chain -- 8 ms each, a fifth of which went into starting and draining the worker
+        # threads' pipelines 375 times.)
+        t0 = time.perf_counter()
+        eng.run(batch_per_chain=batch, max_props=4200)
+        rate = 4000.0 / max(1e-6, time.perf_counter() - t0)       # proposals per chain and second
         done0 = sum(eng.result(c)["n_props"] for c in range(chains))
         ranks.barrier()
         t0 = time.perf_counter()
-        target = 200
-        while time.perf_counter() - t0 < seconds:
-            target += 4000
-            eng.run(batch_per_chain=batch, max_props=target)
+        eng.run(batch_per_chain=batch, max_props=4200 + max(4000, int(rate * seconds)))
         ranks.barrier()
         dt = ranks.max(time.perf_counter() - t0)
         res = [eng.result(c, current=True) for c in range(chains)]

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -27,6 +28,12 @@
 #include "../../include/bsr_hip.h"
 #include "bsr_internal.h"
 #include "bsr_span.h"
+
+#if defined(__x86_64__) || defined(__i386__)
+#define BSR_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define BSR_CPU_RELAX() std::this_thread::yield()
+#endif
 
 namespace {
 
@@ -1822,12 +1829,35 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     int slot = -1;  // >= 0: this group's worker thread owns that batch slot
     bool inflight = false;
   };
+  // A group's chains are independent of each other between the batch's assembly and its results (a chain's candidates
+  // depend on its own trees and its own random stream; consuming them touches that chain alone, the rare accept takes the
+  // context lock), so a group of several chains deals the per-chain halves of its cycle -- generate() and consume() -- to
+  // HELPER threads of its own: the batch the GPU launches stays the group's (64 tapes cost the chip little more than
+  // 32), the threads that generate and consume are as many as the chains.  A chain always goes to the same thread
+  // (index in the group modulo the group's threads: what it generated is in that core's cache when it is consumed);
+  // the worker posts a round (kind + per-chain arguments), does its own share and goes on once every helper has
+  // reported the round done, so nothing else touches a chain while a helper works on it.
+  enum { JOB_GENERATE = 0, JOB_CONSUME = 1 };
+  struct HelperCtl {
+    std::atomic<uint32_t> go{0}, done{0};
+    char pad[56];
+  };
   struct Group {
     std::vector<ChainS*> chains;
     Lane lane[3];   // the batch being consumed next and up to two generated ahead of it
     int fifo[3] = {0, 0, 0}, n_fly = 0;   // lanes in flight, oldest first
     double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
     double evt_ema = 0.0;   // share of this group's chain batches that ended in an event lately (lookahead pays while it is low)
+    // the round on offer (written by the worker between rounds only)
+    int job_kind = JOB_GENERATE, job_lane = 0;
+    std::vector<int> room_of, ahead_of;               // JOB_GENERATE: per chain, room < 0: not live
+    std::vector<int> ev_of, rc_of;                    // JOB_CONSUME: per chain, index of its span in the MH scan; its return code
+    std::vector<char> broke_of;
+    std::vector<std::vector<DeferredAccept>> deferred_of;
+    std::unique_ptr<HelperCtl[]> ctl;
+    std::atomic<int> quit{0};
+    uint32_t round = 0;
+    int n_helpers = 0;
   };
   auto is_live = [&](const ChainS& c) { return c.inited && !c.done && (max_props < 0 || c.n_props < max_props); };
   std::vector<ChainS*> live;
@@ -1885,6 +1915,82 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   const bool use_mh = e->device_mh && !trace && e->K > 1;
   const bool memo_on = e->score_memo && !use_mh;   // (the device-side MH scan wants every proposal's score on the device)
 
+  // the per-chain half of a round
+  auto chain_job = [&](Group& g, size_t ci) {
+    ChainS& c = *g.chains[ci];
+    if (g.job_kind == JOB_GENERATE) {
+      if (g.room_of[ci] > 0) generate(e, c, g.room_of[ci], g.ahead_of[ci], memo_on, use_mh);
+      else if (g.room_of[ci] == 0) c.cands.clear();
+      return;
+    }
+    Lane& L = g.lane[g.job_lane];
+    const int li = g.job_lane;
+    g.rc_of[ci] = BSR_OK;
+    g.broke_of[ci] = 0;
+    g.deferred_of[ci].clear();
+    if (L.span[ci].second == 0) return;
+    if (!L.valid[ci] || c.done) {   // generated behind a batch that did not end as speculated (or that ended the chain): thrown away unseen
+      c.n_discard += (int64_t)L.cands[ci].size();
+      L.cands[ci].clear();
+      return;
+    }
+    const bsr_event* ev = use_mh ? &L.events[g.ev_of[ci]] : nullptr;
+    c.cands.swap(L.cands[ci]);
+    c.end_state = L.end_state[ci];
+    c.start_state = L.start_state[ci];
+    if (memo_on)   // what the GPU scored for this chain's (unchanged) state: kept for the repeats to come
+      for (size_t q = 0; q < c.cands.size(); ++q) {
+        const size_t at = (size_t)L.span[ci].first + q;
+        if (at < L.hit.size() && !L.hit[at]) c.memo.put(c.cands[q].ghash, c.cands[q].gcheck, L.res[at]);
+      }
+    bool more_ahead = false;
+    for (int ol = 0; ol < 3; ++ol) {
+      const Lane& O = g.lane[ol];
+      more_ahead = more_ahead || (ol != li && O.inflight && ci < O.valid.size() && O.valid[ci] && O.span[ci].second > 0);
+    }
+    bool broke = false;
+    g.rc_of[ci] = consume(e, c, L.res.data() + L.span[ci].first, L.span[ci].first, L.slot, ev, more_ahead, &broke,
+                          L.compact ? L.gpu_of.data() : nullptr, &g.deferred_of[ci]);
+    g.broke_of[ci] = broke ? 1 : 0;
+  };
+  auto run_round = [&](Group& g, int kind, int lane) {
+    g.job_kind = kind;
+    g.job_lane = lane;
+    const size_t nc = g.chains.size();
+    if (g.n_helpers == 0) {
+      for (size_t ci = 0; ci < nc; ++ci) chain_job(g, ci);
+      return;
+    }
+    const size_t T = (size_t)g.n_helpers + 1;
+    ++g.round;
+    for (int h = 0; h < g.n_helpers; ++h) g.ctl[h].go.store(g.round, std::memory_order_release);
+    for (size_t ci = 0; ci < nc; ci += T) chain_job(g, ci);
+    for (int h = 0; h < g.n_helpers; ++h)
+      for (int spins = 0; g.ctl[h].done.load(std::memory_order_acquire) != g.round; ++spins) {
+        if (spins < 4096) BSR_CPU_RELAX();
+        else std::this_thread::yield();
+      }
+  };
+  auto helper = [&](Group& g, int h) {
+    bsr_internal_place_thread();
+    const size_t T = (size_t)g.n_helpers + 1;
+    uint32_t seen = 0;
+    for (int spins = 0;; ++spins) {
+      if (g.quit.load(std::memory_order_acquire)) break;
+      const uint32_t r = g.ctl[h].go.load(std::memory_order_acquire);
+      if (r != seen) {
+        seen = r;
+        for (size_t ci = (size_t)h + 1; ci < g.chains.size(); ci += T) chain_job(g, ci);
+        g.ctl[h].done.store(r, std::memory_order_release);
+        spins = 0;
+        continue;
+      }
+      // a worker's round comes every few tens of microseconds while the run lasts: spin for about that long, then give
+      // the CPU away between looks
+      if (spins < 20000) BSR_CPU_RELAX();
+      else std::this_thread::yield();
+    }
+  };
   // generates and submits the batch of lane `li`; ahead: behind the candidates the group's other lane has in flight
   auto submit = [&](Group& g, int li, bool ahead) -> int {
     Lane& L = g.lane[li];
@@ -1910,13 +2016,13 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     for (ChainS* c : g.chains) n_live += is_live(*c) ? 1 : 0;
     if (n_live == 0) return BSR_OK;
     const int per = std::max(1, std::min<int>(batch_per_chain, per_group_cap / n_live));
+    // generating phase: every live chain's candidates (the group's helper threads take their chains' share)
+    const double tg0 = now_s();
+    g.room_of.assign(nc, -1);
+    g.ahead_of.assign(nc, 0);
     for (size_t ci = 0; ci < nc; ++ci) {
       ChainS* c = g.chains[ci];
-      L.cands[ci].clear();
-      if (!is_live(*c)) {
-        L.span.push_back({(int)L.chs.size(), 0});
-        continue;
-      }
+      if (!is_live(*c)) continue;
       // what this chain has in flight ahead of the new candidates (the other lane's share, unless an event voided it)
       int n_ahead = 0;
       if (ahead)
@@ -1928,10 +2034,19 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       // speculate only about as far as this chain's batches have recently been consumed
       if (c->run_ema < 1e8) room = std::min(room, std::max(2, (int)std::ceil(2.0 * c->run_ema)));
       if (max_props >= 0) room = (int)std::min<int64_t>(room, max_props - c->n_props - n_ahead);
-      const double tg0 = now_s();
-      if (room > 0) generate(e, *c, room, n_ahead, memo_on, use_mh);
-      else c->cands.clear();
-      g.t_gen += now_s() - tg0;
+      g.room_of[ci] = std::max(0, room);
+      g.ahead_of[ci] = n_ahead;
+    }
+    run_round(g, JOB_GENERATE, li);
+    g.t_gen += now_s() - tg0;
+    for (size_t ci = 0; ci < nc; ++ci) {
+      ChainS* c = g.chains[ci];
+      L.cands[ci].clear();
+      if (g.room_of[ci] < 0) {
+        L.span.push_back({(int)L.chs.size(), 0});
+        continue;
+      }
+      const int room = g.room_of[ci];
       L.span.push_back({(int)L.chs.size(), (int)c->cands.size()});
       for (const Cand& cd : c->cands) {
         if (memo_on) {
@@ -2032,41 +2147,28 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
       for (size_t i = 0; i < L.hit.size(); ++i)
         if (L.hit[i]) L.res[i] = L.hit_val[hv++];
     }
+    const size_t nc = g.chains.size();
+    g.ev_of.assign(nc, 0);
+    g.rc_of.assign(nc, BSR_OK);
+    g.broke_of.assign(nc, 0);
+    g.deferred_of.resize(nc);
     int sp = 0;  // chains with proposals in this batch, in order: the spans of the MH scan
+    for (size_t i = 0; i < nc; ++i)
+      if (L.span[i].second != 0) g.ev_of[i] = sp++;
+    std::vector<char> counted(nc, 0);
+    for (size_t i = 0; i < nc; ++i) counted[i] = L.span[i].second != 0 && L.valid[i] && !g.chains[i]->done;
+    run_round(g, JOB_CONSUME, li);
     std::vector<DeferredAccept> deferred;   // accepts answered from the score memo: their device half runs behind the loop
-    for (size_t i = 0; i < g.chains.size(); ++i) {
-      if (L.span[i].second == 0) continue;
-      ChainS& c = *g.chains[i];
-      const bsr_event* ev = use_mh ? &L.events[sp] : nullptr;
-      ++sp;
-      if (!L.valid[i] || c.done) {   // generated behind a batch that did not end as speculated (or that ended the chain): thrown away unseen
-        c.n_discard += (int64_t)L.cands[i].size();
-        L.cands[i].clear();
-        continue;
-      }
-      c.cands.swap(L.cands[i]);
-      c.end_state = L.end_state[i];
-      c.start_state = L.start_state[i];
-      if (memo_on)   // what the GPU scored for this chain's (unchanged) state: kept for the repeats to come
-        for (size_t q = 0; q < c.cands.size(); ++q) {
-          const size_t at = (size_t)L.span[i].first + q;
-          if (at < L.hit.size() && !L.hit[at]) c.memo.put(c.cands[q].ghash, c.cands[q].gcheck, L.res[at]);
-        }
-      bool more_ahead = false;
-      for (int ol = 0; ol < 3; ++ol) {
-        const Lane& O = g.lane[ol];
-        more_ahead = more_ahead || (ol != li && O.inflight && i < O.valid.size() && O.valid[i] && O.span[i].second > 0);
-      }
-      bool broke = false;
-      r = consume(e, c, L.res.data() + L.span[i].first, L.span[i].first, L.slot, ev, more_ahead, &broke,
-                  L.compact ? L.gpu_of.data() : nullptr, &deferred);
-      g.evt_ema = 0.9 * g.evt_ema + (broke ? 0.1 : 0.0);
-      if (broke)   // what was generated behind these is void
+    for (size_t i = 0; i < nc; ++i) {
+      if (!counted[i]) continue;
+      g.evt_ema = 0.9 * g.evt_ema + (g.broke_of[i] ? 0.1 : 0.0);
+      if (g.broke_of[i])   // what was generated behind these is void
         for (int ol = 0; ol < 3; ++ol) {
           Lane& O = g.lane[ol];
           if (ol != li && O.inflight && i < O.valid.size()) O.valid[i] = 0;
         }
-      if (r != BSR_OK) return r;
+      if (g.rc_of[i] != BSR_OK) return g.rc_of[i];
+      deferred.insert(deferred.end(), g.deferred_of[i].begin(), g.deferred_of[i].end());
     }
     // every chain of the batch has been consumed: the lane's slot is free for the one-tape batches of the accepts that
     // were answered from the memo (run inside the loop they replaced the staged batch the later chains of it
@@ -2124,10 +2226,41 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         first_rc.compare_exchange_strong(expect, r);
       }
     };
-    std::vector<std::thread> th;
+    // Helper threads (Group::ctl): ONE per group of several chains, as far as the CPUs left over next to the workers and
+    // the library's two submission threads allow -- the CPU budget of the rank and the L3 domain its threads are
+    // confined to (csrc/bsr_place.hip: 8 cores and their SMT siblings on the hosts of MI355X boxes; helpers spin between
+    // rounds, so a thread more than there are CPUs stalls everybody: 16 chains with 12 helpers 3.4 M consumed
+    // proposals/s against 6.3 M with 4).  Measured, 8 chains x 32, K = 3, N = 100k (profiles/r06_engine_helpers.txt): none
+    // 4.1 M/s, one per group 4.4-4.7 M/s; 16 chains 6.3-6.4 M/s; a second batch ahead next to them, threads outside the
+    // L3 domain or two groups of four threads: no better.  BSR_ENGINE_HELPERS: the total (0 = none), dealt one per group
+    // and round.
+    int cpus = (int)std::floor(bsr_internal_cpu_budget());
+    if (bsr_internal_placed_cpus() > 0) cpus = std::min(cpus, bsr_internal_placed_cpus());
+    int helpers_left = std::max(0, cpus - n_groups - 2);
+    int per_group = 1;
+    if (getenv("BSR_ENGINE_HELPERS")) {
+      helpers_left = std::max(0, atoi(getenv("BSR_ENGINE_HELPERS")));
+      per_group = 1 << 20;
+    }
+    for (bool any = true; any && helpers_left > 0;) {
+      any = false;
+      for (Group& g : groups)
+        if (helpers_left > 0 && g.n_helpers < per_group && g.n_helpers + 1 < (int)g.chains.size()) {
+          ++g.n_helpers;
+          --helpers_left;
+          any = true;
+        }
+    }
+    std::vector<std::thread> th, hth;
+    for (Group& g : groups)
+      if (g.n_helpers > 0) g.ctl.reset(new HelperCtl[g.n_helpers]);
+    for (Group& g : groups)
+      for (int h = 0; h < g.n_helpers; ++h) hth.emplace_back(helper, std::ref(g), h);
     for (int gi = 1; gi < n_groups; ++gi) th.emplace_back(worker, std::ref(groups[gi]), true);
     worker(groups[0], false);
     for (auto& t : th) t.join();
+    for (Group& g : groups) g.quit.store(1, std::memory_order_release);
+    for (auto& t : hth) t.join();
     rc = first_rc.load();
   } else {
     for (Group& g : groups) {

@@ -273,6 +273,8 @@ __attribute__((visibility("hidden"))) void bsr_internal_lock(bsr_ctx* c);
 __attribute__((visibility("hidden"))) void bsr_internal_unlock(bsr_ctx* c);
 // CPUs this process may use (cgroup quota / local ranks): sizes the submission threads and the sampler's worker threads
 __attribute__((visibility("hidden"))) double bsr_internal_cpu_budget();
+// CPUs of the L3 domain the library's threads are confined to (csrc/bsr_place.hip; 0: no placement)
+__attribute__((visibility("hidden"))) int bsr_internal_placed_cpus();
 // confines the calling thread (a thread the library started) to the library's CPUs: one L3 domain of the host
 __attribute__((visibility("hidden"))) void bsr_internal_place_thread();
 

@@ -62,3 +62,7 @@ __attribute__((visibility("hidden"))) void bsr_internal_place_thread() {
   (void)pthread_setaffinity_np(pthread_self(), sizeof g_lib_cpus, &g_lib_cpus);
 }
 
+// CPUs of the set the library's threads are confined to (0: no placement): the sampler sizes its helper threads by it
+__attribute__((visibility("hidden"))) int bsr_internal_placed_cpus() {
+  return g_lib_cpus_ok.load(std::memory_order_acquire) ? CPU_COUNT(&g_lib_cpus) : 0;
+}

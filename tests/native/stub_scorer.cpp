@@ -389,3 +389,4 @@ void bsr_internal_unlock(bsr_ctx* c) { c->mu.unlock(); }
 void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi) { *lo = c->lo.data(); *hi = c->hi.data(); }
 double bsr_internal_cpu_budget() { return 16.0; }
 void bsr_internal_place_thread() {}
+int bsr_internal_placed_cpus() { return 0; }

@@ -182,3 +182,33 @@ def test_the_score_memo_changes_nothing_a_chain_does(monkeypatch, n_chains, grou
     looks = sum(s[1] for s in out["1"][1])
     assert sum(s[0] for s in out["0"][1]) == 0
     assert looks > 0 and hits / looks > 0.03, (hits, looks)
+
+
+@pytest.mark.parametrize("n_chains,groups,helpers", [(8, 4, "4"), (8, 2, "6"), (16, 4, "4"), (6, 1, "5")])
+def test_helper_threads_change_nothing_a_chain_does(monkeypatch, n_chains, groups, helpers):
+    """A group of several chains deals the per-chain halves of its cycle (generate, consume) to helper threads of its own
+    (csrc/bsr_engine.hip: Group::ctl, round 6); a chain's candidates depend on its own trees and random stream only, so the
+    chains must end exactly where they end without helpers -- trees, counters, Beta, RMSE history (codes/bsr_class.py:99:
+    the reference runs its chains one after the other)."""
+    from bsr.chain import DeviceScorer
+    from bsr.native import NativeEngine
+    from bsr.node import Express
+    X, y = _c4_data()
+    K, val = 3, 60
+    out = {}
+    monkeypatch.setenv("BSR_ENGINE_GROUPS", str(groups))
+    for h in (helpers, "0"):
+        monkeypatch.setenv("BSR_ENGINE_HELPERS", h)
+        scorer = DeviceScorer(X, y, K, n_chains=n_chains, max_batch=32 * n_chains)
+        eng = NativeEngine(scorer.ctx, n_chains, X.shape[1], val=val)
+        for c in range(n_chains):
+            eng.seed(c, 3000 + c)
+            eng.init_chain(c)
+        eng.run(batch_per_chain=32)
+        res = [eng.result(c) for c in range(n_chains)]
+        eng.close()
+        scorer.close()
+        out[h] = [([Express(t) for t in r["roots"]], r["n_props"], r["n_accept"], r["n_rank_rejects"],
+                   r["beta"].tobytes(), tuple(r["errs"])) for r in res]
+    assert out[helpers] == out["0"]
+    assert sum(r[2] for r in out["0"]) > 0 and all(r[1] > 0 for r in out["0"])
