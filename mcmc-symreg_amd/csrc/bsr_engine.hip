@@ -352,8 +352,10 @@ struct Params {
   // log(1 + depth) beta
   enum { DEPTH_TAB = 64 };
   double fs_term[DEPTH_TAB], fs_op[DEPTH_TAB];
+  double grow_prob[DEPTH_TAB];   // grow's 1 / (1 + depth)^-beta (codes/funcs.py:79), by the call grow made per node
   void fill_depth_tables() {
     for (int dpt = 0; dpt < DEPTH_TAB; ++dpt) {
+      grow_prob[dpt] = 1 / std::pow(1 + dpt, -beta);
       double ls = 0;
       ls += flog(1 - 1 / std::pow(1 + dpt, -beta));
       ls -= std::log((double)n_feature);
@@ -399,7 +401,7 @@ void grow(Tree& t, int i, const Params& P, double sigma_a, double sigma_b, Legac
   const int depth = t.n[i].depth;
   bool pick = true;
   if (depth > 0) {
-    const double prob = 1 / std::pow(1 + depth, -P.beta);
+    const double prob = depth < Params::DEPTH_TAB ? P.grow_prob[depth] : 1 / std::pow(1 + depth, -P.beta);
     if (r.uniform() > prob) {
       t.n[i].feature = (int)r.randint(0, P.n_feature);  // :83, overwritten by the second draw at :99
       t.n[i].type = 0;
@@ -521,29 +523,61 @@ int count_terms(const Tree& t, int root, int* total) {
   return nt;
 }
 
-// One structural proposal on the private copy `t` (codes/funcs.py:406-923)
-void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, LegacyRng& r, Move& mv) {
-  int Root = t.root;
-  BSR_SCRATCH(int, tree);
-  preorder(t, Root, tree);
-  mv.ln_nodes.clear();
-  mv.last_a.clear();
-  mv.last_b.clear();
-  BSR_SCRATCH(int, term);
-  BSR_SCRATCH(int, nterm);
-  BSR_SCRATCH(int, detcd);
+// What a proposal's first lines derive from the tree it starts from (codes/funcs.py:406-480: the node lists of the tree,
+// its ln nodes and their parameters, the candidates for a detransformation) -- the same for every proposal of tree k of
+// a chain until that tree is replaced, and a chain makes ~1 000 proposals between two accepted ones: kept per (chain, k)
+// with the compact copy of the tree the proposals start from (`base`: nodes in pre-order, so its node list is 0..n-1).
+struct PropSetup {
+  Tree base;
+  std::vector<int> term, nterm, detcd, ln_nodes;
+  std::vector<double> last_a, last_b;
+};
+void prop_lists(const Tree& t, const std::vector<int>& tree, std::vector<int>& term, std::vector<int>& nterm,
+                std::vector<int>& detcd, std::vector<int>& ln_nodes, std::vector<double>& last_a, std::vector<double>& last_b) {
+  ln_nodes.clear();
+  last_a.clear();
+  last_b.clear();
+  term.clear();
+  nterm.clear();
   for (int i : tree) {
     if (t.n[i].op == OP_LN && t.n[i].type == 1) {
-      mv.ln_nodes.push_back(i);
-      mv.last_a.push_back(t.n[i].a);
-      mv.last_b.push_back(t.n[i].b);
+      ln_nodes.push_back(i);
+      last_a.push_back(t.n[i].a);
+      last_b.push_back(t.n[i].b);
     }
     (t.n[i].type == 0 ? term : nterm).push_back(i);
   }
+  detr_candidates(t, tree, detcd);
+}
+void build_setup(const Tree& src, PropSetup& ps) {
+  clone_into(src, src.root, ps.base);
+  BSR_SCRATCH(int, tree);
+  preorder(ps.base, ps.base.root, tree);
+  prop_lists(ps.base, tree, ps.term, ps.nterm, ps.detcd, ps.ln_nodes, ps.last_a, ps.last_b);
+}
+
+// One structural proposal on the private copy `t` (codes/funcs.py:406-923); ps: `t` is a copy of ps->base
+void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, LegacyRng& r, Move& mv, const PropSetup* ps = nullptr) {
+  int Root = t.root;
+  BSR_SCRATCH(int, tree_own);
+  BSR_SCRATCH(int, term_own);
+  BSR_SCRATCH(int, nterm_own);
+  BSR_SCRATCH(int, detcd_own);
+  if (ps) {
+    mv.ln_nodes = ps->ln_nodes;
+    mv.last_a = ps->last_a;
+    mv.last_b = ps->last_b;
+  } else {
+    preorder(t, Root, tree_own);
+    prop_lists(t, tree_own, term_own, nterm_own, detcd_own, mv.ln_nodes, mv.last_a, mv.last_b);
+  }
+  const std::vector<int>& term = ps ? ps->term : term_own;
+  const std::vector<int>& nterm = ps ? ps->nterm : nterm_own;
+  const std::vector<int>& detcd = ps ? ps->detcd : detcd_own;
+  const size_t n_tree = ps ? ps->base.n.size() : tree_own.size();   // nodes of the tree (ps: node i is the i-th in pre-order)
   const int ltNum = (int)mv.ln_nodes.size();
   int change = CH_NONE;
   double Q = 1, Qinv = 1;
-  detr_candidates(t, tree, detcd);
 
   const double p_stay = 0.25 * ltNum / (ltNum + 3);                                    // :475-480
   const double p_grow = (1 - p_stay) * std::min(1.0, 4.0 / ((double)nterm.size() + 2)) / 3;
@@ -631,7 +665,8 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
     }
     t.n[Root].parent = -1;
     up_depth(t, Root);
-    std::vector<int> nt_order, ndet;
+    BSR_SCRATCH(int, nt_order);
+    BSR_SCRATCH(int, ndet);
     preorder(t, Root, nt_order);
     int new_lt = 0;
     for (int i : nt_order) new_lt += (t.n[i].op == OP_LN && t.n[i].type == 1);
@@ -645,7 +680,8 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
     if (cut >= 0) Qinv = Qinv * fexp(fstruc0(t, cut, P, sigma_a, sigma_b));  // cut keeps its stale depths
   } else if (u <= p_stay + p_grow + p_prune + p_detr + p_trans) {                       // :679-786
     action = A_TRANS;
-    const int ins = tree[r.randint(0, (int64_t)tree.size())];
+    const int64_t ins_at = r.randint(0, (int64_t)n_tree);
+    const int ins = ps ? (int)ins_at : tree_own[(size_t)ins_at];
     const int k = choose_op(P, r);
     const int nn = t.add(t.n[ins].depth);
     t.n[nn].op = P.op_code[k];
@@ -664,16 +700,17 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
     t.n[ins].parent = nn;
     if (t.n[nn].type == 1) {
       up_depth(t, Root);
-      Q = p_trans * P.w[k] / (double)tree.size();
+      Q = p_trans * P.w[k] / (double)n_tree;
     } else {
       const int nr = t.add(t.n[nn].depth + 1);
       t.n[nn].right = nr;
       t.n[nr].parent = nn;
       up_depth(t, Root);
       grow(t, nr, P, sigma_a, sigma_b, r);
-      Q = p_trans * P.w[k] * fexp(fstruc0(t, nr, P, sigma_a, sigma_b)) / (double)tree.size();
+      Q = p_trans * P.w[k] * fexp(fstruc0(t, nr, P, sigma_a, sigma_b)) / (double)n_tree;
     }
-    std::vector<int> nt_order, ndet;
+    BSR_SCRATCH(int, nt_order);
+    BSR_SCRATCH(int, ndet);
     preorder(t, Root, nt_order);
     int new_lt = 0;
     for (int i : nt_order) new_lt += (t.n[i].op == OP_LN && t.n[i].type == 1);
@@ -755,9 +792,17 @@ void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, Legacy
                  double* sb2_out, double* hratio, double* detjacob) {
   BSR_SCRATCH(int, order);
   BSR_SCRATCH(int, lns);
-  preorder(t, t.root, order);
-  for (int i : order)
-    if (t.n[i].op == OP_LN && t.n[i].type == 1) lns.push_back(i);
+  bool any_ln = false;   // (four trees in five hold no ln node at all, attached or cut off: nothing to list then)
+  for (const TNode& nd : t.n)
+    if (nd.op == OP_LN && nd.type == 1) {
+      any_ln = true;
+      break;
+    }
+  if (any_ln) {
+    preorder(t, t.root, order);
+    for (int i : order)
+      if (t.n[i].op == OP_LN && t.n[i].type == 1) lns.push_back(i);
+  }
   double new_sa2 = invgamma_rvs(r, 1);                                                  // :945-946
   double new_sb2 = invgamma_rvs(r, 1);
   const std::vector<double>& last_a = mv.last_a;
@@ -1111,6 +1156,12 @@ struct ChainS {
   std::vector<double> siga, sigb, Beta, errs;
   std::vector<double> fs_old_s, fs_old_p;
   std::vector<char> fs_old_ok;
+  std::vector<PropSetup> setup;     // per tree k: what its proposals start from (valid while setup_ok[k])
+  std::vector<char> setup_ok;
+  // storage of the candidates that have been consumed or thrown away, for the ones generated next (a candidate's tree
+  // and tape were two allocations per proposal)
+  std::vector<std::vector<TNode>> pool_nodes;
+  std::vector<std::vector<bsr_node>> pool_tape;
   double sigma = 1.0, sse_old = 0.0;
   int total = 0, count = 0;
   bool done = false, inited = false, last_stale = false;
@@ -1143,6 +1194,21 @@ struct ChainS {
   LegacyRng gen_start;     // the stream in front of the batch generate() built last (travels with the batch: Lane::start_state)
   LegacyRng start_state;   // the stream in front of the batch being consumed (what the candidates' marks are replayed from)
 };
+
+// the end of a list of candidates: their storage goes to the chain's pools
+void recycle(ChainS& c, std::vector<Cand>& v) {
+  for (Cand& cd : v) {
+    if (cd.tree.n.capacity() > 0 && c.pool_nodes.size() < 256) {
+      c.pool_nodes.emplace_back();
+      c.pool_nodes.back().swap(cd.tree.n);
+    }
+    if (cd.tape.capacity() > 0 && c.pool_tape.size() < 256) {
+      c.pool_tape.emplace_back();
+      c.pool_tape.back().swap(cd.tape);
+    }
+  }
+  v.clear();
+}
 
 }  // namespace
 
@@ -1199,6 +1265,7 @@ int refresh_chain(bsr_engine* e, ChainS& c) {
   // every fitted value of a non-finite old state is NaN: Series.sum(skipna=True) gives 0.0, ndarray sum NaN
   c.sse_old = any ? (e->y_is_series ? 0.0 : kNaN) : info.sse_old;
   std::fill(c.fs_old_ok.begin(), c.fs_old_ok.end(), 0);
+  std::fill(c.setup_ok.begin(), c.setup_ok.end(), 0);
   return BSR_OK;
 }
 
@@ -1228,6 +1295,8 @@ int init_chain(bsr_engine* e, ChainS& c) {  // codes/bsr_class.py:116-163
   c.fs_old_s.assign(K, 0.0);
   c.fs_old_p.assign(K, 0.0);
   c.fs_old_ok.assign(K, 0);
+  c.setup.resize(K);
+  c.setup_ok.assign(K, 0);
   c.def_ema.assign(K, 0.0);
   c.gate_memo.clear();        // (a chain object is used again for the next restart: nothing of the last one's state stands)
   c.gate_pass_memo.clear();
@@ -1392,7 +1461,7 @@ std::string tree_text(const Tree& t, int i) {
 // `ahead`: candidates of this chain generated before and not consumed yet (a batch in flight: they are assumed to
 // end as speculated); the new ones continue the sweep behind them, from the random stream where it stands
 void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on = false, bool device_mh = true) {
-  c.cands.clear();
+  recycle(c, c.cands);
   c.cands.reserve((size_t)std::max(0, max_n));
   c.gen_start = c.rng;   // (one copy of the stream's state per batch; the candidates carry positions in it)
   int total = c.total + ahead, count = (c.count + ahead) % e->K;
@@ -1400,11 +1469,25 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on =
     if (count == 0 && total >= e->val) break;  // `while total < val` is only tested between sweeps
     c.cands.emplace_back();
     Cand& cd = c.cands.back();
+    if (!c.pool_nodes.empty()) {
+      cd.tree.n.swap(c.pool_nodes.back());
+      c.pool_nodes.pop_back();
+    }
+    if (!c.pool_tape.empty()) {
+      cd.tape.swap(c.pool_tape.back());
+      c.pool_tape.pop_back();
+      cd.tape.clear();
+    }
     const int k = count;
     cd.k = k;
-    clone_into(c.roots[k], c.roots[k].root, cd.tree);
-    Move mv;
-    prop_inplace(cd.tree, e->P, c.siga[k], c.sigb[k], c.rng, mv);
+    if (!c.setup_ok[k]) {
+      build_setup(c.roots[k], c.setup[k]);
+      c.setup_ok[k] = 1;
+    }
+    cd.tree.n.reserve(c.setup[k].base.n.size() + 8);
+    cd.tree = c.setup[k].base;
+    static thread_local Move mv;   // (keeps its lists' storage; every field is set by prop_inplace)
+    prop_inplace(cd.tree, e->P, c.siga[k], c.sigb[k], c.rng, mv, &c.setup[k]);
     cd.new_sigma = invgamma_rvs(c.rng, 4);
     aux_inplace(cd.tree, mv, c.siga[k], c.sigb[k], c.rng, &cd.new_sa2, &cd.new_sb2, &cd.hratio, &cd.detjacob);
     cd.change = mv.change;
@@ -1693,7 +1776,7 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
   if (broke) c.run_ema = (c.run_ema > 1e8) ? used : 0.7 * c.run_ema + 0.3 * used;
   else if (c.run_ema < 1e8) c.run_ema = 0.7 * c.run_ema + 0.3 * (2.0 * used);
   if (!c.done && c.count == 0 && c.total >= e->val) c.done = true;
-  c.cands.clear();
+  recycle(c, c.cands);
   return BSR_OK;
 }
 
@@ -1920,7 +2003,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     ChainS& c = *g.chains[ci];
     if (g.job_kind == JOB_GENERATE) {
       if (g.room_of[ci] > 0) generate(e, c, g.room_of[ci], g.ahead_of[ci], memo_on, use_mh);
-      else if (g.room_of[ci] == 0) c.cands.clear();
+      else if (g.room_of[ci] == 0) recycle(c, c.cands);
       return;
     }
     Lane& L = g.lane[g.job_lane];
@@ -1931,7 +2014,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     if (L.span[ci].second == 0) return;
     if (!L.valid[ci] || c.done) {   // generated behind a batch that did not end as speculated (or that ended the chain): thrown away unseen
       c.n_discard += (int64_t)L.cands[ci].size();
-      L.cands[ci].clear();
+      recycle(c, L.cands[ci]);
       return;
     }
     const bsr_event* ev = use_mh ? &L.events[g.ev_of[ci]] : nullptr;
@@ -2041,7 +2124,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     g.t_gen += now_s() - tg0;
     for (size_t ci = 0; ci < nc; ++ci) {
       ChainS* c = g.chains[ci];
-      L.cands[ci].clear();
+      recycle(*c, L.cands[ci]);
       if (g.room_of[ci] < 0) {
         L.span.push_back({(int)L.chs.size(), 0});
         continue;
