@@ -1911,6 +1911,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     int32_t ticket = -1;
     int slot = -1;  // >= 0: this group's worker thread owns that batch slot
     bool inflight = false;
+    double t_sent = 0;   // when the batch was handed to the library (BSR_ENGINE_PROF: the latency of the batches waited for)
+    int n_sent = 0;      // ... and how many tapes it held
   };
   // A group's chains are independent of each other between the batch's assembly and its results (a chain's candidates
   // depend on its own trees and its own random stream; consuming them touches that chain alone, the rare accept takes the
@@ -1930,6 +1932,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     Lane lane[3];   // the batch being consumed next and up to two generated ahead of it
     int fifo[3] = {0, 0, 0}, n_fly = 0;   // lanes in flight, oldest first
     double t_gen = 0, t_submit = 0, t_wait = 0, t_consume = 0;
+    double lat_waited = 0;                                   // BSR_ENGINE_PROF: submit -> results, summed over the batches waited for
+    int64_t n_batches = 0, n_waited = 0, n_tapes = 0, n_cands = 0;
     double evt_ema = 0.0;   // share of this group's chain batches that ended in an event lately (lookahead pays while it is low)
     // the round on offer (written by the worker between rounds only)
     int job_kind = JOB_GENERATE, job_lane = 0;
@@ -2200,7 +2204,12 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
                                        (int)L.chs.size(), L.terms.data(), L.mhflags.data(), L.spans.data(), n_sp,
                                        &L.ticket)
                  : bsr_score_submit(e->ctx, rows_p, off_p, chs_p, ks_p, sig_p, n_gpu, &L.ticket);
-    g.t_submit += now_s() - ts0;
+    L.t_sent = now_s();
+    L.n_sent = n_gpu;
+    g.t_submit += L.t_sent - ts0;
+    g.n_batches += 1;
+    g.n_tapes += n_gpu;
+    g.n_cands += (int64_t)L.chs.size();
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_submit: ") + bsr_last_error(e->ctx));
     L.inflight = true;
     return BSR_OK;
@@ -2223,6 +2232,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
                         : bsr_score_wait(e->ctx, L.ticket, res_p);
     const double tw1 = now_s();
     g.t_wait += tw1 - tw0;
+    if (!L.no_gpu && tw1 - tw0 > 2e-6) {   // (waited for: its age is its latency)
+      g.n_waited += 1;
+      g.lat_waited += tw1 - L.t_sent;
+    }
     if (r != BSR_OK) return efail(e, r, std::string("bsr_score_wait: ") + bsr_last_error(e->ctx));
     if (L.compact) {   // the GPU's scores to their places, the memo's next to them
       for (size_t j = 0; j < L.gpu_pos.size(); ++j) L.res[L.gpu_pos[j]] = L.g_res[j];
@@ -2370,7 +2383,10 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         }
     }
   }
+  double lat_w = 0;
+  int64_t nb = 0, nw = 0, nt = 0, ncd = 0;
   for (const Group& g : groups) {
+    lat_w += g.lat_waited; nb += g.n_batches; nw += g.n_waited; nt += g.n_tapes; ncd += g.n_cands;
     e->t_gen += g.t_gen;
     e->t_submit += g.t_submit;
     e->t_wait += g.t_wait;
@@ -2381,6 +2397,8 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
   if (getenv("BSR_ENGINE_PROF")) {
     fprintf(stderr, "bsr_engine_run (%s): generate %.3f s, submit %.3f s, wait %.3f s, consume %.3f s (thread-seconds)\n",
             threaded ? "worker threads" : "one thread", e->t_gen, e->t_submit, e->t_wait, e->t_consume);
+    fprintf(stderr, "  this call: %lld batches to the GPU, %.1f tapes of %.1f candidates each; %lld waited for, %.1f us from submission to results\n",
+            (long long)nb, nb ? (double)nt / nb : 0.0, nb ? (double)ncd / nb : 0.0, (long long)nw, nw ? 1e6 * lat_w / nw : 0.0);
     int64_t a = 0, g = 0, ps = 0, ok = 0, rj = 0, np_ = 0;
     for (const ChainS& c : e->chains) {
       a += c.n_accept; g += c.n_evt_gate; ps += c.n_evt_pass; ok += c.n_pred_ok; rj += c.n_rank_rej; np_ += c.n_props;

@@ -436,14 +436,17 @@ __global__ __launch_bounds__(BSR_SOLVE_WAVES * BSR_WAVE) void k_solve(const Prop
   // cannot start on a CU that hosts even one of these waves); eight or sixteen per workgroup measured slower -- the
   // bigger workgroup itself waits longer for a CU with that many registers free
   const int wave_id = threadIdx.x >> 6;
-  const int p = blockIdx.x * BSR_SOLVE_WAVES + wave_id;
+  // (the same in every lane of the wave, and said so: the proposal's descriptor then comes in by scalar loads, whole, with
+  // the first field asked for -- as vector loads its fields arrived one dependent round trip after the other)
+  const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * BSR_SOLVE_WAVES + wave_id);
   if (p >= P) return;
   const int lane = threadIdx.x & 63;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   __shared__ double sh_all_c[BSR_SOLVE_WAVES][BSR_NQ_MAX];
+  __shared__ double sh_all_ck[BSR_SOLVE_WAVES][3 * BSR_WAVE];   // the wave's copy of its chain's block (bsr_solve.h)
   double* sh_c = sh_all_c[wave_id];
 
-  solve_proposal<false>(dsc, cks, p, n_rb, part1, N, coef, outv, rank_floor, flagged, mhv, lane, sh_c);
+  solve_proposal<false, true>(dsc, cks, p, n_rb, part1, N, coef, outv, rank_floor, flagged, mhv, lane, sh_c, sh_all_ck[wave_id]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

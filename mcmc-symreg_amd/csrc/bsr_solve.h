@@ -34,7 +34,18 @@ struct SolveIn {
   double rank_floor;  // lower bound of the relative rank tolerance (0 in f64; a few eps_f32 when columns are f32)
   int exact;          // 1: singular values by Jacobi whatever the margin (BSR_SOLVE_EXACT=1; the standalone ylogLike)
   MhRes* mh;          // device-side copy of (loglik, rank) for the MH scan (k_events)
+#ifdef BSR_SOLVE_STAMPS
+  unsigned long long st[4];   // clock at the wave's start, behind the records' loads, behind their reduction, at solve_any
+#endif
 };
+// -DBSR_SOLVE_STAMPS (a measuring build, never shipped: BSR_EXTRA_FLAGS of build.sh): a proposal settled by the fast tier
+// returns, in beta[0..7], the shader-clock cycles its wave spent loading the partial records, reducing them, between
+// that and the solve, in the solve's steps 1, 2 and 3, behind them, and in all (tools/probes/solve_stamps.py).
+#ifdef BSR_SOLVE_STAMPS
+#define BSR_SOLVE_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define BSR_SOLVE_STAMP(v)
+#endif
 template <int K>
 __device__ __forceinline__ void solve_regs(const SolveIn& in, int lane, bsr_score* out);
 template <int K>
@@ -73,13 +84,17 @@ __device__ __forceinline__ void rot_coeffs(double alpha, double beta, double gam
   *sn = ok ? s0 : 0.0;
 }
 
+// s / d for d a power of two (the columns' prescales are: bsr_refresh.hip): exact like the IEEE quotient, by the exponent --
+// two instructions instead of the division's thirty-odd, once per factor entry
+__device__ __forceinline__ double pow2_quot(double s, double d) { return ldexp(s, 1 - __builtin_amdgcn_frexp_exp(d)); }
+
 // entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
 __device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
   if (m == K - 1) return (i < K) ? in.c[i < K ? i : 0] : rho;
   const int j = (m < in.k) ? m : m + 1;            // sibling tree
   if (i > j || i >= K) return 0.0;
   const double dj = in.ck->d[j];
-  return (dj != 0.0) ? in.ck->R[i * BSR_NQ_MAX + j] * (in.s / dj) : 0.0;
+  return (dj != 0.0) ? in.ck->R[i * BSR_NQ_MAX + j] * pow2_quot(in.s, dj) : 0.0;
 }
 
 __device__ __forceinline__ void store_score(const SolveIn& in, int K, bsr_score* out, double ll, double sse, double smin,
@@ -363,9 +378,9 @@ __device__ __forceinline__ void solve_cols(const SolveIn& in, int lane, bsr_scor
 //      substitution) -- four tolerances above => rank = K for certain.  In between (a band a few hundred wide around
 //      N eps, where also numpy's own SVD of the N x K matrix is within rounding of its threshold) and for anything
 //      that is not finite: the one-sided Jacobi SVD below, as for every proposal until round 5.
-//   3. rank = K: the ridge fit min |g1 - tau T b|^2 + 1e-6 |b|^2 (codes/funcs.py:1151-1155) by Givens rotations of
-//      [tau T; 1e-3 I] (K (K + 1) / 2 of them: backward stable at any condition number the gate lets through, no
-//      normal equations), b by back substitution, the misfit as the residual VECTOR g1 - tau T b plus the frame
+//   3. rank = K: the ridge fit min |g1 - tau T b|^2 + 1e-6 |b|^2 (codes/funcs.py:1151-1155) by K Householder reflections
+//      of [tau T; 1e-3 I] (backward stable at any condition number the gate lets through, no normal equations; until
+//      the middle of round 6 K (K + 1) / 2 Givens rotations: twice the instructions at K = 8), b by back substitution, the misfit as the residual VECTOR g1 - tau T b plus the frame
 //      direction the columns do not span (g_K) -- the quantities of the Jacobi path, computed from a QR instead of an SVD.
 //   4. rank < K: the reference returns before ylogLike (codes/funcs.py:1226-1228): there is no log-likelihood to
 //      report -- loglik, sse and beta are NaN, rank is a bound (the diagonal entries above the tolerance, at most
@@ -397,6 +412,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
     for (int i = 0; i < M; ++i) n2 = fma(W[i][j], W[i][j], n2);
     colmax2 = fmax(colmax2, n2);
   }
+  BSR_SOLVE_STAMP(t_a);
   // 1. rows (m, m + 1) for the Hessenberg columns m = k..K-2, then rows (K-1, K) for the candidate's column
 #pragma unroll
   for (int m = 0; m < K; ++m) {
@@ -420,6 +436,7 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
       }
     }
   }
+  BSR_SOLVE_STAMP(t_b);
   // 2. T^-1 (upper triangular) by back substitution, the bounds, the verdict
   double Y[K][K];
   double mind = INFINITY, frobT2 = 0.0, frobY2 = 0.0;
@@ -472,39 +489,57 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
     for (int i = 0; i <= j; ++i) frobY2 = fma(Y[i][j], Y[i][j], frobY2);
   const double smin_lb = rot_rsq(frobY2);   // 1 / |T^-1|_F
   if (!(smin_lb > 4.0 * tolrel * smax_ub)) return false;   // the band around the tolerance (or NaN): the exact tier decides
-  // 3. ridge: rotate [tau T; sqrt(1e-6) I | g1; 0] to triangular form, row of the identity by row
+  BSR_SOLVE_STAMP(t_c);
+  // 3. ridge: [tau T; sqrt(1e-6) I | g1; 0] to triangular form, column by column, by Householder reflections.  Column
+  //    j's entries to remove sit in the identity's rows 0..j (row j's own 1e-3 and what the earlier columns' reflections
+  //    filled in), so one reflection over (T row j, identity rows 0..j) does what j + 1 rotations did until this round:
+  //    one square root and one reciprocal per COLUMN instead of one square root per ENTRY -- ~500 instead of ~1 050
+  //    instructions at K = 8 (every lane runs the whole chain: the instruction count is what the wave pays), as
+  //    backward stable as the rotations, no normal equations.  v = x + sign(a) |x| e1 (no cancellation).
   const double tau = in.tau;
   double T2[K][K], g2[K], invd[K];
+  double E[K][K], ge[K];   // the identity's rows as they fill in: E[e][l] for l > the column being worked on; their right-hand sides
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     g2[i] = g[i];
+    ge[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) E[i][j] = (j == i) ? 1e-3 : 0.0;
 #pragma unroll
     for (int j = i; j < K; ++j) T2[i][j] = tau * W[i][j];
   }
 #pragma unroll
-  for (int e = 0; e < K; ++e) {
-    double E[K], ge = 0.0;   // the identity's row e: sqrt(eps) at column e, filled in to the right as it is rotated away
+  for (int j = 0; j < K; ++j) {
+    const double a = T2[j][j];
+    double s2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < K; ++j) E[j] = (j == e) ? 1e-3 : 0.0;
+    for (int e = 0; e <= j; ++e) s2 = fma(E[e][j], E[e][j], s2);
+    const double n2 = fma(a, a, s2);
+    const double nrm = n2 * rot_rsq(n2);            // |x|
+    const double v0 = a + copysign(nrm, a);         // v = (v0, E[0..j][j])
+    const double coef = rot_rcp(nrm * fabs(v0));    // 2 / v.v = 1 / (|x| (|x| + |a|))
+    const double alpha = -copysign(nrm, a);         // the column's new diagonal entry
+    T2[j][j] = alpha;
+    invd[j] = rot_rcp(alpha);
 #pragma unroll
-    for (int j = e; j < K; ++j) {
-      const double a = T2[j][j], b = E[j];
-      const double n2 = fma(a, a, b * b);
-      const double ri = rot_rsq(n2);
-      const double cs = a * ri, sn = b * ri;
-      T2[j][j] = n2 * ri;
-      if (j == e) invd[j] = ri;   // (row j's last rotation: 1 / sqrt(n2) IS the reciprocal of its final diagonal entry)
+    for (int l = j + 1; l < K; ++l) {
+      double w = v0 * T2[j][l];
 #pragma unroll
-      for (int l = j + 1; l < K; ++l) {
-        const double t0 = T2[j][l], t1 = E[l];
-        T2[j][l] = fma(cs, t0, sn * t1);
-        E[l] = fma(cs, t1, -(sn * t0));
-      }
-      const double q0 = g2[j];
-      g2[j] = fma(cs, q0, sn * ge);
-      ge = fma(cs, ge, -(sn * q0));
+      for (int e = 0; e <= j; ++e) w = fma(E[e][j], E[e][l], w);
+      w *= coef;
+      T2[j][l] = fma(-w, v0, T2[j][l]);
+#pragma unroll
+      for (int e = 0; e <= j; ++e) E[e][l] = fma(-w, E[e][j], E[e][l]);
     }
+    double wg = v0 * g2[j];
+#pragma unroll
+    for (int e = 0; e <= j; ++e) wg = fma(E[e][j], ge[e], wg);
+    wg *= coef;
+    g2[j] = fma(-wg, v0, g2[j]);
+#pragma unroll
+    for (int e = 0; e <= j; ++e) ge[e] = fma(-wg, E[e][j], ge[e]);
   }
+  BSR_SOLVE_STAMP(t_d);
   double bt[K];
 #pragma unroll
   for (int i = K - 1; i >= 0; --i) {
@@ -543,6 +578,19 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
       const int tree = (i == K - 1) ? k : ((i < k) ? i : i + 1);
       out->beta[tree] = bt[i];
     }
+#ifdef BSR_SOLVE_STAMPS
+    {
+      const unsigned long long t_e = __builtin_readcyclecounter();
+      out->beta[0] = (double)(in.st[1] - in.st[0]);
+      out->beta[1] = (double)(in.st[2] - in.st[1]);
+      out->beta[2] = (double)(t_a - in.st[2]);
+      out->beta[3] = (double)(t_b - t_a);
+      out->beta[4] = (double)(t_c - t_b);
+      out->beta[5] = (double)(t_d - t_c);
+      out->beta[6] = (double)(t_e - t_d);
+      out->beta[7] = (double)(t_e - in.st[0]);
+    }
+#endif
   }
   return true;
 }
@@ -579,37 +627,78 @@ __device__ __forceinline__ void solve_any(const SolveIn& in, int lane, bsr_score
 // reduction), then rank gate / OLS / log-likelihood, or -- a candidate (nearly) inside the span of the current columns --
 // hands it to the residual pass through the flagged list.  sh_c: BSR_NQ_MAX doubles of LDS of the wave's own.
 // UNCACHED: the records sit in uncached memory and were written by other waves of THIS launch (read around the caches).
-template <bool UNCACHED>
+template <bool UNCACHED, bool STAGED = false>
 __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, const ChainB* __restrict__ cks, int p, int n_rb,
                                                const double* __restrict__ part1, int64_t N, PropCoef* __restrict__ coef,
                                                bsr_score* __restrict__ outv, double rank_floor, int32_t* __restrict__ flagged,
-                                               MhRes* __restrict__ mhv, int lane, double* sh_c) {
+                                               MhRes* __restrict__ mhv, int lane, double* sh_c, double* sh_ck = nullptr) {
+  BSR_SOLVE_STAMP(t_s0);
+  // The chain's block (R, Q^T y, prescales: 141 words) is read some forty times below, entry by entry at indices that
+  // depend on k -- as loads from device memory each waited for on its own that was 5 of k_solve's 11 us at K = 8
+  // (-DBSR_SOLVE_STAMPS).  STAGED (k_solve, sh_ck: 3 * BSR_WAVE doubles of LDS of the wave's own): the wave fetches the block once, three words per lane, under the partial
+  // records' own flight, and everything behind reads its copy in LDS.
+  constexpr int CK_WORDS = (int)(sizeof(ChainB) / sizeof(double));
+  static_assert(sizeof(ChainB) % sizeof(double) == 0 && CK_WORDS <= 3 * BSR_WAVE, "three words per lane hold a ChainB");
+  const ChainB* ck_dev = cks + dsc[p].ck;
+  // (every field of the descriptor that is used below, asked for here: with a uniform p -- k_solve -- they are scalar
+  // loads that travel together with the first one instead of one round trip each where they are used)
+  const int d_mode = dsc[p].mode, d_K = dsc[p].K, d_k = dsc[p].k, d_nq = dsc[p].nq, d_dup = dsc[p].self_dup;
+  const double d_s = dsc[p].s, d_sigma = dsc[p].sigma;
+  double ckw[3] = {0.0, 0.0, 0.0};
+  if constexpr (STAGED) {
+    if (d_mode != BSR_MODE_EVAL) {   // (an evaluate-only tape belongs to no chain: no block to fetch -- its index is -1)
+      const double* src = reinterpret_cast<const double*>(ck_dev);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (lane + q * BSR_WAVE < CK_WORDS) ckw[q] = src[lane + q * BSR_WAVE];
+    }
+  }
   double sum[BSR_NQ_MAX + 2];
 #pragma unroll
   for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = 0.0;
   double amax = 0.0;
   uint32_t fl = 0;
-  for (int rb = lane; rb < n_rb; rb += BSR_WAVE) {
+  // two records per lane and turn, both in flight together (the sums take them in the order of the plain loop)
+  for (int rb = lane; rb < n_rb; rb += 2 * BSR_WAVE) {
+    const bool two = rb + BSR_WAVE < n_rb;
     const double* qp = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
-    double q[BSR_P1_WORDS];
+    const double* qp2 = qp + (two ? (size_t)BSR_WAVE * BSR_P1_WORDS : 0);
+    double q[BSR_P1_WORDS], q2[BSR_P1_WORDS];
 #pragma unroll
     for (int i = 0; i < BSR_P1_WORDS; ++i) q[i] = UNCACHED ? __builtin_nontemporal_load(qp + i) : qp[i];
+#pragma unroll
+    for (int i = 0; i < BSR_P1_WORDS; ++i) q2[i] = UNCACHED ? __builtin_nontemporal_load(qp2 + i) : qp2[i];
 #pragma unroll
     for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += q[i];
     amax = fmax(amax, q[10]);
     // the census of a partial record: inf in a row <=> its max|z| is inf; NaN in a row <=> its |s z|^2 is NaN (the tile
     // pass leaves word 11 zero and the census to these two tests; the work-queue pass also sets the bits itself)
     fl |= (uint32_t)q[11] | ((q[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q[8]) ? BSR_F_NAN : 0u);
+    // (selects, not a branch: behind a branch the compiler sinks the second record's loads and they wait their turn.
+    // x + 0.0 leaves every x as it is -- the sums start at +0.0 and can never be -0.0)
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += two ? q2[i] : 0.0;
+    amax = fmax(amax, two ? q2[10] : 0.0);
+    fl |= two ? ((uint32_t)q2[11] | ((q2[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q2[8]) ? BSR_F_NAN : 0u)) : 0u;
   }
+  if constexpr (STAGED) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (lane + q * BSR_WAVE < CK_WORDS) sh_ck[lane + q * BSR_WAVE] = ckw[q];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+  }
+  BSR_SOLVE_STAMP(t_s1);
 #pragma unroll
   for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = wave_sum(sum[i]);
   amax = wave_max(amax);
   fl = wave_or(fl);
   if (fl & BSR_F_INF) amax = INFINITY;
+  BSR_SOLVE_STAMP(t_s2);
 
   PropCoef* cf = coef + p;
   bsr_score* out = outv + p;
-  if (dsc[p].mode == BSR_MODE_EVAL) {
+  if (d_mode == BSR_MODE_EVAL) {
     if (lane == 0) {
       cf->skip = 1;
       out->maxabs = amax;
@@ -621,9 +710,9 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
     }
     return;
   }
-  const int K = dsc[p].K, k = dsc[p].k, nq = dsc[p].nq;
-  const double s = dsc[p].s;
-  const ChainB* ck = cks + dsc[p].ck;
+  const int K = d_K, k = d_k, nq = d_nq;
+  const double s = d_s;
+  const ChainB* ck = STAGED ? reinterpret_cast<const ChainB*>(sh_ck) : ck_dev;
   const uint32_t flags = fl | ck->flags_k[k];
   const double scale_ref = fmax(ck->m_other[k], amax);
   if (flags & (BSR_F_INF | BSR_F_NAN)) {  // matrix_rank: inf -> 0, NaN -> LinAlgError (reported as -1)
@@ -680,7 +769,7 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   // what used to be flagged): then w = 0 exactly, which is what the residual pass would measure (|w|^2 ~ 1e-32 |s z|^2,
   // below the cut) -- the same arithmetic follows, without the pass.  The claim is only trusted when the one-pass
   // figure agrees that the candidate is in the span.
-  const bool known_in_span = ambiguous && (dsc[p].self_dup & 1) != 0;
+  const bool known_in_span = ambiguous && (d_dup & 1) != 0;
   if (ambiguous && !known_in_span) {
     if (lane < BSR_NQ_MAX) cf->c[lane] = (lane < nq) ? sh_c[lane] : 0.0;
     if (lane == 0) {
@@ -705,7 +794,7 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   in.wy = known_in_span ? 0.0 : zy - cqy;
   in.tau = 1.0 / (s * scale_ref);
   in.s = s;
-  in.sigma = dsc[p].sigma;
+  in.sigma = d_sigma;
   in.scale = scale_ref;
   in.maxabs = amax;
   in.K = K;
@@ -713,8 +802,11 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   in.N = N;
   in.flags = flags;
   in.rank_floor = rank_floor;
-  in.exact = (dsc[p].self_dup & 2) ? 1 : 0;
+  in.exact = (d_dup & 2) ? 1 : 0;
   in.mh = mhv + p;
+#ifdef BSR_SOLVE_STAMPS
+  in.st[0] = t_s0; in.st[1] = t_s1; in.st[2] = t_s2; in.st[3] = 0;
+#endif
   solve_any(in, lane, out);
 
 }
