@@ -2322,7 +2322,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         first_rc.compare_exchange_strong(expect, r);
       }
     };
-    // Helper threads (Group::ctl): ONE per group of several chains, as far as the CPUs left over next to the workers and
+    // Helper threads (Group::ctl): ONE per group of several chains, as far as HALF the CPUs left over next to the workers and
     // the library's two submission threads allow -- the CPU budget of the rank and the L3 domain its threads are
     // confined to (csrc/bsr_place.hip: 8 cores and their SMT siblings on the hosts of MI355X boxes; helpers spin between
     // rounds, so a thread more than there are CPUs stalls everybody: 16 chains with 12 helpers 3.4 M consumed
@@ -2332,7 +2332,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
     // and round.
     int cpus = (int)std::floor(bsr_internal_cpu_budget());
     if (bsr_internal_placed_cpus() > 0) cpus = std::min(cpus, bsr_internal_placed_cpus());
-    int helpers_left = std::max(0, cpus - n_groups - 2);
+    int helpers_left = std::max(0, (cpus - n_groups - 2) / 2);   // (half of what is left: with every CPU taken they cost more than they bring -- 8 CPUs: 4.36 M/s with two helpers, 4.44 M/s with none)
     int per_group = 1;
     if (getenv("BSR_ENGINE_HELPERS")) {
       helpers_left = std::max(0, atoi(getenv("BSR_ENGINE_HELPERS")));

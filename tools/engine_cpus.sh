@@ -1,6 +1,6 @@
 #!/bin/bash
 # What the native sampler (8 chains on one GPU: config 4's per-GPU share) consumes per second with 2, 4, 6, 8 and all CPUs,
-# and with 4 / 6 / 8 chain groups (= generating threads): the prediction for a rank of the 8-GPU run.
+# with and without the groups' helper threads: the prediction for a rank of the 8-GPU run.
 #   bash tools/engine_cpus.sh [out.txt]
 out=${1:-/dev/stdout}
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -42,12 +42,9 @@ PY
 )
   echo "$label | cpus $n | $* | $line" | tee -a $out
 }
-for n in 0 8 6 4 2; do
-  run "default groups" $n X=1
+for n in 0 12 10 8 6 4 2; do
+  run "default (four groups, helper threads as the CPUs allow)" $n X=1
 done
-for g in 6 8; do
-  for n in 0 8 6; do
-    run "groups $g" $n BSR_ENGINE_GROUPS=$g
-  done
-done
-run "groups 8, 3 submission threads" 0 BSR_ENGINE_GROUPS=8 BSR_SUBMIT_THREADS=3
+run "no helper threads" 0 BSR_ENGINE_HELPERS=0
+run "no helper threads" 8 BSR_ENGINE_HELPERS=0
+run "groups 8" 0 BSR_ENGINE_GROUPS=8
