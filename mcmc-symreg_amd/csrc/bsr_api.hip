@@ -1522,11 +1522,7 @@ extern "C" int bsr_refresh(bsr_ctx* c, int32_t chain, bsr_chain_info* info) {
 // worker threads each own one).
 int bsr_internal_submit(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                         const int32_t* which_k, const double* sigma, int32_t B) {
-  // (the native sampler's worker threads: the batch's packets are written by the submitting thread itself.  A worker
-  // waits for its batches a third of its time anyway, the hand-over to a submission thread only added to what it waits
-  // for, and two busy threads fewer share the rank's L3 domain: eight chains 4.70 -> 4.9 M consumed proposals/s,
-  // profiles/r06_submit_threads_engine_ab.txt)
-  return bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0, false, true);
+  return bsr_internal_submit_mh(c, si, rows, tape_off, chain, which_k, sigma, B, nullptr, nullptr, nullptr, 0, false);
 }
 
 // The staging of a submitted batch from the slot's copies of its inputs (rows_copy / off_copy / sub_*): streams and tape
@@ -1580,7 +1576,7 @@ static int stage_submitted(bsr_ctx* c, BatchSlot& s, int B, TailJob* job) {
 // growth, a schedule beyond its capacity) surfaces at the wait, like a failed launch.
 int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* tape_off, const int32_t* chain,
                            const int32_t* which_k, const double* sigma, int32_t B, const double* terms8,
-                           const int32_t* mhflags, const int32_t* span_off, int32_t n_spans, bool defer, bool issue_here) {
+                           const int32_t* mhflags, const int32_t* span_off, int32_t n_spans, bool defer) {
   if (!c->has_y || c->K <= 0) return fail(c, BSR_E_STATE, "bsr_score_submit: context has no y / no chains");
   if (c->poisoned.load(std::memory_order_relaxed))
     return fail(c, BSR_E_STATE, "the context is poisoned: a directly dispatched batch never completed (destroy the context)");
@@ -1660,8 +1656,7 @@ int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32
   ++s.gen;
   s.tail_rc = BSR_OK;
   s.tail_wanted = s.tail_gen.load(std::memory_order_relaxed) + 1;
-  // issue_here: only where issuing is cheap for the caller -- direct dispatch (through HIP a batch is seven runtime calls)
-  if (c->launcher && !(issue_here && c->aql && !c->aql_off)) {
+  if (c->launcher) {
     launcher_push(c, job);
   } else {
     rc = issue_batch(c, s, job);

@@ -265,7 +265,7 @@ __attribute__((visibility("hidden"))) int bsr_internal_wait(bsr_ctx* c, int slot
 __attribute__((visibility("hidden"))) int bsr_internal_submit_mh(bsr_ctx* c, int slot, const bsr_node* rows, const int32_t* tape_off,
                            const int32_t* chain, const int32_t* which_k, const double* sigma, int32_t B,
                            const double* terms8, const int32_t* flags, const int32_t* span_off, int32_t n_spans,
-                           bool defer = false, bool issue_here = false);
+                           bool defer = false);
 __attribute__((visibility("hidden"))) int bsr_internal_wait_mh(bsr_ctx* c, int slot, bsr_score* out, bsr_event* events);
 __attribute__((visibility("hidden"))) int bsr_internal_commit(bsr_ctx* c, int slot, int32_t chain, int32_t k, int32_t idx);
 __attribute__((visibility("hidden"))) void bsr_internal_feature_range(const bsr_ctx* c, const double** lo, const double** hi);

@@ -365,7 +365,7 @@ int bsr_score_wait_mh(bsr_ctx*, int32_t, bsr_score*, bsr_event*) { return BSR_E_
 // passes its lone chain group's batches this way, with staging deferred)
 extern "C++" int bsr_internal_submit_mh(bsr_ctx* c, int si, const bsr_node* rows, const int32_t* off, const int32_t* chain,
                            const int32_t* which_k, const double* sigma, int32_t B, const double*, const int32_t*,
-                           const int32_t*, int32_t n_spans, bool, bool) {
+                           const int32_t*, int32_t n_spans, bool) {
   if (n_spans > 0) return BSR_E_STATE;
   return do_submit(c, si, rows, off, chain, which_k, sigma, B);
 }
