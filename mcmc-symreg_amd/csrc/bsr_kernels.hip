@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BSR_SOLVE_WAVES * BSR_WAVE) void k_solve(const Prop
   const int lane = threadIdx.x & 63;
   const PropDesc CONSTANT_AS* dsc = as_const(desc);
   __shared__ double sh_all_c[BSR_SOLVE_WAVES][BSR_NQ_MAX];
-  __shared__ double sh_all_ck[BSR_SOLVE_WAVES][3 * BSR_WAVE];   // the wave's copy of its chain's block (bsr_solve.h)
+  __shared__ double sh_all_ck[BSR_SOLVE_WAVES][BSR_SOLVE_CK_WORDS];   // the wave's copy of its chain's block (bsr_solve.h): 3.6 KB with sh_all_c
   double* sh_c = sh_all_c[wave_id];
 
   solve_proposal<false, true>(dsc, cks, p, n_rb, part1, N, coef, outv, rank_floor, flagged, mhv, lane, sh_c, sh_all_ck[wave_id]);

@@ -21,6 +21,8 @@
 // contribution), measured as a residual vector, never as a difference of squares.  The only O(N) inputs are c,
 // |s z|^2, s z.y from pass 1 -- or rho^2, w.y from the direct residual pass when rho^2 = |s z|^2 - |c|^2 would
 // cancel (candidate nearly inside the span of the current columns).
+#define BSR_SOLVE_CK_WORDS 104   // doubles of a k_solve wave's LDS copy of its chain's block (ChainB: 101)
+
 struct SolveIn {
   const ChainB* ck;
   const double* c;   // LDS: projections of s*z on the basis (K values)
@@ -633,23 +635,28 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
                                                bsr_score* __restrict__ outv, double rank_floor, int32_t* __restrict__ flagged,
                                                MhRes* __restrict__ mhv, int lane, double* sh_c, double* sh_ck = nullptr) {
   BSR_SOLVE_STAMP(t_s0);
-  // The chain's block (R, Q^T y, prescales: 141 words) is read some forty times below, entry by entry at indices that
+  // The chain's block (R, Q^T y, prescales: 101 words) is read some forty times below, entry by entry at indices that
   // depend on k -- as loads from device memory each waited for on its own that was 5 of k_solve's 11 us at K = 8
-  // (-DBSR_SOLVE_STAMPS).  STAGED (k_solve, sh_ck: 3 * BSR_WAVE doubles of LDS of the wave's own): the wave fetches the block once, three words per lane, under the partial
+  // (-DBSR_SOLVE_STAMPS).  STAGED (k_solve, sh_ck: BSR_SOLVE_CK_WORDS doubles of LDS of the wave's own): the wave fetches the block once, two words per lane, under the partial
   // records' own flight, and everything behind reads its copy in LDS.
+  // (BSR_SOLVE_CK_WORDS doubles per wave: with the waves' projections 3.6 KB per workgroup -- what must fit the 4 KB of LDS
+  // a tile or streaming workgroup of the NEXT batch leaves free on its CU.  With 6 KB -- three words per lane, the first
+  // version -- k_solve waited for those workgroups to end wherever they take all they may: config 5's fp32 step went from
+  // 69.5 to 77.6 us.)
   constexpr int CK_WORDS = (int)(sizeof(ChainB) / sizeof(double));
-  static_assert(sizeof(ChainB) % sizeof(double) == 0 && CK_WORDS <= 3 * BSR_WAVE, "three words per lane hold a ChainB");
+  static_assert(sizeof(ChainB) % sizeof(double) == 0 && CK_WORDS <= BSR_SOLVE_CK_WORDS && BSR_SOLVE_CK_WORDS <= 2 * BSR_WAVE,
+                "two words per lane hold a ChainB");
   const ChainB* ck_dev = cks + dsc[p].ck;
   // (every field of the descriptor that is used below, asked for here: with a uniform p -- k_solve -- they are scalar
   // loads that travel together with the first one instead of one round trip each where they are used)
   const int d_mode = dsc[p].mode, d_K = dsc[p].K, d_k = dsc[p].k, d_nq = dsc[p].nq, d_dup = dsc[p].self_dup;
   const double d_s = dsc[p].s, d_sigma = dsc[p].sigma;
-  double ckw[3] = {0.0, 0.0, 0.0};
+  double ckw[2] = {0.0, 0.0};
   if constexpr (STAGED) {
     if (d_mode != BSR_MODE_EVAL) {   // (an evaluate-only tape belongs to no chain: no block to fetch -- its index is -1)
       const double* src = reinterpret_cast<const double*>(ck_dev);
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 2; ++q)
         if (lane + q * BSR_WAVE < CK_WORDS) ckw[q] = src[lane + q * BSR_WAVE];
     }
   }
@@ -683,7 +690,7 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   }
   if constexpr (STAGED) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < 2; ++q)
       if (lane + q * BSR_WAVE < CK_WORDS) sh_ck[lane + q * BSR_WAVE] = ckw[q];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
