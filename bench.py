@@ -358,8 +358,18 @@ def occupancy_leg(wl, ranks, depth):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     roots = [[flatten(ch.roots[k]) for k in range(wl["K"])] for ch in wl["chains"]]
-    return mod.measure(wl["X"], wl["y"], wl["K"], roots, wl["packed"][:32], depth=depth, steps=2500, ring=192,
-                       device=ranks.device())
+    # three windows of the ring's last 192 launches (~2 ms each: one scheduling hiccup of the host inside a window moved
+    # the figure from 0.70 to 0.52 between two runs of the same build); the median one is reported, all three listed
+    runs = [mod.measure(wl["X"], wl["y"], wl["K"], roots, wl["packed"][:32], depth=depth, steps=2500, ring=192,
+                        device=ranks.device()) for _ in range(3)]
+    ok = [r for r in runs if "error" not in r]
+    if not ok:
+        return runs[0]
+    ok.sort(key=lambda r: r["occupancy_of_256_cus"])
+    res = dict(ok[len(ok) // 2])
+    res["occupancy_each_window"] = [r["occupancy_of_256_cus"] for r in runs if "error" not in r]
+    res["step_us_each_window"] = [r["step_us"] for r in runs if "error" not in r]
+    return res
 
 
 def refuse_debug_knobs():
