@@ -803,8 +803,16 @@ void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, Legacy
     for (int i : order)
       if (t.n[i].op == OP_LN && t.n[i].type == 1) lns.push_back(i);
   }
-  double new_sa2 = invgamma_rvs(r, 1);                                                  // :945-946
-  double new_sb2 = invgamma_rvs(r, 1);
+  // :945-946 draw a pair that only the shrinking move keeps (:1030-1031 and :1127-1128 draw it again): the other moves
+  // take the two uniforms off the stream and skip the logarithm and the division of values nobody reads
+  double new_sa2 = 0.0, new_sb2 = 0.0;
+  if (mv.change == CH_SHRINK) {
+    new_sa2 = invgamma_rvs(r, 1);
+    new_sb2 = invgamma_rvs(r, 1);
+  } else {
+    (void)r.uniform();
+    (void)r.uniform();
+  }
   const std::vector<double>& last_a = mv.last_a;
   const std::vector<double>& last_b = mv.last_b;
   *hratio = kNaN;
@@ -2321,6 +2329,7 @@ extern "C" int bsr_engine_run(bsr_engine* e, int32_t batch_per_chain, int64_t ma
         int expect = BSR_OK;
         first_rc.compare_exchange_strong(expect, r);
       }
+      g.quit.store(1, std::memory_order_release);   // this group's helpers are done with it (they spin between rounds)
     };
     // Helper threads (Group::ctl): ONE per group of several chains, as far as HALF the CPUs left over next to the workers and
     // the library's two submission threads allow -- the CPU budget of the rank and the L3 domain its threads are
