@@ -863,6 +863,25 @@ def main():
                 ex["c2_unpinned"] = unpinned_leg(args)
             except Exception as exc:
                 ex["c2_unpinned"] = {"error": repr(exc)}
+            try:
+                # The headline's step is a batch of 64 speculative proposals of ONE chain: about what a chain can use (its
+                # sampler keeps 3 x 32 in flight and throws ~8 % away).  The same workload with deeper batches, for the
+                # record: a launch's fixed costs -- the row slice staged into LDS, three dependent kernels in one queue --
+                # are shared by more tapes, but a lone chain would discard most of a batch this deep.
+                sweep = {}
+                for b in (128, 256):
+                    a2 = argparse.Namespace(**vars(args))
+                    a2.batch, a2.chains = b, 0
+                    w3 = build_workload("c2", a2, ranks)
+                    generate_batches(w3, 24)
+                    t3 = timed_region(w3, ranks, 40, 10, args.depth, 0.4)
+                    sweep["B%d" % b] = {"value": ranks.world * w3["P"] * t3["n_steps"] / t3["elapsed"],
+                                        "us_per_step": 1e6 * t3["elapsed"] / t3["n_steps"], "verified": t3["verified"]}
+                    w3["scorer"].close()
+                ex["c2_batch_sweep"] = {"metric": "MH proposals scored/sec, one chain, deeper speculative batches (N=100k, d=10, K=3)",
+                                        "unit": "proposals/s", "headline_B": out["config"]["speculative_batch"], **sweep}
+            except Exception as exc:
+                ex["c2_batch_sweep"] = {"error": repr(exc)}
         out["extra"] = ex
     if ranks.rank == 0:
         print(json.dumps(out))
