@@ -196,3 +196,17 @@ def test_the_assembly_tape_loop_of_the_whole_slice_pass_keeps_the_compiler_out()
         # the operator table: sixteen 128-byte slots on a 2 KB boundary (the dispatch ORs the slot's offset into the address)
         tab = [l for l in block if re.search(r"// 0*[0-9A-F]*[08]00: ", l) and "s_branch" in l]
         assert tab, n
+
+
+def test_k_solve_fits_the_lds_a_row_pass_workgroup_leaves_free():
+    """A tile or streaming workgroup takes all the LDS of its CU but 4 KB (csrc/bsr_tile.hip: tile_lds_bytes_max).  k_solve of
+    batch n runs while the row pass of batch n + 1 holds the CUs: with 6 KB of LDS (the first version of its staged copy of
+    the chain's block) it waited for those workgroups to end and config 5's fp32 step went from 69.5 to 77.6 us
+    (profiles/r06_k_solve_lds_ab.txt).  It must stay under the 4 KB."""
+    path = os.path.join(CSRC, "build", "bsr_kernels.resources.txt")
+    if not os.path.exists(path):
+        _report("bsr_kernels")
+    txt = open(path).read()
+    m = re.search(r"Function Name: _Z7k_solve\S*.*?LDS Size \[bytes/block\]: (\d+)", txt, re.S)
+    assert m, "k_solve not in the resource report"
+    assert int(m.group(1)) <= 4096, m.group(1)
