@@ -529,17 +529,20 @@ def gather_trees(wl, ranks):
     return len(got)
 
 
-def engine_leg(args, ranks, chains=8, batch=32, seconds=3.0):
+def engine_leg(args, ranks, chains=8, batch=None, seconds=3.0):
     """End-to-end chain throughput: the native sampler drives `chains` chains on this rank's GPU (consumed MH proposals
     per second, host proposal generation and accept path included), then the accepted trees of all ranks are gathered.
-    chains=8, batch=32: config 4's per-GPU share; chains=1: config 2's single chain."""
+    chains=8: config 4's per-GPU share; chains=1: config 2's single chain; batch=None: the library's default for the data set
+    (bsr.native.default_batch: 64 here)."""
     import numpy as np
     from bsr import dist as D
     from bsr.chain import DeviceScorer
     from bsr.native import NativeEngine
     W = WORKLOADS["c4"]
     X, y = synth(W["N"], W["d"], seed=0)
-    from bsr.native import batch_shape
+    from bsr.native import batch_shape, default_batch
+    if not batch:      # what BSR.fit / bsr.sharded.run_rank take where the caller names none
+        batch = default_batch(W["N"], W["d"], W["K"])
     tc, tb = batch_shape(chains, batch, W["K"])     # (as BSR.fit and bsr.sharded create their contexts)
     scorer = DeviceScorer(X, y, W["K"], n_chains=chains, max_batch=chains * batch, device=ranks.device(),
                           dtype=args.dtype, typical_chains=tc, typical_batch=tb)
@@ -840,7 +843,7 @@ def main():
         except Exception as exc:
             ex["c4_native_engine"] = {"error": repr(exc)}
         try:
-            ex["c2_native_engine"] = engine_leg(args, ranks, chains=1, batch=32, seconds=2.0)   # (BSR.fit's default batch)
+            ex["c2_native_engine"] = engine_leg(args, ranks, chains=1, seconds=2.0)   # (BSR.fit's default batch)
             # what a single chain CONSUMES next to what the headline scores (speculative batches of a frozen state):
             out["consumed_per_s"] = ex["c2_native_engine"]["value"]
         except Exception as exc:

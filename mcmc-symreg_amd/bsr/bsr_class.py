@@ -3,7 +3,8 @@
 Constructor arguments, fit/predict/model/complexity and the fitted attributes roots_/betas_/train_err_ keep the
 reference's meaning.  Extra keyword-only options (defaults preserve the reference's behaviour):
   device, dtype          GPU index and compute type ("f64" | "f32")
-  batch                  speculative proposals per launch and chain
+  batch                  speculative proposals per launch and chain (None: bsr.native.default_batch -- 64 where a row slice
+                         sits in LDS whole, 32 for data sets that stream)
   engine                 "native": the C++ sampler of libbsr_hip.so drives the GPU (default); "python": the
                          bsr.chain / bsr.proposal implementation of the same algorithm (same results)
   chain_seeds            None: chains run one after the other on the global numpy RNG stream exactly like the
@@ -37,7 +38,7 @@ except Exception:  # pragma: no cover
 
 class BSR(BaseEstimator, RegressorMixin):
     def __init__(self, treeNum=3, itrNum=5000, alpha1=0.4, alpha2=0.4, beta=-1, disp=False, val=100,
-                 device=0, dtype="f64", batch=32, chain_seeds=None, chains_per_launch=8, engine="native",
+                 device=0, dtype="f64", batch=None, chain_seeds=None, chains_per_launch=8, engine="native",
                  devices=None, ops=None, op_weights=None):
         self.treeNum = treeNum
         self.itrNum = itrNum
@@ -165,14 +166,16 @@ class BSR(BaseEstimator, RegressorMixin):
         K = self.treeNum
         if self.devices is not None:
             return self._fit_sharded(X, y, K, y_is_series)
+        from .native import default_batch
+        batch = int(self.batch) if self.batch else default_batch(N, d, K)
         T = self._table()
         seeds = self.chain_seeds
         n_slots = 1 if seeds is None else max(1, min(self.chains_per_launch, len(seeds), self.itrNum))
         tc, tb = (0, 0)
         if self.engine == "native":
             from .native import batch_shape
-            tc, tb = batch_shape(n_slots, self.batch, K)
-        scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, self.batch * n_slots), device=self.device,
+            tc, tb = batch_shape(n_slots, batch, K)
+        scorer = DeviceScorer(X, y, K, n_chains=n_slots, max_batch=max(4, batch * n_slots), device=self.device,
                               dtype=self.dtype, typical_chains=tc, typical_batch=tb)
         self.stats_ = {"proposals": 0, "accepts": 0, "rank_rejects": 0, "discarded": 0}
         results = []
@@ -185,7 +188,7 @@ class BSR(BaseEstimator, RegressorMixin):
                 for _ in range(self.itrNum):
                     ch = Chain(0, scorer, N, d, K, beta=self.beta, val=self.val, table=T, y_is_series=y_is_series,
                                feature_range=(X.min(axis=0), X.max(axis=0)))
-                    run_chains([ch], scorer, batch_per_chain=self.batch)
+                    run_chains([ch], scorer, batch_per_chain=batch)
                     rng.set_state(ch.rng_state)      # the next chain continues the same stream
                     results.append(ch.result())
                     results[-1].update(n_rank_rejects=ch.n_rank_rejects, n_discarded=ch.n_discarded)
@@ -198,7 +201,7 @@ class BSR(BaseEstimator, RegressorMixin):
                         np.random.seed(seeds[ci])
                         chains.append(Chain(slot, scorer, N, d, K, beta=self.beta, val=self.val, table=T,
                                             y_is_series=y_is_series, feature_range=(X.min(axis=0), X.max(axis=0))))
-                    run_chains(chains, scorer, batch_per_chain=self.batch)
+                    run_chains(chains, scorer, batch_per_chain=batch)
                     for ch in chains:
                         results.append(ch.result())
                         results[-1].update(n_rank_rejects=ch.n_rank_rejects, n_discarded=ch.n_discarded)
@@ -230,7 +233,7 @@ class BSR(BaseEstimator, RegressorMixin):
         from .sharded import fit_sharded
         seeds = self.chain_seeds if self.chain_seeds is not None else [1000 + c for c in range(self.itrNum)]
         seeds = [int(v) for v in seeds[:self.itrNum]]
-        recs = fit_sharded(X, y, K=K, seeds=seeds, devices=list(self.devices), batch=self.batch, val=self.val,
+        recs = fit_sharded(X, y, K=K, seeds=seeds, devices=list(self.devices), batch=self.batch or None, val=self.val,
                            beta=self.beta, chains_per_launch=self.chains_per_launch, dtype=self.dtype,
                            y_is_series=y_is_series, ops=None if self.ops is None and self.op_weights is None else self._table().ops,
                            op_weights=None if self.ops is None and self.op_weights is None else self._table().weights)
@@ -246,6 +249,8 @@ class BSR(BaseEstimator, RegressorMixin):
         return
 
     def _fit_native(self, scorer, N, d, K, seeds, n_slots, y_is_series):
+        from .native import default_batch
+        batch = int(self.batch) if self.batch else default_batch(N, d, K)
         from .native import NativeEngine
         eng = NativeEngine(scorer.ctx, n_slots, d, beta=self.beta, val=self.val, y_is_series=y_is_series)
         T = self._table()
@@ -257,7 +262,7 @@ class BSR(BaseEstimator, RegressorMixin):
                 eng.set_numpy_state(0)
                 for _ in range(self.itrNum):
                     eng.init_chain(0)
-                    eng.run(batch_per_chain=self.batch)
+                    eng.run(batch_per_chain=batch)
                     results.append(eng.result(0))
                 np.random.set_state(eng.get_numpy_state(0))
             else:
@@ -267,7 +272,7 @@ class BSR(BaseEstimator, RegressorMixin):
                     for slot, ci in enumerate(wave):
                         eng.seed(slot, seeds[ci])
                         eng.init_chain(slot)
-                    eng.run(batch_per_chain=self.batch)
+                    eng.run(batch_per_chain=batch)
                     for slot, ci in enumerate(wave):
                         results.append(eng.result(slot))
         finally:

@@ -14,6 +14,17 @@ from .tape import NODE_DTYPE, unflatten
 MAX_RECORD_NODES = 4096
 
 
+def default_batch(N, d, K):
+    """Speculative proposals per chain and batch where the caller names none (BSR(batch=None), fit_sharded, run_rank).
+    A batch is drawn on the assumption that every proposal in it is rejected (codes/funcs.py:1300-1303: what is behind the
+    first accept or unforeseen gate verdict is thrown away), so a deeper batch buys fewer, fuller launches with more
+    discarded scores.  Where a launch's fixed costs dominate -- data sets whose row slices sit in LDS whole -- 64 pays
+    (8 chains, N=100k, d=10: 5.4 M consumed proposals/s against 4.9 M at 32, K=8: +4 %, a lone chain +10-20 %;
+    profiles/r06_engine_batch_ab.txt); where the row pass itself is the bound (N=1M, d=50: 0.23 against 0.27 M/s) every
+    discarded score costs, and 32 stays."""
+    return 64 if int(N) * (int(d) + int(K) + 1) <= 8_000_000 else 32
+
+
 def batch_shape(n_chains, batch_per_chain, K):
     """(typical_chains, typical_batch) of the batches the native sampler submits for `n_chains` chains: its worker threads
     take the chains in up to four groups (csrc/bsr_engine.hip: bsr_engine_run; BSR_ENGINE_GROUPS) and a batch holds one

@@ -18,7 +18,7 @@ import numpy as np
 from . import dist as D
 
 
-def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=-1, chains_per_launch=8,
+def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=None, val=100, beta=-1, chains_per_launch=8,
              dtype="f64", y_is_series=True, max_props=-1, scorer=None, ops=None, op_weights=None):
     """Runs this rank's share of len(seeds) chains on `device` with the native sampler and gathers every rank's
     records.  Returns (raw records of ALL chains ordered by chain id: a list of uint8 arrays, decode with
@@ -31,6 +31,9 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
     X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
     n_chains = len(seeds)
+    if not batch:
+        from .native import default_batch
+        batch = default_batch(X.shape[0], X.shape[1], K)
     mine = D.shard(n_chains, world, rank)
     n_slots = max(1, min(chains_per_launch, len(mine)))
     own = scorer is None
@@ -71,7 +74,7 @@ def run_rank(X, y, K, seeds, rank=0, world=1, device=0, batch=32, val=100, beta=
     return allrecs, stats
 
 
-def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, val=100, beta=-1,
+def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=None, val=100, beta=-1,
                 chains_per_launch=8, dtype="f64", y_is_series=True, timeout=None, env_extra=None, ops=None,
                 op_weights=None):
     """Parent side.  Spawns one fresh process per entry of `devices` (this process needs no GPU and must not be
@@ -90,7 +93,7 @@ def fit_sharded(X, y, K=3, seeds=None, n_chains=None, devices=(0,), batch=32, va
                "BSR_DEVICES": ",".join(str(int(d)) for d in devices)}
         if env_extra:
             env.update(env_extra)
-        argv = ["-m", "bsr.sharded", "--data", work, "--out", out, "--K", str(K), "--batch", str(batch),
+        argv = ["-m", "bsr.sharded", "--data", work, "--out", out, "--K", str(K), "--batch", str(int(batch or 0)),
                 "--val", str(val), "--beta", repr(float(beta)), "--chains-per-launch", str(chains_per_launch),
                 "--dtype", dtype, "--y-is-series", "1" if y_is_series else "0"]
         if ops is not None:
@@ -122,7 +125,7 @@ def main(argv=None):
     ap.add_argument("--data", required=True, help="directory holding X.npy, y.npy, seeds.npy")
     ap.add_argument("--out", required=True, help="rank 0 writes the gathered records here (.npz: bsr.dist.load_records)")
     ap.add_argument("--K", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=0, help="speculative proposals per chain and batch (0: bsr.native.default_batch)")
     ap.add_argument("--val", type=int, default=100)
     ap.add_argument("--beta", type=float, default=-1.0)
     ap.add_argument("--chains-per-launch", type=int, default=8)

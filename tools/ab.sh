@@ -27,7 +27,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "m
 import bench
 args = argparse.Namespace(batch=0, chains=0, dtype="f64", burnin=300, rows=0)
 ranks = bench.Ranks()
-a = bench.engine_leg(args, ranks, chains=1, batch=32, seconds=2.0)
+a = bench.engine_leg(args, ranks, chains=1, seconds=2.0)
 b = bench.engine_leg(args, ranks)
 print("one chain %.0f consumed/s (memo %.3f, discarded %.3f); eight chains %.0f (memo %.3f, discarded %.3f)" % (
     a["value"], a.get("memo_answered_fraction_of_generated", 0), a["discarded_fraction"],

@@ -35,7 +35,7 @@ import bench
 args = argparse.Namespace(batch=0, chains=0, dtype="f64", burnin=300, rows=0)
 ranks = bench.Ranks()
 b = bench.engine_leg(args, ranks)
-a = bench.engine_leg(args, ranks, chains=1, batch=32, seconds=2.0)
+a = bench.engine_leg(args, ranks, chains=1, seconds=2.0)
 print("eight chains %.2f M consumed/s (memo %.2f, discarded %.3f, %s threads); one chain %.2f M" % (
     b["value"] / 1e6, b.get("memo_answered_fraction_of_generated", 0), b["discarded_fraction"], b.get("threads", "?"), a["value"] / 1e6))
 PY
