@@ -90,13 +90,18 @@ __device__ __forceinline__ void rot_coeffs(double alpha, double beta, double gam
 // two instructions instead of the division's thirty-odd, once per factor entry
 __device__ __forceinline__ double pow2_quot(double s, double d) { return ldexp(s, 1 - __builtin_amdgcn_frexp_exp(d)); }
 
-// entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate
+// entry (i, m) of the (K+1) x K factor S, m < K-1 a sibling column, m == K-1 the candidate.  Branch-free on purpose: written
+// with the loads inside the conditions the compiler made every entry a branch with two dependent LDS reads waited for one
+// by one (-DBSR_SOLVE_STAMPS: 8 000 of a K = 8 wave's 21 000 cycles went into filling the factor); this way the reads
+// of all entries go out together and a select picks the value -- the same value.
 __device__ __forceinline__ double factor_entry(const SolveIn& in, int K, int i, int m, double rho) {
   if (m == K - 1) return (i < K) ? in.c[i < K ? i : 0] : rho;
-  const int j = (m < in.k) ? m : m + 1;            // sibling tree
-  if (i > j || i >= K) return 0.0;
+  const int j = (m < in.k) ? m : m + 1;            // sibling tree (j <= K - 1: inside the block whatever k is)
   const double dj = in.ck->d[j];
-  return (dj != 0.0) ? in.ck->R[i * BSR_NQ_MAX + j] * pow2_quot(in.s, dj) : 0.0;
+  const double r = in.ck->R[(i < K ? i : 0) * BSR_NQ_MAX + j];
+  const double sc = pow2_quot(in.s, dj);           // (dj == 0: a number nobody reads)
+  const bool live = (i <= j) & (i < K) & (dj != 0.0);
+  return live ? r * sc : 0.0;                      // (a column that holds inf / NaN enters as zeros: d_j = 0)
 }
 
 __device__ __forceinline__ void store_score(const SolveIn& in, int K, bsr_score* out, double ll, double sse, double smin,
