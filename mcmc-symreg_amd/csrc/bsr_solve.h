@@ -447,15 +447,26 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
   // 2. T^-1 (upper triangular) by back substitution, the bounds, the verdict
   double Y[K][K];
   double mind = INFINITY, frobT2 = 0.0, frobY2 = 0.0;
+  {
+    // (four partial sums: one accumulator made the K (K + 1) / 2 squares a single dependent chain, ~9.5 cycles a link for a
+    // wave that runs alone)
+    double f4[4] = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    mind = fmin(mind, fabs(W[j][j]));
+    for (int j = 0; j < K; ++j) {
+      mind = fmin(mind, fabs(W[j][j]));
 #pragma unroll
-    for (int i = 0; i <= j; ++i) frobT2 = fma(W[i][j], W[i][j], frobT2);
+      for (int i = 0; i <= j; ++i) {
+        f4[n & 3] = fma(W[i][j], W[i][j], f4[n & 3]);
+        ++n;
+      }
+    }
+    frobT2 = (f4[0] + f4[1]) + (f4[2] + f4[3]);
   }
   const double dimmax = (double)((in.N > (int64_t)K) ? in.N : (int64_t)K);
   const double tolrel = fmax(dimmax * 2.220446049250313e-16, in.rank_floor);
-  const double smax_lb = sqrt(colmax2), smax_ub = sqrt(frobT2);
+  // (bounds: the reciprocal square root's estimate and two Newton steps, a third of the IEEE square root's chain)
+  const double smax_lb = colmax2 * rot_rsq(colmax2), smax_ub = frobT2 * rot_rsq(frobT2);
   if (!(isfinite(smax_ub) && smax_ub > 0.0)) return false;
   if (mind < 0.25 * tolrel * smax_lb) {   // 4. rank < K for certain
     int cnt = 0;
@@ -490,10 +501,18 @@ __device__ __forceinline__ bool solve_fast(const SolveIn& in, int lane, bsr_scor
       Y[i][j] = -(acc * Y[i][i]);
     }
   }
+  {
+    double f4[4] = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
 #pragma unroll
-  for (int j = 0; j < K; ++j)
+    for (int j = 0; j < K; ++j)
 #pragma unroll
-    for (int i = 0; i <= j; ++i) frobY2 = fma(Y[i][j], Y[i][j], frobY2);
+      for (int i = 0; i <= j; ++i) {
+        f4[n & 3] = fma(Y[i][j], Y[i][j], f4[n & 3]);
+        ++n;
+      }
+    frobY2 = (f4[0] + f4[1]) + (f4[2] + f4[3]);
+  }
   const double smin_lb = rot_rsq(frobY2);   // 1 / |T^-1|_F
   if (!(smin_lb > 4.0 * tolrel * smax_ub)) return false;   // the band around the tolerance (or NaN): the exact tier decides
   BSR_SOLVE_STAMP(t_c);
@@ -656,42 +675,53 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
   // loads that travel together with the first one instead of one round trip each where they are used)
   const int d_mode = dsc[p].mode, d_K = dsc[p].K, d_k = dsc[p].k, d_nq = dsc[p].nq, d_dup = dsc[p].self_dup;
   const double d_s = dsc[p].s, d_sigma = dsc[p].sigma;
-  double ckw[2] = {0.0, 0.0};
-  if constexpr (STAGED) {
-    if (d_mode != BSR_MODE_EVAL) {   // (an evaluate-only tape belongs to no chain: no block to fetch -- its index is -1)
-      const double* src = reinterpret_cast<const double*>(ck_dev);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (lane + q * BSR_WAVE < CK_WORDS) ckw[q] = src[lane + q * BSR_WAVE];
-    }
-  }
   double sum[BSR_NQ_MAX + 2];
 #pragma unroll
   for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = 0.0;
   double amax = 0.0;
   uint32_t fl = 0;
-  // two records per lane and turn, both in flight together (the sums take them in the order of the plain loop)
-  for (int rb = lane; rb < n_rb; rb += 2 * BSR_WAVE) {
-    const bool two = rb + BSR_WAVE < n_rb;
+  // One turn = two records per lane, both in flight together (the sums take them in the order of the plain loop).
+  // Selects, not branches: behind a branch the compiler sinks the second record's loads and they wait their turn; x + 0.0
+  // leaves every x as it is (the sums start at +0.0 and can never be -0.0).  The census of a partial record: inf in a
+  // row <=> its max|z| is inf; NaN in a row <=> its |s z|^2 is NaN (the tile pass leaves word 11 zero and the census to
+  // these two tests; the work-queue pass also sets the bits itself).
+  auto take = [&](const double (&q)[BSR_P1_WORDS], bool valid) {
+#pragma unroll
+    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += valid ? q[i] : 0.0;
+    amax = fmax(amax, valid ? q[10] : 0.0);
+    fl |= valid ? ((uint32_t)q[11] | ((q[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q[8]) ? BSR_F_NAN : 0u)) : 0u;
+  };
+  auto fetch = [&](double (&q)[BSR_P1_WORDS], int rb) {
     const double* qp = part1 + ((size_t)p * n_rb + rb) * BSR_P1_WORDS;
-    const double* qp2 = qp + (two ? (size_t)BSR_WAVE * BSR_P1_WORDS : 0);
-    double q[BSR_P1_WORDS], q2[BSR_P1_WORDS];
 #pragma unroll
     for (int i = 0; i < BSR_P1_WORDS; ++i) q[i] = UNCACHED ? __builtin_nontemporal_load(qp + i) : qp[i];
+  };
+  double ckw[2] = {0.0, 0.0};
+  {
+    // the first turn's loads go out in front of everything that needs the descriptor (their addresses come from the
+    // kernel's arguments alone): the chain's block, which does, then travels with them instead of a round trip ahead
+    const bool v1 = lane < n_rb, v2 = lane + BSR_WAVE < n_rb;
+    double q[BSR_P1_WORDS], q2[BSR_P1_WORDS];
+    fetch(q, v1 ? lane : 0);
+    fetch(q2, v2 ? lane + BSR_WAVE : 0);
+    if constexpr (STAGED) {
+      if (d_mode != BSR_MODE_EVAL) {   // (an evaluate-only tape belongs to no chain: no block to fetch -- its index is -1)
+        const double* src = reinterpret_cast<const double*>(ck_dev);
 #pragma unroll
-    for (int i = 0; i < BSR_P1_WORDS; ++i) q2[i] = UNCACHED ? __builtin_nontemporal_load(qp2 + i) : qp2[i];
-#pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += q[i];
-    amax = fmax(amax, q[10]);
-    // the census of a partial record: inf in a row <=> its max|z| is inf; NaN in a row <=> its |s z|^2 is NaN (the tile
-    // pass leaves word 11 zero and the census to these two tests; the work-queue pass also sets the bits itself)
-    fl |= (uint32_t)q[11] | ((q[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q[8]) ? BSR_F_NAN : 0u);
-    // (selects, not a branch: behind a branch the compiler sinks the second record's loads and they wait their turn.
-    // x + 0.0 leaves every x as it is -- the sums start at +0.0 and can never be -0.0)
-#pragma unroll
-    for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] += two ? q2[i] : 0.0;
-    amax = fmax(amax, two ? q2[10] : 0.0);
-    fl |= two ? ((uint32_t)q2[11] | ((q2[10] == INFINITY) ? BSR_F_INF : 0u) | (isnan(q2[8]) ? BSR_F_NAN : 0u)) : 0u;
+        for (int w = 0; w < 2; ++w)
+          if (lane + w * BSR_WAVE < CK_WORDS) ckw[w] = src[lane + w * BSR_WAVE];
+      }
+    }
+    take(q, v1);
+    take(q2, v2);
+  }
+  for (int rb = lane + 2 * BSR_WAVE; rb < n_rb; rb += 2 * BSR_WAVE) {
+    const bool two = rb + BSR_WAVE < n_rb;
+    double q[BSR_P1_WORDS], q2[BSR_P1_WORDS];
+    fetch(q, rb);
+    fetch(q2, two ? rb + BSR_WAVE : rb);
+    take(q, true);
+    take(q2, two);
   }
   if constexpr (STAGED) {
 #pragma unroll
@@ -701,8 +731,27 @@ __device__ __forceinline__ void solve_proposal(const PropDesc CONSTANT_AS* dsc, 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
   }
   BSR_SOLVE_STAMP(t_s1);
+  // the ten sums over the wave, eight and two at a time by half-wave and row swaps (bsr_device.h: wave_sum8 -- ~90 vector
+  // instructions with the broadcasts instead of ~200 for ten butterflies of their own: these reductions were the largest
+  // K-independent piece of the kernel after the loads, -DBSR_SOLVE_STAMPS).  A fixed order, as before -- another one.
+  static_assert(BSR_NQ_MAX + 2 == 10, "eight sums and two");
+  {
+    auto lane_of = [](double v, int l) {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    double g[8], lo, hi;
 #pragma unroll
-  for (int i = 0; i < BSR_NQ_MAX + 2; ++i) sum[i] = wave_sum(sum[i]);
+    for (int i = 0; i < 8; ++i) g[i] = sum[i];
+    wave_sum8(g, lo, hi);                       // rows 0..3 of lo: totals 0, 2, 1, 3; of hi: 4, 6, 5, 7
+    double a8 = sum[8], a9 = sum[9];
+    swap32(a8, a9);
+    a8 += a9;                                   // lanes 0-31: sum 8 over both halves; lanes 32-63: sum 9
+    a8 = row_sum16(a8);
+    a8 += dpp_f64<0x142, 0xA>(a8);              // rows 1 and 3 add their left neighbour: row 1 = sum 8, row 3 = sum 9
+    sum[0] = lane_of(lo, 0);  sum[1] = lane_of(lo, 32); sum[2] = lane_of(lo, 16); sum[3] = lane_of(lo, 48);
+    sum[4] = lane_of(hi, 0);  sum[5] = lane_of(hi, 32); sum[6] = lane_of(hi, 16); sum[7] = lane_of(hi, 48);
+    sum[8] = lane_of(a8, 31); sum[9] = lane_of(a8, 63);
+  }
   amax = wave_max(amax);
   fl = wave_or(fl);
   if (fl & BSR_F_INF) amax = INFINITY;
