@@ -23,6 +23,11 @@ build_one() {   # <object dir> <output .so> [extra flags...]
     # fails when the tile row pass spills to scratch (it did once, silently, for 4.5 us per launch)
     # (host code of the units that only launch kernels or run once per context: optimised for size)
     local hostopt=(); case "$s" in bsr_api|bsr_stage) ;; bsr_engine) hostopt=(-Xarch_host -O2) ;; *) hostopt=(-Xarch_host -Os) ;; esac
+    # k_solve / k_rows / k_finalize: the first sixteen words of the kernel arguments arrive in scalar registers with the wave
+    # (gfx940+ kernarg preload; older firmware runs the compiler's compatibility prologue, which asks for all of them at
+    # once) -- these kernels read their arguments piece by piece, a scalar-load round trip each, at the head of a wave whose
+    # whole life is a few microseconds
+    case "$s" in bsr_kernels) hostopt+=(-mllvm -amdgpu-kernarg-preload-count=16) ;; esac
     "$ROCM/bin/hipcc" "${FLAGS[@]}" "${hostopt[@]}" -Rpass-analysis=kernel-resource-usage -c "$here/$s.hip" -o "$obj/$s.o" 2> "$obj/$s.resources.txt" &
     pids+=($!)
   done
