@@ -406,3 +406,16 @@ def test_model_file_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "other.json").write_text('{"format": "something else"}')
         BSR.load(str(tmp_path / "other.json"))
+
+
+def test_default_speculative_batch_follows_the_data_set():
+    """bsr.native.default_batch: 64 speculative proposals per chain and launch where a row slice sits in LDS whole (the
+    reference's own sizes: N = 100, d = 2; the benchmark's N = 100k, d = 10, K = 3 and K = 8), 32 where the data set
+    streams (N = 1M, d = 50: every discarded score costs a share of a 74 us row pass there).  BSR(batch=None) and
+    bsr.sharded take it; an explicit batch wins."""
+    from bsr.native import default_batch
+    from bsr import BSR
+    assert default_batch(100, 2, 3) == 64
+    assert default_batch(100_000, 10, 3) == 64 and default_batch(100_000, 10, 8) == 64
+    assert default_batch(1_000_000, 50, 3) == 32
+    assert BSR(3, 50).batch is None and BSR(3, 50, batch=16).batch == 16
