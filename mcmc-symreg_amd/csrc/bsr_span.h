@@ -111,7 +111,10 @@ inline int unary_sign_rule(int op) {
 
 // linear form and identity of the column a postfix tape computes; false: malformed tape / deeper than max_stack
 inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 26) {
-  LinForm st[28];
+  // (raw storage: an entry is written whole where it is pushed -- twenty-eight default-constructed forms were a fifth of
+  // what a five-node tape's form cost)
+  alignas(LinForm) unsigned char st_raw[28 * sizeof(LinForm)];
+  LinForm* st = reinterpret_cast<LinForm*>(st_raw);
   if (max_stack > 26) max_stack = 26;
   int sp = 0;
   // 1/(1/A) is A to rounding (the moves stack an inverse on an inverse often enough: `1/[1/[x30]]`): the atoms made
@@ -130,10 +133,10 @@ inline bool lin_form(const bsr_node* t, int len, LinForm* out, int max_stack = 2
     if (op == BSR_OP_TERMINAL) {
       if (sp >= max_stack) return false;
       LinForm& f = st[sp];
-      f = LinForm();
+      f.inexact = false;
       f.shash = mix64(0x7465726Dull ^ ((uint64_t)(uint32_t)t[i].feature << 32));
       f.ssign = 1;
-      as_own_atom(f);
+      as_own_atom(f);   // (n, atom[0], coef[0], inexact: with the three fields above, everything a form of one term holds)
       ++sp;
     } else if (op == BSR_OP_ADD || op == BSR_OP_SUB) {
       if (sp < 2) return false;
