@@ -301,7 +301,9 @@ struct SpanBasis {
       ++o.n;
     }
     o.over = o.over || v.over || r.over;
-    v = o;
+    v.n = o.n;                       // (its o.n terms, not the whole 900-byte vector)
+    v.over = o.over;
+    for (int q = 0; q < o.n; ++q) { v.a[q] = o.a[q]; v.c[q] = o.c[q]; }
   }
   void reduce(Vec& v, double scale) const {
     for (const Row& r : rows) {
