@@ -531,7 +531,18 @@ struct PropSetup {
   Tree base;
   std::vector<int> term, nterm, detcd, ln_nodes;
   std::vector<double> last_a, last_b;
+  double p_stay = 0, p_grow = 0, p_prune = 0, p_detr = 0, p_trans = 0, p_rop = 0;   // the move probabilities of codes/funcs.py:475-480
 };
+// (by the reference's own expressions, from the three counts they depend on: seven divisions per proposal otherwise)
+inline void move_probabilities(int ltNum, size_t n_nterm, size_t n_detcd, double* p_stay, double* p_grow, double* p_prune,
+                               double* p_detr, double* p_trans, double* p_rop) {
+  *p_stay = 0.25 * ltNum / (ltNum + 3);                                    // :475-480
+  *p_grow = (1 - *p_stay) * std::min(1.0, 4.0 / ((double)n_nterm + 2)) / 3;
+  *p_prune = (1 - *p_stay) / 3 - *p_grow;
+  *p_detr = (1 - *p_stay) * (1.0 / 3) * (double)n_detcd / (3 + (double)n_detcd);
+  *p_trans = (1 - *p_stay) / 3 - *p_detr;
+  *p_rop = (1 - *p_stay) / 6;
+}
 void prop_lists(const Tree& t, const std::vector<int>& tree, std::vector<int>& term, std::vector<int>& nterm,
                 std::vector<int>& detcd, std::vector<int>& ln_nodes, std::vector<double>& last_a, std::vector<double>& last_b) {
   ln_nodes.clear();
@@ -554,6 +565,8 @@ void build_setup(const Tree& src, PropSetup& ps) {
   BSR_SCRATCH(int, tree);
   preorder(ps.base, ps.base.root, tree);
   prop_lists(ps.base, tree, ps.term, ps.nterm, ps.detcd, ps.ln_nodes, ps.last_a, ps.last_b);
+  move_probabilities((int)ps.ln_nodes.size(), ps.nterm.size(), ps.detcd.size(), &ps.p_stay, &ps.p_grow, &ps.p_prune, &ps.p_detr,
+                     &ps.p_trans, &ps.p_rop);
 }
 
 // One structural proposal on the private copy `t` (codes/funcs.py:406-923); ps: `t` is a copy of ps->base
@@ -579,12 +592,12 @@ void prop_inplace(Tree& t, const Params& P, double sigma_a, double sigma_b, Lega
   int change = CH_NONE;
   double Q = 1, Qinv = 1;
 
-  const double p_stay = 0.25 * ltNum / (ltNum + 3);                                    // :475-480
-  const double p_grow = (1 - p_stay) * std::min(1.0, 4.0 / ((double)nterm.size() + 2)) / 3;
-  const double p_prune = (1 - p_stay) / 3 - p_grow;
-  const double p_detr = (1 - p_stay) * (1.0 / 3) * (double)detcd.size() / (3 + (double)detcd.size());
-  const double p_trans = (1 - p_stay) / 3 - p_detr;
-  const double p_rop = (1 - p_stay) / 6;
+  double p_stay, p_grow, p_prune, p_detr, p_trans, p_rop;
+  if (ps) {
+    p_stay = ps->p_stay; p_grow = ps->p_grow; p_prune = ps->p_prune; p_detr = ps->p_detr; p_trans = ps->p_trans; p_rop = ps->p_rop;
+  } else {
+    move_probabilities(ltNum, nterm.size(), detcd.size(), &p_stay, &p_grow, &p_prune, &p_detr, &p_trans, &p_rop);
+  }
   const double u = r.uniform();                                                         // :483
   int action;
 
@@ -916,18 +929,20 @@ void aux_inplace(Tree& t, const Move& mv, double sigma_a, double sigma_b, Legacy
   } else {                                                                              // :1127-1136
     new_sa2 = invgamma_rvs(r, 1);
     new_sb2 = invgamma_rvs(r, 1);
-    const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
-    BSR_SCRATCH(double, va);
-    BSR_SCRATCH(double, vb);
-    va.resize(lns.size());
-    vb.resize(lns.size());
-    for (size_t i = 0; i < lns.size(); ++i) {
-      va[i] = r.normal(1, sa);
-      vb[i] = r.normal(0, sb);
-    }
-    for (size_t i = 0; i < lns.size(); ++i) {
-      t.n[lns[i]].a = va[i];
-      t.n[lns[i]].b = vb[i];
+    if (!lns.empty()) {   // (four trees in five: no ln node, no square roots either)
+      const double sa = std::sqrt(new_sa2), sb = std::sqrt(new_sb2);
+      BSR_SCRATCH(double, va);
+      BSR_SCRATCH(double, vb);
+      va.resize(lns.size());
+      vb.resize(lns.size());
+      for (size_t i = 0; i < lns.size(); ++i) {
+        va[i] = r.normal(1, sa);
+        vb[i] = r.normal(0, sb);
+      }
+      for (size_t i = 0; i < lns.size(); ++i) {
+        t.n[lns[i]].a = va[i];
+        t.n[lns[i]].b = vb[i];
+      }
     }
   }
   *sa2_out = new_sa2;
@@ -1164,6 +1179,7 @@ struct ChainS {
   std::vector<double> siga, sigb, Beta, errs;
   std::vector<double> fs_old_s, fs_old_p;
   std::vector<char> fs_old_ok;
+  double yll_sse = kNaN, yll_sigma = kNaN, yll_val = 0.0, lp_sigma_val = 0.0;   // consume(): the state's own terms of the log-ratio
   std::vector<PropSetup> setup;     // per tree k: what its proposals start from (valid while setup_ok[k])
   std::vector<char> setup_ok;
   // storage of the candidates that have been consumed or thrown away, for the ones generated next (a candidate's tree
@@ -1545,8 +1561,9 @@ void generate(bsr_engine* e, ChainS& c, int max_n, int ahead = 0, bool memo_on =
   c.end_state = c.rng;
 }
 
+// lp_sigma: flog(invgamma_pdf(sigma, 4)) of the chain's current sigma (the caller keeps it from proposal to proposal)
 double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double sn_p, double so_s, double so_p,
-                 double sigma) {  // codes/funcs.py:1230-1296
+                 double lp_sigma) {  // codes/funcs.py:1230-1296
   const double log_y = yllstar - yll;
   const double log_q = flog(pymax(1e-5, fdiv(c.Qinv, c.Q)));
   double logR;
@@ -1556,7 +1573,7 @@ double log_ratio(const Cand& c, double yllstar, double yll, double sn_s, double 
   } else {
     logR = log_y + (so_s - sn_s) + log_q;
   }
-  return logR + flog(invgamma_pdf(c.new_sigma, 4)) - flog(invgamma_pdf(sigma, 4));
+  return logR + flog(invgamma_pdf(c.new_sigma, 4)) - lp_sigma;
 }
 
 // The device half of an accepted move (codes/bsr_class.py:211-252): the accepted tree's column into the chain's cache,
@@ -1711,13 +1728,21 @@ int consume(bsr_engine* e, ChainS& c, const bsr_score* res, int slot0, int batch
     // memo and the same proposal scored by the GPU then give the same bits, so the memo cannot move a chain.
     const double yllstar = ev ? sc.loglik
                               : -sc.sse / (2 * cd.new_sigma * cd.new_sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * cd.new_sigma * cd.new_sigma);
-    const double yll = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
+    // (the two terms that belong to the chain's state, not to the proposal: the same value for the ~1 000 proposals
+    // between two accepted ones -- three logarithms and an exponential per proposal otherwise)
+    if (!(c.yll_sse == c.sse_old && c.yll_sigma == c.sigma)) {
+      c.yll_sse = c.sse_old;
+      c.yll_sigma = c.sigma;
+      c.yll_val = -c.sse_old / (2 * c.sigma * c.sigma) - 0.5 * (double)e->N * std::log(2 * M_PI * c.sigma * c.sigma);
+      c.lp_sigma_val = flog(invgamma_pdf(c.sigma, 4));
+    }
+    const double yll = c.yll_val;
     const double sn_s = cd.sn_s, sn_p = cd.sn_p;  // fStruc of the proposed tree, computed when it was generated
     if (!c.fs_old_ok[k]) {
       fstruc(c.roots[k], c.roots[k].root, e->P, c.siga[k], c.sigb[k], &c.fs_old_s[k], &c.fs_old_p[k]);
       c.fs_old_ok[k] = 1;
     }
-    const double logR = log_ratio(cd, yllstar, yll, sn_s, sn_p, c.fs_old_s[k], c.fs_old_p[k], c.sigma);
+    const double logR = log_ratio(cd, yllstar, yll, sn_s, sn_p, c.fs_old_s[k], c.fs_old_p[k], c.lp_sigma_val);
     const double alpha = (0 < logR) ? 0 : logR;  // Python's min(logR, 0)
     const bool accepted = !(flog(cd.u) >= alpha);
     if (tr) {
