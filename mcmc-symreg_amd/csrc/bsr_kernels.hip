@@ -44,7 +44,10 @@ int env_int(const char* name, int dflt);   // bsr_api.hip
 #ifndef BSR_SOLVE_WAVES
 #define BSR_SOLVE_WAVES 4   // k_solve: proposals (waves) per workgroup (measured at C2 / K=8, us per step: 4: 17.3 / 27.2,
                            // 8: 17.9 / 29.7, 16: 19.7 / 37.7 -- tools/probes/lib_ab.sh; under direct dispatch, round 5:
-                           // 1: 10.98 / 20.2, 2: 10.7-10.8 / 18.4, 4: 10.6 / 18.2, 8: 10.9-11.0 / 19.1, 16: 12.9 / 25.6)
+                           // 1: 10.98 / 20.2, 2: 10.7-10.8 / 18.4, 4: 10.6 / 18.2, 8: 10.9-11.0 / 19.1, 16: 12.9 / 25.6;
+                           // round 6, the leaner kernel: 1: 10.3 / 16.6, 2: 10.1 / 16.2, 4: 10.1-10.2 / 16.4, 8: 10.3 --
+                           // profiles/r06_solve_waves_ab.txt; eight would also take 7 KB of LDS, more than a row-pass
+                           // workgroup leaves free on its CU)
 #endif
 
 // In-kernel timing stamps (debug builds only: -DBSR_STAMPS): shader-clock samples of the first waves of the PROJECT
