@@ -1,4 +1,7 @@
 # Round-6 measurement set (run on the GPU box): everything DESIGN section 7 and profiles/INDEX.md cite, into gpurun_out/r06/.
+# (The round's LAST builds re-ran parts of it one by one -- `python bench.py`, `bash tools/r06_stats.sh <tag> <workload> [--depth 1]`,
+# `bash tools/engine_cpus.sh`, `python tools/cu_occupancy.py` -- after every change to k_solve and the sampler; profiles/INDEX.md
+# names the command behind each file.  The PMC / traffic passes are from the first full run: the row passes did not change.)
 #   bash tools/measure_r06.sh            (about 12 minutes)
 mkdir -p gpurun_out/r06
 o=gpurun_out/r06
